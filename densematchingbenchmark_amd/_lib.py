@@ -1,0 +1,118 @@
+"""ctypes binding of libdmb_hip.so -- the only way the Python host layer reaches the HIP kernels.
+
+PyTorch is plumbing here: it owns device memory (``tensor.data_ptr()``) and the current HIP stream
+(``torch.cuda.current_stream().cuda_stream``); everything that computes lives behind the C ABI of
+``include/dmb_hip.h``.  There is NO fallback: if the library is missing or a tensor is not a CUDA/HIP
+tensor, the call raises.
+"""
+import ctypes
+import os
+import re
+
+import torch  # imported first on purpose: the library then binds to the HIP runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libdmb_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dmb_hip.h")
+
+_c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
+_P = _c_void_p  # device pointer
+_HI = ctypes.POINTER(ctypes.c_int)  # host int array
+_HF = ctypes.POINTER(ctypes.c_float)  # host float array
+
+# name -> (restype, argtypes)
+SIGNATURES = {
+    "dmb_abi_version": (_c_int, []),
+    "dmb_last_error": (ctypes.c_char_p, []),
+    "dmb_cat_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
+    "dmb_dif_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
+    "dmb_gwc_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
+    "dmb_cat_fms_into_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
+    "dmb_conv3d_packed_floats": (_c_ll, [_c_int, _c_int]),
+    "dmb_deconv3d_packed_floats": (_c_ll, [_c_int, _c_int]),
+    "dmb_conv3d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
+    "dmb_deconv3d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
+    "dmb_conv3d_k3_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 8 + [_P]),
+    "dmb_conv3d_k3_c1_f32": (_c_int, [_P, _P, _c_float, _P, _P] + [_c_int] * 5 + [_P]),
+    "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 7 + [_P]),
+    "dmb_trilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),
+    "dmb_deconv3d_k8s4_c1_f32": (_c_int, [_P, _P, _P] + [_c_int] * 4 + [_P]),
+    "dmb_soft_argmin_f32": (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _HF, _P]),
+    "dmb_soft_argmin_sampled_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _P]),
+    "dmb_local_soft_argmin_f32": (_c_int, [_P, _P, _P] + [_c_int] * 8 + [_c_float, _P]),
+    "dmb_trilinear_soft_argmin_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_c_float, _HF, _P]),
+    "dmb_conf_head_packed_floats": (_c_ll, [_c_int, _c_int]),
+    "dmb_conf_head_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
+    "dmb_conf_head_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 5 + [_P]),
+    "dmb_epe_accum_f64": (_c_int, [_P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
+}
+
+
+def header_symbols():
+    """Every entry point declared in include/dmb_hip.h (used by the CPU-side export test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmb_[a-z0-9_]+)\s*\(", text)))
+
+
+class DmbLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libdmb_hip.so (once).  Raises DmbLibraryError -- never falls back to another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmbLibraryError(
+            "libdmb_hip.so is not built (%s). Run `python -m densematchingbenchmark_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU/PyTorch fallback for this path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().dmb_last_error()
+        raise DmbLibraryError("%s failed with code %d (%s)" % (what, code, msg.decode() if msg else ""))
+
+
+def dev_ptr(t, name="tensor", allow_none=False):
+    """Device pointer of a contiguous FP32 HIP tensor; raises for anything else (no silent CPU path)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise DmbLibraryError("%s is None" % name)
+    if not isinstance(t, torch.Tensor):
+        raise DmbLibraryError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise DmbLibraryError(
+            "%s lives on %s: the dmb HIP path only runs on a GPU (cuda/hip) tensor and has no CPU fallback" % (name, t.device))
+    if t.dtype != torch.float32 and t.dtype != torch.float64 and t.dtype != torch.int64:
+        raise DmbLibraryError("%s has dtype %s; FP32 expected" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise DmbLibraryError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def host_ints(values):
+    arr = (ctypes.c_int * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def host_floats(values):
+    arr = (ctypes.c_float * len(values))(*[float(v) for v in values])
+    return arr

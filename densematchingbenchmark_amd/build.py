@@ -1,0 +1,63 @@
+"""Build recipe for libdmb_hip.so (the C-ABI library declared in include/dmb_hip.h).
+
+Plain ``hipcc --offload-arch=gfx950`` per translation unit, then one ``-shared`` link, all in-tree under
+``densematchingbenchmark_amd/lib/`` so that the built library travels with a repository snapshot.
+hipcc cross-compiles without a GPU.  Run as ``python -m densematchingbenchmark_amd.build``.
+"""
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdmb_hip.so")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+
+SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+    """Compile every HIP source for gfx950 and link libdmb_hip.so.  Returns the library path."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "dmb_common.h"), os.path.join(INCLUDE, "dmb_hip.h")]
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + headers):
+            cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+            if verbose:
+                print("[dmb build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print("[dmb build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB_PATH)

@@ -1,0 +1,183 @@
+// AcfNet confidence head (dmb/modeling/stereo/cmn/cmn.py:10-36,57-69) as one fused kernel:
+//   h    = relu(BN(conv2d_3x3(cost)))      cost: [B, D, H, W] (the disparity axis is the channel axis), Cm maps
+//   conf = sigmoid(sum_m h_m * w2[m])      1x1 conv + sigmoid, fused into the epilogue (h never leaves registers)
+// The 3x3 convolution is an FP32 implicit GEMM on the matrix cores (M = Cm, N = pixels, K = D * 9), same
+// structure as conv3d.hip: A = prepacked weight fragments from L2, B = LDS tile read along the flattened
+// padded (y, x) plane.  The 346.7 GFLOP/pair of AcfNet's three heads is FP32-MFMA-bound.
+#include "dmb_common.h"
+
+namespace dmb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define DMB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ int cd_row2(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+constexpr int CH_CK = 16;  // disparity planes (K channels) staged per chunk
+
+// wp[((kp * 9 + tap) * NTT + nt) * 64 + lane] = w1[m = nt*32 + (lane & 31)][d = 2*kp + (lane >> 5)][tap], zero padded
+__global__ void pack_conf_kernel(const float* __restrict__ w1, float* __restrict__ wp, int Cm, int D, int NTT, int Dpad) {
+  const long long total = (long long)(Dpad / 2) * 9 * NTT * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long long r = i >> 6;
+    const int nt = (int)(r % NTT);
+    r /= NTT;
+    const int tap = (int)(r % 9);
+    const int kp = (int)(r / 9);
+    const int m = nt * 32 + (lane & 31);
+    const int d = 2 * kp + (lane >> 5);
+    wp[i] = (m < Cm && d < D) ? w1[((size_t)m * D + d) * 9 + tap] : 0.f;
+  }
+}
+
+template <int NTT>
+struct CHCfg {
+  static constexpr int WN = NTT;           // one 32-map row tile per wave column
+  static constexpr int WY = 4 / WN;
+  static constexpr int RY = 4;             // output rows per wave
+  static constexpr int TY = RY * WY;
+  static constexpr int TX = 60;
+  static constexpr int P = TX + 2;
+  static constexpr int ROWS = TY + 2;
+  static constexpr int MT = (RY * P + 31) / 32;
+  static constexpr int CH_STRIDE = ROWS * P + 36;
+  static constexpr int LDS_FLOATS = CH_CK * CH_STRIDE + 2 * TY * P;  // + cross-wave reduction scratch
+};
+
+template <int NTT>
+__global__ __launch_bounds__(256, 2) void conf_head_kernel(const float* __restrict__ cost, const float* __restrict__ wp,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ w2, float* __restrict__ conf, int D,
+                                                           int Cm, int H, int W, int ntx, int nty) {
+  using C = CHCfg<NTT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* red = lds + CH_CK * C::CH_STRIDE;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  const int b = t / nty;
+  const int x0 = tx * C::TX, y0 = ty * C::TY;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int wy = wave / C::WN, wn = wave % C::WN;
+  const size_t HW = (size_t)H * W;
+  const float* cb = cost + (size_t)b * D * HW;
+
+  f32x16 acc[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  const float* bbase = lds + h * C::CH_STRIDE + (wy * C::RY) * C::P + j;
+  const int Dpad = cdiv(D, CH_CK) * CH_CK;
+
+  for (int c0 = 0; c0 < Dpad; c0 += CH_CK) {
+    __syncthreads();
+    constexpr int NR = CH_CK * C::ROWS;
+    for (int r = wave; r < NR; r += 4) {
+      const int cl = r / C::ROWS, yy = r % C::ROWS;
+      const int gy = y0 - 1 + yy, gx = x0 - 1 + lane;
+      if (lane < C::P) {
+        float v = 0.f;
+        if (c0 + cl < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = cb[(size_t)(c0 + cl) * HW + (size_t)gy * W + gx];
+        lds[cl * C::CH_STRIDE + yy * C::P + lane] = v;
+      }
+    }
+    __syncthreads();
+    const float* wpc = wp + ((size_t)(c0 / 2) * 9 * NTT + wn) * 64 + lane;
+#pragma unroll
+    for (int cp = 0; cp < CH_CK / 2; ++cp) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        const float a = wpc[((size_t)(cp * 9 + tap) * NTT) * 64];
+        const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::P + dx;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(a, bp[mt * 32], acc[mt]);
+      }
+    }
+  }
+
+  // epilogue: BN + ReLU per map, dot with w2 over the maps held by this lane, then reduce over lane halves
+  // (h) with a cross-lane swap and over wave columns (wn) through LDS.
+  float sc[16], sh[16], wv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = wn * 32 + cd_row2(r, h);
+    const bool ok = m < Cm;
+    sc[r] = ok ? scale[m] : 0.f;
+    sh[r] = ok ? shift[m] : 0.f;
+    wv[r] = ok ? w2[m] : 0.f;
+  }
+  __syncthreads();  // the tile is dead; `red` does not alias it, but keep the barrier pairing simple
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part = fmaf(fmaxf(fmaf(acc[mt][r], sc[r], sh[r]), 0.f), wv[r], part);
+    part += __shfl_xor(part, 32, 64);
+    const int m = mt * 32 + j;
+    if (h == 0 && m < C::RY * C::P) red[(wn * C::TY + wy * C::RY) * C::P + m] = part;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C::TY * C::P; i += 256) {
+    const int ly = i / C::P, lx = i % C::P;
+    const int gy = y0 + ly, gx = x0 + lx;
+    if (lx < C::TX && gy < H && gx < W) {
+      float v = red[i];
+      if (C::WN == 2) v += red[C::TY * C::P + i];
+      conf[(size_t)b * HW + (size_t)gy * W + gx] = 1.f / (1.f + __expf(-v));
+    }
+  }
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+extern "C" long long dmb_conf_head_packed_floats(int Cm, int D) {
+  if (Cm <= 0 || D <= 0) return 0;
+  const int NTT = cdiv(Cm, 32), Dpad = cdiv(D, CH_CK) * CH_CK;
+  return (long long)(Dpad / 2) * 9 * NTT * 64;
+}
+
+extern "C" int dmb_conf_head_pack_weights_f32(const float* w1, float* w1pack, int Cm, int D, void* stream) {
+  if (!w1 || !w1pack || Cm <= 0 || D <= 0) return fail(DMB_EINVAL, "conf_head_pack: bad argument");
+  const int NTT = cdiv(Cm, 32), Dpad = cdiv(D, CH_CK) * CH_CK;
+  if (NTT > 2) return fail(DMB_EUNSUPPORTED, "conf_head: more than 64 intermediate maps");
+  hipLaunchKernelGGL(pack_conf_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w1, w1pack, Cm, D, NTT, Dpad);
+  return launch_status("conf_head_pack launch failed");
+}
+
+template <int NTT>
+static int launch_conf(const float* cost, const float* wp, const float* scale, const float* shift, const float* w2,
+                       float* conf, int B, int D, int Cm, int H, int W, hipStream_t st) {
+  using C = CHCfg<NTT>;
+  const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY);
+  const long long nblk = (long long)B * ntx * nty;
+  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conf_head: grid too large");
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conf_head_kernel<NTT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conf_head_kernel<NTT>), dim3((unsigned)nblk), dim3(256), lds, st, cost, wp, scale, shift, w2, conf,
+                     D, Cm, H, W, ntx, nty);
+  return launch_status("conf_head launch failed");
+}
+
+extern "C" int dmb_conf_head_f32(const float* cost, const float* w1pack, const float* scale, const float* shift,
+                                 const float* w2, float* conf, int B, int D, int Cm, int H, int W, void* stream) {
+  if (!cost || !w1pack || !scale || !shift || !w2 || !conf || B <= 0 || D <= 0 || Cm <= 0 || H <= 0 || W <= 0)
+    return fail(DMB_EINVAL, "conf_head: bad argument");
+  const int NTT = cdiv(Cm, 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (NTT == 1) return launch_conf<1>(cost, w1pack, scale, shift, w2, conf, B, D, Cm, H, W, st);
+  if (NTT == 2) return launch_conf<2>(cost, w1pack, scale, shift, w2, conf, B, D, Cm, H, W, st);
+  return fail(DMB_EUNSUPPORTED, "conf_head: more than 64 intermediate maps");
+}

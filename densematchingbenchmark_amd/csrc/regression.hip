@@ -1,0 +1,498 @@
+// Disparity regression (soft-argmin family), cost up-sampling (trilinear align_corners=True and the
+// AcfNet k8/s4 transposed convolution) and the EPE accumulator.  All HBM-bound: each kernel reads its
+// input volume exactly once with 16-byte loads coalesced along W; reductions over the disparity axis
+// walk planes H*W apart so that every wave instruction still covers 1 KiB of contiguous memory.
+//
+// Reference semantics: dmb/modeling/stereo/disp_predictors/{soft_argmin.py:45-75,
+// faster_soft_argmin.py:51-75, local_soft_argmin.py:48-105}, cost_processors/aggregators/PSMNet.py:74-93,
+// AcfNet.py:55-57,81-83, data/datasets/evaluation/stereo/pixel_error.py:6-73.
+#include "dmb_common.h"
+
+namespace dmb {
+
+// ---------------------------------------------------------------------------------------------------------
+// Online soft-argmin state for one pixel.  exp in FP32 (v_exp_f32 path via __expf), sum(e) and sum(e*d) in
+// FP64 so that the result is the correctly rounded quotient; the reference's own FP32 evaluation sits up to
+// ~1e-4 from this at D=192 on flat distributions.
+// ---------------------------------------------------------------------------------------------------------
+struct SoftState {
+  float m;
+  double s, t;
+  __device__ void init() {
+    m = -INFINITY;
+    s = 0.0;
+    t = 0.0;
+  }
+  // fold a block of N logits with sample values dv[]
+  template <int N>
+  __device__ void fold(const float (&v)[N], const float (&dv)[N]) {
+    float bm = v[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) bm = fmaxf(bm, v[i]);
+    if (bm > m) {
+      const float f = __expf(m - bm);  // m = -inf on the first block -> f = 0
+      s *= (double)f;
+      t *= (double)f;
+      m = bm;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float e = __expf(v[i] - m);
+      s += (double)e;
+      t = fma((double)e, (double)dv[i], t);
+    }
+  }
+  __device__ float result() const { return (float)(t / s); }
+};
+
+constexpr int SA_BLK = 8;  // disparity planes folded per max-rescale step
+
+// cost [B, D, H, W] -> disp [B, 1, H, W]; VEC pixels per thread.
+template <int VEC, bool SAMPLED>
+__global__ __launch_bounds__(256) void soft_argmin_kernel(const float* __restrict__ cost,
+                                                          const float* __restrict__ sample,
+                                                          float* __restrict__ disp, int D, int HW, float alpha,
+                                                          int normalize, DispVal dv) {
+  const int b = blockIdx.y;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (p >= HW) return;
+  const float* cp = cost + (size_t)b * D * HW + p;
+  const float* sp = SAMPLED ? sample + (size_t)b * D * HW + p : nullptr;
+  float out[VEC];
+  if (normalize) {
+    SoftState st[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) st[j].init();
+    int k = 0;
+    for (; k + SA_BLK <= D; k += SA_BLK) {
+      float v[VEC][SA_BLK], d[VEC][SA_BLK];
+#pragma unroll
+      for (int i = 0; i < SA_BLK; ++i) {
+        if constexpr (VEC == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(cp + (size_t)(k + i) * HW);
+          v[0][i] = q.x * alpha; v[1][i] = q.y * alpha; v[2][i] = q.z * alpha; v[3][i] = q.w * alpha;
+          if (SAMPLED) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sp + (size_t)(k + i) * HW);
+            d[0][i] = s4.x; d[1][i] = s4.y; d[2][i] = s4.z; d[3][i] = s4.w;
+          }
+        } else {
+          v[0][i] = cp[(size_t)(k + i) * HW] * alpha;
+          if (SAMPLED) d[0][i] = sp[(size_t)(k + i) * HW];
+        }
+        if (!SAMPLED) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) d[j][i] = dv.v[k + i];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) st[j].template fold<SA_BLK>(v[j], d[j]);
+    }
+    for (; k < D; ++k) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v1[1] = {cp[(size_t)k * HW + j] * alpha};
+        float d1[1] = {SAMPLED ? sp[(size_t)k * HW + j] : dv.v[k]};
+        st[j].template fold<1>(v1, d1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = st[j].result();
+  } else {
+    // normalize=False: disp = sum_k (alpha * c_k) * d_k   (soft_argmin.py:56-59,73)
+    double acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.0;
+    for (int k = 0; k < D; ++k) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float c = cp[(size_t)k * HW + j] * alpha;
+        const float d = SAMPLED ? sp[(size_t)k * HW + j] : dv.v[k];
+        acc[j] = fma((double)c, (double)d, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = (float)acc[j];
+  }
+  float* dp = disp + (size_t)b * HW + p;
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(dp) = make_float4(out[0], out[1], out[2], out[3]);
+  } else {
+    dp[0] = out[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LocalSoftArgmin: arg-max over D (first maximal index, exact FP32 compare on the un-scaled cost,
+// local_soft_argmin.py:65), then a (2R+1)-tap masked softmax around it (:69-103).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LSA_MAX_TAPS = 33;
+
+__global__ __launch_bounds__(256) void local_soft_argmin_kernel(const float* __restrict__ cost,
+                                                                float* __restrict__ disp,
+                                                                long long* __restrict__ argidx, int D, int HW,
+                                                                int radius, int rdil, int start, int dil,
+                                                                float alpha) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float* cp = cost + (size_t)b * D * HW + p;
+  float best = cp[0];
+  int bi = 0;
+  // torch.argmax: NaN counts as maximal and the first occurrence wins
+  bool best_nan = best != best;
+  for (int k = 1; k < D; ++k) {
+    const float v = cp[(size_t)k * HW];
+    if (!best_nan && (v > best || v != v)) {
+      best = v;
+      bi = k;
+      best_nan = v != v;
+    }
+  }
+  if (argidx) argidx[(size_t)b * HW + p] = (long long)bi;
+
+  const int taps = 2 * radius + 1;
+  const float fill = -10000.0f * alpha;
+  float logit[LSA_MAX_TAPS], samp[LSA_MAX_TAPS];
+  float mx = -INFINITY;
+  for (int i = 0; i < taps; ++i) {
+    const int raw = bi + (i - radius) * rdil;
+    const float mask = (raw >= 0 && raw <= D - 1) ? 1.f : 0.f;
+    const int ci = raw < 0 ? 0 : (raw > D - 1 ? D - 1 : raw);
+    const float g = cp[(size_t)ci * HW] * alpha;
+    // gathered * mask + (1 - mask) * (-10000 * alpha)   (local_soft_argmin.py:100)
+    const float l = g * mask + (1.f - mask) * fill;
+    logit[i] = l;
+    samp[i] = (float)start + (float)ci * (float)dil;
+    mx = fmaxf(mx, l);
+  }
+  double s = 0.0, t = 0.0;
+  for (int i = 0; i < taps; ++i) {
+    const float e = __expf(logit[i] - mx);
+    s += (double)e;
+    t = fma((double)e, (double)samp[i], t);
+  }
+  disp[(size_t)b * HW + p] = (float)(t / s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Trilinear, align_corners=True.  Index/weight arithmetic follows ATen's CPU path that the reference's
+// F.interpolate call reaches (area_pixel_compute_scale / compute_indices_weights): FP32 scale
+// (in-1)/(out-1), src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1;
+// evaluation order W, then H, then D.
+// ---------------------------------------------------------------------------------------------------------
+struct Lerp {
+  int i0, i1;
+  float w0, w1;
+};
+__device__ inline Lerp lerp_setup(int dst, int in, float scale) {
+  const float src = scale * (float)dst;
+  Lerp l;
+  l.i0 = (int)src;
+  l.i1 = l.i0 + ((l.i0 < in - 1) ? 1 : 0);
+  float l1 = src - (float)l.i0;
+  l1 = fminf(fmaxf(l1, 0.f), 1.f);
+  l.w1 = l1;
+  l.w0 = 1.f - l1;
+  return l;
+}
+__host__ __device__ inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+__device__ inline float lerp2(float a, float wa, float b, float wb) { return fmaf(b, wb, a * wa); }
+
+// one thread = 4 consecutive output x of one (b, zo, yo) row
+__global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int Di,
+                                                        int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh,
+                                                        float sw) {
+  const int nxb = cdiv(cdiv(Wo, 4), 256);
+  const int xq = (blockIdx.x % nxb) * 256 + threadIdx.x;  // float4 index along Wo
+  const int xo = xq * 4;
+  if (xo >= Wo) return;
+  const int row = blockIdx.x / nxb;  // (zo, yo) flattened: grid.y is limited to 65535
+  const int yo = row % Ho;
+  const int zo = row / Ho;
+  const int b = blockIdx.y;
+  const Lerp lz = lerp_setup(zo, Di, sd), ly = lerp_setup(yo, Hi, sh);
+  const float* xb = x + (size_t)b * Di * Hi * Wi;
+  const float* r00 = xb + ((size_t)lz.i0 * Hi + ly.i0) * Wi;
+  const float* r01 = xb + ((size_t)lz.i0 * Hi + ly.i1) * Wi;
+  const float* r10 = xb + ((size_t)lz.i1 * Hi + ly.i0) * Wi;
+  const float* r11 = xb + ((size_t)lz.i1 * Hi + ly.i1) * Wi;
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int xx = xo + j < Wo ? xo + j : Wo - 1;
+    const Lerp lx = lerp_setup(xx, Wi, sw);
+    const float a00 = lerp2(r00[lx.i0], lx.w0, r00[lx.i1], lx.w1);
+    const float a01 = lerp2(r01[lx.i0], lx.w0, r01[lx.i1], lx.w1);
+    const float a10 = lerp2(r10[lx.i0], lx.w0, r10[lx.i1], lx.w1);
+    const float a11 = lerp2(r11[lx.i0], lx.w0, r11[lx.i1], lx.w1);
+    const float h0 = lerp2(a00, ly.w0, a01, ly.w1);
+    const float h1 = lerp2(a10, ly.w0, a11, ly.w1);
+    o[j] = lerp2(h0, lz.w0, h1, lz.w1);
+  }
+  float* yp = y + (((size_t)b * Do + zo) * Ho + yo) * Wo + xo;
+  if ((Wo & 3) == 0) {
+    *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (xo + j < Wo) yp[j] = o[j];
+  }
+}
+
+// Fused trilinear + soft-argmin: one thread per output pixel walks the Do output planes; the (H,W)-lerped
+// value of each INPUT plane is computed once and reused by the output planes that blend it, with the same
+// arithmetic (and therefore bit-identical logits) as trilinear_kernel.
+__global__ __launch_bounds__(256) void trilinear_soft_argmin_kernel(const float* __restrict__ x,
+                                                                    float* __restrict__ disp, int Di, int Hi, int Wi,
+                                                                    int Do, int Ho, int Wo, float sd, float sh,
+                                                                    float sw, float alpha, DispVal dv) {
+  const int xo = blockIdx.x * 256 + threadIdx.x;
+  if (xo >= Wo) return;
+  const int yo = blockIdx.y, b = blockIdx.z;
+  const Lerp ly = lerp_setup(yo, Hi, sh), lx = lerp_setup(xo, Wi, sw);
+  const float* xb = x + (size_t)b * Di * Hi * Wi;
+  const size_t plane = (size_t)Hi * Wi;
+  const size_t o00 = (size_t)ly.i0 * Wi + lx.i0, o01 = (size_t)ly.i0 * Wi + lx.i1;
+  const size_t o10 = (size_t)ly.i1 * Wi + lx.i0, o11 = (size_t)ly.i1 * Wi + lx.i1;
+  auto hw = [&](int zi) {
+    const float* pz = xb + (size_t)zi * plane;
+    const float a0 = lerp2(pz[o00], lx.w0, pz[o01], lx.w1);
+    const float a1 = lerp2(pz[o10], lx.w0, pz[o11], lx.w1);
+    return lerp2(a0, ly.w0, a1, ly.w1);
+  };
+  SoftState st;
+  st.init();
+  int cz0 = -1, cz1 = -1;
+  float h0 = 0.f, h1 = 0.f;
+  for (int zo = 0; zo < Do; ++zo) {
+    const Lerp lz = lerp_setup(zo, Di, sd);
+    if (lz.i0 != cz0) {
+      if (lz.i0 == cz1) {
+        h0 = h1;
+      } else {
+        h0 = hw(lz.i0);
+      }
+      cz0 = lz.i0;
+    }
+    if (lz.i1 != cz1) {
+      h1 = (lz.i1 == cz0) ? h0 : hw(lz.i1);
+      cz1 = lz.i1;
+    }
+    float v[1] = {lerp2(h0, lz.w0, h1, lz.w1) * alpha};
+    float d[1] = {dv.v[zo]};
+    st.template fold<1>(v, d);
+  }
+  disp[((size_t)b * Ho + yo) * Wo + xo] = st.result();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ConvTranspose3d(1, 1, k=8, s=4, p=2), output exactly 4x: y[o] = sum x[i] * w[k], o = 4i - 2 + k.
+// Per axis an output o sees k in {(o+2)%4, (o+2)%4 + 4} from i = (o+2)/4 and (o+2)/4 - 1.
+// One thread = 4 consecutive output x; FP32 fma chain in ascending (kd, kh, kw).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv_k8s4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, int D, int H, int W) {
+  __shared__ float ws[512];
+  for (int t = threadIdx.x; t < 512; t += 256) ws[t] = w[t];
+  __syncthreads();
+  const int Wo = 4 * W, Ho = 4 * H, Do = 4 * D;
+  const int nxb = cdiv(W, 256);
+  const int q = (blockIdx.x % nxb) * 256 + threadIdx.x;  // input-resolution column: outputs 4q .. 4q+3
+  if (q >= W) return;
+  const int row = blockIdx.x / nxb;
+  const int yo = row % Ho, zo = row / Ho, b = blockIdx.y;
+  const int pz = (zo + 2) & 3, iz = (zo + 2) >> 2;
+  const int py = (yo + 2) & 3, iy = (yo + 2) >> 2;
+  const float* xb = x + (size_t)b * D * H * W;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // ascending kd: kd = pz uses input iz, kd = pz + 4 uses iz - 1
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int kd = pz + 4 * a, zi = iz - a;
+    if (zi < 0 || zi >= D) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int kh = py + 4 * c, yi = iy - c;
+      if (yi < 0 || yi >= H) continue;
+      const float* row = xb + ((size_t)zi * H + yi) * W;
+      const float* wr = ws + (kd * 8 + kh) * 8;
+      const float xm = q > 0 ? row[q - 1] : 0.f;
+      const float x0 = row[q];
+      const float xp = q + 1 < W ? row[q + 1] : 0.f;
+      // output 4q+j: (o+2) = 4q + j + 2 -> j=0: phase 2, i=q ; j=1: phase 3, i=q ; j=2: phase 0, i=q+1 ; j=3: phase 1, i=q+1
+      // taps in ascending kw: kw = phase uses i, kw = phase + 4 uses i - 1
+      acc[0] = fmaf(x0, wr[2], acc[0]);
+      acc[0] = fmaf(xm, wr[6], acc[0]);
+      acc[1] = fmaf(x0, wr[3], acc[1]);
+      acc[1] = fmaf(xm, wr[7], acc[1]);
+      acc[2] = fmaf(xp, wr[0], acc[2]);
+      acc[2] = fmaf(x0, wr[4], acc[2]);
+      acc[3] = fmaf(xp, wr[1], acc[3]);
+      acc[3] = fmaf(x0, wr[5], acc[3]);
+    }
+  }
+  float* yp = y + (((size_t)b * Do + zo) * Ho + yo) * Wo + 4 * q;
+  *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// EPE accumulator: one workgroup per image.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void epe_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                   double* __restrict__ acc, int Hp, int Wp, int H0, int W0, float lb,
+                                                   float ub) {
+  const int b = blockIdx.x;
+  // eval.py:24-29: pad_top = Hp - H0; the crop [pad_top:, :W0] is applied only when pad_top >= 0
+  const bool crop = Hp - H0 >= 0;
+  const int top = crop ? Hp - H0 : 0;
+  const int rows = Hp - top;
+  const int cols = crop ? (W0 < Wp ? W0 : Wp) : Wp;
+  const float* e = est + (size_t)b * Hp * Wp;
+  const float* g = gt + (size_t)b * Hp * Wp;
+  double sum = 0.0;
+  unsigned long long cnt = 0, n1 = 0, n2 = 0, n3 = 0, n5 = 0;
+  const int total = rows * cols;
+  for (int i = threadIdx.x; i < total; i += 1024) {
+    const int r = i / cols, c = i % cols;
+    const size_t o = (size_t)(top + r) * Wp + c;
+    const float gv = g[o];
+    if (gv > lb && gv < ub) {
+      const float a = fabsf(gv - e[o]);
+      sum += (double)a;
+      cnt++;
+      n1 += a > 1.f;
+      n2 += a > 2.f;
+      n3 += a > 3.f;
+      n5 += a > 5.f;
+    }
+  }
+  __shared__ double sh[6][16];
+  double v[6] = {(double)cnt, sum, (double)n1, (double)n2, (double)n3, (double)n5};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double t = v[k];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r[6];
+    for (int k = 0; k < 6; ++k) {
+      r[k] = 0.0;
+      for (int w = 0; w < 16; ++w) r[k] += sh[k][w];
+    }
+    atomicAdd(&acc[0], 1.0);
+    if (r[0] >= 1.0) {  // pixel_error.py:48: an empty mask yields all-zero errors for this image
+      atomicAdd(&acc[1], r[1] / r[0]);
+      atomicAdd(&acc[2], 100.0 * r[2] / r[0]);
+      atomicAdd(&acc[3], 100.0 * r[3] / r[0]);
+      atomicAdd(&acc[4], 100.0 * r[4] / r[0]);
+      atomicAdd(&acc[5], 100.0 * r[5] / r[0]);
+    }
+  }
+}
+
+static int fill_samples(const float* host, int D, DispVal& dv) {
+  if (!host || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
+  for (int k = 0; k < D; ++k) dv.v[k] = host[k];
+  return DMB_OK;
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+extern "C" int dmb_soft_argmin_f32(const float* cost, float* disp, int B, int D, int H, int W, float alpha,
+                                   int normalize, const float* disp_sample_host, void* stream) {
+  if (!cost || !disp || B <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "soft_argmin: bad argument");
+  DispVal dv;
+  if (int e = fill_samples(disp_sample_host, D, dv)) return e;
+  const int HW = H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (HW % 4 == 0) {
+    dim3 grid(cdiv(HW / 4, 256), B);
+    hipLaunchKernelGGL((soft_argmin_kernel<4, false>), grid, dim3(256), 0, st, cost, (const float*)nullptr, disp, D,
+                       HW, alpha, normalize, dv);
+  } else {
+    dim3 grid(cdiv(HW, 256), B);
+    hipLaunchKernelGGL((soft_argmin_kernel<1, false>), grid, dim3(256), 0, st, cost, (const float*)nullptr, disp, D,
+                       HW, alpha, normalize, dv);
+  }
+  return launch_status("soft_argmin launch failed");
+}
+
+extern "C" int dmb_soft_argmin_sampled_f32(const float* cost, const float* sample, float* disp, int B, int D, int H,
+                                           int W, float alpha, int normalize, void* stream) {
+  if (!cost || !sample || !disp || B <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(DMB_EINVAL, "soft_argmin_sampled: bad argument");
+  DispVal dv;  // unused in the sampled instantiation
+  dv.v[0] = 0.f;
+  const int HW = H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (HW % 4 == 0) {
+    dim3 grid(cdiv(HW / 4, 256), B);
+    hipLaunchKernelGGL((soft_argmin_kernel<4, true>), grid, dim3(256), 0, st, cost, sample, disp, D, HW, alpha,
+                       normalize, dv);
+  } else {
+    dim3 grid(cdiv(HW, 256), B);
+    hipLaunchKernelGGL((soft_argmin_kernel<1, true>), grid, dim3(256), 0, st, cost, sample, disp, D, HW, alpha,
+                       normalize, dv);
+  }
+  return launch_status("soft_argmin_sampled launch failed");
+}
+
+extern "C" int dmb_local_soft_argmin_f32(const float* cost, float* disp, long long* argidx, int B, int D, int H,
+                                         int W, int radius, int radius_dilation, int start_disp, int dilation,
+                                         float alpha, void* stream) {
+  if (!cost || !disp || B <= 0 || D <= 0 || H <= 0 || W <= 0 || radius < 0)
+    return fail(DMB_EINVAL, "local_soft_argmin: bad argument");
+  if (2 * radius + 1 > LSA_MAX_TAPS) return fail(DMB_EUNSUPPORTED, "local_soft_argmin: radius > 16");
+  const int HW = H * W;
+  dim3 grid(cdiv(HW, 256), B);
+  hipLaunchKernelGGL(local_soft_argmin_kernel, grid, dim3(256), 0, (hipStream_t)stream, cost, disp, argidx, D, HW,
+                     radius, radius_dilation, start_disp, dilation, alpha);
+  return launch_status("local_soft_argmin launch failed");
+}
+
+extern "C" int dmb_trilinear_ac_f32(const float* x, float* y, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                    void* stream) {
+  if (!x || !y || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0)
+    return fail(DMB_EINVAL, "trilinear: bad argument");
+  if ((long long)cdiv(cdiv(Wo, 4), 256) * Do * Ho > 0x7fffffffLL || B > 65535)
+    return fail(DMB_EUNSUPPORTED, "trilinear: grid too large");
+  dim3 grid(cdiv(cdiv(Wo, 4), 256) * Do * Ho, B);
+  hipLaunchKernelGGL(trilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, Di, Hi, Wi, Do, Ho, Wo,
+                     ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  return launch_status("trilinear launch failed");
+}
+
+extern "C" int dmb_trilinear_soft_argmin_f32(const float* x, float* disp, int B, int Di, int Hi, int Wi, int Do,
+                                             int Ho, int Wo, float alpha, const float* disp_sample_host,
+                                             void* stream) {
+  if (!x || !disp || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0)
+    return fail(DMB_EINVAL, "trilinear_soft_argmin: bad argument");
+  DispVal dv;
+  if (int e = fill_samples(disp_sample_host, Do, dv)) return e;
+  dim3 grid(cdiv(Wo, 256), Ho, B);
+  hipLaunchKernelGGL(trilinear_soft_argmin_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, disp, Di, Hi, Wi, Do,
+                     Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), alpha, dv);
+  return launch_status("trilinear_soft_argmin launch failed");
+}
+
+extern "C" int dmb_deconv3d_k8s4_c1_f32(const float* x, const float* w, float* y, int B, int D, int H, int W,
+                                        void* stream) {
+  if (!x || !w || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv_k8s4: bad argument");
+  if ((long long)cdiv(W, 256) * 16 * D * H > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv_k8s4: grid too large");
+  dim3 grid(cdiv(W, 256) * 16 * D * H, B);
+  hipLaunchKernelGGL(deconv_k8s4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, y, D, H, W);
+  return launch_status("deconv_k8s4 launch failed");
+}
+
+extern "C" int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, int B, int Hp, int Wp, int H0,
+                                 int W0, float lb, float ub, void* stream) {
+  if (!est || !gt || !acc || B <= 0 || Hp <= 0 || Wp <= 0 || H0 <= 0 || W0 <= 0)
+    return fail(DMB_EINVAL, "epe_accum: bad argument");
+  hipLaunchKernelGGL(epe_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, est, gt, acc, Hp, Wp, H0, W0, lb, ub);
+  return launch_status("epe_accum launch failed");
+}

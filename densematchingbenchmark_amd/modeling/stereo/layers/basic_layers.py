@@ -1,0 +1,126 @@
+"""3-D conv + BatchNorm (+ReLU) units of the aggregators, backed by the fused HIP kernels.
+
+Mirrors the factories of dmb/modeling/stereo/layers/basic_layers.py:68-100,160-177 -- same names, same argument
+order, same ``state_dict`` keys (``<unit>.0.weight``, ``<unit>.1.running_mean`` ...) -- but every unit is a
+``FusedConv3d`` whose forward is ONE kernel launch: convolution with BatchNorm folded into a per-channel
+scale/shift, optional residual add and ReLU in the epilogue.  torch.nn modules are kept only as parameter
+containers so that reference checkpoints load with ``load_state_dict``.  Inference only; no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+__all__ = ["FusedConv3d", "HeadConv3d", "conv3d_bn", "conv3d_bn_relu", "deconv3d_bn", "fold_batch_norm"]
+
+
+def fold_batch_norm(bn, conv_bias, out_planes, device):
+    """Eval-mode BN as y = x * scale + shift, folded in FP64 and rounded once:
+    scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ conv_bias * scale)."""
+    if bn is None:
+        if conv_bias is None:
+            return None, None
+        return torch.ones(out_planes, dtype=torch.float32, device=device), conv_bias.detach().float().contiguous()
+    var = bn.running_var.detach().double()
+    mean = bn.running_mean.detach().double()
+    gamma = bn.weight.detach().double() if bn.affine else torch.ones_like(var)
+    beta = bn.bias.detach().double() if bn.affine else torch.zeros_like(var)
+    scale = gamma / torch.sqrt(var + bn.eps)
+    shift = beta - mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().double() * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+def _versions(*tensors):
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+
+
+class FusedConv3d(nn.Sequential):
+    """Sequential(Conv3d | ConvTranspose3d, [BatchNorm3d], [ReLU]) executed as one fused HIP kernel.
+
+    kernel 3 / padding 1 / stride 1|2 convolutions and kernel 3 / stride 2 / padding 1 / output_padding 1
+    transposed convolutions (the only forms the aggregators use).  ``forward(x, residual=None)`` computes
+    ``act(BN(conv(x)) + residual)`` where ``act`` is ReLU iff the unit has one or ``relu=True`` is passed
+    (hourglass.py:67-70,78-81 apply the ReLU after the skip add)."""
+
+    def __init__(self, batch_norm, in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1, bias=True,
+                 relu=False, transposed=False, output_padding=0):
+        layers = []
+        if transposed:
+            if (kernel_size, stride, padding, output_padding) != (3, 2, 1, 1):
+                raise NotImplementedError("HIP transposed conv: only kernel 3, stride 2, padding 1, output_padding 1")
+            layers.append(nn.ConvTranspose3d(in_planes, out_planes, kernel_size, stride=stride, padding=padding,
+                                             output_padding=output_padding, bias=bias))
+        else:
+            if kernel_size != 3 or padding != 1 or dilation != 1 or stride not in (1, 2):
+                raise NotImplementedError("HIP conv3d: only kernel 3, padding 1, dilation 1, stride 1 or 2")
+            layers.append(nn.Conv3d(in_planes, out_planes, kernel_size, stride=stride, padding=padding,
+                                    dilation=dilation, bias=bias))
+        if batch_norm:
+            layers.append(nn.BatchNorm3d(out_planes))
+        if relu:
+            layers.append(nn.ReLU(inplace=True))
+        super().__init__(*layers)
+        self.in_planes, self.out_planes, self.stride = in_planes, out_planes, stride
+        self.transposed, self.has_bn, self.has_relu = transposed, bool(batch_norm), bool(relu)
+        self._cache_key, self._cache = None, None
+
+    def _prepacked(self):
+        conv = self[0]
+        bn = self[1] if self.has_bn else None
+        parts = [conv.weight, conv.bias]
+        if bn is not None:
+            parts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = _versions(*parts)
+        if key != self._cache_key:
+            w = conv.weight.detach()
+            wp = ops.pack_deconv3d_weights(w) if self.transposed else ops.pack_conv3d_weights(w)
+            scale, shift = fold_batch_norm(bn, conv.bias, self.out_planes, w.device)
+            self._cache_key, self._cache = key, (wp, scale, shift)
+        return self._cache
+
+    def forward(self, x, residual=None, relu=None):
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("FusedConv3d is an inference-only HIP path: call model.eval() and run under torch.no_grad()")
+        wp, scale, shift = self._prepacked()
+        act = self.has_relu if relu is None else relu
+        if self.transposed:
+            return ops.deconv3d_k3s2(x, wp, self.out_planes, scale, shift, residual, act)
+        return ops.conv3d_k3(x, wp, self.out_planes, scale, shift, residual, self.stride, act)
+
+
+class HeadConv3d(nn.Conv3d):
+    """nn.Conv3d(C, 1, 3, 1, 1) classifier head (PSMNet.py:46, StereoNet.py:39) on the single-channel HIP kernel;
+    ``forward(x, residual=None)`` fuses the cumulative cost add of PSMNet.py:71-72."""
+
+    def __init__(self, in_planes, bias=False):
+        super().__init__(in_planes, 1, kernel_size=3, stride=1, padding=1, bias=bias)
+        self._bias_key, self._bias_val = None, 0.0
+
+    def forward(self, x, residual=None):
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("HeadConv3d is an inference-only HIP path")
+        b = 0.0
+        if self.bias is not None:
+            key = _versions(self.bias)
+            if key != self._bias_key:  # one device->host read per weight load, not per call
+                self._bias_key, self._bias_val = key, float(self.bias.detach().cpu()[0])
+            b = self._bias_val
+        return ops.conv3d_k3_c1(x, self.weight.detach(), b, residual)
+
+
+def conv3d_bn(batchNorm, in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1, bias=True):
+    """basic_layers.py:68-83."""
+    return FusedConv3d(batchNorm, in_planes, out_planes, kernel_size, stride, padding, dilation, bias, relu=False)
+
+
+def conv3d_bn_relu(batchNorm, in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1, bias=True):
+    """basic_layers.py:160-177."""
+    return FusedConv3d(batchNorm, in_planes, out_planes, kernel_size, stride, padding, dilation, bias, relu=True)
+
+
+def deconv3d_bn(batchNorm, in_planes, out_planes, kernel_size=4, stride=2, padding=1, output_padding=0, bias=True):
+    """basic_layers.py:86-100."""
+    return FusedConv3d(batchNorm, in_planes, out_planes, kernel_size, stride, padding, 1, bias, relu=False,
+                       transposed=True, output_padding=output_padding)

@@ -1,0 +1,246 @@
+"""Functional layer over the C ABI (include/dmb_hip.h): one Python function per entry point.
+
+Only shape bookkeeping and output allocation happen here (PyTorch as the device allocator); every number is
+produced by a HIP kernel of libdmb_hip.so.  All functions raise ``DmbLibraryError`` on CPU tensors -- the
+product path has no fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, dev_ptr, host_floats, host_ints, stream_ptr
+
+
+def disp_index_list(max_disp, start_disp=0, dilation=1):
+    """Integer disparity indices exactly as the reference derives them:
+    ``int(torch.linspace(start, start + max_disp - 1, n)[k])`` with ``n = (max_disp + dilation - 1) // dilation``
+    (cost_processors/utils/cat_fms.py:26-35) -- truncation toward zero of an FP32 linspace."""
+    end_disp = start_disp + max_disp - 1
+    n = (max_disp + dilation - 1) // dilation
+    return [int(v) for v in torch.linspace(start_disp, end_disp, n)]
+
+
+def disp_sample_values(max_disp, start_disp=0, dilation=1):
+    """FP32 disparity sample values of the predictors (disp_predictors/faster_soft_argmin.py:33-44)."""
+    end_disp = start_disp + max_disp - 1
+    n = (max_disp + dilation - 1) // dilation
+    return [float(v) for v in torch.linspace(start_disp, end_disp, n)]
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise _lib.DmbLibraryError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------- volumes
+def cat_fms(left, right, disp_idx):
+    lib = _lib.load()
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    B, C, H, W = left.shape
+    D = len(disp_idx)
+    out = torch.empty((B, 2 * C, D, H, W), dtype=torch.float32, device=left.device)
+    check(lib.dmb_cat_fms_f32(dev_ptr(left), dev_ptr(right), dev_ptr(out), B, C, H, W, D, host_ints(disp_idx),
+                              stream_ptr(left.device)), "dmb_cat_fms_f32")
+    return out
+
+
+def dif_fms(left, right, disp_idx):
+    lib = _lib.load()
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    B, C, H, W = left.shape
+    D = len(disp_idx)
+    out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=left.device)
+    check(lib.dmb_dif_fms_f32(dev_ptr(left), dev_ptr(right), dev_ptr(out), B, C, H, W, D, host_ints(disp_idx),
+                              stream_ptr(left.device)), "dmb_dif_fms_f32")
+    return out
+
+
+def gwc_fms(left, right, disp_idx, num_groups, out=None, out_ch_offset=0):
+    lib = _lib.load()
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    B, C, H, W = left.shape
+    D = len(disp_idx)
+    if out is None:
+        out = torch.empty((B, num_groups, D, H, W), dtype=torch.float32, device=left.device)
+    check(lib.dmb_gwc_fms_f32(dev_ptr(left), dev_ptr(right), dev_ptr(out), B, C, num_groups, H, W, D,
+                              host_ints(disp_idx), out.shape[1], out_ch_offset, stream_ptr(left.device)),
+          "dmb_gwc_fms_f32")
+    return out
+
+
+def cat_fms_into(left, right, disp_idx, out, out_ch_offset):
+    lib = _lib.load()
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    B, C, H, W = left.shape
+    check(lib.dmb_cat_fms_into_f32(dev_ptr(left), dev_ptr(right), dev_ptr(out), B, C, H, W, len(disp_idx),
+                                   host_ints(disp_idx), out.shape[1], out_ch_offset, stream_ptr(left.device)),
+          "dmb_cat_fms_into_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- convs
+def pack_conv3d_weights(w):
+    """nn.Conv3d weight [Co, Ci, 3, 3, 3] -> MFMA A-fragment stream."""
+    lib = _lib.load()
+    w = _f32c(w, "weight")
+    Co, Ci = w.shape[0], w.shape[1]
+    wp = torch.empty((lib.dmb_conv3d_packed_floats(Co, Ci),), dtype=torch.float32, device=w.device)
+    check(lib.dmb_conv3d_pack_weights_f32(dev_ptr(w), dev_ptr(wp), Co, Ci, stream_ptr(w.device)),
+          "dmb_conv3d_pack_weights_f32")
+    return wp
+
+
+def pack_deconv3d_weights(w):
+    """nn.ConvTranspose3d weight [Ci, Co, 3, 3, 3] -> MFMA A-fragment stream."""
+    lib = _lib.load()
+    w = _f32c(w, "weight")
+    Ci, Co = w.shape[0], w.shape[1]
+    wp = torch.empty((lib.dmb_deconv3d_packed_floats(Ci, Co),), dtype=torch.float32, device=w.device)
+    check(lib.dmb_deconv3d_pack_weights_f32(dev_ptr(w), dev_ptr(wp), Ci, Co, stream_ptr(w.device)),
+          "dmb_deconv3d_pack_weights_f32")
+    return wp
+
+
+def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, relu=False):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Ci, D, H, W = x.shape
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Co, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    check(lib.dmb_conv3d_k3_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
+                                dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
+                                B, Ci, Co, D, H, W, stride, int(bool(relu)), stream_ptr(x.device)), "dmb_conv3d_k3_f32")
+    return y
+
+
+def conv3d_k3_c1(x, w, bias=0.0, residual=None):
+    lib = _lib.load()
+    x, w = _f32c(x, "x"), _f32c(w, "weight")
+    B, Ci, D, H, W = x.shape
+    y = torch.empty((B, 1, D, H, W), dtype=torch.float32, device=x.device)
+    check(lib.dmb_conv3d_k3_c1_f32(dev_ptr(x), dev_ptr(w), float(bias), dev_ptr(residual, allow_none=True), dev_ptr(y),
+                                   B, Ci, D, H, W, stream_ptr(x.device)), "dmb_conv3d_k3_c1_f32")
+    return y
+
+
+def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=False):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Ci, D, H, W = x.shape
+    y = torch.empty((B, Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    check(lib.dmb_deconv3d_k3s2_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
+                                    dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
+                                    B, Ci, Co, D, H, W, int(bool(relu)), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- upsampling
+def trilinear_ac(x, out_size):
+    """x: [B, Di, Hi, Wi] (single channel squeezed) -> [B, Do, Ho, Wo], align_corners=True."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = out_size
+    y = torch.empty((B, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib.dmb_trilinear_ac_f32(dev_ptr(x), dev_ptr(y), B, Di, Hi, Wi, Do, Ho, Wo, stream_ptr(x.device)),
+          "dmb_trilinear_ac_f32")
+    return y
+
+
+def deconv3d_k8s4_c1(x, w):
+    """x: [B, D, H, W], w: [8, 8, 8] (ConvTranspose3d(1,1,8,4,2) weight squeezed) -> [B, 4D, 4H, 4W]."""
+    lib = _lib.load()
+    x, w = _f32c(x, "x"), _f32c(w, "weight")
+    B, D, H, W = x.shape
+    y = torch.empty((B, 4 * D, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
+    check(lib.dmb_deconv3d_k8s4_c1_f32(dev_ptr(x), dev_ptr(w), dev_ptr(y), B, D, H, W, stream_ptr(x.device)),
+          "dmb_deconv3d_k8s4_c1_f32")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- regression
+def soft_argmin(cost, disp_values, alpha=1.0, normalize=True):
+    lib = _lib.load()
+    cost = _f32c(cost, "cost_volume")
+    B, D, H, W = cost.shape
+    if len(disp_values) != D:
+        raise _lib.DmbLibraryError("The number of disparity samples should be consistent!")
+    disp = torch.empty((B, 1, H, W), dtype=torch.float32, device=cost.device)
+    check(lib.dmb_soft_argmin_f32(dev_ptr(cost), dev_ptr(disp), B, D, H, W, float(alpha), int(bool(normalize)),
+                                  host_floats(disp_values), stream_ptr(cost.device)), "dmb_soft_argmin_f32")
+    return disp
+
+
+def soft_argmin_sampled(cost, disp_sample, alpha=1.0, normalize=True):
+    lib = _lib.load()
+    cost, disp_sample = _f32c(cost, "cost_volume"), _f32c(disp_sample, "disp_sample")
+    B, D, H, W = cost.shape
+    disp = torch.empty((B, 1, H, W), dtype=torch.float32, device=cost.device)
+    check(lib.dmb_soft_argmin_sampled_f32(dev_ptr(cost), dev_ptr(disp_sample), dev_ptr(disp), B, D, H, W, float(alpha),
+                                          int(bool(normalize)), stream_ptr(cost.device)), "dmb_soft_argmin_sampled_f32")
+    return disp
+
+
+def local_soft_argmin(cost, radius, radius_dilation=1, start_disp=0, dilation=1, alpha=1.0, return_index=False):
+    lib = _lib.load()
+    cost = _f32c(cost, "cost_volume")
+    B, D, H, W = cost.shape
+    disp = torch.empty((B, 1, H, W), dtype=torch.float32, device=cost.device)
+    idx = torch.empty((B, 1, H, W), dtype=torch.int64, device=cost.device) if return_index else None
+    check(lib.dmb_local_soft_argmin_f32(dev_ptr(cost), dev_ptr(disp), dev_ptr(idx, allow_none=True), B, D, H, W,
+                                        int(radius), int(radius_dilation), int(start_disp), int(dilation), float(alpha),
+                                        stream_ptr(cost.device)), "dmb_local_soft_argmin_f32")
+    return (disp, idx) if return_index else disp
+
+
+def trilinear_soft_argmin(x, out_size, disp_values, alpha=1.0):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = out_size
+    disp = torch.empty((B, 1, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib.dmb_trilinear_soft_argmin_f32(dev_ptr(x), dev_ptr(disp), B, Di, Hi, Wi, Do, Ho, Wo, float(alpha),
+                                            host_floats(disp_values), stream_ptr(x.device)),
+          "dmb_trilinear_soft_argmin_f32")
+    return disp
+
+
+# ---------------------------------------------------------------------------------------------- conf head / metrics
+def pack_conf_head_weights(w1):
+    """Conv2d weight [Cm, D, 3, 3] -> fragment stream."""
+    lib = _lib.load()
+    w1 = _f32c(w1, "weight")
+    Cm, D = w1.shape[0], w1.shape[1]
+    wp = torch.empty((lib.dmb_conf_head_packed_floats(Cm, D),), dtype=torch.float32, device=w1.device)
+    check(lib.dmb_conf_head_pack_weights_f32(dev_ptr(w1), dev_ptr(wp), Cm, D, stream_ptr(w1.device)),
+          "dmb_conf_head_pack_weights_f32")
+    return wp
+
+
+def conf_head(cost, w1pack, scale, shift, w2):
+    lib = _lib.load()
+    cost = _f32c(cost, "cost")
+    B, D, H, W = cost.shape
+    Cm = scale.numel()
+    conf = torch.empty((B, 1, H, W), dtype=torch.float32, device=cost.device)
+    check(lib.dmb_conf_head_f32(dev_ptr(cost), dev_ptr(w1pack), dev_ptr(scale), dev_ptr(shift), dev_ptr(w2),
+                                dev_ptr(conf), B, D, Cm, H, W, stream_ptr(cost.device)), "dmb_conf_head_f32")
+    return conf
+
+
+def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
+    """acc: float64[6] device tensor updated in place; est/gt: [B, 1, Hp, Wp]."""
+    lib = _lib.load()
+    est, gt = _f32c(est, "est_disp"), _f32c(gt, "gt_disp")
+    B = est.shape[0]
+    Hp, Wp = est.shape[-2:]
+    H0, W0 = original_size
+    if acc.dtype != torch.float64 or acc.numel() != 6:
+        raise _lib.DmbLibraryError("acc must be a float64[6] tensor")
+    check(lib.dmb_epe_accum_f64(dev_ptr(est), dev_ptr(gt), dev_ptr(acc), B, Hp, Wp, int(H0), int(W0),
+                                float(lower_bound), float(upper_bound), stream_ptr(est.device)), "dmb_epe_accum_f64")
+    return acc

@@ -1,0 +1,180 @@
+/*
+ * dmb_hip.h -- C ABI of libdmb_hip.so: the MI355X (gfx950) cost-volume -> 3-D aggregation
+ * -> disparity-regression path of DenseMatchingBenchmark's dmb.modeling.stereo pipeline.
+ *
+ * Boundary rules:
+ *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch-ROCm caching
+ *     allocator in the Python host layer) unless the parameter name ends in `_host`;
+ *   - all tensors are FP32, contiguous, NC(D)HW exactly as the reference lays them out;
+ *   - `stream` is the caller's hipStream_t (NULL = the legacy default stream); every entry
+ *     point only enqueues work on that stream, never synchronises, never allocates;
+ *   - return value 0 = success, otherwise the hipError_t value of the failing launch or one of
+ *     the DMB_E* codes below.  Nothing here calls exit() (the reference's only native op,
+ *     dmb/ops/spn/src/gaterecurrent2dnoind_kernel.cu:544-549, does; this library does not);
+ *   - no global state; safe to call concurrently on distinct streams.
+ *
+ * Each entry point names the reference interface it replaces (file:line under the reference
+ * tree).  The reference is pure PyTorch on this path, so "replaces" means: the same
+ * arithmetic that those torch calls perform, as one hand-written HIP kernel launch.
+ */
+#ifndef DMB_HIP_H
+#define DMB_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMB_OK 0
+#define DMB_EINVAL 100001   /* bad argument (NULL pointer, non-positive size, D too large ...) */
+#define DMB_EUNSUPPORTED 100002 /* shape outside what the kernels are instantiated for */
+
+#define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
+
+/* ABI version: bumped whenever a signature below changes. */
+int dmb_abi_version(void);
+/* Static string describing the last DMB_E* code returned on this thread ("" if none). */
+const char* dmb_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Cost-volume builders
+ * ---------------------------------------------------------------------------------------- */
+
+/* cat_fms: dmb/modeling/stereo/cost_processors/utils/cat_fms.py:7-48.
+ *   out[b, c,   k, y, x] = L[b, c, y, x]        if in range else 0
+ *   out[b, C+c, k, y, x] = R[b, c, y, x - d_k]  if in range else 0
+ * "in range": d_k > 0 -> x >= d_k;  d_k == 0 -> all x;  d_k < 0 -> x < W + d_k  (cat_fms.py:36-44)
+ * L, R: [B, C, H, W]; out: [B, 2C, D, H, W]; disp_idx_host: D ints on the HOST, d_k as produced by
+ * int(linspace(start, start+max_disp-1, D)[k]) (cat_fms.py:28-35).  Pure copy: bit-exact. */
+int dmb_cat_fms_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,
+                    const int* disp_idx_host, void* stream);
+
+/* dif_fms: dmb/modeling/stereo/cost_processors/utils/dif_fms.py:7-46.
+ *   out[b, c, k, y, x] = L[b, c, y, x] - R[b, c, y, x - d_k] if in range else 0;  out: [B, C, D, H, W]. */
+int dmb_dif_fms_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,
+                    const int* disp_idx_host, void* stream);
+
+/* Group-wise correlation volume (GwcNet).  ABSENT from the reference (README.md:16 only names it);
+ * occupies the COR_FUNCS slot of cost_processors/utils/correlation1d_cost.py:29-31.  Spec:
+ *   out[b, g, k, y, x] = (1/(C/G)) * sum_{c in group g} L[b,c,y,x] * R[b,c,y,x-d_k]  if in range else 0
+ * L, R: [B, C, H, W], C % G == 0; out: [B, G, D, H, W] written into a tensor whose channel count is
+ * `out_channels` at channel offset `out_ch_offset` (so the volume can be produced directly inside a
+ * wider concatenated volume).  Sum order over the group's channels: ascending c, FP32 fma chain. */
+int dmb_gwc_fms_f32(const float* L, const float* R, float* out, int B, int C, int G, int H, int W, int D,
+                    const int* disp_idx_host, int out_channels, int out_ch_offset, void* stream);
+
+/* Same as dmb_cat_fms_f32 but writing into channels [out_ch_offset, out_ch_offset+2C) of a volume with
+ * `out_channels` channels (GwcNet's gwc+concat volume). */
+int dmb_cat_fms_into_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,
+                         const int* disp_idx_host, int out_channels, int out_ch_offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D convolution family (the aggregators' layers)
+ *
+ * Replaces nn.Conv3d / nn.ConvTranspose3d + nn.BatchNorm3d (eval) + residual add + ReLU as composed by
+ * dmb/modeling/stereo/layers/basic_layers.py:68-100,160-177, cost_processors/utils/hourglass.py:62-86 and
+ * cost_processors/aggregators/{PSMNet.py:55-95, AcfNet.py:59-90, StereoNet.py:42-55}.
+ *
+ * Epilogue, in this order (matches the reference's op order):
+ *     v = acc * scale[co] + shift[co]      (scale/shift may be NULL -> 1 / 0; BN and bias folded by caller)
+ *     v = v + residual[...]                (residual may be NULL; same shape as y)
+ *     v = max(v, 0)                        (if relu != 0)
+ * acc is an FP32 fma chain over (ci, kd, kh, kw).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Number of floats of the packed-weight buffer for a k=3 convolution / transposed convolution. */
+long long dmb_conv3d_packed_floats(int Co, int Ci);
+long long dmb_deconv3d_packed_floats(int Ci, int Co);
+
+/* Re-order nn.Conv3d weights [Co, Ci, 3, 3, 3] into the MFMA B-fragment stream the kernels read. */
+int dmb_conv3d_pack_weights_f32(const float* w, float* wpack, int Co, int Ci, void* stream);
+/* Re-order nn.ConvTranspose3d weights [Ci, Co, 3, 3, 3] (stride 2, pad 1, output_padding 1). */
+int dmb_deconv3d_pack_weights_f32(const float* w, float* wpack, int Ci, int Co, void* stream);
+
+/* Conv3d, kernel 3, padding 1, stride 1 or 2 (all three axes).  x: [B, Ci, D, H, W];
+ * y: [B, Co, Do, Ho, Wo] with Do = (D - 1) / stride + 1 etc.  Co in {32, 64}: MFMA implicit GEMM using
+ * wpack from dmb_conv3d_pack_weights_f32.  Ci in {32, 64}. */
+int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
+                      const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
+                      int stride, int relu, void* stream);
+
+/* Conv3d kernel 3 pad 1 stride 1 with ONE output channel (classifier heads: PSMNet.py:46,50,54,
+ * StereoNet.py:39).  w: raw [1, Ci, 3, 3, 3]; bias_host: scalar added to every output; residual may be
+ * NULL (PSMNet.py:71-72 adds the previous level's cost).  y: [B, 1, D, H, W]. */
+int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float* residual, float* y,
+                         int B, int Ci, int D, int H, int W, void* stream);
+
+/* ConvTranspose3d kernel 3, stride 2, padding 1, output_padding 1 (hourglass.py:52-60):
+ * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, 2W];  y[o] += x[i] * w[k] with o = 2i - 1 + k. */
+int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
+                          const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
+                          int relu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cost up-sampling
+ * ---------------------------------------------------------------------------------------- */
+
+/* F.interpolate(mode='trilinear', align_corners=True) of a 1-channel volume (PSMNet.py:77-93):
+ * x: [B, Di, Hi, Wi] -> y: [B, Do, Ho, Wo];  src = dst * (in-1)/(out-1) per axis. */
+int dmb_trilinear_ac_f32(const float* x, float* y, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                         void* stream);
+
+/* nn.ConvTranspose3d(1, 1, kernel 8, stride 4, padding 2, bias=False) called with output_size =
+ * [4D, 4H, 4W] (AcfNet.py:55-57,81-83): y[o] = sum x[i] * w[k], o = 4i - 2 + k.  w: [8, 8, 8]. */
+int dmb_deconv3d_k8s4_c1_f32(const float* x, const float* w, float* y, int B, int D, int H, int W,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Disparity regression
+ * ---------------------------------------------------------------------------------------- */
+
+/* SoftArgmin / FasterSoftArgmin with the module's own linspace samples
+ * (disp_predictors/soft_argmin.py:45-75, faster_soft_argmin.py:51-75):
+ *   p = softmax(alpha * cost, dim=1) if normalize else alpha * cost;  disp = sum_k p_k * (start + k*step)
+ * with the sample values passed as a host array (they are linspace(start, end, D) in FP32).
+ * cost: [B, D, H, W] -> disp: [B, 1, H, W]. */
+int dmb_soft_argmin_f32(const float* cost, float* disp, int B, int D, int H, int W, float alpha,
+                        int normalize, const float* disp_sample_host, void* stream);
+
+/* SoftArgmin with a per-pixel disparity-sample tensor (soft_argmin.py:67-72): sample: [B, D, H, W]. */
+int dmb_soft_argmin_sampled_f32(const float* cost, const float* sample, float* disp, int B, int D, int H,
+                                int W, float alpha, int normalize, void* stream);
+
+/* LocalSoftArgmin (disp_predictors/local_soft_argmin.py:48-105).  argidx (may be NULL) receives the
+ * arg-max index per pixel as int64 [B, 1, H, W] -- the bit-exact "index path" (first maximal index,
+ * torch.argmax semantics). */
+int dmb_local_soft_argmin_f32(const float* cost, float* disp, long long* argidx, int B, int D, int H, int W,
+                              int radius, int radius_dilation, int start_disp, int dilation, float alpha,
+                              void* stream);
+
+/* Opt-in fused fast path: trilinear(align_corners=True) up-sampling of the 1/4-resolution cost
+ * [B, Di, Hi, Wi] to [B, Do, Ho, Wo] + soft-argmin, without materialising the full-resolution volume.
+ * Legal only when the caller does not need `costs` back (SURVEY 7.3 "costs are part of the return
+ * contract"). */
+int dmb_trilinear_soft_argmin_f32(const float* x, float* disp, int B, int Di, int Hi, int Wi, int Do, int Ho,
+                                  int Wo, float alpha, const float* disp_sample_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AcfNet confidence head (cmn/cmn.py:10-36,57-69)
+ *   h = relu(conv2d_3x3(cost, w1) * scale + shift)   w1: [Cm, D, 3, 3], pad 1, no bias, BN folded
+ *   conf = sigmoid(sum_m h_m * w2[m])                w2: [Cm]
+ * cost: [B, D, H, W] -> conf: [B, 1, H, W].  w1pack from dmb_conf_head_pack_weights_f32.
+ * ---------------------------------------------------------------------------------------- */
+long long dmb_conf_head_packed_floats(int Cm, int D);
+int dmb_conf_head_pack_weights_f32(const float* w1, float* w1pack, int Cm, int D, void* stream);
+int dmb_conf_head_f32(const float* cost, const float* w1pack, const float* scale, const float* shift,
+                      const float* w2, float* conf, int B, int D, int Cm, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation accumulator (data/datasets/evaluation/stereo/pixel_error.py:6-73 + eval.py:12-31 crop +
+ * tools/test.py:304-307 averaging).  For every image b: crop est/gt [Hp, Wp] to rows [Hp-H0, Hp) and
+ * columns [0, W0); mask = gt > lb && gt < ub; if the mask is non-empty
+ *     acc[0] += 1; acc[1] += mean|gt-est|; acc[2..5] += 100 * mean(|gt-est| > {1,2,3,5})
+ * (an empty mask contributes an image with all-zero errors, pixel_error.py:48-55).  acc: 6 doubles on
+ * the device, accumulated atomically; the caller zeroes it and all-reduces it across ranks. */
+int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, int B, int Hp, int Wp, int H0, int W0,
+                      float lb, float ub, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMB_HIP_H */

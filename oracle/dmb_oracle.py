@@ -1,0 +1,367 @@
+"""CPU ORACLE for the cost-volume -> 3-D aggregation -> disparity-regression path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``densematchingbenchmark_amd/`` imports this file; only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, and only as the checker / the
+reported CPU baseline -- never as the thing shipped or measured as the product.
+
+What it is: an independent, functional (no nn.Module) PyTorch-CPU restatement of the reference's algorithm
+for every function on the hot path, each citing the reference file:line it follows
+(paths relative to the reference tree).  Parameters are plain dicts keyed by the reference's own
+``state_dict`` names, so a reference checkpoint can drive the oracle directly.
+
+Pinning: ``oracle/gen_golden.py`` imports the real reference (in the build container only) and records
+inputs/outputs under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function here against
+those vectors, including the reference's own known-answer cases (tests/.../test_cat_fms.py:30-40 and
+test_disp_predictors.py:42-102).  The group-wise correlation volume has NO reference implementation
+(README.md:16 only names GwcNet): for that one function parity is UNPINNED and the spec is SURVEY 8-a4.
+
+The primitive index formulas (conv / transposed conv / trilinear) are additionally restated as plain C loop
+nests in ``oracle/dmb_oracle_c.c`` and cross-checked against this file on small shapes.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm3d default, basic_layers.py:75
+
+
+# ------------------------------------------------------------------------------------------------------------
+# disparity samples
+# ------------------------------------------------------------------------------------------------------------
+def disp_index_list(max_disp, start_disp=0, dilation=1):
+    """cost_processors/utils/cat_fms.py:26-35: linspace(start, end, n) then int() (truncation)."""
+    end_disp = start_disp + max_disp - 1
+    n = (max_disp + dilation - 1) // dilation
+    return [int(v) for v in torch.linspace(start_disp, end_disp, n)]
+
+
+def disp_sample_values(max_disp, start_disp=0, dilation=1):
+    """disp_predictors/faster_soft_argmin.py:33-44, soft_argmin.py:41-43."""
+    end_disp = start_disp + max_disp - 1
+    n = (max_disp + dilation - 1) // dilation
+    return torch.linspace(start_disp, end_disp, n)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# cost-volume builders
+# ------------------------------------------------------------------------------------------------------------
+def _valid_x(W, d):
+    """Columns kept for disparity d: cat_fms.py:36-44."""
+    if d > 0:
+        return slice(d, W), slice(0, W - d)
+    if d == 0:
+        return slice(0, W), slice(0, W)
+    return slice(0, W + d), slice(-d, W)
+
+
+def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
+    """cost_processors/utils/cat_fms.py:7-48 (output is always FP32, :32)."""
+    N, C, H, W = reference_fm.shape
+    idx = disp_index_list(max_disp, start_disp, dilation)
+    out = torch.zeros(N, 2 * C, len(idx), H, W, dtype=torch.float32)
+    for k, d in enumerate(idx):
+        if abs(d) >= W:
+            continue
+        xs, xt = _valid_x(W, d)
+        out[:, :C, k, :, xs] = reference_fm[:, :, :, xs]
+        out[:, C:, k, :, xs] = target_fm[:, :, :, xt]
+    return out
+
+
+def dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
+    """cost_processors/utils/dif_fms.py:7-46."""
+    N, C, H, W = reference_fm.shape
+    idx = disp_index_list(max_disp, start_disp, dilation)
+    out = torch.zeros(N, C, len(idx), H, W, dtype=torch.float32)
+    for k, d in enumerate(idx):
+        if abs(d) >= W:
+            continue
+        xs, xt = _valid_x(W, d)
+        out[:, :, k, :, xs] = reference_fm[:, :, :, xs] - target_fm[:, :, :, xt]
+    return out
+
+
+def gwc_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, num_groups=40, disp_sample=None):
+    """Group-wise correlation (GwcNet, "gwc" volume).  NOT IN THE REFERENCE -- parity unpinned; spec SURVEY 8-a4:
+    mean over the C/G channels of a group of L[c, y, x] * R[c, y, x - d], zero outside the valid columns, using the
+    same shifting convention as cat_fms.py:36-44."""
+    N, C, H, W = reference_fm.shape
+    assert C % num_groups == 0
+    cg = C // num_groups
+    idx = disp_index_list(max_disp, start_disp, dilation)
+    out = torch.zeros(N, num_groups, len(idx), H, W, dtype=torch.float32)
+    for k, d in enumerate(idx):
+        if abs(d) >= W:
+            continue
+        xs, xt = _valid_x(W, d)
+        prod = reference_fm[:, :, :, xs] * target_fm[:, :, :, xt]
+        out[:, :, k, :, xs] = prod.view(N, num_groups, cg, H, prod.shape[-1]).mean(dim=2)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# conv + BN (+ReLU) units: layers/basic_layers.py:68-100,160-177
+# ------------------------------------------------------------------------------------------------------------
+def _bn_eval(x, p, prefix):
+    """Eval-mode BatchNorm with running statistics; prefix names the nn.BatchNorm3d/2d module."""
+    w, b = p[prefix + ".weight"], p[prefix + ".bias"]
+    mean, var = p[prefix + ".running_mean"], p[prefix + ".running_var"]
+    return F.batch_norm(x, mean, var, w, b, training=False, eps=BN_EPS)
+
+
+def conv3d_unit(x, p, prefix, stride=1, batch_norm=True, relu=False):
+    """conv3d_bn / conv3d_bn_relu (basic_layers.py:68-83,160-177): Sequential(Conv3d k3 p1, [BN], [ReLU]);
+    ``prefix`` is the Sequential's name, children are .0 (conv), .1 (BN)."""
+    y = F.conv3d(x, p[prefix + ".0.weight"], p.get(prefix + ".0.bias"), stride=stride, padding=1)
+    if batch_norm:
+        y = _bn_eval(y, p, prefix + ".1")
+    return F.relu(y) if relu else y
+
+
+def deconv3d_unit(x, p, prefix, batch_norm=True):
+    """deconv3d_bn (basic_layers.py:86-100) as used by hourglass.py:52-60: k3, stride 2, padding 1, output_padding 1."""
+    y = F.conv_transpose3d(x, p[prefix + ".0.weight"], p.get(prefix + ".0.bias"), stride=2, padding=1, output_padding=1)
+    if batch_norm:
+        y = _bn_eval(y, p, prefix + ".1")
+    return y
+
+
+def hourglass(x, presqu, postsqu, p, prefix, batch_norm=True):
+    """cost_processors/utils/hourglass.py:62-86."""
+    out = conv3d_unit(x, p, prefix + ".conv1", stride=2, batch_norm=batch_norm, relu=True)  # :64
+    pre = conv3d_unit(out, p, prefix + ".conv2", batch_norm=batch_norm)  # :66
+    pre = F.relu(pre + postsqu) if postsqu is not None else F.relu(pre)  # :67-70
+    out = conv3d_unit(pre, p, prefix + ".conv3", stride=2, batch_norm=batch_norm, relu=True)  # :73
+    out = conv3d_unit(out, p, prefix + ".conv4", batch_norm=batch_norm, relu=True)  # :75
+    skip = presqu if presqu is not None else pre
+    post = F.relu(deconv3d_unit(out, p, prefix + ".conv5", batch_norm=batch_norm) + skip)  # :78-81
+    out = deconv3d_unit(post, p, prefix + ".conv6", batch_norm=batch_norm)  # :84
+    return out, pre, post
+
+
+def _trunk(raw_cost, p, prefix, batch_norm):
+    """Shared wiring of PSMAggregator.forward (PSMNet.py:55-72) and AcfAggregator.forward (AcfNet.py:59-76)."""
+    c0 = conv3d_unit(raw_cost, p, prefix + "dres0.0", batch_norm=batch_norm, relu=True)
+    c0 = conv3d_unit(c0, p, prefix + "dres0.1", batch_norm=batch_norm, relu=True)
+    t = conv3d_unit(c0, p, prefix + "dres1.0", batch_norm=batch_norm, relu=True)
+    cost0 = conv3d_unit(t, p, prefix + "dres1.1", batch_norm=batch_norm) + c0
+    out1, pre1, post1 = hourglass(cost0, None, None, p, prefix + "dres2", batch_norm)
+    out1 = out1 + cost0
+    out2, pre2, post2 = hourglass(out1, pre1, post1, p, prefix + "dres3", batch_norm)
+    out2 = out2 + cost0
+    out3, pre3, post3 = hourglass(out2, pre2, post2, p, prefix + "dres4", batch_norm)
+    out3 = out3 + cost0
+
+    def classif(x, name):
+        h = conv3d_unit(x, p, prefix + name + ".0", batch_norm=batch_norm, relu=True)
+        return F.conv3d(h, p[prefix + name + ".1.weight"], p.get(prefix + name + ".1.bias"), padding=1)
+
+    cost1 = classif(out1, "classif1")
+    cost2 = classif(out2, "classif2") + cost1
+    cost3 = classif(out3, "classif3") + cost2
+    return cost1, cost2, cost3
+
+
+def psm_aggregator(raw_cost, p, max_disp, prefix="", batch_norm=True, upsample=True):
+    """cost_processors/aggregators/PSMNet.py:55-95.  Returns [cost3, cost2, cost1] (best first)."""
+    B, C, D, H, W = raw_cost.shape
+    costs = _trunk(raw_cost, p, prefix, batch_norm)
+    if not upsample:
+        return [c.squeeze(1) for c in reversed(costs)]
+    size = [max_disp, H * 4, W * 4]
+    up = [F.interpolate(c, size, mode="trilinear", align_corners=True).squeeze(1) for c in costs]  # :77-93
+    return [up[2], up[1], up[0]]
+
+
+def acf_aggregator(raw_cost, p, max_disp, prefix="", batch_norm=True):
+    """cost_processors/aggregators/AcfNet.py:59-90 (learned k8/s4 ConvTranspose3d upsampling, :81-83)."""
+    B, C, D, H, W = raw_cost.shape
+    costs = _trunk(raw_cost, p, prefix, batch_norm)
+    up = []
+    for i, c in enumerate(costs):
+        w = p[prefix + "deconv%d.weight" % (i + 1)]
+        up.append(F.conv_transpose3d(c, w, None, stride=4, padding=2).squeeze(1))
+    assert up[0].shape[1:] == (max_disp, H * 4, W * 4)
+    return [up[2], up[1], up[0]]
+
+
+def stereonet_aggregator(raw_cost, p, prefix="", batch_norm=True, num=4):
+    """cost_processors/aggregators/StereoNet.py:42-55."""
+    x = raw_cost
+    for i in range(num):
+        x = conv3d_unit(x, p, prefix + "classify.%d" % i, batch_norm=batch_norm, relu=True)
+    cost = F.conv3d(x, p[prefix + "lastconv.weight"], p.get(prefix + "lastconv.bias"), padding=1)
+    return [cost.squeeze(1)]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# disparity predictors
+# ------------------------------------------------------------------------------------------------------------
+def soft_argmin(cost_volume, max_disp, start_disp=0, dilation=1, alpha=1.0, normalize=True, disp_sample=None):
+    """disp_predictors/soft_argmin.py:45-75."""
+    c = cost_volume * alpha
+    prob = F.softmax(c, dim=1) if normalize else c
+    B, D, H, W = c.shape
+    if disp_sample is None:
+        ds = disp_sample_values(max_disp, start_disp, dilation)
+        assert D == ds.numel()
+        disp_sample = ds.view(1, D, 1, 1).expand(B, D, H, W)
+    return torch.sum(prob * disp_sample, dim=1, keepdim=True)
+
+
+def faster_soft_argmin(cost_volume, max_disp, start_disp=0, dilation=1, alpha=1.0, normalize=True):
+    """disp_predictors/faster_soft_argmin.py:51-75: the weighted sum as a frozen Conv3d(1,1,(D,1,1))."""
+    c = cost_volume * alpha
+    prob = F.softmax(c, dim=1) if normalize else c
+    w = disp_sample_values(max_disp, start_disp, dilation).view(1, 1, -1, 1, 1)
+    return F.conv3d(prob.unsqueeze(1), w).squeeze(1)
+
+
+def soft_argmin_f64(cost_volume, max_disp, start_disp=0, dilation=1, alpha=1.0):
+    """FP64 evaluation of the same formula: the 'truth' both FP32 variants of the reference approximate."""
+    c = cost_volume.double() * alpha
+    prob = F.softmax(c, dim=1)
+    ds = disp_sample_values(max_disp, start_disp, dilation).double().view(1, -1, 1, 1)
+    return torch.sum(prob * ds, dim=1, keepdim=True)
+
+
+def local_soft_argmin(cost_volume, max_disp, radius, start_disp=0, dilation=1, radius_dilation=1, alpha=1.0):
+    """disp_predictors/local_soft_argmin.py:48-105.  Returns (disp, argmax index)."""
+    B, D, H, W = cost_volume.shape
+    assert D == (max_disp + dilation - 1) // dilation
+    max_index = torch.argmax(cost_volume, dim=1, keepdim=True)  # :65
+    interval = torch.linspace(-radius * radius_dilation, radius * radius_dilation, 2 * radius + 1).long()  # :69-71
+    index_group = max_index + interval.view(1, -1, 1, 1)  # :76
+    mask = ((index_group >= 0) & (index_group <= D - 1)).type_as(cost_volume)  # :81
+    index_group = index_group.clamp(0, D - 1)  # :82
+    gathered = torch.gather(cost_volume, 1, index_group)  # :86
+    disp_sample = start_disp + index_group.type_as(cost_volume) * dilation  # :89-92
+    gathered = gathered * alpha  # :97
+    prob = F.softmax(gathered * mask + (1 - mask) * (-10000.0 * alpha), dim=1)  # :100
+    return (prob * disp_sample).sum(dim=1, keepdim=True), max_index  # :103
+
+
+# ------------------------------------------------------------------------------------------------------------
+# AcfNet confidence head: cmn/cmn.py:10-36,57-69
+# ------------------------------------------------------------------------------------------------------------
+def conf_head(cost, p, prefix, batch_norm=True):
+    """ConfHead.forward (cmn.py:34-36) + sigmoid (cmn.py:65): returns (conf, conf_cost)."""
+    h = F.conv2d(cost, p[prefix + ".conf_net.0.0.weight"], None, padding=1)
+    if batch_norm:
+        h = _bn_eval(h, p, prefix + ".conf_net.0.1")
+    h = F.relu(h)
+    conf_cost = F.conv2d(h, p[prefix + ".conf_net.1.weight"], None)
+    return torch.sigmoid(conf_cost), conf_cost
+
+
+def cmn_eval(costs, p, alpha, beta, prefix="conf_heads", batch_norm=True):
+    """Cmn.get_confidence / forward in eval (cmn.py:57-84): returns (cost_vars, confs)."""
+    confs = [conf_head(c, p, "%s.%d" % (prefix, i), batch_norm)[0] for i, c in enumerate(costs)]
+    cost_vars = [alpha * (1 - c) + beta for c in confs]
+    return cost_vars, confs
+
+
+# ------------------------------------------------------------------------------------------------------------
+# evaluation: data/datasets/evaluation/stereo/{eval.py:12-31, pixel_error.py:6-73}, tools/test.py:304-307
+# ------------------------------------------------------------------------------------------------------------
+def remove_padding(batch, size):
+    pad_top = batch.shape[-2] - size[-2]
+    if pad_top >= 0:
+        batch = batch[:, :, pad_top:, :size[-1]]
+    return batch
+
+
+def calc_error(est_disp, gt_disp, lb=None, ub=None):
+    mask = torch.ones(gt_disp.shape, dtype=torch.bool)
+    if lb is not None:
+        mask = mask & (gt_disp > lb)
+    if ub is not None:
+        mask = mask & (gt_disp < ub)
+    if mask.float().sum() < 1.0:
+        return {"1px": 0.0, "2px": 0.0, "3px": 0.0, "5px": 0.0, "epe": 0.0}
+    gt, est = gt_disp[mask], est_disp[mask]
+    abs_error = torch.abs(gt - est)
+    total = mask.float().sum()
+    out = {"%dpx" % k: float(torch.sum(torch.gt(abs_error, k).float()) / total * 100) for k in (1, 2, 3, 5)}
+    out["epe"] = float(abs_error.float().mean())
+    return out
+
+
+def dataset_metrics(est_list, gt_list, original_size, lb, ub):
+    """Unweighted mean over images of the per-image error dicts (mmcv LogBuffer.average, tools/test.py:304-307)."""
+    keys = ("epe", "1px", "2px", "3px", "5px")
+    acc = {k: 0.0 for k in keys}
+    n = 0
+    for est, gt in zip(est_list, gt_list):
+        for b in range(est.shape[0]):
+            e = calc_error(remove_padding(est[b:b + 1], original_size), remove_padding(gt[b:b + 1], original_size), lb, ub)
+            for k in keys:
+                acc[k] += e[k]
+            n += 1
+    return {k: acc[k] / max(n, 1) for k in keys}, n
+
+
+# ------------------------------------------------------------------------------------------------------------
+# whole path (what bench.py's cpu_baseline times): SURVEY 8-a1/a13
+# ------------------------------------------------------------------------------------------------------------
+def psmnet_path(ref_fms, tgt_fms, p, max_disp, scale=4, alpha=1.0, prefix="cost_processor.aggregator."):
+    """CatCostProcessor.forward (cost_processors/builder.py:33-40) + [FasterSoftArgmin(c) for c in costs]
+    (models/general_stereo_model.py:51-54) for the PSMNet config (configs/PSMNet/scene_flow.py:19-52)."""
+    raw = cat_fms(ref_fms, tgt_fms, max_disp // scale, 0, 1)
+    costs = psm_aggregator(raw, p, max_disp, prefix)
+    disps = [faster_soft_argmin(c, max_disp, 0, 1, alpha, True) for c in costs]
+    return disps, costs
+
+
+def random_params_psm(seed=0, in_planes=64, classif_gain=300.0, bias=False, acf=False):
+    """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
+    default init produces, drawn with an explicit generator), classifier output convs scaled so that costs
+    are peaked (SURVEY 8-c fixture recipe).  BN statistics are randomised away from (0, 1) so that a wrong
+    fold shows up."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+
+    def conv(name, co, ci, k=3, with_bias=False, transposed=False):
+        fan_in = (co if transposed else ci) * k ** 3
+        bound = 1.0 / math.sqrt(fan_in)
+        shape = (ci, co, k, k, k) if transposed else (co, ci, k, k, k)
+        p[name + ".weight"] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        if with_bias:
+            p[name + ".bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
+
+    def bn(name, c):
+        p[name + ".weight"] = 0.5 + torch.rand(c, generator=g)
+        p[name + ".bias"] = (torch.rand(c, generator=g) - 0.5) * 0.2
+        p[name + ".running_mean"] = (torch.rand(c, generator=g) - 0.5) * 0.2
+        p[name + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+
+    def unit(name, co, ci, with_bias=False, transposed=False):
+        conv(name + ".0", co, ci, with_bias=with_bias, transposed=transposed)
+        bn(name + ".1", co)
+
+    wb = bias or acf
+    unit("dres0.0", 32, in_planes, wb)
+    unit("dres0.1", 32, 32, wb)
+    unit("dres1.0", 32, 32, wb)
+    unit("dres1.1", 32, 32, wb)
+    for hg in ("dres2", "dres3", "dres4"):
+        unit(hg + ".conv1", 64, 32)
+        unit(hg + ".conv2", 64, 64)
+        unit(hg + ".conv3", 64, 64)
+        unit(hg + ".conv4", 64, 64)
+        unit(hg + ".conv5", 64, 64, transposed=True)
+        unit(hg + ".conv6", 32, 64, transposed=True)
+    for i in (1, 2, 3):
+        unit("classif%d.0" % i, 32, 32, wb)
+        conv("classif%d.1" % i, 1, 32)
+        p["classif%d.1.weight" % i] *= classif_gain
+        if acf:
+            fan_in = 1 * 8 ** 3
+            p["deconv%d.weight" % i] = (torch.rand((1, 1, 8, 8, 8), generator=g) * 2 - 1) / math.sqrt(fan_in) * 8.0
+    return p
+
+
+def with_prefix(p, prefix):
+    return {prefix + k: v for k, v in p.items()}

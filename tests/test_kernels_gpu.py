@@ -1,0 +1,232 @@
+"""Parity of every C-ABI entry point (through densematchingbenchmark_amd.ops) against the CPU oracle.
+
+Integer / copy / index paths are compared bit-exactly; floating-point kernels with the tolerance written at
+each assert (FP32 fma-chain vs the oracle's FP32 evaluation in a different summation order)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dmb_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from densematchingbenchmark_amd import ops
+
+    return ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------- volumes (bit-exact)
+@pytest.mark.parametrize("shape,md,sd,dil", [
+    ((1, 1, 3, 4), 5, -2, 2),       # reference known-answer shape (tests/.../test_cat_fms.py:30-40)
+    ((2, 32, 16, 32), 8, 0, 1),
+    ((1, 5, 7, 61), 12, -3, 1),     # W % 4 != 0 -> scalar path
+    ((1, 8, 9, 64), 6, 0, 2),       # dilation 2 -> indices [0, 2, 5]
+    ((1, 4, 5, 12), 20, 0, 1),      # disparities beyond the width
+])
+def test_cat_dif_bit_exact(dev, shape, md, sd, dil):
+    ops = _ops()
+    L, R = _rand(shape, 1), _rand(shape, 2)
+    idx = ops.disp_index_list(md, sd, dil)
+    assert idx == O.disp_index_list(md, sd, dil)
+    got = ops.cat_fms(L.to(dev), R.to(dev), idx).cpu()
+    assert torch.equal(got, O.cat_fms(L, R, md, sd, dil))
+    got = ops.dif_fms(L.to(dev), R.to(dev), idx).cpu()
+    assert torch.equal(got, O.dif_fms(L, R, md, sd, dil))
+
+
+def test_cat_known_answer(dev):
+    ops = _ops()
+    L = torch.arange(1, 13, dtype=torch.float32).view(1, 1, 3, 4)
+    R = torch.arange(13, 25, dtype=torch.float32).view(1, 1, 3, 4)
+    out = ops.cat_fms(L.to(dev), R.to(dev), ops.disp_index_list(5, -2, 2)).cpu()
+    assert out.shape == (1, 2, 3, 3, 4)
+    assert out[0, 0, :, 0].tolist() == [[1, 2, 0, 0], [1, 2, 3, 4], [0, 0, 3, 4]]
+    assert out[0, 1, :, 0].tolist() == [[15, 16, 0, 0], [13, 14, 15, 16], [0, 0, 13, 14]]
+
+
+@pytest.mark.parametrize("C,G", [(16, 2), (32, 8), (12, 12)])
+def test_gwc(dev, C, G):
+    ops = _ops()
+    L, R = _rand((2, C, 6, 40), 3), _rand((2, C, 6, 40), 4)
+    idx = ops.disp_index_list(9, 0, 1)
+    got = ops.gwc_fms(L.to(dev), R.to(dev), idx, G).cpu()
+    ref = O.gwc_fms(L, R, 9, 0, 1, G)
+    assert (got - ref).abs().max().item() <= 2e-6  # <= C/G FP32 products, different summation order
+
+
+# ------------------------------------------------------------------------------------------- conv family
+def _affine(C, seed):
+    g = torch.Generator().manual_seed(seed)
+    return 0.5 + torch.rand(C, generator=g), torch.rand(C, generator=g) - 0.5
+
+
+@pytest.mark.parametrize("Ci,Co,stride", [(32, 32, 1), (64, 32, 1), (64, 64, 1), (32, 64, 1), (32, 64, 2), (64, 64, 2)])
+@pytest.mark.parametrize("shape", [(2, 6, 10, 70), (1, 5, 9, 13)])
+def test_conv3d_k3(dev, Ci, Co, stride, shape):
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 5)
+    w = _rand((Co, Ci, 3, 3, 3), 6, 1.0 / math.sqrt(Ci * 27))
+    sc, sh = _affine(Co, 7)
+    ref = F.conv3d(x, w, None, stride=stride, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+    res = _rand(ref.shape, 8)
+    wp = ops.pack_conv3d_weights(w.to(dev))
+    got = ops.conv3d_k3(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), None, stride, False).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5  # |values| ~ 1, K = Ci*27 FP32 fma chain
+    got = ops.conv3d_k3(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), res.to(dev), stride, True).cpu()
+    assert (got - F.relu(ref + res)).abs().max().item() <= 2e-5
+    got = ops.conv3d_k3(x.to(dev), wp, Co, None, None, None, stride, False).cpu()
+    assert (got - F.conv3d(x, w, None, stride=stride, padding=1)).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("Ci,Co", [(64, 64), (64, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 35), (1, 4, 6, 61)])
+def test_deconv3d(dev, Ci, Co, shape):
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 9)
+    w = _rand((Ci, Co, 3, 3, 3), 10, 1.0 / math.sqrt(Ci * 27 / 8))
+    sc, sh = _affine(Co, 11)
+    ref = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+    ref = ref * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+    res = _rand(ref.shape, 12)
+    wp = ops.pack_deconv3d_weights(w.to(dev))
+    got = ops.deconv3d_k3s2(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), None, False).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5
+    got = ops.deconv3d_k3s2(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), res.to(dev), True).cpu()
+    assert (got - F.relu(ref + res)).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("Ci", [32, 5])
+def test_conv3d_c1(dev, Ci):
+    ops = _ops()
+    x = _rand((2, Ci, 6, 9, 70), 13)
+    w = _rand((1, Ci, 3, 3, 3), 14, 1.0 / math.sqrt(Ci * 27))
+    res = _rand((2, 1, 6, 9, 70), 15)
+    ref = F.conv3d(x, w, torch.tensor([0.25]), padding=1) + res
+    got = ops.conv3d_k3_c1(x.to(dev), w.to(dev), 0.25, res.to(dev)).cpu()
+    assert (got - ref).abs().max().item() <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------- upsampling
+@pytest.mark.parametrize("ins,outs", [((4, 6, 10), (16, 24, 40)), ((3, 5, 7), (11, 17, 30))])
+def test_trilinear(dev, ins, outs):
+    ops = _ops()
+    x = _rand((2,) + ins, 16)
+    ref = F.interpolate(x.unsqueeze(1), list(outs), mode="trilinear", align_corners=True).squeeze(1)
+    got = ops.trilinear_ac(x.to(dev), outs).cpu()
+    assert (got - ref).abs().max().item() <= 2e-6  # same index/weight arithmetic, fma contraction may differ
+
+
+def test_deconv_k8s4(dev):
+    ops = _ops()
+    x = _rand((2, 3, 5, 9), 17)
+    w = _rand((1, 1, 8, 8, 8), 18, 0.1)
+    ref = F.conv_transpose3d(x.unsqueeze(1), w, None, stride=4, padding=2).squeeze(1)
+    got = ops.deconv3d_k8s4_c1(x.to(dev), w.view(8, 8, 8).to(dev)).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------- regression
+@pytest.mark.parametrize("D,HW", [(192, (6, 40)), (24, (5, 13)), (5, (2, 2))])
+@pytest.mark.parametrize("gain", [1.0, 12.0])
+def test_soft_argmin(dev, D, HW, gain):
+    ops = _ops()
+    cost = _rand((2, D) + HW, 19, gain)
+    vals = ops.disp_sample_values(D, 0, 1)
+    got = ops.soft_argmin(cost.to(dev), vals, 1.0, True).cpu()
+    truth = O.soft_argmin_f64(cost, D).float()
+    ref = O.faster_soft_argmin(cost, D)
+    # our FP64-accumulated result is within FP32 rounding of the truth ...
+    assert (got - truth).abs().max().item() <= 2e-5 * max(1.0, D / 64)
+    # ... and the reference's own FP32 evaluation is no closer to the truth than ~1e-4 at D=192
+    assert (got - ref).abs().max().item() <= 1.5e-4
+    got = ops.soft_argmin(cost.to(dev), vals, 0.5, False).cpu()
+    assert (got - O.soft_argmin(cost, D, alpha=0.5, normalize=False)).abs().max().item() <= 1e-3 * gain
+
+
+def test_soft_argmin_known_answer(dev):
+    ops = _ops()
+    cost = torch.ones(1, 5, 2, 2)
+    vals = ops.disp_sample_values(9, -4, 2)
+    assert vals == [-4.0, -2.0, 0.0, 2.0, 4.0]
+    got = ops.soft_argmin(cost.to(dev), vals, 1.0, True).cpu()
+    assert got.abs().max().item() <= 1e-7  # reference prints -5.96e-8 (test_disp_predictors.py:42-102)
+    got = ops.local_soft_argmin(cost.to(dev), 2, 1, -4, 2, 1.0).cpu()
+    assert torch.equal(got, torch.full((1, 1, 2, 2), -2.0))
+
+
+def test_soft_argmin_sampled(dev):
+    ops = _ops()
+    cost = _rand((2, 12, 5, 8), 20, 3.0)
+    samp = _rand((2, 12, 5, 8), 21, 10.0)
+    got = ops.soft_argmin_sampled(cost.to(dev), samp.to(dev), 1.0, True).cpu()
+    ref = O.soft_argmin(cost, 12, disp_sample=samp)
+    assert (got - ref).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("radius,rd,start,dil", [(2, 1, 0, 1), (3, 2, -4, 2), (0, 1, 0, 1)])
+def test_local_soft_argmin(dev, radius, rd, start, dil):
+    ops = _ops()
+    D = 48
+    cost = _rand((2, D, 7, 20), 22, 4.0)
+    cost[0, :, 0, 0] = 1.0          # full tie -> index 0
+    cost[0, 5, 1, 1] = cost[0, 9, 1, 1] = 100.0  # two-way tie -> lowest index
+    cost[1, D - 1, 2, 2] = 50.0     # window clipped at the top
+    got, idx = ops.local_soft_argmin(cost.to(dev), radius, rd, start, dil, 1.0, return_index=True)
+    ref, ridx = O.local_soft_argmin(cost, D * dil, radius, start, dil, rd, 1.0)
+    assert torch.equal(idx.cpu(), ridx)  # index path: bit-exact
+    assert (got.cpu() - ref).abs().max().item() <= 3e-5
+
+
+def test_trilinear_soft_argmin_fused(dev):
+    ops = _ops()
+    x = _rand((2, 6, 8, 12), 23, 3.0)
+    outs = (24, 32, 48)
+    vals = ops.disp_sample_values(24, 0, 1)
+    up = ops.trilinear_ac(x.to(dev), outs)
+    a = ops.soft_argmin(up, vals, 1.0, True)
+    b = ops.trilinear_soft_argmin(x.to(dev), outs, vals, 1.0)
+    assert (a - b).abs().max().item() <= 2e-5  # identical logits; only the max-rescale grouping differs (few ulp at disp ~ 20)
+
+
+# ------------------------------------------------------------------------------------------- conf head / EPE
+@pytest.mark.parametrize("D,Cm", [(48, 16), (192, 64), (20, 6)])
+def test_conf_head(dev, D, Cm):
+    ops = _ops()
+    cost = _rand((2, D, 11, 70), 24)
+    w1 = _rand((Cm, D, 3, 3), 25, 1.0 / math.sqrt(D * 9))
+    w2 = _rand((Cm,), 26, 0.5)
+    sc, sh = _affine(Cm, 27)
+    h = F.relu(F.conv2d(cost, w1, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref = torch.sigmoid(F.conv2d(h, w2.view(1, Cm, 1, 1)))
+    wp = ops.pack_conf_head_weights(w1.to(dev))
+    got = ops.conf_head(cost.to(dev), wp, sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
+    assert (got - ref).abs().max().item() <= 1e-5
+
+
+def test_epe_accumulate(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(28)
+    gt = torch.rand((3, 1, 20, 32), generator=g) * 220 - 10   # some <= 0 and some >= 192 -> masked out
+    est = gt + torch.randn((3, 1, 20, 32), generator=g) * 3
+    gt[2] = -1.0  # an image with an empty mask contributes zeros but still counts (pixel_error.py:48-55)
+    acc = torch.zeros(6, dtype=torch.float64, device=dev)
+    ops.epe_accumulate(est.to(dev), gt.to(dev), acc, (17, 30), 0, 192)
+    ref, n = O.dataset_metrics([est], [gt], (17, 30), 0, 192)
+    acc = acc.cpu()
+    assert acc[0].item() == 3 and n == 3
+    for i, k in enumerate(("epe", "1px", "2px", "3px", "5px")):
+        assert abs(acc[1 + i].item() / 3 - ref[k]) <= 1e-5 * max(1.0, abs(ref[k]))
