@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Headline benchmark: stereo pairs/s through the HIP cost-volume -> aggregation -> regression path.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+Workload (BASELINE.json configs[1]): PSMNet cat-volume + stacked 3-D hourglass + 3x (trilinear up-sampling,
+soft-argmin), 540x960 padded to 544x960, max_disp=192, batch 4 per GPU, FP32.  One "step" = one batch of 4
+synthetic pairs through volume -> aggregator -> 3 disparity maps -> EPE accumulation; inputs (backbone feature
+maps [4, 32, 136, 240] x 2) are resident in HBM before the timed region.  Pairs are sharded over ranks the way
+the reference shards them (pair i -> rank i mod world, tools/test.py:108); the only collective is ONE SUM
+all-reduce of the FP64 EPE accumulator over RCCL at the end of the job (inside the timed region).
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (conv3d k3 s1 32->32, FP32 MFMA bound):
+algorithmic FLOP per launch / mean launch duration measured live with HIP events on the launch stream.
+``cpu_baseline`` times the CPU oracle (a port of the reference's PyTorch-CPU path) on one pair on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from densematchingbenchmark_amd import ops, synthetic  # noqa: E402
+from densematchingbenchmark_amd.config import Config  # noqa: E402
+from densematchingbenchmark_amd.evaluation import EpeAccumulator  # noqa: E402
+from densematchingbenchmark_amd.modeling import build_model  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+PATH_GFLOP_PER_PAIR = 1015.84   # SURVEY.md 8-d, PSMNet 544x960 D=192
+DOMINANT = "conv3d_k3_s1_32to32"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="stereo pairs per GPU per step (cfg2: 4)")
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "PSMNet", "scene_flow.py"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-regression", action="store_true",
+                    help="opt-in fast path: fused up-sampling + soft-argmin, full-resolution costs not materialised")
+    return ap.parse_args()
+
+
+def _pick_threads():
+    """The host has many more hardware threads than torch's CPU conv kernels can use well: time one full-size
+    32->32 3x3x3 layer at a few thread counts (about a second each) and keep the fastest."""
+    import torch.nn.functional as F
+    ncpu = os.cpu_count() or 1
+    cands = sorted({max(1, ncpu // k) for k in (1, 2, 4, 8)} | {min(ncpu, 16)}, reverse=True)
+    x = torch.randn(1, 32, 48, 136, 240)
+    w = torch.randn(32, 32, 3, 3, 3) * 0.03
+    best, best_t = cands[0], float("inf")
+    for n in cands:
+        torch.set_num_threads(n)
+        F.conv3d(x, w, padding=1)
+        t0 = time.perf_counter()
+        F.conv3d(x, w, padding=1)
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = n, dt
+    return best
+
+
+def cpu_baseline(model, cfg, feat_hw, channels):
+    """Oracle (port of the reference's CPU path) on ONE full-size pair: ~10-30 s of host time."""
+    from oracle import dmb_oracle as O   # checker / reported baseline only -- never on the product path
+    cores = _pick_threads()
+    torch.set_num_threads(cores)
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    lf, rf = synthetic.feature_pair(0, channels, feat_hw[0], feat_hw[1])
+    md = cfg.model.max_disp
+    with torch.no_grad():
+        sl, sr = lf[:, :, :32, :64].contiguous(), rf[:, :, :32, :64].contiguous()
+        O.psmnet_path(sl, sr, p, 32)                      # warm-up (thread pool, allocator) on a small crop
+        t0 = time.perf_counter()
+        disps, _ = O.psmnet_path(lf, rf, p, md)
+        dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port",
+                sample="1 pair 544x960 max_disp=192 (cat_fms + PSMAggregator + 3x FasterSoftArgmin), torch CPU FP32, "
+                       "%d threads (fastest of a sweep on a %d-thread host), %.1f s" % (cores, os.cpu_count() or 1, dt)), disps
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = Config.fromfile(args.config)
+    md = cfg.model.max_disp
+    Hp, Wp = cfg.data.eval.input_shape
+    H0, W0 = cfg.data.eval.get("original_shape", cfg.data.eval.input_shape)
+    scale = md // cfg.model.cost_processor.cost_computation.max_disp
+    fh, fw = Hp // scale, Wp // scale
+    C = 32
+    B = args.batch
+
+    model = build_model(cfg).eval()
+    synthetic.init_params_(model, seed=0, classif_gain=30.0)
+    model = model.to(dev)
+    n_ids = len(cfg.get("eval_disparity_id", [0]))
+
+    # inputs resident in HBM before the timed region: this rank's pairs are rank, rank + world, ...
+    left, right = synthetic.feature_batch(rank, world, B, C, fh, fw, dev)
+    gt = synthetic.gt_disparity(rank, B, Hp, Wp, pad_top=Hp - H0, device=dev)
+    acc = EpeAccumulator(dev, n_ids, cfg.model.eval.lower_bound, cfg.model.eval.upper_bound)
+    batch = dict(leftFeature=left, rightFeature=right)
+    fused = args.fused_regression
+
+    def step():
+        if not fused:
+            results, _ = model(batch)
+            disps = results["disps"]
+        else:
+            agg = model.cost_processor.aggregator
+            raw = model.cost_processor.vol_func(left, right, **model.cost_processor.default_args)
+            c1, c2, c3 = agg.trunk(raw)
+            vals = model.disp_predictor._sample_values()
+            disps = [ops.trilinear_soft_argmin(c.squeeze(1), (md, Hp, Wp), vals, model.disp_predictor.alpha)
+                     for c in (c3, c2, c1)]
+        acc.update(disps[:n_ids], gt, (H0, W0))
+        return disps
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            disps = step()
+        acc.acc.zero_()
+        timer = ops.KernelTimer([DOMINANT])
+        ops.set_kernel_timer(timer)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            disps = step()
+        acc.all_reduce()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ops.set_kernel_timer(None)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = tmax.item()
+    pairs = B * args.steps * world
+    value = pairs / elapsed
+    metrics = acc.summary()
+
+    if rank == 0:
+        kms = timer.mean_ms(DOMINANT)
+        d4, h4, w4 = md // scale, fh, fw
+        flop = 2.0 * 27 * 32 * 32 * B * d4 * h4 * w4
+        achieved = flop / (kms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "stereo pairs/s (540x960, max_disp=192)", "value": round(value, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PSMNet cat-volume + 3D hourglass + soft-argmin, 544x960 (540 padded), "
+                                   "max_disp=192, batch %d per GPU%s" % (B, ", fused up-sample+regression" if fused else ""),
+                       "pairs_per_step_per_gpu": B, "sharding": "pair i -> rank i mod world; 1 all-reduce of the EPE accumulator",
+                       "costs_materialised": not fused},
+            "path_tflops": round(value * PATH_GFLOP_PER_PAIR / 1e3, 2),
+            "path_frac_fp32_peak": round(value * PATH_GFLOP_PER_PAIR / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+            "roofline": {"kernel": "conv3d_s1_kernel<32,32> (k3 s1 32->32, [%d,32,%d,%d,%d])" % (B, d4, h4, w4),
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "launch_ms": round(kms, 4), "launches_timed": timer.count(DOMINANT),
+                         "flop_per_launch": flop},
+            "epe_accumulator": metrics[0],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref_disps = cpu_baseline(model, cfg, (fh, fw), C)
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu"] = round(value / base["value"], 1)
+            # parity of the first pair of the last step against the oracle's disparity maps
+            d_gpu = [d[0:1].cpu() for d in disps]
+            if not fused or True:
+                diffs = [(a - b).abs().max().item() for a, b in zip(d_gpu, ref_disps)]
+                out["parity_vs_cpu"] = {"max_abs_disp": [round(x, 7) for x in diffs],
+                                        "epe_delta": [round((a - b).abs().mean().item(), 8) for a, b in zip(d_gpu, ref_disps)]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

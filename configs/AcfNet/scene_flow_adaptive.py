@@ -1,0 +1,21 @@
+# AcfNet (adaptive unimodal cost filtering) on the PSMNet trunk: learned k8/s4 cost up-sampling + confidence heads.
+import os, runpy
+_c = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_common.py"))
+task = 'stereo'
+max_disp = 192
+model = dict(
+    meta_architecture="GeneralizedStereoModel",
+    max_disp=max_disp,
+    batch_norm=True,
+    cost_processor=dict(
+        type='Concatenation',
+        cost_computation=_c['volume']("default", max_disp, 4),
+        cost_aggregator=dict(type="AcfNet", max_disp=max_disp, in_planes=64),
+    ),
+    cmn=dict(num=3, alpha=1.0, beta=1.0, in_planes=max_disp),
+    disp_predictor=_c['predictor']('FASTER', max_disp),
+    eval=_c['evaluation'](max_disp),
+)
+data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960]))
+eval_disparity_id = [0, 1, 2]
+dist_params = dict(backend='nccl')

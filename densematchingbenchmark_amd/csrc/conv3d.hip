@@ -25,6 +25,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DMB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Asynchronous global -> LDS copies (LDS-DMA, buffer_load ... lds): no VGPR round trip, no ds_write.  The LDS
+// destination is the wave-uniform `dst` + lane * size; the global source is base(rsrc) + soffset (scalar) + voffset
+// (per lane).  Zero padding comes for free from the buffer bounds check: a lane whose voffset is DMA_OOB reads 0.
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr unsigned DMA_OOB = 0x80000000u;  // >= any num_records we create (host side checks sizes < 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float* dst_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst_uniform, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float* dst_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst_uniform, 16, voff, soff, 0, 0);
+}
+
 // Row of the 32x32 C/D tile held by accumulator register r of lane-half h (cdna_hip_programming.md s3).
 __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -60,9 +75,9 @@ struct Affine {
 // ---------------------------------------------------------------------------------------------------------
 // Stride-1 kernel.
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_>
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, int SCHED_ = 1>
 struct S1Cfg {
-  static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_;
+  static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_, SCHED = SCHED_;
   static constexpr int WZ = 4 / WN;        // waves along z; one output z-slice per wave
   static constexpr int TZ = WZ;
   static constexpr int P = TX + 2;         // padded row pitch
@@ -73,10 +88,51 @@ struct S1Cfg {
   static constexpr int NTT = COUT / 32;          // 32-channel row tiles in total
   static constexpr int NT = NTT / WN;            // ... per wave
   static constexpr int CH_STRIDE = ZS * PLANE + 36;  // + slack read by discarded columns
-  static constexpr int LDS_FLOATS = CK * CH_STRIDE;
+  static constexpr int NK = (CK / 2) * 27;           // k-steps per chunk
+  static constexpr int IN_FLOATS = CK * CH_STRIDE;   // input tile of one chunk
+  static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;  // + the chunk's weight fragments
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
   static_assert(P <= 64, "one wave stages one tile row per instruction");
-  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0, "shape");
+  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
 };
+
+// Epilogue shared by the three MFMA kernels: v = acc*scale + shift (+ residual) (relu) for the 16 accumulator
+// registers of one 32x32 tile; `o` is the voxel offset inside one channel plane, `cstride` the channel stride.
+// Residual loads are issued as one batch before the stores (one latency per tile instead of sixteen).
+template <int VEC>
+__device__ __forceinline__ void store_tile(const f32x16 (&a)[VEC], const float (&sc)[16], const float (&sh)[16],
+                                           const float* __restrict__ rb, float* __restrict__ yb, int co0, int h,
+                                           unsigned cstride, unsigned o, int relu) {
+  float rv[16][VEC];
+  if (rb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* rp = rb + (size_t)(co0 + cd_row(r, h)) * cstride + o;
+      if (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(rp);
+        rv[r][0] = t.x;
+        rv[r][VEC - 1] = t.y;
+      } else {
+        rv[r][0] = *rp;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      v[e] = fmaf(a[e][r], sc[r], sh[r]);
+      if (rb) v[e] += rv[r][e];
+      if (relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    float* yp = yb + (size_t)(co0 + cd_row(r, h)) * cstride + o;
+    if (VEC == 2)
+      *reinterpret_cast<float2*>(yp) = make_float2(v[0], v[VEC - 1]);
+    else
+      *yp = v[0];
+  }
+}
 
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
@@ -94,11 +150,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
   const int b = t / ntz;
   const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
-  const size_t HW = (size_t)H * W;
-  const float* xb = x + (size_t)b * C::CIN * D * HW;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const float* xb = x + (size_t)b * C::CIN * DHW;
 
   f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -108,57 +164,89 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const float* bbase = lds + h * C::CH_STRIDE + wz * C::PLANE + j;
-
-  for (int c0 = 0; c0 < C::CIN; c0 += C::CK) {
-    __syncthreads();
-    // ---- stage [CK][ZS][ROWS][P] ----
-    constexpr int NR = C::CK * C::ZS * C::ROWS;
-    for (int r = wave; r < NR; r += 4) {
-      const int cl = r / (C::ZS * C::ROWS);
-      const int rem = r % (C::ZS * C::ROWS);
-      const int zz = rem / C::ROWS, yy = rem % C::ROWS;
-      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 1 + lane;
-      if (lane < C::P) {
-        float v = 0.f;
-        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-          v = xb[((size_t)(c0 + cl) * D + gz) * HW + (size_t)gy * W + gx];
-        lds[cl * C::CH_STRIDE + zz * C::PLANE + yy * C::P + lane] = v;
-      }
-    }
-    __syncthreads();
-    // ---- (CK/2) * 27 k-steps ----
-    const float* wpc = wp + ((size_t)(c0 / 2) * 27 * C::NTT + wn * C::NT) * 64 + lane;
+  // ---- staging (LDS-DMA).  Work unit = one (channel, z) plane of the haloed tile = ROWS row copies; the CK*ZS
+  // planes of a chunk are dealt to the 4 waves in contiguous runs.  All copies of chunk i+1 (input rows + the
+  // chunk's weight fragments) are issued before the MFMAs of chunk i and land while they run.
+  constexpr int NPL = C::CK * C::ZS;            // planes per chunk
+  static_assert(NPL % 4 == 0, "planes are dealt evenly to the 4 waves");
+  constexpr int PPW = NPL / 4;                  // planes per wave
+  constexpr int WCH = C::NK * C::NTT * 64;      // weight floats per chunk
+  constexpr int WV4 = (WCH / 4 + 255) / 256;    // 16-byte copies per thread for the weights
+  static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)C::CIN * DHW * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
+  const int gx = x0 - 1 + lane;
+  const unsigned xvoff = (lane < C::P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+  auto stage = [&](int c0, float* buf) {
+    if (lane < C::P) {
 #pragma unroll
-    for (int cp = 0; cp < C::CK / 2; ++cp) {
+      for (int q = 0; q < PPW; ++q) {
+        const int pl = wave * PPW + q, cl = pl / C::ZS, zz = pl - cl * C::ZS;
+        const int gz = z0 - 1 + zz;
+        const bool zok = gz >= 0 && gz < D;
+        const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
+        float* dpl = buf + cl * C::CH_STRIDE + zz * C::PLANE;
 #pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        float a[C::NT];
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) a[nt] = wpc[((size_t)(cp * 27 + tap) * C::NTT + nt) * 64];
-        const float* bp = bbase + 2 * cp * C::CH_STRIDE + dz * C::PLANE + dy * C::P + dx;
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          const float bv = bp[mt * 32];
-#pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(a[nt], bv, acc[mt][nt]);
+        for (int yy = 0; yy < C::ROWS; ++yy) {
+          const int gy = y0 - 1 + yy;
+          const bool ok = zok && gy >= 0 && gy < H;
+          dma4(xrs, ok ? xvoff : DMA_OOB, ok ? zoff + (unsigned)gy * W * 4u : 0u, dpl + yy * C::P);
         }
       }
     }
+#pragma unroll
+    for (int i = 0; i < WV4; ++i) {
+      const int q4 = i * 256 + threadIdx.x;
+      if (q4 < WCH / 4)
+        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
+    }
+  };
+
+  constexpr int NC = C::CIN / C::CK;
+  stage(0, lds);
+  __syncthreads();
+  for (int ci = 0; ci < NC; ++ci) {
+    const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
+    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);  // lands while we compute
+    // ---- NK k-steps on the current buffer; A and B fragments register double-buffered one k-step ahead ----
+    const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
+    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + j;
+    float af[2][C::NT], bf[2][C::MT];
+    auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MT]) {
+      const int cp = ks / 27, tap = ks % 27;
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) a[nt] = abase[(ks * C::NTT + nt) * 64];
+      const float* bp = bbase + 2 * cp * C::CH_STRIDE + dz * C::PLANE + dy * C::P + dx;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[mt * 32];
+    };
+    load_frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < C::NK; ++ks) {
+      if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+      if (C::SCHED == 1) __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS reads ahead of this step's MFMAs
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(af[ks & 1][nt], bf[ks & 1][mt], acc[mt][nt]);
+      if (C::SCHED == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // the compiler drains the DMA (vmcnt(0)) here: next buffer complete, current one free
   }
 
   // ---- epilogue ----
   const int gz = z0 + wz;
   if (gz >= D) return;
-  float* yb = y + (size_t)b * C::COUT * D * HW;
-  const float* rb = res ? res + (size_t)b * C::COUT * D * HW : nullptr;
+  float* yb = y + (size_t)b * C::COUT * DHW;
+  const float* rb = res ? res + (size_t)b * C::COUT * DHW : nullptr;
 #pragma unroll
   for (int nt = 0; nt < C::NT; ++nt) {
+    const int co0 = (wn * C::NT + nt) * 32;
     float sc[16], sh[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = (wn * C::NT + nt) * 32 + cd_row(r, h);
+      const int co = co0 + cd_row(r, h);
       sc[r] = scale ? scale[co] : 1.f;
       sh[r] = shift ? shift[co] : 0.f;
     }
@@ -166,17 +254,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
     for (int mt = 0; mt < C::MT; ++mt) {
       const int m = mt * 32 + j;
       const int ly = m / C::P, lx = m - ly * C::P;
-      const int gy = y0 + ly, gx = x0 + lx;
-      if (m < C::TY * C::P && lx < C::TX && gy < H && gx < W) {
-        const size_t o = (size_t)gz * HW + (size_t)gy * W + gx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = (wn * C::NT + nt) * 32 + cd_row(r, h);
-          float v = fmaf(acc[mt][nt][r], sc[r], sh[r]);
-          if (rb) v += rb[(size_t)co * D * HW + o];
-          if (relu) v = fmaxf(v, 0.f);
-          yb[(size_t)co * D * HW + o] = v;
-        }
+      const int gy = y0 + ly, gxo = x0 + lx;
+      if (m < C::TY * C::P && lx < C::TX && gy < H && gxo < W) {
+        const f32x16 a1[1] = {acc[mt][nt]};
+        store_tile<1>(a1, sc, sh, rb, yb, co0, h, DHW, (unsigned)gz * HW + (unsigned)gy * W + gxo, relu);
       }
     }
   }
@@ -203,12 +284,16 @@ struct S2Cfg {
   static constexpr int NTT = COUT / 32;
   static constexpr int NT = NTT / WN;
   static constexpr int CH_STRIDE = ZS * ZPL + 72;
-  static constexpr int LDS_FLOATS = CK * CH_STRIDE;
-  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0, "shape");
+  static constexpr int NK = (CK / 2) * 27;
+  static constexpr int IN_FLOATS = CK * CH_STRIDE;
+  static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered: 1 workgroup per CU
+  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void conv3d_s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 1) void conv3d_s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ res, float* __restrict__ y, int D,
@@ -224,11 +309,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_s2_kernel(const float* __restri
   const int b = t / ntz;
   const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;  // output coordinates
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
-  const size_t HW = (size_t)H * W;
-  const float* xb = x + (size_t)b * C::CIN * D * HW;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const float* xb = x + (size_t)b * C::CIN * DHW;
 
   f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -238,56 +323,89 @@ __global__ __launch_bounds__(256, 2) void conv3d_s2_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const float* bbase = lds + h * C::CH_STRIDE + (2 * wz) * C::ZPL + 2 * j;
-
-  for (int c0 = 0; c0 < C::CIN; c0 += C::CK) {
-    __syncthreads();
-    constexpr int NR = C::CK * C::ZS * C::INROWS;
-    for (int r = wave; r < NR; r += 4) {
-      const int cl = r / (C::ZS * C::INROWS);
-      const int rem = r % (C::ZS * C::INROWS);
-      const int zz = rem / C::INROWS, ry = rem % C::INROWS;
-      const int gz = 2 * z0 - 1 + zz, gy = 2 * y0 - 1 + ry;
-      const bool rowok = gz >= 0 && gz < D && gy >= 0 && gy < H;
-      float* dst = lds + cl * C::CH_STRIDE + zz * C::ZPL + (ry & 1) * C::PYPL + (ry >> 1) * C::R;
-      const float* src = xb + ((size_t)(c0 + cl) * D + gz) * HW + (size_t)gy * W;
-      for (int col = lane; col < C::INCOLS; col += 64) {
-        const int gx = 2 * x0 - 1 + col;
-        dst[col] = (rowok && gx >= 0 && gx < W) ? src[gx] : 0.f;
-      }
-    }
-    __syncthreads();
-    const float* wpc = wp + ((size_t)(c0 / 2) * 27 * C::NTT + wn * C::NT) * 64 + lane;
+  // ---- staging (LDS-DMA): unit = (channel, input z-slice, 64-column pass) = INROWS row copies; dealt to the
+  // waves in contiguous runs (see conv3d_s1_kernel).  Rows go to the y-parity plane they belong to.
+  constexpr int NPASS = (C::INCOLS + 63) / 64;
+  constexpr int NUNIT = C::CK * C::ZS * NPASS;
+  static_assert(NUNIT % 4 == 0, "units are dealt evenly to the 4 waves");
+  constexpr int UPW = NUNIT / 4;
+  constexpr int WCH = C::NK * C::NTT * 64;
+  constexpr int WV4 = (WCH / 4 + 255) / 256;
+  static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)C::CIN * DHW * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
+  auto stage = [&](int c0, float* buf) {
 #pragma unroll
-    for (int cp = 0; cp < C::CK / 2; ++cp) {
+    for (int q = 0; q < UPW; ++q) {
+      const int uid = wave * UPW + q, pl = uid / NPASS, pass = uid - pl * NPASS;
+      const int cl = pl / C::ZS, zz = pl - cl * C::ZS;
+      const int gz = 2 * z0 - 1 + zz, col = pass * 64 + lane, gx = 2 * x0 - 1 + col;
+      const bool zok = gz >= 0 && gz < D;
+      const unsigned xvoff = (col < C::INCOLS && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+      const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
+      float* dpl = buf + cl * C::CH_STRIDE + zz * C::ZPL + pass * 64;
+      if (col < C::R) {
 #pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        float a[C::NT];
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) a[nt] = wpc[((size_t)(cp * 27 + tap) * C::NTT + nt) * 64];
-        const float* bp = bbase + 2 * cp * C::CH_STRIDE + dz * C::ZPL + (dy & 1) * C::PYPL + (dy >> 1) * C::R + dx;
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          const float bv = bp[mt * 64];
-#pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(a[nt], bv, acc[mt][nt]);
+        for (int ry = 0; ry < C::INROWS; ++ry) {
+          const int gy = 2 * y0 - 1 + ry;
+          const bool ok = zok && gy >= 0 && gy < H;
+          dma4(xrs, ok ? xvoff : DMA_OOB, ok ? zoff + (unsigned)gy * W * 4u : 0u,
+               dpl + (ry & 1) * C::PYPL + (ry >> 1) * C::R);
         }
       }
     }
+#pragma unroll
+    for (int i = 0; i < WV4; ++i) {
+      const int q4 = i * 256 + threadIdx.x;
+      if (q4 < WCH / 4)
+        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
+    }
+  };
+
+  constexpr int NC = C::CIN / C::CK;
+  stage(0, lds);
+  __syncthreads();
+  for (int ci = 0; ci < NC; ++ci) {
+    const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
+    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
+    const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
+    const float* bbase = cur + h * C::CH_STRIDE + (2 * wz) * C::ZPL + 2 * j;
+    float af[2][C::NT], bf[2][C::MT];
+    auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MT]) {
+      const int cp = ks / 27, tap = ks % 27;
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) a[nt] = abase[(ks * C::NTT + nt) * 64];
+      const float* bp = bbase + 2 * cp * C::CH_STRIDE + dz * C::ZPL + (dy & 1) * C::PYPL + (dy >> 1) * C::R + dx;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[mt * 64];
+    };
+    load_frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < C::NK; ++ks) {
+      if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(af[ks & 1][nt], bf[ks & 1][mt], acc[mt][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
   }
 
   const int gz = z0 + wz;
   if (gz >= Do) return;
-  const size_t HWo = (size_t)Ho * Wo;
-  float* yb = y + (size_t)b * C::COUT * Do * HWo;
-  const float* rb = res ? res + (size_t)b * C::COUT * Do * HWo : nullptr;
+  const unsigned HWo = (unsigned)Ho * Wo, DHWo = (unsigned)Do * HWo;
+  float* yb = y + (size_t)b * C::COUT * DHWo;
+  const float* rb = res ? res + (size_t)b * C::COUT * DHWo : nullptr;
 #pragma unroll
   for (int nt = 0; nt < C::NT; ++nt) {
+    const int co0 = (wn * C::NT + nt) * 32;
     float sc[16], sh[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = (wn * C::NT + nt) * 32 + cd_row(r, h);
+      const int co = co0 + cd_row(r, h);
       sc[r] = scale ? scale[co] : 1.f;
       sh[r] = shift ? shift[co] : 0.f;
     }
@@ -295,17 +413,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_s2_kernel(const float* __restri
     for (int mt = 0; mt < C::MT; ++mt) {
       const int m = mt * 32 + j;
       const int ly = m / C::PO, lx = m - ly * C::PO;
-      const int gy = y0 + ly, gx = x0 + lx;
-      if (m < C::TY * C::PO && lx < C::TX && gy < Ho && gx < Wo) {
-        const size_t o = (size_t)gz * HWo + (size_t)gy * Wo + gx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = (wn * C::NT + nt) * 32 + cd_row(r, h);
-          float v = fmaf(acc[mt][nt][r], sc[r], sh[r]);
-          if (rb) v += rb[(size_t)co * Do * HWo + o];
-          if (relu) v = fmaxf(v, 0.f);
-          yb[(size_t)co * Do * HWo + o] = v;
-        }
+      const int gy = y0 + ly, gxo = x0 + lx;
+      if (m < C::TY * C::PO && lx < C::TX && gy < Ho && gxo < Wo) {
+        const f32x16 a1[1] = {acc[mt][nt]};
+        store_tile<1>(a1, sc, sh, rb, yb, co0, h, DHWo, (unsigned)gz * HWo + (unsigned)gy * Wo + gxo, relu);
       }
     }
   }
@@ -330,108 +441,152 @@ struct DCfg {
   static constexpr int NTT = COUT / 32;
   static constexpr int NT = NTT / WN;
   static constexpr int CH_STRIDE = ZS * PLANE + 36;
-  static constexpr int LDS_FLOATS = CK * CH_STRIDE;
+  static constexpr int IN_FLOATS = CK * CH_STRIDE;
+  static constexpr int RUN = 9 * NTT * 64;                    // weight floats of one (channel pair, kz)
+  static constexpr int W_FLOATS = (CK / 2) * 2 * RUN;         // worst case: two kz taps (odd output z)
+  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;           // double buffered: 1 workgroup per CU
   static_assert(P <= 64, "one wave stages one tile row per instruction");
-  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0, "shape");
+  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <class C>
-__global__ __launch_bounds__(256, 2) void deconv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ shift,
-                                                          const float* __restrict__ res, float* __restrict__ y, int D,
-                                                          int H, int W, int ntx, int nty, int ntz, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int py = t & 1, pz = (t >> 1) & 1;
-  t >>= 2;
-  const int tx = t % ntx;
-  t /= ntx;
-  const int ty = t % nty;
-  t /= nty;
-  const int tz = t % ntz;
-  const int b = t / ntz;
-  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;  // input coordinates
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// Body for one z parity PZ.  A workgroup owns an input-resolution tile and produces the outputs of z parity PZ
+// for BOTH y parities and BOTH x parities (4 accumulator sets), so the staged input tile is used by every tap
+// that can touch it: per (channel pair, kz) unit 9*MT*NT MFMAs against 4*MT B reads and 9*NT A reads.
+template <class C, int PZ>
+__device__ __forceinline__ void deconv_body(float* lds, const float* __restrict__ x, const float* __restrict__ wp,
+                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                            const float* __restrict__ res, float* __restrict__ y, int D, int H, int W,
+                                            int b, int x0, int y0, int z0, int relu) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
-  const size_t HW = (size_t)H * W;
-  const float* xb = x + (size_t)b * C::CIN * D * HW;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const float* xb = x + (size_t)b * C::CIN * DHW;
 
-  f32x16 acc[2][C::MT][C::NT];
+  f32x16 acc[2][2][C::MT][C::NT];  // [py][px]
 #pragma unroll
-  for (int px = 0; px < 2; ++px)
+  for (int py = 0; py < 2; ++py)
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
+    for (int px = 0; px < 2; ++px)
 #pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt)
+      for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[px][mt][nt][r] = 0.f;
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[py][px][mt][nt][r] = 0.f;
 
-  const float* bbase = lds + h * C::CH_STRIDE + wz * C::PLANE + j;
-
-  for (int c0 = 0; c0 < C::CIN; c0 += C::CK) {
-    __syncthreads();
-    constexpr int NR = C::CK * C::ZS * C::ROWS;
-    for (int r = wave; r < NR; r += 4) {
-      const int cl = r / (C::ZS * C::ROWS);
-      const int rem = r % (C::ZS * C::ROWS);
-      const int zz = rem / C::ROWS, yy = rem % C::ROWS;
-      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + lane;
-      if (lane < C::P) {
-        float v = 0.f;
-        if (gz < D && gy < H && gx < W) v = xb[((size_t)(c0 + cl) * D + gz) * HW + (size_t)gy * W + gx];
-        lds[cl * C::CH_STRIDE + zz * C::PLANE + yy * C::P + lane] = v;
-      }
-    }
-    __syncthreads();
-    const float* wpc = wp + ((size_t)(c0 / 2) * 27 * C::NTT + wn * C::NT) * 64 + lane;
-#pragma unroll 1
-    for (int cp = 0; cp < C::CK / 2; ++cp) {
-#pragma unroll 1
-      for (int az = 0; az <= pz; ++az) {
-        const int kz = pz ? (az ? 0 : 2) : 1;  // az = input z offset
-#pragma unroll 1
-        for (int ay = 0; ay <= py; ++ay) {
-          const int ky = py ? (ay ? 0 : 2) : 1;
-          const float* wk = wpc + ((size_t)(cp * 27 + kz * 9 + ky * 3) * C::NTT) * 64;
-          const float* bp = bbase + 2 * cp * C::CH_STRIDE + az * C::PLANE + ay * C::P;
-          float a0[C::NT], a1[C::NT], a2[C::NT];
+  // ---- staging: planes (channel, z) dealt to the waves; weights: per channel pair the 9 (ky, kx) taps of each
+  // needed kz, laid out [cp][az][ky][kx][nt][64] with az = 0 -> kz = (PZ ? 2 : 1), az = 1 -> kz = 0.
+  constexpr int NAZ = 1 + PZ;
+  static_assert(C::CK % 4 == 0, "each wave stages whole channels");
+  constexpr int CPW = C::CK / 4;                        // channels per wave per chunk
+  constexpr int WCH4 = (C::CK / 2) * NAZ * C::RUN / 4;  // 16-byte copies per chunk
+  constexpr int WV4 = (WCH4 + 255) / 256;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)C::CIN * DHW * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
+  const int gx = x0 + lane;
+  const unsigned xvoff = (lane < C::P && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+  // weights: per channel pair the 9 (ky, kx) taps of each needed kz, laid out [cp][az][ky][kx][nt][64] with
+  // az = 0 -> kz = (PZ ? 2 : 1), az = 1 -> kz = 0.
+  auto stage = [&](int c0, float* buf) {
+    if (lane < C::P) {
 #pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) {
-            a0[nt] = wk[((size_t)0 * C::NTT + nt) * 64];
-            a1[nt] = wk[((size_t)1 * C::NTT + nt) * 64];
-            a2[nt] = wk[((size_t)2 * C::NTT + nt) * 64];
-          }
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int cl = wave * CPW + cc;
+        float* dc = buf + cl * C::CH_STRIDE;
 #pragma unroll
-          for (int mt = 0; mt < C::MT; ++mt) {
-            const float b0 = bp[mt * 32], b1 = bp[mt * 32 + 1];
+        for (int zz = 0; zz < C::ZS; ++zz) {
+          const bool zok = z0 + zz < D;
+          const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)(z0 + zz) * HW) * 4u;
 #pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt) {
-              acc[0][mt][nt] = DMB_MFMA(a1[nt], b0, acc[0][mt][nt]);  // even x: k=1, i=q
-              acc[1][mt][nt] = DMB_MFMA(a2[nt], b0, acc[1][mt][nt]);  // odd x:  k=2, i=q
-              acc[1][mt][nt] = DMB_MFMA(a0[nt], b1, acc[1][mt][nt]);  //         k=0, i=q+1
-            }
+          for (int yy = 0; yy < C::ROWS; ++yy) {
+            const bool ok = zok && y0 + yy < H;
+            dma4(xrs, ok ? xvoff : DMA_OOB, ok ? zoff + (unsigned)(y0 + yy) * W * 4u : 0u, dc + zz * C::PLANE + yy * C::P);
           }
         }
       }
     }
+#pragma unroll
+    for (int i = 0; i < WV4; ++i) {
+      const int q4 = i * 256 + (int)threadIdx.x;
+      if (q4 < WCH4) {
+        const int run = q4 / (C::RUN / 4), off = q4 - run * (C::RUN / 4);
+        const int cp = run / NAZ, az = run - cp * NAZ;
+        const int kz = PZ ? (az ? 0 : 2) : 1;
+        dma16(wrs, (unsigned)((((c0 / 2 + cp) * 27 + kz * 9) * C::NTT * 64) * 4 + off * 16), 0u,
+              buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
+      }
+    }
+  };
+
+  constexpr int NC = C::CIN / C::CK;
+  constexpr int NU = (C::CK / 2) * NAZ;  // (channel pair, az) units per chunk
+  stage(0, lds);
+  __syncthreads();
+  for (int ci = 0; ci < NC; ++ci) {
+    const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
+    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
+    const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
+    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + j;
+    float af[2][9][C::NT], bf[2][2][2][C::MT];  // bf[buf][ay][ox][mt]
+    auto load_frag = [&](int u, float (&a)[9][C::NT], float (&bq)[2][2][C::MT]) {
+      const int cp = u / NAZ, az = u % NAZ;
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) a[k][nt] = abase[(u * 9 + k) * C::NTT * 64 + nt * 64];
+      const float* bp = bbase + 2 * cp * C::CH_STRIDE + az * C::PLANE;
+#pragma unroll
+      for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) bq[ay][ox][mt] = bp[ay * C::P + ox + mt * 32];
+    };
+    load_frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (u + 1 < NU) load_frag(u + 1, af[(u + 1) & 1], bf[(u + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const auto& a = af[u & 1];
+      const auto& bq = bf[u & 1];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) {
+          // even y (py = 0): ky = 1 from input row ay = 0
+          acc[0][0][mt][nt] = DMB_MFMA(a[3 + 1][nt], bq[0][0][mt], acc[0][0][mt][nt]);  // even x: kx = 1, ox = 0
+          acc[0][1][mt][nt] = DMB_MFMA(a[3 + 2][nt], bq[0][0][mt], acc[0][1][mt][nt]);  // odd x:  kx = 2, ox = 0
+          acc[0][1][mt][nt] = DMB_MFMA(a[3 + 0][nt], bq[0][1][mt], acc[0][1][mt][nt]);  //         kx = 0, ox = 1
+          // odd y (py = 1): ky = 2 from ay = 0, ky = 0 from ay = 1
+          acc[1][0][mt][nt] = DMB_MFMA(a[6 + 1][nt], bq[0][0][mt], acc[1][0][mt][nt]);
+          acc[1][1][mt][nt] = DMB_MFMA(a[6 + 2][nt], bq[0][0][mt], acc[1][1][mt][nt]);
+          acc[1][1][mt][nt] = DMB_MFMA(a[6 + 0][nt], bq[0][1][mt], acc[1][1][mt][nt]);
+          acc[1][0][mt][nt] = DMB_MFMA(a[0 + 1][nt], bq[1][0][mt], acc[1][0][mt][nt]);
+          acc[1][1][mt][nt] = DMB_MFMA(a[0 + 2][nt], bq[1][0][mt], acc[1][1][mt][nt]);
+          acc[1][1][mt][nt] = DMB_MFMA(a[0 + 0][nt], bq[1][1][mt], acc[1][1][mt][nt]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
   }
 
-  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const int Ho = 2 * H, Wo = 2 * W;
   const int gzi = z0 + wz;
   if (gzi >= D) return;
-  const int gz = 2 * gzi + pz;
-  const size_t HWo = (size_t)Ho * Wo;
-  float* yb = y + (size_t)b * C::COUT * Do * HWo;
-  const float* rb = res ? res + (size_t)b * C::COUT * Do * HWo : nullptr;
+  const unsigned gz = 2 * gzi + PZ;
+  const unsigned HWo = (unsigned)Ho * Wo, DHWo = 2u * D * HWo;
+  float* yb = y + (size_t)b * C::COUT * DHWo;
+  const float* rb = res ? res + (size_t)b * C::COUT * DHWo : nullptr;
 #pragma unroll
   for (int nt = 0; nt < C::NT; ++nt) {
+    const int co0 = (wn * C::NT + nt) * 32;
     float sc[16], sh[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = (wn * C::NT + nt) * 32 + cd_row(r, h);
+      const int co = co0 + cd_row(r, h);
       sc[r] = scale ? scale[co] : 1.f;
       sh[r] = shift ? shift[co] : 0.f;
     }
@@ -441,26 +596,36 @@ __global__ __launch_bounds__(256, 2) void deconv3d_kernel(const float* __restric
       const int ly = m / C::P, lx = m - ly * C::P;
       const int gyi = y0 + ly, gxi = x0 + lx;
       if (m < C::TY * C::P && lx < C::TX && gyi < H && gxi < W) {
-        const size_t o = (size_t)gz * HWo + (size_t)(2 * gyi + py) * Wo + 2 * gxi;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = (wn * C::NT + nt) * 32 + cd_row(r, h);
-          float v0 = fmaf(acc[0][mt][nt][r], sc[r], sh[r]);
-          float v1 = fmaf(acc[1][mt][nt][r], sc[r], sh[r]);
-          if (rb) {
-            const float2 rv = *reinterpret_cast<const float2*>(rb + (size_t)co * Do * HWo + o);
-            v0 += rv.x;
-            v1 += rv.y;
-          }
-          if (relu) {
-            v0 = fmaxf(v0, 0.f);
-            v1 = fmaxf(v1, 0.f);
-          }
-          *reinterpret_cast<float2*>(yb + (size_t)co * Do * HWo + o) = make_float2(v0, v1);
+        for (int py = 0; py < 2; ++py) {
+          const f32x16 a2[2] = {acc[py][0][mt][nt], acc[py][1][mt][nt]};
+          store_tile<2>(a2, sc, sh, rb, yb, co0, h, DHWo, gz * HWo + (unsigned)(2 * gyi + py) * Wo + 2u * gxi, relu);
         }
       }
     }
   }
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 1) void deconv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ res, float* __restrict__ y, int D,
+                                                          int H, int W, int ntx, int nty, int ntz, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int pz = t & 1;
+  t >>= 1;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int tz = t % ntz;
+  const int b = t / ntz;
+  if (pz)
+    deconv_body<C, 1>(lds, x, wp, scale, shift, res, y, D, H, W, b, tx * C::TX, ty * C::TY, tz * C::TZ, relu);
+  else
+    deconv_body<C, 0>(lds, x, wp, scale, shift, res, y, D, H, W, b, tx * C::TX, ty * C::TY, tz * C::TZ, relu);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -589,7 +754,7 @@ template <class C>
 static int launch_deconv(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                          float* y, int B, int D, int H, int W, int relu, hipStream_t st) {
   const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
-  const long long nblk = 4LL * B * ntx * nty * ntz;
+  const long long nblk = 2LL * B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
@@ -626,16 +791,23 @@ extern "C" int dmb_deconv3d_pack_weights_f32(const float* w, float* wpack, int C
   return pack_common(w, wpack, Co, Ci, 1, stream);
 }
 
+static int g_dev_sched = 1;
+extern "C" void dmb_dev_set_option(int key, int value) {  // development knob, not part of the ABI
+  if (key == 0) g_dev_sched = value;
+}
+
 extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                  const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int stride, int relu, void* stream) {
   if (!x || !wpack || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
-    if (Ci == 32 && Co == 32) return launch_s1<S1Cfg<32, 32, 4, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 64 && Co == 32) return launch_s1<S1Cfg<64, 32, 4, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 64 && Co == 64) return launch_s1<S1Cfg<64, 64, 4, 60, 8, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 32 && Co == 64) return launch_s1<S1Cfg<32, 64, 4, 60, 8, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 32 && Co == 32 && g_dev_sched == 0) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 0>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 32 && Co == 32 && g_dev_sched == 2) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 32 && Co == 32) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 64 && Co == 32) return launch_s1<S1Cfg<64, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 64 && Co == 64) return launch_s1<S1Cfg<64, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 32 && Co == 64) return launch_s1<S1Cfg<32, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   } else if (stride == 2) {
     if (Ci == 32 && Co == 64) return launch_s2<S2Cfg<32, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 64 && Co == 64) return launch_s2<S2Cfg<64, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
@@ -648,8 +820,8 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
                                      int relu, void* stream) {
   if (!x || !wpack || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv3d: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  if (Ci == 64 && Co == 64) return launch_deconv<DCfg<64, 64, 2, 60, 16, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-  if (Ci == 64 && Co == 32) return launch_deconv<DCfg<64, 32, 2, 60, 16, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+  if (Ci == 64 && Co == 64) return launch_deconv<DCfg<64, 64, 2, 60, 8, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+  if (Ci == 64 && Co == 32) return launch_deconv<DCfg<64, 32, 2, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   return fail(DMB_EUNSUPPORTED, "deconv3d: (Ci, Co) not instantiated");
 }
 

@@ -1,0 +1,74 @@
+"""AcfNet confidence measurement network, inference side: drop-in for cmn/cmn.py:10-92."""
+import torch.nn as nn
+
+from .... import ops
+from ..layers.basic_layers import _versions, fold_batch_norm
+
+
+class ConfHead(nn.Module):
+    """Conv2d(in_planes -> in_planes//3, 3x3, no bias) + BN + ReLU + Conv2d(-> 1, 1x1, no bias), cmn.py:21-32.
+    ``state_dict`` keys as in the reference: conf_net.0.0.weight, conf_net.0.1.*, conf_net.1.weight.
+    ``forward`` returns the confidence MAP (sigmoid applied): the fused kernel never materialises the logit."""
+
+    def __init__(self, in_planes, batch_norm=True):
+        super().__init__()
+        self.in_planes = in_planes
+        self.sec_in_planes = int(in_planes // 3) if int(in_planes // 3) > 0 else 1
+        first = [nn.Conv2d(in_planes, self.sec_in_planes, 3, 1, 1, bias=False)]
+        if batch_norm:
+            first.append(nn.BatchNorm2d(self.sec_in_planes))
+        first.append(nn.ReLU(inplace=True))
+        self.conf_net = nn.Sequential(nn.Sequential(*first), nn.Conv2d(self.sec_in_planes, 1, 1, 1, 0, bias=False))
+        self.batch_norm = batch_norm
+        self._key, self._cache = None, None
+
+    def _prepacked(self):
+        conv1 = self.conf_net[0][0]
+        bn = self.conf_net[0][1] if self.batch_norm else None
+        conv2 = self.conf_net[1]
+        parts = [conv1.weight, conv2.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn else [])
+        key = _versions(*parts)
+        if key != self._key:
+            w1 = conv1.weight.detach()
+            scale, shift = fold_batch_norm(bn, None, self.sec_in_planes, w1.device)
+            if scale is None:
+                import torch
+                scale = torch.ones(self.sec_in_planes, device=w1.device)
+                shift = torch.zeros(self.sec_in_planes, device=w1.device)
+            self._key = key
+            self._cache = (ops.pack_conf_head_weights(w1), scale, shift, conv2.weight.detach().reshape(-1).contiguous())
+        return self._cache
+
+    def forward(self, cost):
+        wp, scale, shift, w2 = self._prepacked()
+        return ops.conf_head(cost, wp, scale, shift, w2)
+
+
+class Cmn(nn.Module):
+    """Eval-mode ``forward(costs, target=None) -> (cost_vars, confs)`` (cmn.py:57-84).  The training branch (NLL
+    loss on the confidence logits) is outside the HIP path."""
+
+    def __init__(self, cfg, in_planes, num, alpha, beta):
+        super().__init__()
+        self.cfg = cfg.copy()
+        batch_norm = self.cfg.model.batch_norm
+        self.conf_heads = nn.ModuleList([ConfHead(in_planes, batch_norm) for _ in range(num)])
+        self.alpha, self.beta = alpha, beta
+
+    def get_confidence(self, costs):
+        assert len(self.conf_heads) == len(costs), "NUM of confidence heads({}) must be equal to NUM" \
+                                                   "of cost volumes({})".format(len(self.conf_heads), len(costs))
+        confs = [head(cost) for cost, head in zip(costs, self.conf_heads)]
+        cost_vars = [self.alpha * (1 - conf) + self.beta for conf in confs]
+        return confs, cost_vars
+
+    def forward(self, costs, target=None):
+        if self.training:
+            raise NotImplementedError("Cmn training (confidence NLL loss) is outside the HIP inference path")
+        confs, cost_vars = self.get_confidence(costs)
+        return cost_vars, confs
+
+
+def build_cmn(cfg):
+    c = cfg.model.cmn
+    return Cmn(cfg, c.in_planes, c.num, c.alpha, c.beta)

@@ -1,0 +1,36 @@
+"""AcfNet cost aggregation: drop-in for cost_processors/aggregators/AcfNet.py:8-90."""
+import torch.nn as nn
+
+from ..... import ops
+from ...layers.basic_layers import HeadConv3d, conv3d_bn, conv3d_bn_relu
+from ..utils.hourglass import Hourglass
+from .PSMNet import PSMAggregator
+
+
+class AcfAggregator(PSMAggregator):
+    """Same trunk wiring as PSMAggregator but dres0/dres1/classif*.0 convs carry a bias (AcfNet.py:31-52 omit
+    ``bias=False``) and the up-sampling is three learned ConvTranspose3d(1, 1, 8, 4, 2) (AcfNet.py:55-57,81-83)."""
+
+    def __init__(self, max_disp, in_planes=64, batch_norm=True):
+        nn.Module.__init__(self)
+        self.max_disp, self.in_planes, self.batch_norm = max_disp, in_planes, batch_norm
+        bn = batch_norm
+        self.dres0 = nn.Sequential(conv3d_bn_relu(bn, in_planes, 32, 3, 1, 1), conv3d_bn_relu(bn, 32, 32, 3, 1, 1))
+        self.dres1 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1), conv3d_bn(bn, 32, 32, 3, 1, 1))
+        self.dres2 = Hourglass(in_planes=32, batch_norm=bn)
+        self.dres3 = Hourglass(in_planes=32, batch_norm=bn)
+        self.dres4 = Hourglass(in_planes=32, batch_norm=bn)
+        self.classif1 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1), HeadConv3d(32, bias=False))
+        self.classif2 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1), HeadConv3d(32, bias=False))
+        self.classif3 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1), HeadConv3d(32, bias=False))
+        self.deconv1 = nn.ConvTranspose3d(1, 1, 8, 4, 2, bias=False)
+        self.deconv2 = nn.ConvTranspose3d(1, 1, 8, 4, 2, bias=False)
+        self.deconv3 = nn.ConvTranspose3d(1, 1, 8, 4, 2, bias=False)
+
+    def forward(self, raw_cost):
+        B, C, D, H, W = raw_cost.shape
+        if D * 4 != self.max_disp:
+            raise ValueError("AcfAggregator up-samples exactly 4x: raw volume has %d planes, max_disp=%d" % (D, self.max_disp))
+        cost1, cost2, cost3 = self.trunk(raw_cost)
+        pairs = ((cost3, self.deconv3), (cost2, self.deconv2), (cost1, self.deconv1))
+        return [ops.deconv3d_k8s4_c1(c.squeeze(1), m.weight.detach().view(8, 8, 8)) for c, m in pairs]

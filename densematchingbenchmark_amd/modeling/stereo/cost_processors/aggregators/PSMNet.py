@@ -1,0 +1,45 @@
+"""PSMNet stacked-hourglass cost aggregation: drop-in for cost_processors/aggregators/PSMNet.py:9-95."""
+import torch.nn as nn
+
+from ..... import ops
+from ...layers.basic_layers import HeadConv3d, conv3d_bn, conv3d_bn_relu
+from ..utils.hourglass import Hourglass
+
+
+class PSMAggregator(nn.Module):
+    """raw_cost [B, in_planes, D/4, H/4, W/4] -> [cost3, cost2, cost1], each [B, max_disp, H, W] (best first).
+    25 fused MFMA conv launches + 3 head convs + 3 trilinear up-samplings; all biases absent (PSMNet.py:31-54)."""
+
+    def __init__(self, max_disp, in_planes=64, batch_norm=True):
+        super().__init__()
+        self.max_disp, self.in_planes, self.batch_norm = max_disp, in_planes, batch_norm
+        bn = batch_norm
+        self.dres0 = nn.Sequential(conv3d_bn_relu(bn, in_planes, 32, 3, 1, 1, bias=False),
+                                   conv3d_bn_relu(bn, 32, 32, 3, 1, 1, bias=False))
+        self.dres1 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1, bias=False),
+                                   conv3d_bn(bn, 32, 32, 3, 1, 1, bias=False))
+        self.dres2 = Hourglass(in_planes=32, batch_norm=bn)
+        self.dres3 = Hourglass(in_planes=32, batch_norm=bn)
+        self.dres4 = Hourglass(in_planes=32, batch_norm=bn)
+        self.classif1 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1, bias=False), HeadConv3d(32, bias=False))
+        self.classif2 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1, bias=False), HeadConv3d(32, bias=False))
+        self.classif3 = nn.Sequential(conv3d_bn_relu(bn, 32, 32, 3, 1, 1, bias=False), HeadConv3d(32, bias=False))
+
+    def trunk(self, raw_cost):
+        """PSMNet.py:58-72 at 1/4 resolution: returns (cost1, cost2, cost3), each [B, 1, D/4, H/4, W/4]."""
+        cost0 = self.dres0(raw_cost)
+        cost0 = self.dres1[1](self.dres1[0](cost0), residual=cost0)      # dres1(cost0) + cost0
+        out1, pre1, post1 = self.dres2(cost0, None, None, skip=cost0)    # out1 + cost0 fused into conv6
+        out2, pre2, post2 = self.dres3(out1, pre1, post1, skip=cost0)
+        out3, pre3, post3 = self.dres4(out2, pre2, post2, skip=cost0)
+        cost1 = self.classif1[1](self.classif1[0](out1))
+        cost2 = self.classif2[1](self.classif2[0](out2), residual=cost1)  # classif2(out2) + cost1
+        cost3 = self.classif3[1](self.classif3[0](out3), residual=cost2)
+        return cost1, cost2, cost3
+
+    def forward(self, raw_cost):
+        B, C, D, H, W = raw_cost.shape
+        cost1, cost2, cost3 = self.trunk(raw_cost)
+        size = (self.max_disp, H * 4, W * 4)                             # PSMNet.py:75-88, align_corners=True
+        up = [ops.trilinear_ac(c.squeeze(1), size) for c in (cost3, cost2, cost1)]
+        return up

@@ -1,0 +1,54 @@
+"""cost_processors/builder.py:21-107: cost processors = volume builder + aggregator, selected by config strings."""
+import torch.nn as nn
+
+from .aggregators import build_cost_aggregator
+from .utils.cat_fms import CAT_FUNCS
+from .utils.dif_fms import DIF_FUNCS
+from .utils.gwc_fms import COR_FUNCS
+
+
+class _VolumeThenAggregate(nn.Module):
+    """Shared body of Cat/Dif/CorCostProcessor (builder.py:21-86): pick the builder function from ``FUNCS`` by
+    ``cost_computation.type``, keep the remaining keys as its kwargs, build the aggregator."""
+    FUNCS = None
+
+    def __init__(self, cfg):
+        super().__init__()
+        comp = cfg.model.cost_processor.cost_computation
+        self.vol_func = self.FUNCS[comp.get('type', 'default')]
+        self.default_args = comp.copy()
+        self.default_args.pop('type')
+        self.aggregator = build_cost_aggregator(cfg)
+
+    def forward(self, ref_fms, tgt_fms, disp_sample=None):
+        raw_cost = self.vol_func(ref_fms, tgt_fms, disp_sample=disp_sample, **self.default_args)
+        return self.aggregator(raw_cost)
+
+
+class CatCostProcessor(_VolumeThenAggregate):
+    FUNCS = CAT_FUNCS
+
+
+class DifCostProcessor(_VolumeThenAggregate):
+    FUNCS = DIF_FUNCS
+
+
+class CorCostProcessor(_VolumeThenAggregate):
+    FUNCS = COR_FUNCS
+
+
+PROCESSORS = {
+    'Difference': DifCostProcessor,
+    'Concatenation': CatCostProcessor,
+    'Correlation': CorCostProcessor,
+}
+_OFF_PATH = ('DeepPruner', 'AnyNet')
+
+
+def build_cost_processor(cfg):
+    proc_type = cfg.model.cost_processor.type
+    if proc_type in _OFF_PATH:
+        raise NotImplementedError("cost_processor '%s' is outside the HIP hot path" % proc_type)
+    assert proc_type in PROCESSORS, "cost_processor type not found, excepted: {}," \
+                                    "but got {}".format(PROCESSORS.keys(), proc_type)
+    return PROCESSORS[proc_type](cfg=cfg)

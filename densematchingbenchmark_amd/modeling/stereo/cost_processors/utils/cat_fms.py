@@ -1,0 +1,21 @@
+"""Concatenation cost volume: drop-in for dmb/modeling/stereo/cost_processors/utils/cat_fms.py (``CAT_FUNCS``)."""
+from ..... import ops
+
+
+def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
+    """[B, C, H, W] x 2 -> [B, 2C, D, H, W]; same arguments and semantics as cat_fms.py:7-48 (``disp_sample`` is
+    ignored there too).  One HIP kernel launch instead of 2*D strided slice copies; output is FP32 (cat_fms.py:32)."""
+    idx = ops.disp_index_list(max_disp, start_disp, dilation)
+    return ops.cat_fms(reference_fm.float(), target_fm.float(), idx)
+
+
+def fast_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
+    """cat_fms.py:51-82 depends on F.grid_sample's torch-version-specific align_corners default and is not
+    equivalent to cat_fms; it is outside the HIP path."""
+    raise NotImplementedError("cost_computation type 'fast_mode' is not on the HIP path; use type='default'")
+
+
+CAT_FUNCS = dict(
+    default=cat_fms,
+    fast_mode=fast_cat_fms,
+)

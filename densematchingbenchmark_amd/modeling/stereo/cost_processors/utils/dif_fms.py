@@ -1,0 +1,20 @@
+"""Difference cost volume: drop-in for dmb/modeling/stereo/cost_processors/utils/dif_fms.py (``DIF_FUNCS``)."""
+from ..... import ops
+
+
+def dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None,
+            normalize=False, p=1.0):
+    """[B, C, H, W] x 2 -> [B, C, D, H, W] (dif_fms.py:7-46; ``normalize``/``p`` are unused there as well)."""
+    idx = ops.disp_index_list(max_disp, start_disp, dilation)
+    return ops.dif_fms(reference_fm.float(), target_fm.float(), idx)
+
+
+def fast_dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None,
+                 normalize=False, p=1.0):
+    raise NotImplementedError("cost_computation type 'fast_mode' is not on the HIP path; use type='default'")
+
+
+DIF_FUNCS = dict(
+    default=dif_fms,
+    fast_mode=fast_dif_fms,
+)

@@ -1,0 +1,36 @@
+"""FasterSoftArgmin: drop-in for disp_predictors/faster_soft_argmin.py:6-75."""
+import torch
+import torch.nn as nn
+
+from .... import ops
+from .soft_argmin import _SoftArgminBase
+
+
+class FasterSoftArgmin(_SoftArgminBase):
+    """Keeps the frozen ``disp_regression`` Conv3d(1, 1, (D, 1, 1)) so that ``state_dict`` matches the reference
+    (``disp_predictor.disp_regression.weight`` [1, 1, D, 1, 1], faster_soft_argmin.py:46-49); the forward reads
+    the sample values from that weight and runs the same fused kernel as SoftArgmin.  ``disp_sample`` is ignored,
+    as in the reference (:28-29)."""
+
+    def __init__(self, max_disp, start_disp=0, dilation=1, alpha=1.0, normalize=True):
+        super().__init__(max_disp, start_disp, dilation, alpha, normalize)
+        disp_sample = torch.linspace(self.start_disp, self.end_disp, self.disp_sample_number)
+        self.disp_regression = nn.Conv3d(1, 1, (self.disp_sample_number, 1, 1), 1, 0, bias=False)
+        self.disp_regression.weight.data = disp_sample.view(1, 1, -1, 1, 1).clone()
+        self.disp_regression.weight.requires_grad = False
+        self._vals_key, self._vals = None, None
+
+    def _sample_values(self):
+        w = self.disp_regression.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if key != self._vals_key:
+            self._vals_key, self._vals = key, w.detach().reshape(-1).cpu().tolist()
+        return self._vals
+
+    def forward(self, cost_volume, disp_sample=None):
+        self._check(cost_volume)
+        return ops.soft_argmin(cost_volume, self._sample_values(), self.alpha, self.normalize)
+
+    @property
+    def name(self):
+        return 'FasterSoftArgmin'

@@ -1,0 +1,42 @@
+"""The caller of the hot path: eval-mode contract of models/general_stereo_model.py:14-92.
+
+The 2-D feature backbone is NOT part of this path: pass any ``nn.Module`` with the reference's
+``backbone(left, right) -> (ref_fms, tgt_fms)`` contract (e.g. the reference's own PSMNetBackbone on stock
+PyTorch-ROCm), or feed pre-computed features with ``batch['leftFeature'] / batch['rightFeature']``."""
+import torch
+import torch.nn as nn
+
+from ..cmn import build_cmn
+from ..cost_processors import build_cost_processor
+from ..disp_predictors import build_disp_predictor
+
+
+class GeneralizedStereoModel(nn.Module):
+    def __init__(self, cfg, backbone=None):
+        super().__init__()
+        self.cfg = cfg.copy()
+        self.max_disp = cfg.model.max_disp
+        self.backbone = backbone
+        self.cost_processor = build_cost_processor(cfg)
+        self.cmn = build_cmn(cfg) if 'cmn' in cfg.model else None
+        self.disp_predictor = build_disp_predictor(cfg)
+        if 'disp_refinement' in cfg.model and cfg.model.get('require_refinement', False):
+            raise NotImplementedError("disp_refinement is outside the HIP hot path (SURVEY 8-f2)")
+
+    def forward(self, batch):
+        if self.training:
+            raise NotImplementedError("training (losses, backward) is outside the HIP inference path")
+        if 'leftFeature' in batch:
+            ref_fms, tgt_fms = batch['leftFeature'], batch['rightFeature']
+        else:
+            if self.backbone is None:
+                raise ValueError("no backbone attached: provide batch['leftFeature'] and batch['rightFeature']")
+            ref_fms, tgt_fms = self.backbone(batch['leftImage'], batch['rightImage'])
+        with torch.no_grad():
+            costs = self.cost_processor(ref_fms, tgt_fms)            # general_stereo_model.py:51
+            disps = [self.disp_predictor(cost) for cost in costs]    # :54
+            results = dict(disps=disps, costs=costs)                 # :82-85
+            if self.cmn is not None:
+                variance, confs = self.cmn(costs, batch.get('leftDisp'))  # :87-90
+                results.update(confs=confs)
+        return results, {}

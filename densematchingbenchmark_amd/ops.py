@@ -26,6 +26,48 @@ def disp_sample_values(max_disp, start_disp=0, dilation=1):
     return [float(v) for v in torch.linspace(start_disp, end_disp, n)]
 
 
+class KernelTimer:
+    """HIP-event timing of selected launches on the stream they are enqueued on (torch's current stream is the
+    stream handed to the C ABI).  Used by bench.py to measure the dominant kernel's launch duration live inside
+    the timed region; disabled (None) otherwise."""
+
+    def __init__(self, tags):
+        self.tags = set(tags)
+        self.events = {t: [] for t in self.tags}
+        self._open = None
+
+    def start(self, tag):
+        if tag in self.tags:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._open = (tag, e0)
+
+    def stop(self, tag):
+        if self._open is not None and self._open[0] == tag:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.events[tag].append((self._open[1], e1))
+            self._open = None
+
+    def reset(self):
+        self.events = {t: [] for t in self.tags}
+
+    def mean_ms(self, tag):
+        ev = self.events[tag]
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else float("nan")
+
+    def count(self, tag):
+        return len(self.events[tag])
+
+
+_kernel_timer = None
+
+
+def set_kernel_timer(timer):
+    global _kernel_timer
+    _kernel_timer = timer
+
+
 def _f32c(t, name):
     if t.dtype != torch.float32:
         raise _lib.DmbLibraryError("%s must be float32, got %s" % (name, t.dtype))
@@ -109,9 +151,14 @@ def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, rel
     y = torch.empty((B, Co, Do, Ho, Wo), dtype=torch.float32, device=x.device)
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    tag = "conv3d_k3_s%d_%dto%d" % (stride, Ci, Co)
+    if _kernel_timer is not None:
+        _kernel_timer.start(tag)
     check(lib.dmb_conv3d_k3_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                 dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
                                 B, Ci, Co, D, H, W, stride, int(bool(relu)), stream_ptr(x.device)), "dmb_conv3d_k3_f32")
+    if _kernel_timer is not None:
+        _kernel_timer.stop(tag)
     return y
 
 

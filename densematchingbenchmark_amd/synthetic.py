@@ -1,0 +1,82 @@
+"""Seeded synthetic weights and inputs for benchmarks and smoke tests (no datasets / checkpoints offline).
+
+Weights: PyTorch default initialisation drawn from an explicit generator, BatchNorm statistics moved away from
+(0, 1), and the three classifier output convolutions scaled by ``classif_gain`` so that the regressed cost
+volumes are peaked instead of the degenerate near-constant volume default init produces.
+Inputs: feature maps ``randn`` seeded by ``1234 + global_pair_index`` and a smooth synthetic
+ground-truth disparity field in (1, 150) px."""
+import math
+
+import torch
+
+
+def init_params_(module, seed=0, classif_gain=30.0):
+    """In-place, deterministic re-initialisation of every parameter/buffer of a cost-processor style module."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        shape = tuple(v.shape)
+        if k.endswith("disp_regression.weight"):
+            continue  # frozen disparity samples of FasterSoftArgmin
+        if k.endswith("running_var"):
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif k.endswith("running_mean"):
+            t = (torch.rand(shape, generator=g) - 0.5) * 0.2
+        elif v.dim() == 1 and k.endswith(".1.weight"):      # BatchNorm gamma inside a (conv, bn[, relu]) unit
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif v.dim() == 1:                                   # conv bias / BatchNorm beta
+            t = (torch.rand(shape, generator=g) - 0.5) * 0.2
+        else:                                                # conv weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+            fan_in = v[0].numel() if "deconv" not in k and not _is_transposed(module, k) else v[:, 0].numel()
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(max(fan_in, 1))
+            if any(k.endswith("classif%d.1.weight" % i) for i in (1, 2, 3)) or k.endswith("lastconv.weight"):
+                t = t * classif_gain
+            if "deconv" in k:                                # AcfNet's learned 4x up-sampling: keep O(1) gain
+                t = t * 8.0
+        new[k] = t.to(v.dtype)
+    module.load_state_dict(new, strict=False)
+    return module
+
+
+def _is_transposed(module, key):
+    name = key.rsplit(".", 1)[0]
+    try:
+        sub = module.get_submodule(name)
+    except AttributeError:
+        return False
+    return isinstance(sub, (torch.nn.ConvTranspose3d, torch.nn.ConvTranspose2d))
+
+
+def feature_pair(global_pair_index, channels, height, width, device="cpu"):
+    """Left/right feature maps [1, C, H, W] for one stereo pair."""
+    g = torch.Generator().manual_seed(1234 + int(global_pair_index))
+    left = torch.randn((1, channels, height, width), generator=g)
+    right = torch.randn((1, channels, height, width), generator=g)
+    return left.to(device), right.to(device)
+
+
+def feature_batch(first_pair_index, stride, batch, channels, height, width, device="cpu"):
+    """Batch of pairs ``first, first+stride, ...`` -- the reference shards pair i to rank i mod world
+    (tools/test.py:108), so a rank's local batch is strided by the world size."""
+    pairs = [feature_pair(first_pair_index + j * stride, channels, height, width) for j in range(batch)]
+    left = torch.cat([p[0] for p in pairs]).to(device)
+    right = torch.cat([p[1] for p in pairs]).to(device)
+    return left, right
+
+
+def gt_disparity(global_pair_index, batch, height, width, pad_top=0, device="cpu"):
+    """Smooth ground-truth field in (1, 150) px, zero in the padded rows (masked out by lower_bound=0)."""
+    g = torch.Generator().manual_seed(4321 + int(global_pair_index))
+    ph = torch.rand((batch, 4), generator=g) * 6.283
+    ys = torch.linspace(0, 1, height).view(1, height, 1)
+    xs = torch.linspace(0, 1, width).view(1, 1, width)
+    f = (torch.sin(2.5 * ys + ph[:, 0].view(-1, 1, 1)) * torch.cos(3.5 * xs + ph[:, 1].view(-1, 1, 1))
+         + torch.sin(1.5 * (xs + ys) + ph[:, 2].view(-1, 1, 1)))
+    d = 75.5 + 37.0 * f
+    d = d.clamp(1.5, 149.5)
+    if pad_top > 0:
+        d[:, :pad_top, :] = 0.0
+    return d.unsqueeze(1).contiguous().to(device)

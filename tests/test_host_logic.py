@@ -1,0 +1,148 @@
+"""CPU-side tests: C-ABI exports, config loader, registries, state-dict interop, loud failure without a GPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from densematchingbenchmark_amd import _lib, ops
+from densematchingbenchmark_amd.config import Config
+from tests._util import golden
+
+PSM_CFG = dict(
+    model=dict(
+        meta_architecture="GeneralizedStereoModel", max_disp=192, batch_norm=True,
+        cost_processor=dict(type='Concatenation',
+                            cost_computation=dict(type="default", max_disp=48, start_disp=0, dilation=1),
+                            cost_aggregator=dict(type="PSMNet", max_disp=192, in_planes=64)),
+        disp_predictor=dict(type='FASTER', max_disp=192, start_disp=0, dilation=1, alpha=1.0, normalize=True),
+    ))
+
+
+def _cfg(**over):
+    cfg = Config(PSM_CFG)
+    for k, v in over.items():
+        node = cfg
+        parts = k.split("__")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    syms = _lib.header_symbols()
+    assert len(syms) >= 23
+    for s in syms:
+        assert hasattr(lib, s), "libdmb_hip.so does not export %s" % s
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes table and include/dmb_hip.h disagree"
+    assert lib.dmb_abi_version() == 1
+    assert lib.dmb_conv3d_packed_floats(32, 64) == 32 * 64 * 27
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate arguments before touching the device, so this runs on a CPU-only box."""
+    lib = _lib.load()
+    idx = ops.host_ints([0])
+    assert lib.dmb_cat_fms_f32(None, None, None, 1, 1, 1, 1, 1, idx, None) == 100001
+    assert b"volume" in lib.dmb_last_error()
+    assert lib.dmb_conv3d_k3_f32(None, None, None, None, None, None, 1, 32, 32, 4, 4, 4, 1, 0, None) == 100001
+    assert lib.dmb_soft_argmin_f32(None, None, 1, 4, 2, 2, 1.0, 1, ops.host_floats([0, 1, 2, 3]), None) == 100001
+
+
+def test_no_cpu_fallback():
+    x = torch.zeros(1, 4, 2, 2)
+    with pytest.raises(_lib.DmbLibraryError, match="no CPU fallback"):
+        ops.soft_argmin(x, [0.0, 1.0, 2.0, 3.0])
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.cat_fms(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4), [0, 1])
+
+
+def test_disp_lists_match_reference_convention():
+    assert ops.disp_index_list(6, 0, 2) == [0, 2, 5]          # truncation of an FP32 linspace
+    assert ops.disp_index_list(5, -2, 2) == [-2, 0, 2]
+    assert ops.disp_sample_values(9, -4, 2) == [-4.0, -2.0, 0.0, 2.0, 4.0]
+
+
+def test_config_loader_reads_reference_style_files(tmp_path):
+    f = tmp_path / "cfg.py"
+    f.write_text("import os.path as osp\nmax_disp = 64\nmodel = dict(max_disp=max_disp, batch_norm=True,\n"
+                 "  cost_processor=dict(type='Concatenation', cost_computation=dict(type='default', max_disp=int(max_disp // 4))))\n")
+    cfg = Config.fromfile(str(f))
+    assert cfg.model.cost_processor.cost_computation.max_disp == 16
+    c = cfg.model.cost_processor.cost_computation.copy()
+    assert c.pop('type') == 'default' and 'type' in cfg.model.cost_processor.cost_computation
+    assert cfg.model.get('cmn') is None and 'osp' not in cfg
+
+
+def test_registries_and_builders():
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors import PROCESSORS, build_cost_processor
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.aggregators import AGGREGATORS
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import CAT_FUNCS
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.dif_fms import DIF_FUNCS
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.gwc_fms import COR_FUNCS
+    from densematchingbenchmark_amd.modeling.stereo.disp_predictors import PREDICTORS, build_disp_predictor
+    assert set(PROCESSORS) == {'Difference', 'Concatenation', 'Correlation'}
+    assert {'PSMNet', 'AcfNet', 'StereoNet'} <= set(AGGREGATORS)
+    assert set(CAT_FUNCS) == {'default', 'fast_mode'} and set(DIF_FUNCS) == {'default', 'fast_mode'}
+    assert 'default' in COR_FUNCS and set(PREDICTORS) == {'DEFAULT', 'FASTER', 'LOCAL'}
+    cp = build_cost_processor(_cfg())
+    assert cp.default_args == dict(max_disp=48, start_disp=0, dilation=1)
+    assert type(cp.aggregator).__name__ == 'PSMAggregator' and cp.aggregator.max_disp == 192
+    with pytest.raises(AssertionError):
+        build_cost_processor(_cfg(model__cost_processor__type='Nope'))
+    with pytest.raises(NotImplementedError):
+        build_cost_processor(_cfg(model__cost_processor__type='AnyNet'))
+    dp = build_disp_predictor(_cfg(model__disp_predictor__type='LOCAL', model__disp_predictor__radius=3))
+    assert dp.name == 'LocalSoftArgmin' and dp.radius == 3
+    with pytest.raises(ValueError, match="expected 4D input"):
+        build_disp_predictor(_cfg())(torch.zeros(2, 3, 4))
+
+
+@pytest.mark.parametrize("tag,rel", [("psmnet", "PSMNet/scene_flow.py"), ("acfnet", "AcfNet/scene_flow_adaptive.py"),
+                                     ("stereonet", "StereoNet/scene_flow_8x_2stage.py")])
+def test_state_dict_keys_match_reference(tag, rel):
+    """Checkpoint interop: same parameter/buffer names and shapes as the reference's modules."""
+    from densematchingbenchmark_amd.modeling import build_model
+    want = set(str(s) for s in golden("state_dict_keys.npz")[tag])
+    cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", rel)
+    cfg = Config.fromfile(cfg_path)
+    model = build_model(cfg)
+    got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items())
+    assert got == want, (sorted(got - want)[:5], sorted(want - got)[:5])
+    n = {"psmnet": 154, "acfnet": 185, "stereonet": 31}[tag]
+    assert len(got) == n
+
+
+def test_bn_fold_matches_batch_norm():
+    from densematchingbenchmark_amd.modeling.stereo.layers.basic_layers import fold_batch_norm
+    bn = torch.nn.BatchNorm3d(8).eval()
+    g = torch.Generator().manual_seed(0)
+    bn.weight.data, bn.bias.data = torch.rand(8, generator=g) + 0.5, torch.rand(8, generator=g) - 0.5
+    bn.running_mean, bn.running_var = torch.rand(8, generator=g) - 0.5, torch.rand(8, generator=g) + 0.5
+    bias = torch.rand(8, generator=g)
+    x = torch.randn(2, 8, 3, 4, 5, generator=g)
+    scale, shift = fold_batch_norm(bn, bias, 8, x.device)
+    ref = bn(x + bias.view(1, -1, 1, 1, 1))
+    assert (x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) - ref).abs().max().item() <= 1e-6
+
+
+def test_modules_refuse_training_and_cpu():
+    from densematchingbenchmark_amd.modeling import build_model
+    m = build_model(_cfg())
+    feats = dict(leftFeature=torch.zeros(1, 32, 16, 16), rightFeature=torch.zeros(1, 32, 16, 16))
+    with pytest.raises(NotImplementedError):
+        m.train()(feats)
+    with pytest.raises(_lib.DmbLibraryError):
+        m.eval()(feats)
+
+
+def test_remove_padding_views():
+    from densematchingbenchmark_amd.evaluation import remove_padding
+    x = torch.arange(2 * 1 * 6 * 8, dtype=torch.float32).view(2, 1, 6, 8)
+    y = remove_padding(x, (4, 5))
+    assert y.shape == (2, 1, 4, 5) and torch.equal(y, x[:, :, 2:, :5])
+    assert remove_padding(x, (9, 5)).shape == x.shape            # negative pad_top: untouched (eval.py:26-29)
+    assert remove_padding({"a": [x]}, (4, 5))["a"][0].shape == (2, 1, 4, 5)

@@ -1,0 +1,120 @@
+"""Pin the CPU oracle (oracle/dmb_oracle.py) against vectors produced by the REAL reference
+(tests/golden/*.npz, written by oracle/gen_golden.py in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dmb_oracle as O
+from tests._util import golden, maxdiff, rand, sha
+
+
+def test_disp_index_truncation():
+    # max_disp=6, dilation=2 -> [0, 2, 5] (int() of an FP32 linspace)
+    assert O.disp_index_list(6, 0, 2) == [0, 2, 5]
+    assert O.disp_index_list(5, -2, 2) == [-2, 0, 2]
+    assert O.disp_index_list(48, 0, 1) == list(range(48))
+
+
+def test_volumes_known_answer_and_seeded():
+    g = golden("volumes.npz")
+    L = torch.arange(1, 13, dtype=torch.float32).view(1, 1, 3, 4)
+    R = torch.arange(13, 25, dtype=torch.float32).view(1, 1, 3, 4)
+    assert np.array_equal(O.cat_fms(L, R, 5, -2, 2).numpy(), g["ka_cat"])
+    assert np.array_equal(O.dif_fms(L, R, 5, -2, 2).numpy(), g["ka_dif"])
+    # the values the reference's own test prints (tests/.../test_cat_fms.py:30-40)
+    assert g["ka_cat"][0, 0, :, 0].tolist() == [[1, 2, 0, 0], [1, 2, 3, 4], [0, 0, 3, 4]]
+    assert g["ka_cat"][0, 1, :, 0].tolist() == [[15, 16, 0, 0], [13, 14, 15, 16], [0, 0, 13, 14]]
+    assert g["ka_dif"][0, 0, :, 0].tolist() == [[-14, -14, 0, 0], [-12, -12, -12, -12], [0, 0, -10, -10]]
+    for i, row in enumerate(g["cases"]):
+        shape, (md, sd, dil, seed) = tuple(int(v) for v in row[:4]), (int(v) for v in row[4:])
+        a, b = rand(shape, seed), rand(shape, seed + 1000)
+        c, d = O.cat_fms(a, b, md, sd, dil), O.dif_fms(a, b, md, sd, dil)
+        assert sha(c) == str(g["cat_sha_%d" % i]) and sha(d) == str(g["dif_sha_%d" % i])  # bit-exact
+        if "cat_%d" % i in g:
+            assert np.array_equal(c.numpy(), g["cat_%d" % i]) and np.array_equal(d.numpy(), g["dif_%d" % i])
+
+
+def test_predictors():
+    g = golden("predictors.npz")
+    ones = torch.ones(1, 5, 2, 2)
+    kw = dict(max_disp=9, start_disp=-4, dilation=2, alpha=1.0)
+    assert maxdiff(O.soft_argmin(ones, **kw), g["ka_soft"]) <= 1e-7
+    assert maxdiff(O.faster_soft_argmin(ones, **kw), g["ka_faster"]) <= 1e-7
+    assert np.array_equal(O.local_soft_argmin(ones, radius=2, **kw)[0].numpy(), g["ka_local"])
+    assert float(g["ka_local"].max()) == -2.0 and abs(float(g["ka_soft"].max())) < 1e-6
+    for tag in ("flat", "peaked", "d192"):
+        D, seed = (int(v) for v in g[tag + "_meta"])
+        cost = rand((2, D, 6, 10), seed, float(g[tag + "_gain"][0]))
+        assert maxdiff(O.soft_argmin(cost, D), g[tag + "_soft"]) <= 2e-5
+        assert maxdiff(O.faster_soft_argmin(cost, D), g[tag + "_faster"]) <= 2e-5
+        disp, idx = O.local_soft_argmin(cost, D, 2)
+        assert np.array_equal(idx.numpy(), g[tag + "_argmax"])          # index path bit-exact
+        assert maxdiff(disp, g[tag + "_local"]) <= 2e-5
+        # the FP64 truth is where the reference's two FP32 variants meet (within ~1e-4 at D=192)
+        assert maxdiff(O.soft_argmin_f64(cost, D).float(), g[tag + "_faster"]) <= 1.5e-4
+    cost = rand((1, 12, 4, 6), 204, 5.0)
+    assert maxdiff(O.soft_argmin(cost, 24, -6, 2, 0.7), g["dil_soft"]) <= 1e-5
+    assert maxdiff(O.local_soft_argmin(cost, 24, 3, -6, 2, 2, 0.7)[0], g["dil_local"]) <= 1e-5
+    assert maxdiff(O.soft_argmin(cost, 12, 0, 1, 0.5, normalize=False), g["nonorm_soft"]) <= 1e-4
+    samp = rand((1, 12, 4, 6), 205, 10.0)
+    assert maxdiff(O.soft_argmin(cost, 12, disp_sample=samp), g["sampled_soft"]) <= 1e-5
+
+
+def test_aggregators():
+    g = golden("aggregators.npz")
+    raw = rand((1, 64, 8, 16, 32), 301)
+    p = O.random_params_psm(seed=0, classif_gain=30.0)
+    costs = O.psm_aggregator(raw, p, 32)
+    for c, k in zip(costs, ("psm_cost3", "psm_cost2", "psm_cost1")):
+        assert maxdiff(c[:, ::4, ::8, :], g[k]) <= 1e-5
+    for c, k in zip(costs, ("psm_disp3", "psm_disp2", "psm_disp1")):
+        assert maxdiff(O.faster_soft_argmin(c, 32), g[k]) <= 1e-5
+    assert np.ptp(g["psm_cost3"]) > 2.0  # the fixture is peaked, not the degenerate default-init volume
+    # hourglass wiring incl. presqu/postsqu cross links
+    c0 = O.conv3d_unit(O.conv3d_unit(raw, p, "dres0.0", relu=True), p, "dres0.1", relu=True)
+    c0 = O.conv3d_unit(O.conv3d_unit(c0, p, "dres1.0", relu=True), p, "dres1.1") + c0
+    o1, pre1, post1 = O.hourglass(c0, None, None, p, "dres2")
+    assert maxdiff(o1[:, ::8], g["hg_out"]) <= 1e-5 and maxdiff(pre1[:, ::16], g["hg_pre"]) <= 1e-5
+    assert maxdiff(post1[:, ::16], g["hg_post"]) <= 1e-5
+    o2, pre2, post2 = O.hourglass(o1 + c0, pre1, post1, p, "dres3")
+    assert maxdiff(o2[:, ::8], g["hg2_out"]) <= 1e-5 and maxdiff(pre2[:, ::16], g["hg2_pre"]) <= 1e-5
+    assert maxdiff(post2[:, ::16], g["hg2_post"]) <= 1e-5
+
+    p = O.random_params_psm(seed=1, classif_gain=30.0, acf=True)
+    costs = O.acf_aggregator(raw, p, 32)
+    for c, k in zip(costs, ("acf_cost3", "acf_cost2", "acf_cost1")):
+        assert maxdiff(c[:, ::4, ::8, :], g[k]) <= 2e-5
+    for i, c in enumerate(costs):
+        hp = {"h." + k[len("confp_%d_" % i):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("confp_%d_" % i)}
+        conf, conf_cost = O.conf_head(c, hp, "h")
+        assert maxdiff(conf_cost, g["conf_cost_%d" % i]) <= 2e-5 and maxdiff(conf, g["conf_%d" % i]) <= 1e-5
+
+    sp = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("snp_")}
+    cost = O.stereonet_aggregator(rand((2, 32, 6, 10, 20), 302), sp)[0]
+    assert maxdiff(cost, g["sn_cost"]) <= 1e-5
+
+
+def test_psmnet_path_cfg1():
+    """BASELINE config #1 (PSMNet, 256x512, max_disp 64) through the reference's own builders."""
+    g = golden("psmnet_path_cfg1.npz")
+    p = O.with_prefix(O.random_params_psm(seed=2, classif_gain=30.0), "cost_processor.aggregator.")
+    lf, rf = rand((1, 32, 64, 128), 401), rand((1, 32, 64, 128), 402)
+    disps, costs = O.psmnet_path(lf, rf, p, 64)
+    for i, (d, c) in enumerate(zip(disps, costs)):
+        assert maxdiff(d[:, :, ::2, ::2], g["disp%d" % (3 - i)]) <= 2e-5
+        assert maxdiff(c[:, ::8, ::32, :], g["cost%d_rows" % (3 - i)]) <= 2e-5
+
+
+def test_evaluation():
+    g = golden("evaluation.npz")
+    gen = torch.Generator().manual_seed(501)
+    gt = torch.rand((3, 1, 20, 32), generator=gen) * 220 - 10
+    est = gt + torch.randn((3, 1, 20, 32), generator=gen) * 3
+    gt[2] = -1.0
+    crop = O.remove_padding(est, (17, 30))
+    assert list(crop.shape) == g["cropped_shape"].tolist() and sha(crop) == str(g["cropped_sha"])
+    for b in range(3):
+        e = O.calc_error(O.remove_padding(est[b:b + 1], (17, 30)), O.remove_padding(gt[b:b + 1], (17, 30)), 0, 192)
+        got = np.array([e[k] for k in ("epe", "1px", "2px", "3px", "5px")])
+        assert np.allclose(got, g["img%d" % b], rtol=1e-6, atol=1e-6)
+    assert g["img2"].tolist() == [0, 0, 0, 0, 0]
