@@ -113,7 +113,7 @@ def main():
     B = args.batch
 
     model = build_model(cfg).eval()
-    synthetic.init_params_(model, seed=0, classif_gain=30.0)
+    synthetic.init_params_(model, seed=0, classif_gain=10.0)
     model = model.to(dev)
     n_ids = len(cfg.get("eval_disparity_id", [0]))
 

@@ -634,16 +634,18 @@ __global__ __launch_bounds__(256, 1) void deconv3d_kernel(const float* __restric
 // uniform (scalar loads -> SGPR operands of v_fmac_f32), each thread produces 4 consecutive x from 6-float
 // LDS rows.  acc order: ci ascending, then (kd, kh, kw) ascending -- the same FP32 fma chain as above.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int C1_TX = 64, C1_TY = 4, C1_TZ = 4, C1_CK = 4;
-constexpr int C1_P = C1_TX + 4;  // 66 used, even pitch keeps 8-byte alignment
-constexpr int C1_PLANE = (C1_TY + 2) * C1_P;
-constexpr int C1_CH = (C1_TZ + 2) * C1_PLANE;
+constexpr int C1_TX = 60, C1_TY = 4, C1_TZ = 4, C1_CK = 4;
+constexpr int C1_P = C1_TX + 2;                   // 62: one LDS-DMA row per wave instruction, even pitch (8-byte reads)
+constexpr int C1_ROWS = C1_TY + 2, C1_ZS = C1_TZ + 2;
+constexpr int C1_PLANE = C1_ROWS * C1_P;
+constexpr int C1_CH = C1_ZS * C1_PLANE + 4;
+constexpr int C1_BUF = C1_CK * C1_CH;
 
-__global__ __launch_bounds__(256) void conv3d_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        float bias, const float* __restrict__ res,
-                                                        float* __restrict__ y, int Ci, int D, int H, int W, int ntx,
-                                                        int nty, int ntz) {
-  __shared__ float lds[C1_CK * C1_CH];
+__global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float bias, const float* __restrict__ res,
+                                                           float* __restrict__ y, int Ci, int D, int H, int W, int ntx,
+                                                           int nty, int ntz) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 * C1_BUF floats
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
   t /= ntx;
@@ -652,61 +654,88 @@ __global__ __launch_bounds__(256) void conv3d_c1_kernel(const float* __restrict_
   const int tz = t % ntz;
   const int b = t / ntz;
   const int x0 = tx * C1_TX, y0 = ty * C1_TY, z0 = tz * C1_TZ;
-  const size_t HW = (size_t)H * W;
-  const float* xb = x + (size_t)b * Ci * D * HW;
-  const int lxq = threadIdx.x & 15;         // 16 threads x 4 outputs along x
-  const int lyz = threadIdx.x >> 4;         // 16 (y, z) rows
-  const int ly = lyz & 3, lz = lyz >> 2;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const float* xb = x + (size_t)b * Ci * DHW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // compute mapping: 15 threads x 4 outputs along x, 16 (y, z) rows; threads 240..255 only help staging
+  const int lxq = threadIdx.x % 15, lyz = threadIdx.x / 15;
+  const bool worker = lyz < 16;
+  const int ly = lyz & 3, lz = (lyz >> 2) & 3;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
-  for (int c0 = 0; c0 < Ci; c0 += C1_CK) {
-    __syncthreads();
-    constexpr int NR = C1_CK * (C1_TZ + 2) * (C1_TY + 2);
-    for (int r = wave; r < NR; r += 4) {
-      const int cl = r / ((C1_TZ + 2) * (C1_TY + 2));
-      const int rem = r % ((C1_TZ + 2) * (C1_TY + 2));
-      const int zz = rem / (C1_TY + 2), yy = rem % (C1_TY + 2);
-      const int gz = z0 - 1 + zz, gy = y0 - 1 + yy;
-      const bool rowok = (c0 + cl) < Ci && gz >= 0 && gz < D && gy >= 0 && gy < H;
-      for (int col = lane; col < C1_TX + 2; col += 64) {
-        const int gx = x0 - 1 + col;
-        lds[cl * C1_CH + zz * C1_PLANE + yy * C1_P + col] =
-            (rowok && gx >= 0 && gx < W) ? xb[((size_t)(c0 + cl) * D + gz) * HW + (size_t)gy * W + gx] : 0.f;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
+  const int gx = x0 - 1 + lane;
+  const unsigned xvoff = (lane < C1_P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+  constexpr int PPW = C1_CK * C1_ZS / 4;  // 6 planes per wave per chunk
+  auto stage = [&](int c0, float* buf) {
+    if (lane < C1_P) {
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) {
+        const int pl = wave * PPW + q, cl = pl / C1_ZS, zz = pl - cl * C1_ZS;
+        const int gz = z0 - 1 + zz;
+        const bool zok = gz >= 0 && gz < D && c0 + cl < Ci;
+        const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
+        float* dpl = buf + cl * C1_CH + zz * C1_PLANE;
+#pragma unroll
+        for (int yy = 0; yy < C1_ROWS; ++yy) {
+          const int gy = y0 - 1 + yy;
+          const bool ok = zok && gy >= 0 && gy < H;
+          dma4(xrs, ok ? xvoff : DMA_OOB, ok ? zoff + (unsigned)gy * W * 4u : 0u, dpl + yy * C1_P);
+        }
+      }
+    }
+  };
+
+  const int NC = (Ci + C1_CK - 1) / C1_CK;
+  stage(0, lds);
+  __syncthreads();
+  for (int ci = 0; ci < NC; ++ci) {
+    const float* cur = lds + (ci & 1) * C1_BUF;
+    if (ci + 1 < NC) stage((ci + 1) * C1_CK, lds + ((ci + 1) & 1) * C1_BUF);
+    if (worker) {
+#pragma unroll
+      for (int cl = 0; cl < C1_CK; ++cl) {
+        const int c = ci * C1_CK + cl;
+        const float* wc = w + (size_t)min(c, Ci - 1) * 27;  // channels past Ci were staged as zeros
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const float* row = cur + cl * C1_CH + (lz + dz) * C1_PLANE + (ly + dy) * C1_P + lxq * 4;
+            const float2 q0 = *reinterpret_cast<const float2*>(row);
+            const float2 q1 = *reinterpret_cast<const float2*>(row + 2);
+            const float2 q2 = *reinterpret_cast<const float2*>(row + 4);
+            const float v[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const float wv = wc[dz * 9 + dy * 3 + dx];
+#pragma unroll
+              for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + dx], wv, acc[o]);
+            }
+          }
       }
     }
     __syncthreads();
-    const int nc = (Ci - c0) < C1_CK ? (Ci - c0) : C1_CK;
-    for (int cl = 0; cl < nc; ++cl) {
-      const float* wc = w + (size_t)(c0 + cl) * 27;
+  }
+  const int gz = z0 + lz, gy = y0 + ly, gxo = x0 + lxq * 4;
+  if (worker && gz < D && gy < H && gxo < W) {
+    const size_t o = (size_t)b * DHW + (size_t)gz * HW + (size_t)gy * W + gxo;
+    if ((W & 3) == 0) {  // gxo % 4 == 0 and W % 4 == 0: the four outputs are one aligned 16-byte word
+      float4 v = make_float4(acc[0] + bias, acc[1] + bias, acc[2] + bias, acc[3] + bias);
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(y + o) = v;
+    } else {
 #pragma unroll
-      for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const float* row = lds + cl * C1_CH + (lz + dz) * C1_PLANE + (ly + dy) * C1_P + lxq * 4;
-          const float2 q0 = *reinterpret_cast<const float2*>(row);
-          const float2 q1 = *reinterpret_cast<const float2*>(row + 2);
-          const float2 q2 = *reinterpret_cast<const float2*>(row + 4);
-          const float v[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const float wv = wc[dz * 9 + dy * 3 + dx];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + dx], wv, acc[o]);
-          }
+      for (int i = 0; i < 4; ++i)
+        if (gxo + i < W) {
+          float v = acc[i] + bias;
+          if (res) v += res[o + i];
+          y[o + i] = v;
         }
     }
-  }
-  const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lxq * 4;
-  if (gz < D && gy < H) {
-    const size_t o = (size_t)b * D * HW + (size_t)gz * HW + (size_t)gy * W + gx;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (gx + i < W) {
-        float v = acc[i] + bias;
-        if (res) v += res[o + i];
-        y[o + i] = v;
-      }
   }
 }
 
@@ -800,6 +829,8 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
                                  const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int stride, int relu, void* stream) {
   if (!x || !wpack || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d: bad argument");
+  if ((long long)(Ci > Co ? Ci : Co) * D * H * W * 4 >= 0x7fffffffLL)
+    return fail(DMB_EUNSUPPORTED, "conv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
     if (Ci == 32 && Co == 32 && g_dev_sched == 0) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 0>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
@@ -819,6 +850,8 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
                                      const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                      int relu, void* stream) {
   if (!x || !wpack || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv3d: bad argument");
+  if ((long long)(Ci > 8 * Co ? Ci : 8 * Co) * D * H * W * 4 >= 0x7fffffffLL)
+    return fail(DMB_EUNSUPPORTED, "deconv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   if (Ci == 64 && Co == 64) return launch_deconv<DCfg<64, 64, 2, 60, 8, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   if (Ci == 64 && Co == 32) return launch_deconv<DCfg<64, 32, 2, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
@@ -831,7 +864,15 @@ extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, 
   const int ntx = cdiv(W, C1_TX), nty = cdiv(H, C1_TY), ntz = cdiv(D, C1_TZ);
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: grid too large");
-  hipLaunchKernelGGL(conv3d_c1_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, w, bias, residual, y,
+  const size_t lds = (size_t)2 * C1_BUF * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_c1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  if ((long long)Ci * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: tensor too large for 32-bit offsets");
+  hipLaunchKernelGGL(conv3d_c1_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, x, w, bias, residual, y,
                      Ci, D, H, W, ntx, nty, ntz);
   return launch_status("conv3d_c1 launch failed");
 }

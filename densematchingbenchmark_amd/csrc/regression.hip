@@ -8,14 +8,23 @@
 // AcfNet.py:55-57,81-83, data/datasets/evaluation/stereo/pixel_error.py:6-73.
 #include "dmb_common.h"
 
+// No implicit fma contraction in this file: the interpolation index/weight arithmetic must round exactly like the
+// reference's (ATen CPU) float code -- src = scale * dst rounded, THEN lambda = src - floor(src) -- or lambda moves
+// by an ulp of src (~6e-5 at src ~ 900) and the up-sampled costs with it.  Explicit fmaf() calls are unaffected.
+#pragma clang fp contract(off)
+
 namespace dmb {
 
 // ---------------------------------------------------------------------------------------------------------
-// Online soft-argmin state for one pixel.  exp in FP32 (v_exp_f32 path via __expf), sum(e) and sum(e*d) in
+// Online soft-argmin state for one pixel.  exp in FP32 (__expf), sum(e) and sum(e*d) in
 // FP64 so that the result is the correctly rounded quotient; the reference's own FP32 evaluation sits up to
 // ~1e-4 from this at D=192 on flat distributions.
 // ---------------------------------------------------------------------------------------------------------
 struct SoftState {
+  // Lazy running maximum: the reference point m moves only when a block maximum exceeds it by more than
+  // SOFT_SLACK, so a pixel sees at most (cost range / SOFT_SLACK) + 1 rescales instead of up to D on monotone cost
+  // profiles (each rescale multiplies by an inexact exp); terms may exceed 1 (<= e^SOFT_SLACK), sums are FP64.
+  static constexpr float SOFT_SLACK = 11.0f;
   float m;
   double s, t;
   __device__ void init() {
@@ -29,10 +38,10 @@ struct SoftState {
     float bm = v[0];
 #pragma unroll
     for (int i = 1; i < N; ++i) bm = fmaxf(bm, v[i]);
-    if (bm > m) {
-      const float f = __expf(m - bm);  // m = -inf on the first block -> f = 0
-      s *= (double)f;
-      t *= (double)f;
+    if (bm > m + SOFT_SLACK) {
+      const double f = (m == -INFINITY) ? 0.0 : (double)__expf(m - bm);
+      s *= f;
+      t *= f;
       m = bm;
     }
 #pragma unroll

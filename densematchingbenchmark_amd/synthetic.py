@@ -10,7 +10,7 @@ import math
 import torch
 
 
-def init_params_(module, seed=0, classif_gain=30.0):
+def init_params_(module, seed=0, classif_gain=10.0):
     """In-place, deterministic re-initialisation of every parameter/buffer of a cost-processor style module."""
     g = torch.Generator().manual_seed(seed)
     sd = module.state_dict()

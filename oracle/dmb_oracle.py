@@ -315,7 +315,7 @@ def psmnet_path(ref_fms, tgt_fms, p, max_disp, scale=4, alpha=1.0, prefix="cost_
     return disps, costs
 
 
-def random_params_psm(seed=0, in_planes=64, classif_gain=30.0, bias=False, acf=False):
+def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs
     are peaked (SURVEY 8-c fixture recipe).  BN statistics are randomised away from (0, 1) so that a wrong

@@ -63,13 +63,13 @@ def test_predictors():
 def test_aggregators():
     g = golden("aggregators.npz")
     raw = rand((1, 64, 8, 16, 32), 301)
-    p = O.random_params_psm(seed=0, classif_gain=30.0)
+    p = O.random_params_psm(seed=0, classif_gain=10.0)
     costs = O.psm_aggregator(raw, p, 32)
     for c, k in zip(costs, ("psm_cost3", "psm_cost2", "psm_cost1")):
         assert maxdiff(c[:, ::4, ::8, :], g[k]) <= 1e-5
     for c, k in zip(costs, ("psm_disp3", "psm_disp2", "psm_disp1")):
         assert maxdiff(O.faster_soft_argmin(c, 32), g[k]) <= 1e-5
-    assert np.ptp(g["psm_cost3"]) > 2.0  # the fixture is peaked, not the degenerate default-init volume
+    assert np.ptp(g["psm_cost3"]) > 1.0  # the fixture is peaked, not the degenerate default-init volume (ptp ~ 8e-3)
     # hourglass wiring incl. presqu/postsqu cross links
     c0 = O.conv3d_unit(O.conv3d_unit(raw, p, "dres0.0", relu=True), p, "dres0.1", relu=True)
     c0 = O.conv3d_unit(O.conv3d_unit(c0, p, "dres1.0", relu=True), p, "dres1.1") + c0
@@ -80,7 +80,7 @@ def test_aggregators():
     assert maxdiff(o2[:, ::8], g["hg2_out"]) <= 1e-5 and maxdiff(pre2[:, ::16], g["hg2_pre"]) <= 1e-5
     assert maxdiff(post2[:, ::16], g["hg2_post"]) <= 1e-5
 
-    p = O.random_params_psm(seed=1, classif_gain=30.0, acf=True)
+    p = O.random_params_psm(seed=1, classif_gain=10.0, acf=True)
     costs = O.acf_aggregator(raw, p, 32)
     for c, k in zip(costs, ("acf_cost3", "acf_cost2", "acf_cost1")):
         assert maxdiff(c[:, ::4, ::8, :], g[k]) <= 2e-5
@@ -97,7 +97,7 @@ def test_aggregators():
 def test_psmnet_path_cfg1():
     """BASELINE config #1 (PSMNet, 256x512, max_disp 64) through the reference's own builders."""
     g = golden("psmnet_path_cfg1.npz")
-    p = O.with_prefix(O.random_params_psm(seed=2, classif_gain=30.0), "cost_processor.aggregator.")
+    p = O.with_prefix(O.random_params_psm(seed=2, classif_gain=10.0), "cost_processor.aggregator.")
     lf, rf = rand((1, 32, 64, 128), 401), rand((1, 32, 64, 128), 402)
     disps, costs = O.psmnet_path(lf, rf, p, 64)
     for i, (d, c) in enumerate(zip(disps, costs)):
