@@ -44,7 +44,7 @@ SIGNATURES = {
     "dmb_conf_head_packed_floats": (_c_ll, [_c_int, _c_int]),
     "dmb_conf_head_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conf_head_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 5 + [_P]),
-    "dmb_epe_accum_f64": (_c_int, [_P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
+    "dmb_epe_accum_f64": (_c_int, [_P, _P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
 }
 
 

@@ -346,12 +346,15 @@ __global__ __launch_bounds__(256) void deconv_k8s4_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// EPE accumulator: one workgroup per image.
+// EPE accumulator.  Pass 1: EPE_SLICES workgroups per image reduce a slice each and add six partial sums to the
+// per-image workspace; pass 2: one thread per image turns them into the image's means and adds those to acc.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void epe_kernel(const float* __restrict__ est, const float* __restrict__ gt,
-                                                   double* __restrict__ acc, int Hp, int Wp, int H0, int W0, float lb,
-                                                   float ub) {
-  const int b = blockIdx.x;
+constexpr int EPE_SLICES = 64;
+
+__global__ __launch_bounds__(256) void epe_partial_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                          double* __restrict__ ws, int Hp, int Wp, int H0, int W0,
+                                                          float lb, float ub) {
+  const int b = blockIdx.y;
   // eval.py:24-29: pad_top = Hp - H0; the crop [pad_top:, :W0] is applied only when pad_top >= 0
   const bool crop = Hp - H0 >= 0;
   const int top = crop ? Hp - H0 : 0;
@@ -360,10 +363,10 @@ __global__ __launch_bounds__(1024) void epe_kernel(const float* __restrict__ est
   const float* e = est + (size_t)b * Hp * Wp;
   const float* g = gt + (size_t)b * Hp * Wp;
   double sum = 0.0;
-  unsigned long long cnt = 0, n1 = 0, n2 = 0, n3 = 0, n5 = 0;
+  unsigned cnt = 0, n1 = 0, n2 = 0, n3 = 0, n5 = 0;
   const int total = rows * cols;
-  for (int i = threadIdx.x; i < total; i += 1024) {
-    const int r = i / cols, c = i % cols;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += EPE_SLICES * 256) {
+    const int r = i / cols, c = i - r * cols;
     const size_t o = (size_t)(top + r) * Wp + c;
     const float gv = g[o];
     if (gv > lb && gv < ub) {
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(1024) void epe_kernel(const float* __restrict__ est
       n5 += a > 5.f;
     }
   }
-  __shared__ double sh[6][16];
+  __shared__ double sh[6][4];
   double v[6] = {(double)cnt, sum, (double)n1, (double)n2, (double)n3, (double)n5};
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -385,20 +388,23 @@ __global__ __launch_bounds__(1024) void epe_kernel(const float* __restrict__ est
     if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double r[6];
-    for (int k = 0; k < 6; ++k) {
-      r[k] = 0.0;
-      for (int w = 0; w < 16; ++w) r[k] += sh[k][w];
-    }
-    atomicAdd(&acc[0], 1.0);
-    if (r[0] >= 1.0) {  // pixel_error.py:48: an empty mask yields all-zero errors for this image
-      atomicAdd(&acc[1], r[1] / r[0]);
-      atomicAdd(&acc[2], 100.0 * r[2] / r[0]);
-      atomicAdd(&acc[3], 100.0 * r[3] / r[0]);
-      atomicAdd(&acc[4], 100.0 * r[4] / r[0]);
-      atomicAdd(&acc[5], 100.0 * r[5] / r[0]);
-    }
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    atomicAdd(&ws[b * 6 + k], sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3]);
+  }
+}
+
+__global__ void epe_finalize_kernel(const double* __restrict__ ws, double* __restrict__ acc, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* r = ws + b * 6;
+  atomicAdd(&acc[0], 1.0);
+  if (r[0] >= 1.0) {  // pixel_error.py:48: an empty mask yields all-zero errors for this image
+    atomicAdd(&acc[1], r[1] / r[0]);
+    atomicAdd(&acc[2], 100.0 * r[2] / r[0]);
+    atomicAdd(&acc[3], 100.0 * r[3] / r[0]);
+    atomicAdd(&acc[4], 100.0 * r[4] / r[0]);
+    atomicAdd(&acc[5], 100.0 * r[5] / r[0]);
   }
 }
 
@@ -498,10 +504,14 @@ extern "C" int dmb_deconv3d_k8s4_c1_f32(const float* x, const float* w, float* y
   return launch_status("deconv_k8s4 launch failed");
 }
 
-extern "C" int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, int B, int Hp, int Wp, int H0,
-                                 int W0, float lb, float ub, void* stream) {
-  if (!est || !gt || !acc || B <= 0 || Hp <= 0 || Wp <= 0 || H0 <= 0 || W0 <= 0)
+extern "C" int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* workspace, int B, int Hp,
+                                 int Wp, int H0, int W0, float lb, float ub, void* stream) {
+  if (!est || !gt || !acc || !workspace || B <= 0 || B > 65535 || Hp <= 0 || Wp <= 0 || H0 <= 0 || W0 <= 0)
     return fail(DMB_EINVAL, "epe_accum: bad argument");
-  hipLaunchKernelGGL(epe_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, est, gt, acc, Hp, Wp, H0, W0, lb, ub);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 6 * B, st);
+  if (e != hipSuccess) return fail((int)e, "epe_accum: workspace memset failed");
+  hipLaunchKernelGGL(epe_partial_kernel, dim3(EPE_SLICES, B), dim3(256), 0, st, est, gt, workspace, Hp, Wp, H0, W0, lb, ub);
+  hipLaunchKernelGGL(epe_finalize_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, workspace, acc, B);
   return launch_status("epe_accum launch failed");
 }

@@ -288,6 +288,7 @@ def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
     H0, W0 = original_size
     if acc.dtype != torch.float64 or acc.numel() != 6:
         raise _lib.DmbLibraryError("acc must be a float64[6] tensor")
-    check(lib.dmb_epe_accum_f64(dev_ptr(est), dev_ptr(gt), dev_ptr(acc), B, Hp, Wp, int(H0), int(W0),
+    ws = torch.empty((B, 6), dtype=torch.float64, device=est.device)
+    check(lib.dmb_epe_accum_f64(dev_ptr(est), dev_ptr(gt), dev_ptr(acc), dev_ptr(ws), B, Hp, Wp, int(H0), int(W0),
                                 float(lower_bound), float(upper_bound), stream_ptr(est.device)), "dmb_epe_accum_f64")
     return acc

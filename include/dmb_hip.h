@@ -170,9 +170,10 @@ int dmb_conf_head_f32(const float* cost, const float* w1pack, const float* scale
  * columns [0, W0); mask = gt > lb && gt < ub; if the mask is non-empty
  *     acc[0] += 1; acc[1] += mean|gt-est|; acc[2..5] += 100 * mean(|gt-est| > {1,2,3,5})
  * (an empty mask contributes an image with all-zero errors, pixel_error.py:48-55).  acc: 6 doubles on
- * the device, accumulated atomically; the caller zeroes it and all-reduces it across ranks. */
-int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, int B, int Hp, int Wp, int H0, int W0,
-                      float lb, float ub, void* stream);
+ * the device, accumulated atomically; the caller zeroes it and all-reduces it across ranks.  workspace: 6*B
+ * doubles of caller-owned device scratch (cleared by the call on `stream`). */
+int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* workspace, int B, int Hp, int Wp,
+                      int H0, int W0, float lb, float ub, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: two processes over gloo.  The HIP kernels cannot run here, so each rank fills its accumulator
+rows from the oracle's per-image errors for ITS shard (pair i -> rank i mod world); the test checks the sharding,
+the single SUM all-reduce and the mean-over-images summary against the oracle evaluated on the whole dataset."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from densematchingbenchmark_amd.evaluation import EpeAccumulator, local_batches, shard_indices
+from oracle import dmb_oracle as O
+
+NUM_PAIRS, WORLD = 7, 2
+
+
+def _pair(i):
+    g = torch.Generator().manual_seed(9000 + i)
+    gt = torch.rand((1, 1, 12, 20), generator=g) * 220 - 10
+    est = gt + torch.randn((1, 1, 12, 20), generator=g) * 2
+    return est, gt
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    acc = EpeAccumulator(torch.device("cpu"), 1, 0, 192)
+    mine = shard_indices(NUM_PAIRS, rank, world)
+    for chunk in local_batches(mine, 2):
+        for i in chunk:
+            est, gt = _pair(i)
+            e = O.calc_error(O.remove_padding(est, (10, 18)), O.remove_padding(gt, (10, 18)), 0, 192)
+            acc.acc[0] += torch.tensor([1.0] + [e[k] for k in ("epe", "1px", "2px", "3px", "5px")], dtype=torch.float64)
+    acc.all_reduce()
+    s = acc.summary()[0]
+    out.put((rank, mine, int(acc.acc[0, 0].item()), [s[k] for k in ("epe", "1px", "2px", "3px", "5px")]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_indices_partition():
+    all_idx = sorted(i for r in range(4) for i in shard_indices(10, r, 4))
+    assert all_idx == list(range(10)) and shard_indices(10, 1, 4) == [1, 5, 9]
+    assert local_batches([0, 2, 4, 6, 8], 2) == [[0, 2], [4, 6], [8]]
+
+
+def test_two_rank_all_reduce_matches_whole_dataset():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(WORLD)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ests, gts = zip(*[_pair(i) for i in range(NUM_PAIRS)])
+    ref, n = O.dataset_metrics(list(ests), list(gts), (10, 18), 0, 192)
+    shards = sorted(i for _, mine, _, _ in got for i in mine)
+    assert shards == list(range(NUM_PAIRS))
+    for rank, mine, count, vals in got:
+        assert count == NUM_PAIRS == n          # every rank sees the whole-job image count after the all-reduce
+        assert np.allclose(vals, [ref[k] for k in ("epe", "1px", "2px", "3px", "5px")], rtol=1e-9, atol=1e-9)
