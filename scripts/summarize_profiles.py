@@ -1,0 +1,76 @@
+"""Turn the rocprofv3 CSVs of scripts/profile.sh (under gpurun_out/prof_<tag>/) into the small tracked files under
+profiles/: per-kernel time stats, per-kernel PMC means, and pmc_dominant.json (HBM bytes per launch of the dominant
+kernel, which bench.py reports as roofline.traffic).
+
+Counter handling follows MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+counts 64 B per 128-B request, i.e. HALF the bytes actually fetched -- calibrated here on soft_argmin_kernel, whose
+one pass over the [4,192,544,960] FP32 volume must fetch 1.604 GB -- so fetch bytes = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE is exact (trilinear_kernel writes exactly 1.604 GB)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+DST = os.path.join(ROOT, "profiles")
+os.makedirs(DST, exist_ok=True)
+
+
+def short(name):
+    n = name.replace("void ", "").replace("dmb::", "")
+    return n.split("(")[0]
+
+
+rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "trace_kernel_stats.csv"))))
+with open(os.path.join(DST, tag + "_kernel_stats.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 5 --warmup 2  (MI355X, batch 4)\n")
+    f.write("kernel,calls,total_ms,avg_us,percent,min_us,max_us\n")
+    for r in rows:
+        if float(r["Percentage"]) < 0.05:
+            continue
+        f.write("%s,%s,%.3f,%.1f,%s,%.1f,%.1f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                  float(r["AverageNs"]) / 1e3, r["Percentage"], float(r["MinNs"]) / 1e3,
+                                                  float(r["MaxNs"]) / 1e3))
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    path = os.path.join(SRC, d, "pmc_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if d == "pmc_sq" and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+counters = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_BUSY_CYCLES",
+            "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]
+with open(os.path.join(DST, tag + "_pmc.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --pmc <one group per pass> -- python bench.py --no-cpu-baseline --steps 1 --warmup 1; "
+            "means per launch.  hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction, see "
+            "scripts/summarize_profiles.py); mfma_util = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); "
+            "mfma_gflop = MOPS_F32 * 512 / 1e9\n")
+    f.write("kernel,launches," + ",".join(counters) + ",hbm_bytes,mfma_util,mfma_gflop,pmc_pass_us\n")
+    for k, v in sorted(pmc.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
+        if not k.startswith(("conv3d", "deconv3d", "trilinear", "soft_argmin", "volume", "epe", "conf_head", "gwc")):
+            continue
+        m = {c: (sum(v[c]) / len(v[c]) if v.get(c) else float("nan")) for c in counters}
+        hbm = 2 * m["FETCH_SIZE"] * 1024 + m["WRITE_SIZE"] * 1024
+        util = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024) if m["GRBM_GUI_ACTIVE"] == m["GRBM_GUI_ACTIVE"] else float("nan")
+        f.write("%s,%d,%s,%.4g,%.4f,%.2f,%.1f\n" % (k, len(v.get("GRBM_GUI_ACTIVE", v.get("FETCH_SIZE", []))),
+                                                   ",".join("%.6g" % m[c] for c in counters), hbm, util,
+                                                   m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / 1e9,
+                                                   sum(dur[k]) / len(dur[k]) if dur[k] else float("nan")))
+dom = [k for k in pmc if k.startswith("conv3d_s1_kernel<S1Cfg<32, 32")]
+if dom:
+    v = pmc[dom[0]]
+    fetch, write = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+    json.dump({"kernel": dom[0], "round": tag, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+               "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
+               "note": "gfx950: FETCH_SIZE counts half of the fetched bytes (calibrated on soft_argmin_kernel); WRITE_SIZE exact"},
+              open(os.path.join(DST, "pmc_dominant.json"), "w"), indent=1)
+print(open(os.path.join(DST, tag + "_kernel_stats.csv")).read())
+print(open(os.path.join(DST, tag + "_pmc.csv")).read()[:3000])
