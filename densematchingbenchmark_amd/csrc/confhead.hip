@@ -1,18 +1,15 @@
 // AcfNet confidence head (dmb/modeling/stereo/cmn/cmn.py:10-36,57-69) as one fused kernel:
 //   h    = relu(BN(conv2d_3x3(cost)))      cost: [B, D, H, W] (the disparity axis is the channel axis), Cm maps
 //   conf = sigmoid(sum_m h_m * w2[m])      1x1 conv + sigmoid, fused into the epilogue (h never leaves registers)
-// The 3x3 convolution is an FP32 implicit GEMM on the matrix cores (M = Cm, N = pixels, K = D * 9), same
-// structure as conv3d.hip: A = prepacked weight fragments from L2, B = LDS tile read along the flattened
-// padded (y, x) plane.  The 346.7 GFLOP/pair of AcfNet's three heads is FP32-MFMA-bound.
+// The 3x3 convolution is an FP32 implicit GEMM on the matrix cores (M = Cm, N = pixels, K = D * 9) with the same
+// structure as conv3d.hip: LDS-DMA staged, double-buffered chunks of CH_CK disparity planes (input tile + the
+// chunk's prepacked weight fragments), B fragments read along the flattened padded (y, x) plane, A/B fragments
+// register double-buffered one k-step ahead of the MFMAs.  346.7 GFLOP/pair for AcfNet's three heads: MFMA-bound.
 #include "dmb_common.h"
 
 namespace dmb {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define DMB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-__device__ __forceinline__ int cd_row2(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-constexpr int CH_CK = 16;  // disparity planes (K channels) staged per chunk
+constexpr int CH_CK = 8;  // disparity planes (K channels) staged per chunk
 
 // wp[((kp * 9 + tap) * NTT + nt) * 64 + lane] = w1[m = nt*32 + (lane & 31)][d = 2*kp + (lane >> 5)][tap], zero padded
 __global__ void pack_conf_kernel(const float* __restrict__ w1, float* __restrict__ wp, int Cm, int D, int NTT, int Dpad) {
@@ -41,7 +38,15 @@ struct CHCfg {
   static constexpr int ROWS = TY + 2;
   static constexpr int MT = (RY * P + 31) / 32;
   static constexpr int CH_STRIDE = ROWS * P + 36;
-  static constexpr int LDS_FLOATS = CH_CK * CH_STRIDE + 2 * TY * P;  // + cross-wave reduction scratch
+  static constexpr int NK = (CH_CK / 2) * 9;
+  static constexpr int IN_FLOATS = CH_CK * CH_STRIDE;
+  static constexpr int W_FLOATS = NK * NTT * 64;
+  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+  static constexpr int RED_FLOATS = 2 * TY * P;                      // cross-wave reduction scratch
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;                  // the reduction scratch aliases buffer 0
+  static_assert(RED_FLOATS <= BUF_FLOATS, "reduction scratch fits one buffer");
+  static_assert(IN_FLOATS % 4 == 0 && W_FLOATS % 4 == 0, "16-byte aligned weight region");
+  static_assert((CH_CK * ROWS) % 4 == 0, "rows are dealt evenly to the 4 waves");
 };
 
 template <int NTT>
@@ -52,18 +57,19 @@ __global__ __launch_bounds__(256, 2) void conf_head_kernel(const float* __restri
                                                            int Cm, int H, int W, int ntx, int nty) {
   using C = CHCfg<NTT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* red = lds + CH_CK * C::CH_STRIDE;
+  float* red = lds;  // used only after the last chunk's barrier, when the tile buffers are dead
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
   t /= ntx;
   const int ty = t % nty;
   const int b = t / nty;
   const int x0 = tx * C::TX, y0 = ty * C::TY;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wy = wave / C::WN, wn = wave % C::WN;
-  const size_t HW = (size_t)H * W;
+  const unsigned HW = (unsigned)H * W;
   const float* cb = cost + (size_t)b * D * HW;
+  const int Dpad = cdiv(D, CH_CK) * CH_CK;
 
   f32x16 acc[C::MT];
 #pragma unroll
@@ -71,34 +77,60 @@ __global__ __launch_bounds__(256, 2) void conf_head_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  const float* bbase = lds + h * C::CH_STRIDE + (wy * C::RY) * C::P + j;
-  const int Dpad = cdiv(D, CH_CK) * CH_CK;
+  // ---- staging (LDS-DMA): rows of the haloed tile dealt to the waves in contiguous runs; planes past D and the
+  // zero padding come from the buffer bounds check.
+  constexpr int RPW = CH_CK * C::ROWS / 4;  // rows per wave per chunk
+  constexpr int WV4 = (C::W_FLOATS / 4 + 255) / 256;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(cb, (unsigned)D * HW * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)((Dpad / 2) * 9 * NTT * 64) * 4u);
+  const int gx = x0 - 1 + lane;
+  const unsigned xvoff = (lane < C::P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+  auto stage = [&](int c0, float* buf) {
+    if (lane < C::P) {
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int rid = wave * RPW + q, cl = rid / C::ROWS, yy = rid - cl * C::ROWS;
+        const int gy = y0 - 1 + yy;
+        const bool ok = c0 + cl < D && gy >= 0 && gy < H;
+        dma4(xrs, ok ? xvoff : DMA_OOB, ok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W) * 4u : 0u,
+             buf + cl * C::CH_STRIDE + yy * C::P);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WV4; ++i) {
+      const int q4 = i * 256 + threadIdx.x;
+      if (q4 < C::W_FLOATS / 4)
+        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (9 * NTT * 64 * 4), buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
+    }
+  };
 
-  for (int c0 = 0; c0 < Dpad; c0 += CH_CK) {
-    __syncthreads();
-    constexpr int NR = CH_CK * C::ROWS;
-    for (int r = wave; r < NR; r += 4) {
-      const int cl = r / C::ROWS, yy = r % C::ROWS;
-      const int gy = y0 - 1 + yy, gx = x0 - 1 + lane;
-      if (lane < C::P) {
-        float v = 0.f;
-        if (c0 + cl < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = cb[(size_t)(c0 + cl) * HW + (size_t)gy * W + gx];
-        lds[cl * C::CH_STRIDE + yy * C::P + lane] = v;
-      }
+  const int NC = Dpad / CH_CK;
+  stage(0, lds);
+  __syncthreads();
+  for (int ci = 0; ci < NC; ++ci) {
+    const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
+    if (ci + 1 < NC) stage((ci + 1) * CH_CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
+    const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
+    const float* bbase = cur + h * C::CH_STRIDE + (wy * C::RY) * C::P + j;
+    float af[2], bf[2][C::MT];
+    auto load_frag = [&](int ks, float& a, float (&bq)[C::MT]) {
+      const int cp = ks / 9, tap = ks % 9;
+      const int dy = tap / 3, dx = tap % 3;
+      a = abase[ks * NTT * 64];
+      const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::P + dx;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[mt * 32];
+    };
+    load_frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < C::NK; ++ks) {
+      if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(af[ks & 1], bf[ks & 1][mt], acc[mt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    const float* wpc = wp + ((size_t)(c0 / 2) * 9 * NTT + wn) * 64 + lane;
-#pragma unroll
-    for (int cp = 0; cp < CH_CK / 2; ++cp) {
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-        const float a = wpc[((size_t)(cp * 9 + tap) * NTT) * 64];
-        const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::P + dx;
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(a, bp[mt * 32], acc[mt]);
-      }
-    }
   }
 
   // epilogue: BN + ReLU per map, dot with w2 over the maps held by this lane, then reduce over lane halves
@@ -106,13 +138,12 @@ __global__ __launch_bounds__(256, 2) void conf_head_kernel(const float* __restri
   float sc[16], sh[16], wv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int m = wn * 32 + cd_row2(r, h);
+    const int m = wn * 32 + cd_row(r, h);
     const bool ok = m < Cm;
     sc[r] = ok ? scale[m] : 0.f;
     sh[r] = ok ? shift[m] : 0.f;
     wv[r] = ok ? w2[m] : 0.f;
   }
-  __syncthreads();  // the tile is dead; `red` does not alias it, but keep the barrier pairing simple
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt) {
     float part = 0.f;
@@ -125,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void conf_head_kernel(const float* __restri
   __syncthreads();
   for (int i = threadIdx.x; i < C::TY * C::P; i += 256) {
     const int ly = i / C::P, lx = i % C::P;
-    const int gy = y0 + ly, gx = x0 + lx;
-    if (lx < C::TX && gy < H && gx < W) {
+    const int gy = y0 + ly, gxo = x0 + lx;
+    if (lx < C::TX && gy < H && gxo < W) {
       float v = red[i];
       if (C::WN == 2) v += red[C::TY * C::P + i];
-      conf[(size_t)b * HW + (size_t)gy * W + gx] = 1.f / (1.f + __expf(-v));
+      conf[(size_t)b * HW + (size_t)gy * W + gxo] = 1.f / (1.f + __expf(-v));
     }
   }
 }
@@ -162,8 +193,8 @@ static int launch_conf(const float* cost, const float* wp, const float* scale, c
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conf_head_kernel<NTT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conf_head_kernel<NTT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL((conf_head_kernel<NTT>), dim3((unsigned)nblk), dim3(256), lds, st, cost, wp, scale, shift, w2, conf,
@@ -175,6 +206,7 @@ extern "C" int dmb_conf_head_f32(const float* cost, const float* w1pack, const f
                                  const float* w2, float* conf, int B, int D, int Cm, int H, int W, void* stream) {
   if (!cost || !w1pack || !scale || !shift || !w2 || !conf || B <= 0 || D <= 0 || Cm <= 0 || H <= 0 || W <= 0)
     return fail(DMB_EINVAL, "conf_head: bad argument");
+  if ((long long)D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conf_head: one batch item must stay below 2 GiB");
   const int NTT = cdiv(Cm, 32);
   hipStream_t st = (hipStream_t)stream;
   if (NTT == 1) return launch_conf<1>(cost, w1pack, scale, shift, w2, conf, B, D, Cm, H, W, st);

@@ -21,28 +21,6 @@
 
 namespace dmb {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define DMB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// Asynchronous global -> LDS copies (LDS-DMA, buffer_load ... lds): no VGPR round trip, no ds_write.  The LDS
-// destination is the wave-uniform `dst` + lane * size; the global source is base(rsrc) + soffset (scalar) + voffset
-// (per lane).  Zero padding comes for free from the buffer bounds check: a lane whose voffset is DMA_OOB reads 0.
-typedef __attribute__((address_space(3))) void* lptr_t;
-constexpr unsigned DMA_OOB = 0x80000000u;  // >= any num_records we create (host side checks sizes < 2 GiB)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float* dst_uniform) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst_uniform, 4, voff, soff, 0, 0);
-}
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float* dst_uniform) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst_uniform, 16, voff, soff, 0, 0);
-}
-
-// Row of the 32x32 C/D tile held by accumulator register r of lane-half h (cdna_hip_programming.md s3).
-__device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
 // ---------------------------------------------------------------------------------------------------------
 // Weight prepack: A fragments in k-step order.
 //   wp[((kp * 27 + tap) * NTT + nt) * 64 + lane] = W(co = nt*32 + (lane & 31), ci = 2*kp + (lane >> 5), tap)
@@ -287,13 +265,14 @@ struct S2Cfg {
   static constexpr int NK = (CK / 2) * 27;
   static constexpr int IN_FLOATS = CK * CH_STRIDE;
   static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;
-  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered: 1 workgroup per CU
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
+  static constexpr int WPE = (LDS_FLOATS * 4 * 2 <= 160 * 1024) ? 2 : 1;  // workgroups per CU the LDS admits
   static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
 template <class C>
-__global__ __launch_bounds__(256, 1) void conv3d_s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ res, float* __restrict__ y, int D,
@@ -327,8 +306,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2_kernel(const float* __restri
   // waves in contiguous runs (see conv3d_s1_kernel).  Rows go to the y-parity plane they belong to.
   constexpr int NPASS = (C::INCOLS + 63) / 64;
   constexpr int NUNIT = C::CK * C::ZS * NPASS;
-  static_assert(NUNIT % 4 == 0, "units are dealt evenly to the 4 waves");
-  constexpr int UPW = NUNIT / 4;
+  constexpr int UPW = (NUNIT + 3) / 4;
   constexpr int WCH = C::NK * C::NTT * 64;
   constexpr int WV4 = (WCH / 4 + 255) / 256;
   static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
@@ -338,6 +316,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
       const int uid = wave * UPW + q, pl = uid / NPASS, pass = uid - pl * NPASS;
+      if (uid >= NUNIT) continue;
       const int cl = pl / C::ZS, zz = pl - cl * C::ZS;
       const int gz = 2 * z0 - 1 + zz, col = pass * 64 + lane, gx = 2 * x0 - 1 + col;
       const bool zok = gz >= 0 && gz < D;
@@ -445,7 +424,8 @@ struct DCfg {
   static constexpr int RUN = 9 * NTT * 64;                    // weight floats of one (channel pair, kz)
   static constexpr int W_FLOATS = (CK / 2) * 2 * RUN;         // worst case: two kz taps (odd output z)
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
-  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;           // double buffered: 1 workgroup per CU
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;           // double buffered
+  static constexpr int WPE = (LDS_FLOATS * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
   static_assert(P <= 64, "one wave stages one tile row per instruction");
   static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
@@ -607,7 +587,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
 }
 
 template <class C>
-__global__ __launch_bounds__(256, 1) void deconv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, C::WPE) void deconv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ res, float* __restrict__ y, int D,
@@ -657,9 +637,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restri
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   const float* xb = x + (size_t)b * Ci * DHW;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  // compute mapping: 15 threads x 4 outputs along x, 16 (y, z) rows; threads 240..255 only help staging
-  const int lxq = threadIdx.x % 15, lyz = threadIdx.x / 15;
-  const bool worker = lyz < 16;
+  // compute mapping: 16 lanes per (y, z) row, 15 of them x 4 outputs along x (the 16th only helps staging), so a
+  // 32-lane LDS access group covers exactly two tile rows, whose banks are disjoint because the row pitch is
+  // 2 mod 4 floats: no bank conflicts on the 8-byte reads.
+  const int lxq = threadIdx.x & 15, lyz = threadIdx.x >> 4;
+  const bool worker = lxq < 15;
   const int ly = lyz & 3, lz = (lyz >> 2) & 3;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -820,11 +802,6 @@ extern "C" int dmb_deconv3d_pack_weights_f32(const float* w, float* wpack, int C
   return pack_common(w, wpack, Co, Ci, 1, stream);
 }
 
-static int g_dev_sched = 1;
-extern "C" void dmb_dev_set_option(int key, int value) {  // development knob, not part of the ABI
-  if (key == 0) g_dev_sched = value;
-}
-
 extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                  const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int stride, int relu, void* stream) {
@@ -833,15 +810,15 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     return fail(DMB_EUNSUPPORTED, "conv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
-    if (Ci == 32 && Co == 32 && g_dev_sched == 0) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 0>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 32 && Co == 32 && g_dev_sched == 2) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 32 && Co == 32 && g_dev_opts[0] == 0) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 0>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 32 && Co == 32 && g_dev_opts[0] == 2) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 32 && Co == 32) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 64 && Co == 32) return launch_s1<S1Cfg<64, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 64 && Co == 64) return launch_s1<S1Cfg<64, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 32 && Co == 64) return launch_s1<S1Cfg<32, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   } else if (stride == 2) {
-    if (Ci == 32 && Co == 64) return launch_s2<S2Cfg<32, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 64 && Co == 64) return launch_s2<S2Cfg<64, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 32 && Co == 64) return launch_s2<S2Cfg<32, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 64 && Co == 64) return launch_s2<S2Cfg<64, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   }
   return fail(DMB_EUNSUPPORTED, "conv3d: (Ci, Co, stride) not instantiated");
 }
@@ -854,7 +831,7 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
     return fail(DMB_EUNSUPPORTED, "deconv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   if (Ci == 64 && Co == 64) return launch_deconv<DCfg<64, 64, 2, 60, 8, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-  if (Ci == 64 && Co == 32) return launch_deconv<DCfg<64, 32, 2, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+  if (Ci == 64 && Co == 32) return launch_deconv<DCfg<64, 32, 1, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   return fail(DMB_EUNSUPPORTED, "deconv3d: (Ci, Co) not instantiated");
 }
 

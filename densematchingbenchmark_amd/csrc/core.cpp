@@ -6,5 +6,14 @@ static thread_local const char* g_last_error = "";
 void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 }  // namespace dmb
 
-extern "C" int dmb_abi_version(void) { return 1; }
+namespace dmb {
+int g_dev_opts[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // development knobs (kernel variant selection in micro-benchmarks)
+}
+// Development knob, NOT part of the ABI (absent from include/dmb_hip.h): key 0 = conv scheduling variant,
+// key 1 = 1 forces the VALU form of the group-wise correlation.
+extern "C" void dmb_dev_set_option(int key, int value) {
+  if (key >= 0 && key < 8) dmb::g_dev_opts[key] = value;
+}
+
+extern "C" int dmb_abi_version(void) { return 2; }
 extern "C" const char* dmb_last_error(void) { return dmb::g_last_error; }

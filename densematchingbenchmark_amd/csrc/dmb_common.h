@@ -6,6 +6,7 @@
 namespace dmb {
 
 void set_last_error(const char* msg);
+extern int g_dev_opts[8];
 
 inline int fail(int code, const char* msg) {
   set_last_error(msg);
@@ -43,5 +44,34 @@ __device__ inline int xcd_remap(int bid, int nblk) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA / LDS-DMA helpers shared by the implicit-GEMM kernels (conv3d.hip, confhead.hip, gwc_mfma.hip)
+// ------------------------------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DMB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// Asynchronous global -> LDS copies (LDS-DMA, buffer_load ... lds): no VGPR round trip, no ds_write.  The LDS
+// destination is the wave-uniform `dst` + lane * size; the global source is base(rsrc) + soffset (scalar) + voffset
+// (per lane).  Zero padding comes for free from the buffer bounds check: a lane whose voffset is DMA_OOB reads 0.
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr unsigned DMA_OOB = 0x80000000u;  // >= any num_records we create (host side checks sizes < 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float* dst_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst_uniform, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float* dst_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst_uniform, 16, voff, soff, 0, 0);
+}
+
+// Row of the 32x32 C/D tile held by accumulator register r of lane-half h (cdna_hip_programming.md s3).
+__device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+#endif  // __HIPCC__
 
 }  // namespace dmb

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(256) void gwc_kernel(const float* __restrict__ L, c
   }
 }
 
+int gwc_mfma_dispatch(const float* L, const float* R, float* out, int B, int C, int G, int H, int W, int D,
+                      const DispIdx& idx, int out_channels, int och_off, hipStream_t st);  // gwc_mfma.hip
+
 static int disp_range(const int* idx, int D, DispIdx& out, int& dpos, int& dneg) {
   if (!idx || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
   dpos = 0;
@@ -192,6 +195,10 @@ extern "C" int dmb_gwc_fms_f32(const float* L, const float* R, float* out, int B
   int dpos, dneg;
   if (int e = disp_range(disp_idx_host, D, idx, dpos, dneg)) return e;
   const int CG = C / G;
+  if (!g_dev_opts[1]) {  // matrix-core form whenever it applies (0 <= d_k <= 64, even channels per group)
+    const int rc = gwc_mfma_dispatch(L, R, out, B, C, G, H, W, D, idx, out_channels, out_ch_offset, (hipStream_t)stream);
+    if (rc != DMB_EUNSUPPORTED) return rc;
+  }
   const size_t lds = (size_t)CG * (256 + dpos + dneg) * sizeof(float);
   if (lds > 64 * 1024) return fail(DMB_EUNSUPPORTED, "gwc: disparity range too wide for the LDS window");
   dim3 grid(cdiv(H * W, 256), G, B);

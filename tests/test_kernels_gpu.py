@@ -53,14 +53,25 @@ def test_cat_known_answer(dev):
     assert out[0, 1, :, 0].tolist() == [[15, 16, 0, 0], [13, 14, 15, 16], [0, 0, 13, 14]]
 
 
-@pytest.mark.parametrize("C,G", [(16, 2), (32, 8), (12, 12)])
-def test_gwc(dev, C, G):
+@pytest.mark.parametrize("C,G", [(16, 2), (32, 8), (12, 12), (320, 40)])
+@pytest.mark.parametrize("W,md,sd", [(40, 9, 0), (300, 48, 0), (70, 12, -3)])
+def test_gwc(dev, C, G, W, md, sd):
+    """MFMA form (0 <= d <= 64, even channels/group) and VALU form (everything else) against the oracle, and --
+    where both apply -- against each other bit for bit (same ascending-channel FMA chain)."""
+    from densematchingbenchmark_amd import _lib
     ops = _ops()
-    L, R = _rand((2, C, 6, 40), 3), _rand((2, C, 6, 40), 4)
-    idx = ops.disp_index_list(9, 0, 1)
+    L, R = _rand((2, C, 5, W), 3), _rand((2, C, 5, W), 4)
+    idx = ops.disp_index_list(md, sd, 1)
     got = ops.gwc_fms(L.to(dev), R.to(dev), idx, G).cpu()
-    ref = O.gwc_fms(L, R, 9, 0, 1, G)
-    assert (got - ref).abs().max().item() <= 2e-6  # <= C/G FP32 products, different summation order
+    ref = O.gwc_fms(L, R, md, sd, 1, G)
+    assert (got - ref).abs().max().item() <= 3e-6  # <= C/G FP32 products, different summation order
+    lib = _lib.load()
+    lib.dmb_dev_set_option(1, 1)   # force the VALU kernel
+    try:
+        valu = ops.gwc_fms(L.to(dev), R.to(dev), idx, G).cpu()
+    finally:
+        lib.dmb_dev_set_option(1, 0)
+    assert torch.equal(valu, got)
 
 
 # ------------------------------------------------------------------------------------------- conv family
