@@ -118,8 +118,17 @@ def main():
     n_ids = len(cfg.get("eval_disparity_id", [0]))
 
     # inputs resident in HBM before the timed region: this rank's pairs are rank, rank + world, ...
-    left, right = synthetic.feature_batch(rank, world, B, C, fh, fw, dev)
-    gt = synthetic.gt_disparity(rank, B, Hp, Wp, pad_top=Hp - H0, device=dev)
+    ptype = cfg.model.cost_processor.type
+    if ptype == "Correlation":   # GwcNet-style: (320-ch correlation features, 12-ch concat features) per view
+        lg, rg = synthetic.feature_batch(rank, world, B, 320, fh, fw, dev)
+        lc, rc = synthetic.feature_batch(rank + 100000, world, B, 12, fh, fw, dev)
+        left, right = (lg, lc), (rg, rc)
+    else:
+        left, right = synthetic.feature_batch(rank, world, B, C, fh, fw, dev)
+    pred_scale = md // cfg.model.disp_predictor.max_disp   # StereoNet regresses at 1/8 resolution
+    gt = synthetic.gt_disparity(rank, B, Hp // pred_scale, Wp // pred_scale, pad_top=(Hp - H0) // pred_scale, device=dev)
+    if pred_scale > 1:
+        gt = gt / pred_scale
     acc = EpeAccumulator(dev, n_ids, cfg.model.eval.lower_bound, cfg.model.eval.upper_bound)
     batch = dict(leftFeature=left, rightFeature=right)
     fused = args.fused_regression
@@ -135,7 +144,7 @@ def main():
             vals = model.disp_predictor._sample_values()
             disps = [ops.trilinear_soft_argmin(c.squeeze(1), (md, Hp, Wp), vals, model.disp_predictor.alpha)
                      for c in (c3, c2, c1)]
-        acc.update(disps[:n_ids], gt, (H0, W0))
+        acc.update(disps[:n_ids], gt, (H0 // pred_scale, W0 // pred_scale))
         return disps
 
     def fence():
@@ -184,8 +193,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PSMNet cat-volume + 3D hourglass + soft-argmin, 544x960 (540 padded), "
-                                   "max_disp=192, batch %d per GPU%s" % (B, ", fused up-sample+regression" if fused else ""),
+            "config": {"workload": "%s %s-volume + 3D aggregation + soft-argmin, %dx%d (%dx%d padded), "
+                                   "max_disp=%d, batch %d per GPU%s" % (cfg.model.cost_processor.cost_aggregator.type, ptype, Hp, Wp, H0, W0, md, B,
+                                                                        ", fused up-sample+regression" if fused else ""),
                        "pairs_per_step_per_gpu": B, "sharding": "pair i -> rank i mod world; 1 all-reduce of the EPE accumulator",
                        "costs_materialised": not fused},
             "path_tflops": round(value * PATH_GFLOP_PER_PAIR / 1e3, 2),
@@ -197,7 +207,7 @@ def main():
                          "flop_per_launch": flop},
             "epe_accumulator": metrics[0],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and ptype == "Concatenation":
             base, ref_disps = cpu_baseline(model, cfg, (fh, fw), C)
             out["cpu_baseline"] = base
             out["speedup_vs_cpu"] = round(value / base["value"], 1)

@@ -315,6 +315,35 @@ def psmnet_path(ref_fms, tgt_fms, p, max_disp, scale=4, alpha=1.0, prefix="cost_
     return disps, costs
 
 
+def acfnet_path(ref_fms, tgt_fms, p, max_disp, cmn_alpha=1.0, cmn_beta=1.0, scale=4, alpha=1.0):
+    """AcfNet eval forward of the path (configs/AcfNet/scene_flow_adaptive.py through general_stereo_model.py:48-90):
+    cat volume -> AcfAggregator -> FasterSoftArgmin per level -> Cmn confidences.  ``p`` uses model-level names."""
+    raw = cat_fms(ref_fms, tgt_fms, max_disp // scale, 0, 1)
+    costs = acf_aggregator(raw, p, max_disp, "cost_processor.aggregator.")
+    disps = [faster_soft_argmin(c, max_disp, 0, 1, alpha, True) for c in costs]
+    cost_vars, confs = cmn_eval(costs, p, cmn_alpha, cmn_beta, prefix="cmn.conf_heads")
+    return disps, costs, confs
+
+
+def stereonet_path(ref_fms, tgt_fms, p, max_disp, scale=8, alpha=1.0, num=4):
+    """StereoNet cost path (configs/StereoNet/scene_flow_8x_2stage.py): dif volume at 1/scale -> StereoNetAggregator
+    -> FasterSoftArgmin over max_disp // scale samples (the refinement stages are outside the path)."""
+    raw = dif_fms(ref_fms, tgt_fms, max_disp // scale, 0, 1)
+    costs = stereonet_aggregator(raw, p, "cost_processor.aggregator.", num=num)
+    disps = [faster_soft_argmin(c, max_disp // scale, 0, 1, alpha, True) for c in costs]
+    return disps, costs
+
+
+def gwcnet_path(ref_fms, tgt_fms, p, max_disp, num_groups=40, scale=4, alpha=1.0):
+    """GwcNet-style path (no reference implementation; spec SURVEY 8-a4): [gwc(G groups) | cat(2 x 12)] volume ->
+    PSMAggregator(in_planes = G + 24) -> FasterSoftArgmin.  ref_fms / tgt_fms = (correlation feats, concat feats)."""
+    (lg, lc), (rg, rc) = ref_fms, tgt_fms
+    raw = torch.cat([gwc_fms(lg, rg, max_disp // scale, 0, 1, num_groups), cat_fms(lc, rc, max_disp // scale, 0, 1)], dim=1)
+    costs = psm_aggregator(raw, p, max_disp, "cost_processor.aggregator.")
+    disps = [faster_soft_argmin(c, max_disp, 0, 1, alpha, True) for c in costs]
+    return disps, costs
+
+
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs

@@ -146,3 +146,18 @@ def test_remove_padding_views():
     assert y.shape == (2, 1, 4, 5) and torch.equal(y, x[:, :, 2:, :5])
     assert remove_padding(x, (9, 5)).shape == x.shape            # negative pad_top: untouched (eval.py:26-29)
     assert remove_padding({"a": [x]}, (4, 5))["a"][0].shape == (2, 1, 4, 5)
+
+
+def test_result_pkl_layout_matches_reference_reader(tmp_path):
+    """tools/view_cost.py:71-84 access pattern on a file written by save_result."""
+    import pickle
+    from densematchingbenchmark_amd.result_io import save_result
+    res = dict(disps=[torch.rand(1, 1, 8, 12)], costs=[torch.rand(1, 6, 8, 12)])
+    ori = dict(leftImage=torch.zeros(3, 6, 10), rightImage=torch.zeros(3, 6, 10), leftDisp=torch.rand(6, 10), rightDisp=None)
+    path = save_result(res, ori, str(tmp_path / "pair0"), original_size=(6, 10))
+    with open(path, "rb") as fp:
+        r = pickle.load(fp)
+    est = r['Result']['disps'][0][0, 0, ].cpu().numpy()
+    vol = r['Result']['costs'][0][0].cpu().numpy()
+    assert est.shape == (6, 10) and vol.shape == (6, 6, 10) and r['OriginalData']['leftDisp'].shape == (6, 10)
+    assert np.array_equal(est, res['disps'][0][0, 0, 2:, :10].numpy())   # top/right padding removed (eval.py:24-29)

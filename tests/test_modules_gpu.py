@@ -256,3 +256,71 @@ def test_full_size_psmnet_pair_vs_oracle(dev):
         assert (a - b).abs().mean().item() <= 5e-5            # EPE delta vs the reference arithmetic (target 1e-4)
         assert (a.double() - t).abs().mean().item() <= 2e-5   # EPE delta vs the truth
         assert maxdiff(a, b) <= 5e-4
+
+
+def _built(cfg_rel, seed, tweak=None):
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", cfg_rel))
+    if tweak:
+        tweak(cfg)
+    model = build_model(cfg).eval()
+    synthetic.init_params_(model, seed=seed, classif_gain=10.0)
+    return cfg, model
+
+
+def _acf32(cfg):
+    cfg.model.max_disp = 32
+    cfg.model.cost_processor.cost_computation.max_disp = 8
+    cfg.model.cost_processor.cost_aggregator.max_disp = 32
+    cfg.model.disp_predictor.max_disp = 32
+    cfg.model.cmn.in_planes = 32
+
+
+def test_acfnet_model_vs_reference_golden(dev):
+    """BASELINE configs[3] wiring: cat volume -> AcfAggregator (learned k8/s4 up-sampling) -> soft-argmin + Cmn
+    confidences, against outputs of the reference's own build_cost_processor / Cmn on the same parameters."""
+    g = golden("acfnet_path.npz")
+    cfg, model = _built("AcfNet/scene_flow_adaptive.py", 5, _acf32)
+    model = model.to(dev)
+    lf, rf = rand((2, 32, 16, 32), 411), rand((2, 32, 16, 32), 412)
+    results, _ = model(dict(leftFeature=lf.to(dev), rightFeature=rf.to(dev)))
+    assert set(results) == {"disps", "costs", "confs"}
+    for i in range(3):
+        assert maxdiff(results["disps"][i], g["disp%d" % (3 - i)]) <= DISP_TOL
+        assert maxdiff(results["confs"][i], g["conf%d" % (3 - i)]) <= 1e-5
+        assert maxdiff(results["costs"][i][:, ::4, ::8, :], g["cost%d_rows" % (3 - i)]) <= COST_TOL
+    variance, confs = model.cmn(results["costs"])
+    assert maxdiff(variance[0], g["var3"]) <= 1e-5
+
+
+def test_stereonet_model_vs_reference_golden(dev):
+    """BASELINE configs[4] wiring: dif volume at 1/8 -> StereoNetAggregator -> soft-argmin over 24 samples."""
+    g = golden("stereonet_path.npz")
+    cfg, model = _built("StereoNet/scene_flow_8x_2stage.py", 6)
+    model = model.to(dev)
+    lf, rf = rand((2, 32, 20, 36), 421), rand((2, 32, 20, 36), 422)
+    results, _ = model(dict(leftFeature=lf.to(dev), rightFeature=rf.to(dev)))
+    assert len(results["disps"]) == 1
+    assert maxdiff(results["costs"][0], g["cost"]) <= 2e-5 and maxdiff(results["disps"][0], g["disp"]) <= DISP_TOL
+
+
+def test_gwcnet_model_vs_oracle(dev):
+    """BASELINE configs[2]: no reference implementation exists (parity UNPINNED) -- the oracle states the spec."""
+    def tweak(cfg):
+        cfg.model.max_disp = 32
+        cfg.model.cost_processor.cost_computation.max_disp = 8
+        cfg.model.cost_processor.cost_aggregator.max_disp = 32
+        cfg.model.disp_predictor.max_disp = 32
+    cfg, model = _built("GwcNet/scene_flow.py", 7, tweak)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    lg, rg = rand((1, 320, 16, 32), 431), rand((1, 320, 16, 32), 432)
+    lc, rc = rand((1, 12, 16, 32), 433), rand((1, 12, 16, 32), 434)
+    model = model.to(dev)
+    results, _ = model(dict(leftFeature=(lg.to(dev), lc.to(dev)), rightFeature=(rg.to(dev), rc.to(dev))))
+    disps, costs = O.gwcnet_path((lg, lc), (rg, rc), p, 32)
+    for a, b in zip(results["disps"], disps):
+        assert maxdiff(a, b) <= DISP_TOL
+    for a, b in zip(results["costs"], costs):
+        assert maxdiff(a, b) <= COST_TOL
