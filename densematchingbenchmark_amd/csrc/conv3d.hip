@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
   static_assert(NPL % 4 == 0, "planes are dealt evenly to the 4 waves");
   constexpr int PPW = NPL / 4;                  // planes per wave
   constexpr int WCH = C::NK * C::NTT * 64;      // weight floats per chunk
-  constexpr int WV4 = (WCH / 4 + 255) / 256;    // 16-byte copies per thread for the weights
-  static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
+  static_assert(WCH % 16 == 0, "weights are staged with 16-byte copies, evenly over 4 waves");
+  constexpr int WPW = WCH / 16;                 // 16-byte words per wave
+  constexpr int WI = (WPW + 63) / 64;           // copy instructions per wave
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)C::CIN * DHW * 4u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
   const int gx = x0 - 1 + lane;
@@ -172,11 +173,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
         }
       }
     }
+    // weights: WCH/4 16-byte words split evenly over the 4 waves (WPW each, in WI instructions per wave), so that
+    // every wave issues the same number of copies and a counted s_waitcnt vmcnt(N) means the same thing in all of them
 #pragma unroll
-    for (int i = 0; i < WV4; ++i) {
-      const int q4 = i * 256 + threadIdx.x;
-      if (q4 < WCH / 4)
-        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
+    for (int i = 0; i < WI; ++i) {
+      const int q4 = wave * WPW + i * 64 + lane;
+      if (i * 64 + lane < WPW)
+        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + C::IN_FLOATS + (wave * WPW + i * 64) * 4);
     }
   };
 
@@ -203,12 +206,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
 #pragma unroll
     for (int ks = 0; ks < C::NK; ++ks) {
       if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
-      if (C::SCHED == 1) __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS reads ahead of this step's MFMAs
+      if (C::SCHED != 0) __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS reads ahead of this step's MFMAs
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(af[ks & 1][nt], bf[ks & 1][mt], acc[mt][nt]);
-      if (C::SCHED == 1) __builtin_amdgcn_sched_barrier(0);
+      if (C::SCHED != 0) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // the compiler drains the DMA (vmcnt(0)) here: next buffer complete, current one free
   }
@@ -811,7 +814,6 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
     if (Ci == 32 && Co == 32 && g_dev_opts[0] == 0) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 0>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 32 && Co == 32 && g_dev_opts[0] == 2) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 32 && Co == 32) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 64 && Co == 32) return launch_s1<S1Cfg<64, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 64 && Co == 64) return launch_s1<S1Cfg<64, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);

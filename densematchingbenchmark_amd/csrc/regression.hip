@@ -249,67 +249,75 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict_
   }
 }
 
-// Row-staged variant for up-sampling by >= 2x: one workgroup = 4 consecutive output rows of one output plane.  The
-// (at most) 4 input rows x 2 input planes they blend are staged in LDS once, so an output costs ~3 LDS reads instead
-// of 8 L1/L2 reads; arithmetic and its order are exactly those of trilinear_kernel (bit-identical results).
-constexpr int TRI_MAXR = 4;
-
-__device__ __forceinline__ float pick4(const float (&a)[TRI_MAXR], int i) {
-  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
-}
-
-__global__ __launch_bounds__(256) void trilinear_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int Di,
+// Column-streaming variant (the one used for real volumes): one thread owns 4 consecutive output x of one output row
+// and walks ALL output planes.  The (H, W)-interpolated value of an input plane is computed once per thread and
+// reused by every output plane that blends it, so an output costs ~0.4 L1/L2 reads instead of 8; no LDS, no barrier,
+// stores are 16 bytes per lane and 1 KiB contiguous per wave.  Same arithmetic and order as trilinear_kernel
+// (W, then H, then D), hence bit-identical results.
+__global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __restrict__ x, float* __restrict__ y, int Di,
                                                              int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh,
-                                                             float sw) {
-  extern __shared__ __attribute__((aligned(16))) float rows[];  // [2][TRI_MAXR][Wi]
-  const int nyg = cdiv(Ho, 4);
-  const int zo = blockIdx.x / nyg, yo0 = (blockIdx.x % nyg) * 4;
-  const int b = blockIdx.y;
-  const Lerp lz = lerp_setup(zo, Di, sd);
-  Lerp ly[4];
+                                                             float sw, int zsplit) {
+  const int nxq = cdiv(Wo, 4);
+  const int nxb = cdiv(nxq, 256);
+  const int xq = (blockIdx.x % nxb) * 256 + threadIdx.x;
+  if (xq >= nxq) return;
+  const int zpart = blockIdx.x / nxb;   // this thread walks output planes [zbeg, zend)
+  const int zbeg = (int)((long long)Do * zpart / zsplit), zend = (int)((long long)Do * (zpart + 1) / zsplit);
+  const int xo = xq * 4, yo = blockIdx.y, b = blockIdx.z;
+  const Lerp ly = lerp_setup(yo, Hi, sh);
+  Lerp lx[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) ly[r] = lerp_setup(min(yo0 + r, Ho - 1), Hi, sh);
-  const int ymin = ly[0].i0;
-  const int nr = min(ly[3].i1 - ymin + 1, TRI_MAXR);
+  for (int j = 0; j < 4; ++j) lx[j] = lerp_setup(min(xo + j, Wo - 1), Wi, sw);
   const float* xb = x + (size_t)b * Di * Hi * Wi;
-  for (int t = threadIdx.x; t < 2 * nr * Wi; t += 256) {
-    const int zz = t / (nr * Wi), rem = t - zz * nr * Wi, r = rem / Wi, c = rem - r * Wi;
-    rows[(zz * TRI_MAXR + r) * Wi + c] = xb[((size_t)(zz ? lz.i1 : lz.i0) * Hi + ymin + r) * Wi + c];
-  }
-  __syncthreads();
-  for (int xq = threadIdx.x; xq * 4 < Wo; xq += 256) {
-    const int xo = xq * 4;
-    float o[4][4];
+  const size_t plane = (size_t)Hi * Wi;
+  const float* r0 = xb + (size_t)ly.i0 * Wi;
+  const float* r1 = xb + (size_t)ly.i1 * Wi;
+  auto hw = [&](int zi, float (&o)[4]) {
+    const float* p0 = r0 + (size_t)zi * plane;
+    const float* p1 = r1 + (size_t)zi * plane;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const Lerp lx = lerp_setup(min(xo + j, Wo - 1), Wi, sw);
-      float a[2][TRI_MAXR];
-#pragma unroll
-      for (int zz = 0; zz < 2; ++zz)
-#pragma unroll
-        for (int r = 0; r < TRI_MAXR; ++r) {
-          const float* rp = rows + (zz * TRI_MAXR + r) * Wi;
-          a[zz][r] = r < nr ? lerp2(rp[lx.i0], lx.w0, rp[lx.i1], lx.w1) : 0.f;
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h0 = lerp2(pick4(a[0], ly[r].i0 - ymin), ly[r].w0, pick4(a[0], ly[r].i1 - ymin), ly[r].w1);
-        const float h1 = lerp2(pick4(a[1], ly[r].i0 - ymin), ly[r].w0, pick4(a[1], ly[r].i1 - ymin), ly[r].w1);
-        o[r][j] = lerp2(h0, lz.w0, h1, lz.w1);
-      }
+      const float a0 = lerp2(p0[lx[j].i0], lx[j].w0, p0[lx[j].i1], lx[j].w1);
+      const float a1 = lerp2(p1[lx[j].i0], lx[j].w0, p1[lx[j].i1], lx[j].w1);
+      o[j] = lerp2(a0, ly.w0, a1, ly.w1);
     }
+  };
+  float h0[4], h1[4];
+  int cz0 = -1, cz1 = -1;
+  const size_t ostride = (size_t)Ho * Wo;
+  float* yp = y + ((size_t)b * Do * Ho + yo) * Wo + xo + (size_t)zbeg * ostride;
+  const bool vec = (Wo & 3) == 0;
+  for (int zo = zbeg; zo < zend; ++zo) {
+    const Lerp lz = lerp_setup(zo, Di, sd);
+    if (lz.i0 != cz0) {
+      if (lz.i0 == cz1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (yo0 + r >= Ho) break;
-      float* yp = y + (((size_t)b * Do + zo) * Ho + yo0 + r) * Wo + xo;
-      if ((Wo & 3) == 0) {
-        *reinterpret_cast<float4*>(yp) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+        for (int j = 0; j < 4; ++j) h0[j] = h1[j];
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (xo + j < Wo) yp[j] = o[r][j];
+        hw(lz.i0, h0);
       }
+      cz0 = lz.i0;
     }
+    if (lz.i1 != cz1) {
+      if (lz.i1 == cz0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h1[j] = h0[j];
+      } else {
+        hw(lz.i1, h1);
+      }
+      cz1 = lz.i1;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = lerp2(h0[j], lz.w0, h1[j], lz.w1);
+    if (vec) {
+      *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (xo + j < Wo) yp[j] = o[j];
+    }
+    yp += ostride;
   }
 }
 
@@ -541,11 +549,13 @@ extern "C" int dmb_trilinear_ac_f32(const float* x, float* y, int B, int Di, int
   if ((long long)cdiv(cdiv(Wo, 4), 256) * Do * Ho > 0x7fffffffLL || B > 65535)
     return fail(DMB_EUNSUPPORTED, "trilinear: grid too large");
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)2 * TRI_MAXR * Wi * sizeof(float);
-  if (Ho >= 2 * Hi - 1 && Ho >= 4 && lds <= 64 * 1024 && (long long)Do * cdiv(Ho, 4) <= 0x7fffffffLL) {
-    // up-sampling by >= 2x: 4 consecutive output rows touch at most TRI_MAXR input rows
-    hipLaunchKernelGGL(trilinear_rows_kernel, dim3(Do * cdiv(Ho, 4), B), dim3(256), lds, st, x, y, Di, Hi, Wi, Do, Ho, Wo,
-                       ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  if (Ho <= 65535 && B <= 65535) {
+    // split the plane walk only when the (row, column-block) grid alone cannot fill the chip
+    const long long nblk0 = (long long)cdiv(cdiv(Wo, 4), 256) * Ho * B;
+    int zsplit = 1;
+    while (nblk0 * zsplit < 2048 && zsplit * 2 <= Do && zsplit < 16) zsplit *= 2;
+    hipLaunchKernelGGL(trilinear_zcol_kernel, dim3(cdiv(cdiv(Wo, 4), 256) * zsplit, Ho, B), dim3(256), 0, st, x, y, Di, Hi,
+                       Wi, Do, Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), zsplit);
   } else {
     dim3 grid(cdiv(cdiv(Wo, 4), 256) * Do * Ho, B);
     hipLaunchKernelGGL(trilinear_kernel, grid, dim3(256), 0, st, x, y, Di, Hi, Wi, Do, Ho, Wo,

@@ -52,7 +52,7 @@ print("B =", B)
 from densematchingbenchmark_amd import _lib
 _l = _lib.load()
 if hasattr(_l, "dmb_dev_set_option"):
-    for v in (0, 1, 2):
+    for v in (1, 0, 1):
         _l.dmb_dev_set_option(0, v)
         conv_case(32, 32, 1, D, H, W, "conv s1 32->32 full sched=%d" % v)
     _l.dmb_dev_set_option(0, 1)
