@@ -434,46 +434,52 @@ struct DCfg {
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
-// Body for one z parity PZ.  A workgroup owns an input-resolution tile and produces the outputs of z parity PZ
-// for BOTH y parities and BOTH x parities (4 accumulator sets), so the staged input tile is used by every tap
-// that can touch it: per (channel pair, kz) unit 9*MT*NT MFMAs against 4*MT B reads and 9*NT A reads.
+// Body for one z parity PZ.  A work item = (input-resolution tile, z parity): the outputs of z parity PZ for BOTH y
+// parities and BOTH x parities (4 accumulator sets), so the staged input tile is used by every tap that can touch it:
+// per (channel pair, kz) unit 9*MT*NT MFMAs against 4*MT B reads and 9*NT A reads.
+// The kernel is PERSISTENT: a workgroup walks tiles first, first + stride, ... and the chunk pipeline runs across
+// tiles (the first chunk of the next tile is copied while the last chunk of this one is multiplied).  A work item
+// here lasts only 40-75 k cycles, so a per-item prologue (DMA latency with idle matrix cores) and a workgroup
+// re-dispatch per item would cost 15-25 %.
 template <class C, int PZ>
 __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict__ x, const float* __restrict__ wp,
                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                             const float* __restrict__ res, float* __restrict__ y, int D, int H, int W,
-                                            int b, int x0, int y0, int z0, int relu) {
+                                            int ntx, int nty, int ntz, int first, int stride, int ntiles, int relu) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
-  const float* xb = x + (size_t)b * C::CIN * DHW;
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + stride - 1) / stride;
 
-  f32x16 acc[2][2][C::MT][C::NT];  // [py][px]
-#pragma unroll
-  for (int py = 0; py < 2; ++py)
-#pragma unroll
-    for (int px = 0; px < 2; ++px)
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[py][px][mt][nt][r] = 0.f;
+  struct Tile {
+    int b, x0, y0, z0;
+  };
+  auto tile_at = [&](int it) {
+    int t = first + it * stride;
+    Tile tl;
+    tl.x0 = (t % ntx) * C::TX;
+    t /= ntx;
+    tl.y0 = (t % nty) * C::TY;
+    t /= nty;
+    tl.z0 = (t % ntz) * C::TZ;
+    tl.b = t / ntz;
+    return tl;
+  };
 
-  // ---- staging: planes (channel, z) dealt to the waves; weights: per channel pair the 9 (ky, kx) taps of each
-  // needed kz, laid out [cp][az][ky][kx][nt][64] with az = 0 -> kz = (PZ ? 2 : 1), az = 1 -> kz = 0.
+  // ---- staging: whole channels per wave; weights: per channel pair the 9 (ky, kx) taps of each needed kz, laid
+  // out [cp][az][ky][kx][nt][64] with az = 0 -> kz = (PZ ? 2 : 1), az = 1 -> kz = 0.
   constexpr int NAZ = 1 + PZ;
   static_assert(C::CK % 4 == 0, "each wave stages whole channels");
   constexpr int CPW = C::CK / 4;                        // channels per wave per chunk
   constexpr int WCH4 = (C::CK / 2) * NAZ * C::RUN / 4;  // 16-byte copies per chunk
   constexpr int WV4 = (WCH4 + 255) / 256;
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)C::CIN * DHW * 4u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
-  const int gx = x0 + lane;
-  const unsigned xvoff = (lane < C::P && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
-  // weights: per channel pair the 9 (ky, kx) taps of each needed kz, laid out [cp][az][ky][kx][nt][64] with
-  // az = 0 -> kz = (PZ ? 2 : 1), az = 1 -> kz = 0.
-  auto stage = [&](int c0, float* buf) {
+  auto stage = [&](const Tile& tl, int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * C::CIN * DHW, (unsigned)C::CIN * DHW * 4u);
+    const int gx = tl.x0 + lane;
+    const unsigned xvoff = (lane < C::P && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
     if (lane < C::P) {
 #pragma unroll
       for (int cc = 0; cc < CPW; ++cc) {
@@ -481,12 +487,13 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
         float* dc = buf + cl * C::CH_STRIDE;
 #pragma unroll
         for (int zz = 0; zz < C::ZS; ++zz) {
-          const bool zok = z0 + zz < D;
-          const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)(z0 + zz) * HW) * 4u;
+          const bool zok = tl.z0 + zz < D;
+          const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)(tl.z0 + zz) * HW) * 4u;
 #pragma unroll
           for (int yy = 0; yy < C::ROWS; ++yy) {
-            const bool ok = zok && y0 + yy < H;
-            dma4(xrs, ok ? xvoff : DMA_OOB, ok ? zoff + (unsigned)(y0 + yy) * W * 4u : 0u, dc + zz * C::PLANE + yy * C::P);
+            const bool ok = zok && tl.y0 + yy < H;
+            dma4(xrs, ok ? xvoff : DMA_OOB, ok ? zoff + (unsigned)(tl.y0 + yy) * W * 4u : 0u,
+                 dc + zz * C::PLANE + yy * C::P);
           }
         }
       }
@@ -506,109 +513,130 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
 
   constexpr int NC = C::CIN / C::CK;
   constexpr int NU = (C::CK / 2) * NAZ;  // (channel pair, az) units per chunk
-  stage(0, lds);
-  __syncthreads();
-  for (int ci = 0; ci < NC; ++ci) {
-    const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
-    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
-    const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + j;
-    float af[2][9][C::NT], bf[2][2][2][C::MT];  // bf[buf][ay][ox][mt]
-    auto load_frag = [&](int u, float (&a)[9][C::NT], float (&bq)[2][2][C::MT]) {
-      const int cp = u / NAZ, az = u % NAZ;
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) a[k][nt] = abase[(u * 9 + k) * C::NTT * 64 + nt * 64];
-      const float* bp = bbase + 2 * cp * C::CH_STRIDE + az * C::PLANE;
-#pragma unroll
-      for (int ay = 0; ay < 2; ++ay)
-#pragma unroll
-        for (int ox = 0; ox < 2; ++ox)
-#pragma unroll
-          for (int mt = 0; mt < C::MT; ++mt) bq[ay][ox][mt] = bp[ay * C::P + ox + mt * 32];
-    };
-    load_frag(0, af[0], bf[0]);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (u + 1 < NU) load_frag(u + 1, af[(u + 1) & 1], bf[(u + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      const auto& a = af[u & 1];
-      const auto& bq = bf[u & 1];
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) {
-          // even y (py = 0): ky = 1 from input row ay = 0
-          acc[0][0][mt][nt] = DMB_MFMA(a[3 + 1][nt], bq[0][0][mt], acc[0][0][mt][nt]);  // even x: kx = 1, ox = 0
-          acc[0][1][mt][nt] = DMB_MFMA(a[3 + 2][nt], bq[0][0][mt], acc[0][1][mt][nt]);  // odd x:  kx = 2, ox = 0
-          acc[0][1][mt][nt] = DMB_MFMA(a[3 + 0][nt], bq[0][1][mt], acc[0][1][mt][nt]);  //         kx = 0, ox = 1
-          // odd y (py = 1): ky = 2 from ay = 0, ky = 0 from ay = 1
-          acc[1][0][mt][nt] = DMB_MFMA(a[6 + 1][nt], bq[0][0][mt], acc[1][0][mt][nt]);
-          acc[1][1][mt][nt] = DMB_MFMA(a[6 + 2][nt], bq[0][0][mt], acc[1][1][mt][nt]);
-          acc[1][1][mt][nt] = DMB_MFMA(a[6 + 0][nt], bq[0][1][mt], acc[1][1][mt][nt]);
-          acc[1][0][mt][nt] = DMB_MFMA(a[0 + 1][nt], bq[1][0][mt], acc[1][0][mt][nt]);
-          acc[1][1][mt][nt] = DMB_MFMA(a[0 + 2][nt], bq[1][0][mt], acc[1][1][mt][nt]);
-          acc[1][1][mt][nt] = DMB_MFMA(a[0 + 0][nt], bq[1][1][mt], acc[1][1][mt][nt]);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-  }
-
   const int Ho = 2 * H, Wo = 2 * W;
-  const int gzi = z0 + wz;
-  if (gzi >= D) return;
-  const unsigned gz = 2 * gzi + PZ;
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = 2u * D * HWo;
-  float* yb = y + (size_t)b * C::COUT * DHWo;
-  const float* rb = res ? res + (size_t)b * C::COUT * DHWo : nullptr;
+  Tile cur_t = tile_at(0);
+  stage(cur_t, 0, lds);
+  __syncthreads();
+  int g = 0;  // chunks consumed by this workgroup so far: selects the LDS buffer
+  for (int it = 0; it < my_tiles; ++it) {
+    const bool has_next = it + 1 < my_tiles;
+    Tile next_t = cur_t;
+    if (has_next) next_t = tile_at(it + 1);
+
+    f32x16 acc[2][2][C::MT][C::NT];  // [py][px]
 #pragma unroll
-  for (int nt = 0; nt < C::NT; ++nt) {
-    const int co0 = (wn * C::NT + nt) * 32;
-    float sc[16], sh[16];
+    for (int py = 0; py < 2; ++py)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + cd_row(r, h);
-      sc[r] = scale ? scale[co] : 1.f;
-      sh[r] = shift ? shift[co] : 0.f;
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[py][px][mt][nt][r] = 0.f;
+
+    for (int ci = 0; ci < NC; ++ci, ++g) {
+      const float* cur = lds + (g & 1) * C::BUF_FLOATS;
+      float* nxt = lds + ((g + 1) & 1) * C::BUF_FLOATS;
+      if (ci + 1 < NC)
+        stage(cur_t, (ci + 1) * C::CK, nxt);
+      else if (has_next)
+        stage(next_t, 0, nxt);
+      const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
+      const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + j;
+      float af[2][9][C::NT], bf[2][2][2][C::MT];  // bf[buf][ay][ox][mt]
+      auto load_frag = [&](int u, float (&a)[9][C::NT], float (&bq)[2][2][C::MT]) {
+        const int cp = u / NAZ, az = u % NAZ;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt) a[k][nt] = abase[(u * 9 + k) * C::NTT * 64 + nt * 64];
+        const float* bp = bbase + 2 * cp * C::CH_STRIDE + az * C::PLANE;
+#pragma unroll
+        for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+          for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) bq[ay][ox][mt] = bp[ay * C::P + ox + mt * 32];
+      };
+      load_frag(0, af[0], bf[0]);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (u + 1 < NU) load_frag(u + 1, af[(u + 1) & 1], bf[(u + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const auto& a = af[u & 1];
+        const auto& bq = bf[u & 1];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt) {
+            // even y (py = 0): ky = 1 from input row ay = 0
+            acc[0][0][mt][nt] = DMB_MFMA(a[3 + 1][nt], bq[0][0][mt], acc[0][0][mt][nt]);  // even x: kx = 1, ox = 0
+            acc[0][1][mt][nt] = DMB_MFMA(a[3 + 2][nt], bq[0][0][mt], acc[0][1][mt][nt]);  // odd x:  kx = 2, ox = 0
+            acc[0][1][mt][nt] = DMB_MFMA(a[3 + 0][nt], bq[0][1][mt], acc[0][1][mt][nt]);  //         kx = 0, ox = 1
+            // odd y (py = 1): ky = 2 from ay = 0, ky = 0 from ay = 1
+            acc[1][0][mt][nt] = DMB_MFMA(a[6 + 1][nt], bq[0][0][mt], acc[1][0][mt][nt]);
+            acc[1][1][mt][nt] = DMB_MFMA(a[6 + 2][nt], bq[0][0][mt], acc[1][1][mt][nt]);
+            acc[1][1][mt][nt] = DMB_MFMA(a[6 + 0][nt], bq[0][1][mt], acc[1][1][mt][nt]);
+            acc[1][0][mt][nt] = DMB_MFMA(a[0 + 1][nt], bq[1][0][mt], acc[1][0][mt][nt]);
+            acc[1][1][mt][nt] = DMB_MFMA(a[0 + 2][nt], bq[1][0][mt], acc[1][1][mt][nt]);
+            acc[1][1][mt][nt] = DMB_MFMA(a[0 + 0][nt], bq[1][1][mt], acc[1][1][mt][nt]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
     }
+
+    // ---- epilogue of cur_t ----
+    const int gzi = cur_t.z0 + wz;
+    if (gzi < D) {
+      const unsigned gz = 2 * gzi + PZ;
+      float* yb = y + (size_t)cur_t.b * C::COUT * DHWo;
+      const float* rb = res ? res + (size_t)cur_t.b * C::COUT * DHWo : nullptr;
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt) {
-      const int m = mt * 32 + j;
-      const int ly = m / C::P, lx = m - ly * C::P;
-      const int gyi = y0 + ly, gxi = x0 + lx;
-      if (m < C::TY * C::P && lx < C::TX && gyi < H && gxi < W) {
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const int co0 = (wn * C::NT + nt) * 32;
+        float sc[16], sh[16];
 #pragma unroll
-        for (int py = 0; py < 2; ++py) {
-          const f32x16 a2[2] = {acc[py][0][mt][nt], acc[py][1][mt][nt]};
-          store_tile<2>(a2, sc, sh, rb, yb, co0, h, DHWo, gz * HWo + (unsigned)(2 * gyi + py) * Wo + 2u * gxi, relu);
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + cd_row(r, h);
+          sc[r] = scale ? scale[co] : 1.f;
+          sh[r] = shift ? shift[co] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const int m = mt * 32 + j;
+          const int ly = m / C::P, lx = m - ly * C::P;
+          const int gyi = cur_t.y0 + ly, gxi = cur_t.x0 + lx;
+          if (m < C::TY * C::P && lx < C::TX && gyi < H && gxi < W) {
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+              const f32x16 a2[2] = {acc[py][0][mt][nt], acc[py][1][mt][nt]};
+              store_tile<2>(a2, sc, sh, rb, yb, co0, h, DHWo, gz * HWo + (unsigned)(2 * gyi + py) * Wo + 2u * gxi, relu);
+            }
+          }
         }
       }
     }
+    cur_t = next_t;
   }
 }
 
+// Workgroups [0, g0) take the even-z work items, the rest the odd-z ones (which carry twice the MFMAs).
 template <class C>
 __global__ __launch_bounds__(256, C::WPE) void deconv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ shift,
-                                                          const float* __restrict__ res, float* __restrict__ y, int D,
-                                                          int H, int W, int ntx, int nty, int ntz, int relu) {
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ res, float* __restrict__ y,
+                                                               int D, int H, int W, int ntx, int nty, int ntz, int ntiles,
+                                                               int g0, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int pz = t & 1;
-  t >>= 1;
-  const int tx = t % ntx;
-  t /= ntx;
-  const int ty = t % nty;
-  t /= nty;
-  const int tz = t % ntz;
-  const int b = t / ntz;
-  if (pz)
-    deconv_body<C, 1>(lds, x, wp, scale, shift, res, y, D, H, W, b, tx * C::TX, ty * C::TY, tz * C::TZ, relu);
+  if ((int)blockIdx.x < g0)
+    deconv_body<C, 0>(lds, x, wp, scale, shift, res, y, D, H, W, ntx, nty, ntz, blockIdx.x, g0, ntiles, relu);
   else
-    deconv_body<C, 0>(lds, x, wp, scale, shift, res, y, D, H, W, b, tx * C::TX, ty * C::TY, tz * C::TZ, relu);
+    deconv_body<C, 1>(lds, x, wp, scale, shift, res, y, D, H, W, ntx, nty, ntz, blockIdx.x - g0, gridDim.x - g0, ntiles,
+                      relu);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -768,17 +796,34 @@ template <class C>
 static int launch_deconv(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                          float* y, int B, int D, int H, int W, int relu, hipStream_t st) {
   const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
-  const long long nblk = 2LL * B * ntx * nty * ntz;
-  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
+  const long long ntiles = (long long)B * ntx * nty * ntz;
+  if (ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
+  static int ncu = 256;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_kernel<C>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
     attr_set = true;
   }
-  hipLaunchKernelGGL((deconv3d_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, D, H,
-                     W, ntx, nty, ntz, relu);
+  // persistent grid: C::WPE workgroups per CU; a third of them walk the even-z items, two thirds the odd-z items
+  // (twice the work each).  With fewer items than slots every workgroup gets exactly one item.
+  const long long slots = (long long)C::WPE * ncu;
+  long long g0, g1;
+  if (2 * ntiles <= slots) {
+    g0 = g1 = ntiles;
+  } else {
+    g0 = slots / 3 > 0 ? slots / 3 : 1;
+    g1 = slots - g0;
+    if (g0 > ntiles) g0 = ntiles;
+    if (g1 > ntiles) g1 = ntiles;
+  }
+  hipLaunchKernelGGL((deconv3d_kernel<C>), dim3((unsigned)(g0 + g1)), dim3(256), lds, st, x, wp, scale, shift, res, y, D, H,
+                     W, ntx, nty, ntz, (int)ntiles, (int)g0, relu);
   return launch_status("deconv3d launch failed");
 }
 
@@ -832,7 +877,7 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
   if ((long long)(Ci > 8 * Co ? Ci : 8 * Co) * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "deconv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-  if (Ci == 64 && Co == 64) return launch_deconv<DCfg<64, 64, 2, 60, 8, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+  if (Ci == 64 && Co == 64) return launch_deconv<DCfg<64, 64, 1, 60, 4, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   if (Ci == 64 && Co == 32) return launch_deconv<DCfg<64, 32, 1, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
   return fail(DMB_EUNSUPPORTED, "deconv3d: (Ci, Co) not instantiated");
 }
