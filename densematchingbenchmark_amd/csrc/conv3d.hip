@@ -53,16 +53,37 @@ struct Affine {
 // ---------------------------------------------------------------------------------------------------------
 // Stride-1 kernel.
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, int SCHED_ = 1>
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, int SCHED_ = 1, bool ROWPAIR_ = false>
 struct S1Cfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_, SCHED = SCHED_;
+  static constexpr bool ROWPAIR = ROWPAIR_;
   static constexpr int WZ = 4 / WN;        // waves along z; one output z-slice per wave
   static constexpr int TZ = WZ;
   static constexpr int P = TX + 2;         // padded row pitch
   static constexpr int ROWS = TY + 2;
   static constexpr int PLANE = ROWS * P;
   static constexpr int ZS = TZ + 2;
-  static constexpr int MT = (TY * P + 31) / 32;  // 32-voxel column tiles per wave
+  // How the 32 columns (voxels) of an MFMA B tile map onto the LDS tile:
+  //  - flattened (default): 32 consecutive positions of the padded (y, x) plane; works for any TX, but the 2 halo
+  //    columns per row and the last partial tile are computed and discarded (6 % at TX = 60, TY = 4);
+  //  - row pair (TX % 16 == 0, TY % 2 == 0): 16 columns of row r (lanes 0-15) + the same 16 columns of row r + 1
+  //    (lanes 16-31): every computed voxel is a real output.  Used when W is a multiple of TX.
+  static constexpr int XS = TX / 16;
+  static constexpr int MT = ROWPAIR ? (TY / 2) * XS : (TY * P + 31) / 32;  // 32-voxel column tiles per wave
+  __device__ static constexpr int lane_off(int j) { return ROWPAIR ? (j >> 4) * P + (j & 15) : j; }
+  __device__ static constexpr int tile_off(int mt) { return ROWPAIR ? 2 * (mt / XS) * P + (mt % XS) * 16 : mt * 32; }
+  __device__ static void decode(int mt, int j, int& ly, int& lx, bool& valid) {
+    if (ROWPAIR) {
+      ly = 2 * (mt / XS) + (j >> 4);
+      lx = (mt % XS) * 16 + (j & 15);
+      valid = true;
+    } else {
+      const int m = mt * 32 + j;
+      ly = m / P;
+      lx = m - ly * P;
+      valid = m < TY * P && lx < TX;
+    }
+  }
   static constexpr int NTT = COUT / 32;          // 32-channel row tiles in total
   static constexpr int NT = NTT / WN;            // ... per wave
   static constexpr int CH_STRIDE = ZS * PLANE + 36;  // + slack read by discarded columns
@@ -72,6 +93,7 @@ struct S1Cfg {
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
   static_assert(P <= 64, "one wave stages one tile row per instruction");
   static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
+  static_assert(!ROWPAIR || (TX % 16 == 0 && TY % 2 == 0), "row-pair tiles need TX % 16 == 0 and an even TY");
 };
 
 // Epilogue shared by the three MFMA kernels: v = acc*scale + shift (+ residual) (relu) for the 16 accumulator
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
     if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);  // lands while we compute
     // ---- NK k-steps on the current buffer; A and B fragments register double-buffered one k-step ahead ----
     const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + j;
+    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + C::lane_off(j);
     float af[2][C::NT], bf[2][C::MT];
     auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MT]) {
       const int cp = ks / 27, tap = ks % 27;
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
       for (int nt = 0; nt < C::NT; ++nt) a[nt] = abase[(ks * C::NTT + nt) * 64];
       const float* bp = bbase + 2 * cp * C::CH_STRIDE + dz * C::PLANE + dy * C::P + dx;
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[mt * 32];
+      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[C::tile_off(mt)];
     };
     load_frag(0, af[0], bf[0]);
 #pragma unroll
@@ -233,10 +255,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
     }
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt) {
-      const int m = mt * 32 + j;
-      const int ly = m / C::P, lx = m - ly * C::P;
+      int ly, lx;
+      bool valid;
+      C::decode(mt, j, ly, lx, valid);
       const int gy = y0 + ly, gxo = x0 + lx;
-      if (m < C::TY * C::P && lx < C::TX && gy < H && gxo < W) {
+      if (valid && gy < H && gxo < W) {
         const f32x16 a1[1] = {acc[mt][nt]};
         store_tile<1>(a1, sc, sh, rb, yb, co0, h, DHW, (unsigned)gz * HW + (unsigned)gy * W + gxo, relu);
       }
@@ -645,11 +668,11 @@ __global__ __launch_bounds__(256, C::WPE) void deconv3d_kernel(const float* __re
 // uniform (scalar loads -> SGPR operands of v_fmac_f32), each thread produces 4 consecutive x from 6-float
 // LDS rows.  acc order: ci ascending, then (kd, kh, kw) ascending -- the same FP32 fma chain as above.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int C1_TX = 60, C1_TY = 4, C1_TZ = 4, C1_CK = 4;
-constexpr int C1_P = C1_TX + 2;                   // 62: one LDS-DMA row per wave instruction, even pitch (8-byte reads)
+constexpr int C1_TX = 60, C1_TY = 4, C1_TZ = 8, C1_CK = 2;
+constexpr int C1_P = C1_TX + 2;                     // 62: one LDS-DMA row per wave instruction, even pitch (8-byte reads)
 constexpr int C1_ROWS = C1_TY + 2, C1_ZS = C1_TZ + 2;
-constexpr int C1_PLANE = C1_ROWS * C1_P;
-constexpr int C1_CH = C1_ZS * C1_PLANE + 4;
+constexpr int C1_PLANE = C1_ROWS * C1_P + 2;        // 374 = 2 (mod 4): z-neighbour lanes hit disjoint banks
+constexpr int C1_CH = C1_ZS * C1_PLANE + 2;
 constexpr int C1_BUF = C1_CK * C1_CH;
 
 __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -668,18 +691,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restri
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   const float* xb = x + (size_t)b * Ci * DHW;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  // compute mapping: 16 lanes per (y, z) row, 15 of them x 4 outputs along x (the 16th only helps staging), so a
-  // 32-lane LDS access group covers exactly two tile rows, whose banks are disjoint because the row pitch is
-  // 2 mod 4 floats: no bank conflicts on the 8-byte reads.
-  const int lxq = threadIdx.x & 15, lyz = threadIdx.x >> 4;
+  // compute mapping: a thread owns 4 consecutive x of TWO adjacent rows of one z-slice (8 independent accumulators,
+  // every LDS row it loads feeds up to 2 x 3 x 4 fmas).  16 lanes per row pair (15 active); lanes 16-31 of a 32-lane
+  // LDS access group take the next z-slice, whose plane offset is 2 mod 4 floats -> disjoint banks, no conflicts.
+  const int lxq = threadIdx.x & 15;
+  const int lz = ((threadIdx.x >> 6) << 1) | ((threadIdx.x >> 4) & 1);   // 0..7
+  const int lyp = (threadIdx.x >> 5) & 1;                                // row pair: rows 2*lyp, 2*lyp + 1
   const bool worker = lxq < 15;
-  const int ly = lyz & 3, lz = (lyz >> 2) & 3;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
   const int gx = x0 - 1 + lane;
   const unsigned xvoff = (lane < C1_P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
-  constexpr int PPW = C1_CK * C1_ZS / 4;  // 6 planes per wave per chunk
+  constexpr int PPW = C1_CK * C1_ZS / 4;  // 5 planes per wave per chunk
+  static_assert((C1_CK * C1_ZS) % 4 == 0, "planes are dealt evenly to the 4 waves");
   auto stage = [&](int c0, float* buf) {
     if (lane < C1_P) {
 #pragma unroll
@@ -711,43 +736,54 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restri
         const int c = ci * C1_CK + cl;
         const float* wc = w + (size_t)min(c, Ci - 1) * 27;  // channels past Ci were staged as zeros
 #pragma unroll
-        for (int dz = 0; dz < 3; ++dz)
+        for (int dz = 0; dz < 3; ++dz) {
+          float v[4][6];
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy) {
-            const float* row = cur + cl * C1_CH + (lz + dz) * C1_PLANE + (ly + dy) * C1_P + lxq * 4;
+          for (int r = 0; r < 4; ++r) {
+            const float* row = cur + cl * C1_CH + (lz + dz) * C1_PLANE + (2 * lyp + r) * C1_P + lxq * 4;
             const float2 q0 = *reinterpret_cast<const float2*>(row);
             const float2 q1 = *reinterpret_cast<const float2*>(row + 2);
             const float2 q2 = *reinterpret_cast<const float2*>(row + 4);
-            const float v[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+            v[r][0] = q0.x; v[r][1] = q0.y; v[r][2] = q1.x; v[r][3] = q1.y; v[r][4] = q2.x; v[r][5] = q2.y;
+          }
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
               const float wv = wc[dz * 9 + dy * 3 + dx];
 #pragma unroll
-              for (int o = 0; o < 4; ++o) acc[o] = fmaf(v[o + dx], wv, acc[o]);
+              for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[oy][o] = fmaf(v[oy + dy][o + dx], wv, acc[oy][o]);
             }
-          }
+        }
       }
     }
     __syncthreads();
   }
-  const int gz = z0 + lz, gy = y0 + ly, gxo = x0 + lxq * 4;
-  if (worker && gz < D && gy < H && gxo < W) {
-    const size_t o = (size_t)b * DHW + (size_t)gz * HW + (size_t)gy * W + gxo;
-    if ((W & 3) == 0) {  // gxo % 4 == 0 and W % 4 == 0: the four outputs are one aligned 16-byte word
-      float4 v = make_float4(acc[0] + bias, acc[1] + bias, acc[2] + bias, acc[3] + bias);
-      if (res) {
-        const float4 r = *reinterpret_cast<const float4*>(res + o);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      }
-      *reinterpret_cast<float4*>(y + o) = v;
-    } else {
+  const int gz = z0 + lz, gxo = x0 + lxq * 4;
+  if (worker && gz < D && gxo < W) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (gxo + i < W) {
-          float v = acc[i] + bias;
-          if (res) v += res[o + i];
-          y[o + i] = v;
+    for (int oy = 0; oy < 2; ++oy) {
+      const int gy = y0 + 2 * lyp + oy;
+      if (gy >= H) continue;
+      const size_t o = (size_t)b * DHW + (size_t)gz * HW + (size_t)gy * W + gxo;
+      if ((W & 3) == 0) {  // gxo % 4 == 0 and W % 4 == 0: the four outputs are one aligned 16-byte word
+        float4 v = make_float4(acc[oy][0] + bias, acc[oy][1] + bias, acc[oy][2] + bias, acc[oy][3] + bias);
+        if (res) {
+          const float4 r = *reinterpret_cast<const float4*>(res + o);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
+        *reinterpret_cast<float4*>(y + o) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (gxo + i < W) {
+            float v = acc[oy][i] + bias;
+            if (res) v += res[o + i];
+            y[o + i] = v;
+          }
+      }
     }
   }
 }
@@ -859,6 +895,9 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
     if (Ci == 32 && Co == 32 && g_dev_opts[0] == 0) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 0>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0;  // every computed voxel is a real output
+    if (Ci == 32 && Co == 32 && rp) return launch_s1<S1Cfg<32, 32, 4, 48, 2, 1, 1, true>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Ci == 64 && Co == 32 && rp) return launch_s1<S1Cfg<64, 32, 4, 48, 2, 1, 1, true>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 32 && Co == 32) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 64 && Co == 32) return launch_s1<S1Cfg<64, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
     if (Ci == 64 && Co == 64) return launch_s1<S1Cfg<64, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
