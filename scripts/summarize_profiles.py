@@ -65,6 +65,7 @@ with open(os.path.join(DST, tag + "_pmc.csv"), "w") as f:
                                                    m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / 1e9,
                                                    sum(dur[k]) / len(dur[k]) if dur[k] else float("nan")))
 dom = [k for k in pmc if k.startswith("conv3d_s1_kernel<S1Cfg<32, 32")]
+dom.sort(key=lambda k: -sum(pmc[k].get("GRBM_GUI_ACTIVE", [0])))
 if dom:
     v = pmc[dom[0]]
     fetch, write = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
