@@ -26,9 +26,10 @@ namespace dmb {
 //   wp[((kp * 27 + tap) * NTT + nt) * 64 + lane] = W(co = nt*32 + (lane & 31), ci = 2*kp + (lane >> 5), tap)
 // For nn.Conv3d W(co, ci, tap) = w[co][ci][tap]; for nn.ConvTranspose3d W(co, ci, tap) = w[ci][co][tap].
 // ---------------------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int transposed) {
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Cipad,
+                                    int transposed) {
   const int NTT = Co / 32;
-  const long long total = (long long)Ci * 27 * Co;
+  const long long total = (long long)Cipad * 27 * Co;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63);
     long long r = i >> 6;
@@ -38,7 +39,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int kp = (int)(r / 27);
     const int co = nt * 32 + (lane & 31);
     const int ci = 2 * kp + (lane >> 5);
-    wp[i] = transposed ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap];
+    float v = 0.f;  // channels >= Ci are zero padding (the kernels consume Ci rounded up to their chunk size)
+    if (ci < Ci) v = transposed ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap];
+    wp[i] = v;
   }
 }
 
@@ -92,7 +95,7 @@ struct S1Cfg {
   static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;  // + the chunk's weight fragments
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
   static_assert(P <= 64, "one wave stages one tile row per instruction");
-  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
+  static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(!ROWPAIR || (TX % 16 == 0 && TY % 2 == 0), "row-pair tiles need TX % 16 == 0 and an even TY");
 };
 
@@ -138,8 +141,8 @@ template <class C>
 __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ res, float* __restrict__ y, int D,
-                                                           int H, int W, int ntx, int nty, int ntz, int relu) {
+                                                           const float* __restrict__ res, float* __restrict__ y, int Ci,
+                                                           int D, int H, int W, int ntx, int nty, int ntz, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
-  const float* xb = x + (size_t)b * C::CIN * DHW;
+  const float* xb = x + (size_t)b * Ci * DHW;
 
   f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
   static_assert(WCH % 16 == 0, "weights are staged with 16-byte copies, evenly over 4 waves");
   constexpr int WPW = WCH / 16;                 // 16-byte words per wave
   constexpr int WI = (WPW + 63) / 64;           // copy instructions per wave
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)C::CIN * DHW * 4u);
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   const int gx = x0 - 1 + lane;
   const unsigned xvoff = (lane < C::P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
   auto stage = [&](int c0, float* buf) {
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
       for (int q = 0; q < PPW; ++q) {
         const int pl = wave * PPW + q, cl = pl / C::ZS, zz = pl - cl * C::ZS;
         const int gz = z0 - 1 + zz;
-        const bool zok = gz >= 0 && gz < D;
+        const bool zok = gz >= 0 && gz < D && c0 + cl < Ci;
         const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
         float* dpl = buf + cl * C::CH_STRIDE + zz * C::PLANE;
 #pragma unroll
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
     }
   };
 
-  constexpr int NC = C::CIN / C::CK;
+  const int NC = cdiv(Ci, C::CK);  // a partial last chunk reads zeros (bounds check) against zero-padded weights
   stage(0, lds);
   __syncthreads();
   for (int ci = 0; ci < NC; ++ci) {
@@ -293,7 +296,7 @@ struct S2Cfg {
   static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
   static constexpr int WPE = (LDS_FLOATS * 4 * 2 <= 160 * 1024) ? 2 : 1;  // workgroups per CU the LDS admits
-  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
+  static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
@@ -301,8 +304,8 @@ template <class C>
 __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ res, float* __restrict__ y, int D,
-                                                           int H, int W, int Do, int Ho, int Wo, int ntx, int nty,
+                                                           const float* __restrict__ res, float* __restrict__ y, int Ci,
+                                                           int D, int H, int W, int Do, int Ho, int Wo, int ntx, int nty,
                                                            int ntz, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
-  const float* xb = x + (size_t)b * C::CIN * DHW;
+  const float* xb = x + (size_t)b * Ci * DHW;
 
   f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -336,8 +339,8 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   constexpr int WCH = C::NK * C::NTT * 64;
   constexpr int WV4 = (WCH / 4 + 255) / 256;
   static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)C::CIN * DHW * 4u);
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   auto stage = [&](int c0, float* buf) {
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
       if (uid >= NUNIT) continue;
       const int cl = pl / C::ZS, zz = pl - cl * C::ZS;
       const int gz = 2 * z0 - 1 + zz, col = pass * 64 + lane, gx = 2 * x0 - 1 + col;
-      const bool zok = gz >= 0 && gz < D;
+      const bool zok = gz >= 0 && gz < D && c0 + cl < Ci;
       const unsigned xvoff = (col < C::INCOLS && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
       const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
       float* dpl = buf + cl * C::CH_STRIDE + zz * C::ZPL + pass * 64;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
     }
   };
 
-  constexpr int NC = C::CIN / C::CK;
+  const int NC = cdiv(Ci, C::CK);  // a partial last chunk reads zeros (bounds check) against zero-padded weights
   stage(0, lds);
   __syncthreads();
   for (int ci = 0; ci < NC; ++ci) {
@@ -453,7 +456,7 @@ struct DCfg {
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;           // double buffered
   static constexpr int WPE = (LDS_FLOATS * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
   static_assert(P <= 64, "one wave stages one tile row per instruction");
-  static_assert(CIN % CK == 0 && CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
+  static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
@@ -467,8 +470,9 @@ struct DCfg {
 template <class C, int PZ>
 __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict__ x, const float* __restrict__ wp,
                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                            const float* __restrict__ res, float* __restrict__ y, int D, int H, int W,
-                                            int ntx, int nty, int ntz, int first, int stride, int ntiles, int relu) {
+                                            const float* __restrict__ res, float* __restrict__ y, int Ci, int D, int H,
+                                            int W, int ntx, int nty, int ntz, int first, int stride, int ntiles,
+                                            int relu) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
@@ -498,9 +502,9 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   constexpr int CPW = C::CK / 4;                        // channels per wave per chunk
   constexpr int WCH4 = (C::CK / 2) * NAZ * C::RUN / 4;  // 16-byte copies per chunk
   constexpr int WV4 = (WCH4 + 255) / 256;
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(C::CIN * 27 * C::COUT) * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   auto stage = [&](const Tile& tl, int c0, float* buf) {
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * C::CIN * DHW, (unsigned)C::CIN * DHW * 4u);
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * Ci * DHW, (unsigned)Ci * DHW * 4u);
     const int gx = tl.x0 + lane;
     const unsigned xvoff = (lane < C::P && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
     if (lane < C::P) {
@@ -510,7 +514,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
         float* dc = buf + cl * C::CH_STRIDE;
 #pragma unroll
         for (int zz = 0; zz < C::ZS; ++zz) {
-          const bool zok = tl.z0 + zz < D;
+          const bool zok = tl.z0 + zz < D && c0 + cl < Ci;
           const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)(tl.z0 + zz) * HW) * 4u;
 #pragma unroll
           for (int yy = 0; yy < C::ROWS; ++yy) {
@@ -534,7 +538,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
     }
   };
 
-  constexpr int NC = C::CIN / C::CK;
+  const int NC = cdiv(Ci, C::CK);  // a partial last chunk reads zeros (bounds check) against zero-padded weights
   constexpr int NU = (C::CK / 2) * NAZ;  // (channel pair, az) units per chunk
   const int Ho = 2 * H, Wo = 2 * W;
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = 2u * D * HWo;
@@ -652,14 +656,14 @@ __global__ __launch_bounds__(256, C::WPE) void deconv3d_kernel(const float* __re
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ res, float* __restrict__ y,
-                                                               int D, int H, int W, int ntx, int nty, int ntz, int ntiles,
-                                                               int g0, int relu) {
+                                                               int Ci, int D, int H, int W, int ntx, int nty, int ntz,
+                                                               int ntiles, int g0, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x < g0)
-    deconv_body<C, 0>(lds, x, wp, scale, shift, res, y, D, H, W, ntx, nty, ntz, blockIdx.x, g0, ntiles, relu);
+    deconv_body<C, 0>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, ntx, nty, ntz, blockIdx.x, g0, ntiles, relu);
   else
-    deconv_body<C, 1>(lds, x, wp, scale, shift, res, y, D, H, W, ntx, nty, ntz, blockIdx.x - g0, gridDim.x - g0, ntiles,
-                      relu);
+    deconv_body<C, 1>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, ntx, nty, ntz, blockIdx.x - g0, gridDim.x - g0,
+                      ntiles, relu);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restri
 
 template <class C>
 static int launch_s1(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                     float* y, int B, int D, int H, int W, int relu, hipStream_t st) {
+                     float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
   const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
@@ -804,14 +808,14 @@ static int launch_s1(const float* x, const float* wp, const float* scale, const 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3d_s1_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, D, H,
-                     W, ntx, nty, ntz, relu);
+  hipLaunchKernelGGL((conv3d_s1_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
+                     H, W, ntx, nty, ntz, relu);
   return launch_status("conv3d stride-1 launch failed");
 }
 
 template <class C>
 static int launch_s2(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                     float* y, int B, int D, int H, int W, int relu, hipStream_t st) {
+                     float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
   const int Do = (D - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int ntx = cdiv(Wo, C::TX), nty = cdiv(Ho, C::TY), ntz = cdiv(Do, C::TZ);
   const long long nblk = (long long)B * ntx * nty * ntz;
@@ -823,14 +827,14 @@ static int launch_s2(const float* x, const float* wp, const float* scale, const 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3d_s2_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, D, H,
-                     W, Do, Ho, Wo, ntx, nty, ntz, relu);
+  hipLaunchKernelGGL((conv3d_s2_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
+                     H, W, Do, Ho, Wo, ntx, nty, ntz, relu);
   return launch_status("conv3d stride-2 launch failed");
 }
 
 template <class C>
 static int launch_deconv(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                         float* y, int B, int D, int H, int W, int relu, hipStream_t st) {
+                         float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
   const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long ntiles = (long long)B * ntx * nty * ntz;
   if (ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
@@ -858,8 +862,8 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
     if (g0 > ntiles) g0 = ntiles;
     if (g1 > ntiles) g1 = ntiles;
   }
-  hipLaunchKernelGGL((deconv3d_kernel<C>), dim3((unsigned)(g0 + g1)), dim3(256), lds, st, x, wp, scale, shift, res, y, D, H,
-                     W, ntx, nty, ntz, (int)ntiles, (int)g0, relu);
+  hipLaunchKernelGGL((deconv3d_kernel<C>), dim3((unsigned)(g0 + g1)), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci,
+                     D, H, W, ntx, nty, ntz, (int)ntiles, (int)g0, relu);
   return launch_status("deconv3d launch failed");
 }
 
@@ -867,15 +871,17 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
 
 using namespace dmb;
 
-extern "C" long long dmb_conv3d_packed_floats(int Co, int Ci) { return (long long)Co * Ci * 27; }
-extern "C" long long dmb_deconv3d_packed_floats(int Ci, int Co) { return (long long)Co * Ci * 27; }
+static int ci_padded(int Ci) { return (Ci + 7) / 8 * 8; }  // covers every kernel's channel-chunk size
+extern "C" long long dmb_conv3d_packed_floats(int Co, int Ci) { return (long long)Co * ci_padded(Ci) * 27; }
+extern "C" long long dmb_deconv3d_packed_floats(int Ci, int Co) { return (long long)Co * ci_padded(Ci) * 27; }
 
 static int pack_common(const float* w, float* wp, int Co, int Ci, int transposed, void* stream) {
-  if (!w || !wp || Co <= 0 || Ci <= 0 || Co % 32 != 0 || Ci % 2 != 0)
-    return fail(DMB_EINVAL, "pack_weights: Co must be a multiple of 32 and Ci even");
-  const long long total = (long long)Co * Ci * 27;
+  if (!w || !wp || Co <= 0 || Ci <= 0 || Co % 32 != 0)
+    return fail(DMB_EINVAL, "pack_weights: Co must be a multiple of 32");
+  const long long total = (long long)Co * ci_padded(Ci) * 27;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci, transposed);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci, ci_padded(Ci),
+                     transposed);
   return launch_status("pack_weights launch failed");
 }
 
@@ -886,39 +892,51 @@ extern "C" int dmb_deconv3d_pack_weights_f32(const float* w, float* wpack, int C
   return pack_common(w, wpack, Co, Ci, 1, stream);
 }
 
+// Tile choice for the stride-1 kernel.  Row-pair tiles (TX = 48) when W is a multiple of 48: nothing is discarded.
+// Otherwise the flattened mapping with the TX (60 or 52) that wastes fewer columns for this W.
+static int flat_tx(int W) {
+  const int w60 = cdiv(W, 60) * 60, w52 = cdiv(W, 52) * 52;
+  // useful fraction = W / padded width * (TX / (TX + 2)) * (TY*P / (MT*32))
+  const double e60 = (double)W / w60 * (60.0 / 62.0) * (248.0 / 256.0);
+  const double e52 = (double)W / w52 * (52.0 / 54.0) * (216.0 / 224.0);
+  return e52 > e60 ? 52 : 60;
+}
+
 extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                  const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int stride, int relu, void* stream) {
-  if (!x || !wpack || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d: bad argument");
+  if (!x || !wpack || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d: bad argument");
   if ((long long)(Ci > Co ? Ci : Co) * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "conv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
+#define DMB_S1(CO, TX, WN, RP) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, RP>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
   if (stride == 1) {
-    if (Ci == 32 && Co == 32 && g_dev_opts[0] == 0) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1, 0>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0;  // every computed voxel is a real output
-    if (Ci == 32 && Co == 32 && rp) return launch_s1<S1Cfg<32, 32, 4, 48, 2, 1, 1, true>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 64 && Co == 32 && rp) return launch_s1<S1Cfg<64, 32, 4, 48, 2, 1, 1, true>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 32 && Co == 32) return launch_s1<S1Cfg<32, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 64 && Co == 32) return launch_s1<S1Cfg<64, 32, 4, 60, 2, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 64 && Co == 64) return launch_s1<S1Cfg<64, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 32 && Co == 64) return launch_s1<S1Cfg<32, 64, 4, 60, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0;
+    const int tx = flat_tx(W);
+    if (Co == 32) {
+      if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, false>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      if (rp) return DMB_S1(32, 48, 1, true);
+      return tx == 52 ? DMB_S1(32, 52, 1, false) : DMB_S1(32, 60, 1, false);
+    }
+    if (Co == 64) return tx == 52 ? DMB_S1(64, 52, 2, false) : DMB_S1(64, 60, 2, false);
   } else if (stride == 2) {
-    if (Ci == 32 && Co == 64) return launch_s2<S2Cfg<32, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-    if (Ci == 64 && Co == 64) return launch_s2<S2Cfg<64, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
+    if (Co == 64) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+    if (Co == 32) return launch_s2<S2Cfg<0, 32, 4, 30, 2, 1>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
   }
-  return fail(DMB_EUNSUPPORTED, "conv3d: (Ci, Co, stride) not instantiated");
+#undef DMB_S1
+  return fail(DMB_EUNSUPPORTED, "conv3d: output channels must be 32 or 64 (or 1: dmb_conv3d_k3_c1_f32), stride 1 or 2");
 }
 
 extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                      const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                      int relu, void* stream) {
-  if (!x || !wpack || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv3d: bad argument");
+  if (!x || !wpack || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv3d: bad argument");
   if ((long long)(Ci > 8 * Co ? Ci : 8 * Co) * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "deconv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-  if (Ci == 64 && Co == 64) return launch_deconv<DCfg<64, 64, 1, 60, 4, 2>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-  if (Ci == 64 && Co == 32) return launch_deconv<DCfg<64, 32, 1, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, D, H, W, relu, st);
-  return fail(DMB_EUNSUPPORTED, "deconv3d: (Ci, Co) not instantiated");
+  if (Co == 64) return launch_deconv<DCfg<0, 64, 1, 60, 4, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+  if (Co == 32) return launch_deconv<DCfg<0, 32, 1, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+  return fail(DMB_EUNSUPPORTED, "deconv3d: output channels must be 32 or 64");
 }
 
 extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float* residual, float* y,

@@ -81,7 +81,8 @@ int dmb_cat_fms_into_f32(const float* L, const float* R, float* out, int B, int 
  * acc is an FP32 fma chain over (ci, kd, kh, kw).
  * ---------------------------------------------------------------------------------------- */
 
-/* Number of floats of the packed-weight buffer for a k=3 convolution / transposed convolution. */
+/* Number of floats of the packed-weight buffer for a k=3 convolution / transposed convolution (input channels are
+ * zero-padded to a multiple of 8 inside the packed stream, so any Ci >= 1 is accepted). */
 long long dmb_conv3d_packed_floats(int Co, int Ci);
 long long dmb_deconv3d_packed_floats(int Ci, int Co);
 
@@ -92,7 +93,7 @@ int dmb_deconv3d_pack_weights_f32(const float* w, float* wpack, int Ci, int Co, 
 
 /* Conv3d, kernel 3, padding 1, stride 1 or 2 (all three axes).  x: [B, Ci, D, H, W];
  * y: [B, Co, Do, Ho, Wo] with Do = (D - 1) / stride + 1 etc.  Co in {32, 64}: MFMA implicit GEMM using
- * wpack from dmb_conv3d_pack_weights_f32.  Ci in {32, 64}. */
+ * wpack from dmb_conv3d_pack_weights_f32.  Any Ci >= 1.  One batch item of x / y must stay below 2 GiB. */
 int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                       const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                       int stride, int relu, void* stream);

@@ -100,7 +100,27 @@ def test_conv3d_k3(dev, Ci, Co, stride, shape):
     assert (got - F.conv3d(x, w, None, stride=stride, padding=1)).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("Ci,Co", [(64, 64), (64, 32)])
+@pytest.mark.parametrize("Ci,Co,stride,shape", [
+    (5, 32, 1, (1, 4, 6, 50)),      # odd channel count: zero-padded weight fragments + bounds-checked copies
+    (40, 64, 1, (1, 3, 5, 48)),     # row-pair width with 64 output channels -> flattened path
+    (24, 32, 1, (2, 5, 7, 96)),     # W % 48 == 0 -> row-pair tiles
+    (12, 32, 2, (1, 6, 9, 21)),
+    (7, 64, 2, (1, 5, 8, 33)),
+    (32, 32, 1, (1, 3, 6, 156)),    # StereoNet width: TX = 52 tiles
+])
+def test_conv3d_any_channels(dev, Ci, Co, stride, shape):
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 31)
+    w = _rand((Co, Ci, 3, 3, 3), 32, 1.0 / math.sqrt(Ci * 27))
+    sc, sh = _affine(Co, 33)
+    ref = F.conv3d(x, w, None, stride=stride, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+    wp = ops.pack_conv3d_weights(w.to(dev))
+    got = ops.conv3d_k3(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), None, stride, True).cpu()
+    assert (got - F.relu(ref)).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("Ci,Co", [(64, 64), (64, 32), (20, 32), (9, 64)])
 @pytest.mark.parametrize("shape", [(2, 3, 5, 35), (1, 4, 6, 61)])
 def test_deconv3d(dev, Ci, Co, shape):
     ops = _ops()
