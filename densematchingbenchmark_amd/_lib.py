@@ -44,6 +44,11 @@ SIGNATURES = {
     "dmb_conf_head_packed_floats": (_c_ll, [_c_int, _c_int]),
     "dmb_conf_head_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conf_head_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 5 + [_P]),
+    "dmb_conv2d_packed_floats": (_c_ll, [_c_int, _c_int, _c_int]),
+    "dmb_conv2d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),
+    "dmb_conv2d_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 12 + [_P]),
+    "dmb_avgpool2d_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),
+    "dmb_bilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 8 + [_P]),
     "dmb_epe_accum_f64": (_c_int, [_P, _P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
 }
 

@@ -1,0 +1,308 @@
+// 2-D convolution family of the PSMNet feature backbone (the first "next" row):
+// dmb/modeling/stereo/backbones/PSMNet.py:8-129 + layers/basic_layers.py:31-46,105-123,219-243 (conv_bn,
+// conv_bn_relu, BasicBlock).  Same FP32 implicit-GEMM design as conv3d.hip / confhead.hip:
+//   y[co, p] = sum_{ci, tap} w[co, ci, tap] * x[ci, p * stride + (tap - KS/2) * DIL]    M = Cout, N = pixels, K = Cin*KS*KS
+// v_mfma_f32_32x32x2_f32, A = prepacked weight fragments, B = row-pair tiles of the haloed LDS tile (lanes 0-15: 16
+// pixels of row r, lanes 16-31: the same columns of row r + 1), LDS-DMA double-buffered chunks of CK input channels
+// (input rows + the chunk's weight fragments), fragments register double-buffered one k-step ahead.
+// One kernel covers kernel size 1 / 3, dilation 1 / 2 (compile time) and stride 1 / 2 (run time: a stride-2 layer
+// evaluates the stride-1 grid and stores the even pixels -- only two small layers of the backbone are strided).
+// Input and output may be channel windows of wider tensors (the 320-channel SPP concat is written in place).
+#include "dmb_common.h"
+
+namespace dmb {
+
+constexpr int C2_CK = 8;  // packed weight streams are zero-padded to a multiple of this many input channels
+
+// wp[((kp * KK + tap) * NTT + nt) * 64 + lane] = w[co = nt*32 + (lane & 31)][ci = 2*kp + (lane >> 5)][tap]; zero padded
+__global__ void pack_conv2d_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Cipad, int KK,
+                                   int NTT) {
+  const long long total = (long long)(Cipad / 2) * KK * NTT * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long long r = i >> 6;
+    const int nt = (int)(r % NTT);
+    r /= NTT;
+    const int tap = (int)(r % KK);
+    const int kp = (int)(r / KK);
+    const int co = nt * 32 + (lane & 31);
+    const int ci = 2 * kp + (lane >> 5);
+    wp[i] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * KK + tap] : 0.f;
+  }
+}
+
+template <int NTT_, int KS_, int DIL_>
+struct C2Cfg {
+  static constexpr int NTT = NTT_, KS = KS_, DIL = DIL_;
+  static constexpr int WN = NTT;               // one 32-channel row tile per wave column (1, 2 or 4)
+  static constexpr int WY = 4 / WN;            // waves stacked along y
+  static constexpr int RY = 4;                 // output rows per wave (two row pairs)
+  static constexpr int TY = RY * WY, TX = 48;
+  static constexpr int HALO = (KS / 2) * DIL;
+  static constexpr int P = TX + 2 * HALO;
+  static constexpr int ROWS = TY + 2 * HALO;
+  static constexpr int XS = TX / 16;
+  static constexpr int MT = (RY / 2) * XS;     // 6 row-pair tiles per wave
+  static constexpr int KK = KS * KS;
+  static constexpr int CK = (NTT == 4) ? 4 : 8;   // input channels per chunk (the 128-row weight chunk is 4x larger)
+  static constexpr int CH_STRIDE = ROWS * P + 4;
+  static constexpr int NK = (CK / 2) * KK;  // k-steps per chunk
+  static constexpr int IN_FLOATS = (CK * CH_STRIDE + 3) / 4 * 4;
+  static constexpr int W_FLOATS = NK * NTT * 64;
+  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;
+  static_assert(P <= 64, "one wave stages one tile row per instruction");
+  static_assert((CK * ROWS) % 4 == 0 && C2_CK % CK == 0, "rows are dealt evenly to the 4 waves");
+  static_assert(W_FLOATS % 16 == 0, "weights are copied with 16-byte words, evenly over 4 waves");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ res, float* __restrict__ y, int Ci,
+                                                        int Co, int H, int W, int stride, int relu, int in_ctot,
+                                                        int out_ctot, int res_ctot, int ntx, int nty) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  const int b = t / nty;
+  const int x0 = tx * C::TX, y0 = ty * C::TY;   // stride-1 grid coordinates
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int wy = wave / C::WN, wn = wave % C::WN;
+  const unsigned HW = (unsigned)H * W;
+  const float* xb = x + (size_t)b * in_ctot * HW;
+  const int Cipad = cdiv(Ci, C2_CK) * C2_CK;
+
+  f32x16 acc[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  constexpr int RPW = C::CK * C::ROWS / 4;   // tile rows per wave per chunk
+  constexpr int WPW = C::W_FLOATS / 16;      // 16-byte weight words per wave
+  constexpr int WI = (WPW + 63) / 64;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * HW * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)((Cipad / 2) * C::KK * C::NTT * 64) * 4u);
+  const int gx = x0 - C::HALO + lane;
+  const unsigned xvoff = (lane < C::P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+  auto stage = [&](int c0, float* buf) {
+    if (lane < C::P) {
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int rid = wave * RPW + q, cl = rid / C::ROWS, yy = rid - cl * C::ROWS;
+        const int gy = y0 - C::HALO + yy;
+        const bool ok = c0 + cl < Ci && gy >= 0 && gy < H;
+        dma4(xrs, ok ? xvoff : DMA_OOB, ok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W) * 4u : 0u,
+             buf + cl * C::CH_STRIDE + yy * C::P);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int q4 = wave * WPW + i * 64 + lane;
+      if (i * 64 + lane < WPW)
+        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (C::KK * C::NTT * 64 * 4), buf + C::IN_FLOATS + (wave * WPW + i * 64) * 4);
+    }
+  };
+
+  const int NC = Cipad / C::CK;
+  stage(0, lds);
+  __syncthreads();
+  for (int ci = 0; ci < NC; ++ci) {
+    const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
+    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
+    const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
+    const float* bbase = cur + h * C::CH_STRIDE + (wy * C::RY) * C::P + (j >> 4) * C::P + (j & 15);
+    float af[2], bf[2][C::MT];
+    auto load_frag = [&](int ks, float& a, float (&bq)[C::MT]) {
+      const int cp = ks / C::KK, tap = ks % C::KK;
+      const int dy = tap / C::KS, dx = tap % C::KS;
+      a = abase[ks * C::NTT * 64];
+      const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::DIL * C::P + dx * C::DIL;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[2 * (mt / C::XS) * C::P + (mt % C::XS) * 16];
+    };
+    load_frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < C::NK; ++ks) {
+      if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(af[ks & 1], bf[ks & 1][mt], acc[mt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: BN scale/shift -> + residual -> ReLU (basic_layers.py:219-243 adds the skip AFTER conv2's BN, no ReLU)
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const unsigned HWo = (unsigned)Ho * Wo;
+  float* yb = y + (size_t)b * out_ctot * HWo;
+  const float* rb = res ? res + (size_t)b * res_ctot * HWo : nullptr;
+  float sc[16], sh[16];
+  bool cok[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = wn * 32 + cd_row(r, h);
+    cok[r] = co < Co;
+    sc[r] = (scale && cok[r]) ? scale[co] : 1.f;
+    sh[r] = (shift && cok[r]) ? shift[co] : 0.f;
+  }
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+    const int gy = y0 + wy * C::RY + 2 * (mt / C::XS) + (j >> 4);
+    const int gxo = x0 + (mt % C::XS) * 16 + (j & 15);
+    const bool keep = gy < H && gxo < W && (stride == 1 || (((gy | gxo) & 1) == 0));
+    if (keep) {
+      const unsigned o = (unsigned)(gy / stride) * Wo + (unsigned)(gxo / stride);
+      float rv[16];
+      if (rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = cok[r] ? rb[(size_t)(wn * 32 + cd_row(r, h)) * HWo + o] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = fmaf(acc[mt][r], sc[r], sh[r]);
+        if (rb) v += rv[r];
+        if (relu) v = fmaxf(v, 0.f);
+        if (cok[r]) yb[(size_t)(wn * 32 + cd_row(r, h)) * HWo + o] = v;
+      }
+    }
+  }
+}
+
+// nn.AvgPool2d(k, stride=k) (PSMNet.py:43-58): one thread per output element, FP32 sum in row-major order / k^2.
+__global__ __launch_bounds__(256) void avgpool2d_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C,
+                                                        int H, int W, int k, int Ho, int Wo, int in_ctot, int in_coff) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= (long long)B * C * Ho * Wo) return;
+  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+  const long long bc = i / ((long long)Wo * Ho);
+  const long long b = bc / C, c = bc - b * C;
+  const float* p = x + (((b * in_ctot + in_coff + c) * H) + (long long)yo * k) * W + (long long)xo * k;
+  float s = 0.f;
+  for (int a = 0; a < k; ++a)
+    for (int c = 0; c < k; ++c) s += p[(long long)a * W + c];
+  y[i] = s / (float)(k * k);
+}
+
+// F.interpolate(mode='bilinear', align_corners=True) (PSMNet.py:95-117) into a channel window of a wider tensor.
+// Same contraction-free index arithmetic as the trilinear kernel (regression.hip).
+__global__ __launch_bounds__(256) void bilinear_ac_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Hi,
+                                                          int Wi, int Ho, int Wo, float sh, float sw, int out_ctot,
+                                                          int out_coff) {
+#pragma clang fp contract(off)
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= (long long)C * Ho * Wo) return;
+  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), c = (int)(i / ((long long)Wo * Ho));
+  const float sy = sh * (float)yo, sx = sw * (float)xo;
+  int y0 = (int)sy, x0 = (int)sx;
+  y0 = y0 > Hi - 1 ? Hi - 1 : y0;
+  x0 = x0 > Wi - 1 ? Wi - 1 : x0;
+  const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+  float ly = sy - (float)y0, lx = sx - (float)x0;
+  ly = fminf(fmaxf(ly, 0.f), 1.f);
+  lx = fminf(fmaxf(lx, 0.f), 1.f);
+  const float* p = x + ((size_t)b * C + c) * Hi * Wi;
+  const float a0 = fmaf(p[(size_t)y0 * Wi + x1], lx, p[(size_t)y0 * Wi + x0] * (1.f - lx));
+  const float a1 = fmaf(p[(size_t)y1 * Wi + x1], lx, p[(size_t)y1 * Wi + x0] * (1.f - lx));
+  y[(((size_t)b * out_ctot + out_coff + c) * Ho + yo) * Wo + xo] = fmaf(a1, ly, a0 * (1.f - ly));
+}
+
+template <class C>
+static int launch_conv2d(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                         float* y, int B, int Ci, int Co, int H, int W, int stride, int relu, int in_ctot, int out_ctot,
+                         int res_ctot, hipStream_t st) {
+  const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY);
+  const long long nblk = (long long)B * ntx * nty;
+  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: grid too large");
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv2d_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, Co, H,
+                     W, stride, relu, in_ctot, out_ctot, res_ctot, ntx, nty);
+  return launch_status("conv2d launch failed");
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+static int c2_cipad(int Ci) { return cdiv(Ci, C2_CK) * C2_CK; }
+
+extern "C" long long dmb_conv2d_packed_floats(int Co, int Ci, int ksize) {
+  if (Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3)) return 0;
+  return (long long)(c2_cipad(Ci) / 2) * ksize * ksize * cdiv(Co, 32) * 64;
+}
+
+extern "C" int dmb_conv2d_pack_weights_f32(const float* w, float* wpack, int Co, int Ci, int ksize, void* stream) {
+  if (!w || !wpack || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3)) return fail(DMB_EINVAL, "conv2d_pack: bad argument");
+  const int NTT = cdiv(Co, 32);
+  if (NTT != 1 && NTT != 2 && NTT != 4) return fail(DMB_EUNSUPPORTED, "conv2d: output channels must fit 32, 64 or 128");
+  hipLaunchKernelGGL(pack_conv2d_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, wpack, Co, Ci, c2_cipad(Ci),
+                     ksize * ksize, NTT);
+  return launch_status("conv2d_pack launch failed");
+}
+
+extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* scale, const float* shift,
+                              const float* residual, float* y, int B, int Ci, int Co, int H, int W, int ksize, int stride,
+                              int dilation, int relu, int in_channels_total, int out_channels_total,
+                              int res_channels_total, void* stream) {
+  if (!x || !wpack || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv2d: bad argument");
+  if (stride != 1 && stride != 2) return fail(DMB_EUNSUPPORTED, "conv2d: stride must be 1 or 2");
+  if (in_channels_total < Ci || out_channels_total < Co || (residual && res_channels_total < Co))
+    return fail(DMB_EINVAL, "conv2d: channel window");
+  if ((long long)in_channels_total * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: one batch item must stay below 2 GiB");
+  const int NTT = cdiv(Co, 32);
+  hipStream_t st = (hipStream_t)stream;
+#define DMB_C2(N, K, DL)                                                                                              \
+  return launch_conv2d<C2Cfg<N, K, DL>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, stride, relu,            \
+                                        in_channels_total, out_channels_total, res_channels_total, st)
+  if (ksize == 3 && dilation == 1) {
+    if (NTT == 1) DMB_C2(1, 3, 1);
+    if (NTT == 2) DMB_C2(2, 3, 1);
+    if (NTT == 4) DMB_C2(4, 3, 1);
+  } else if (ksize == 3 && dilation == 2) {
+    if (NTT == 1) DMB_C2(1, 3, 2);
+    if (NTT == 2) DMB_C2(2, 3, 2);
+    if (NTT == 4) DMB_C2(4, 3, 2);
+  } else if (ksize == 1) {
+    if (NTT == 1) DMB_C2(1, 1, 1);
+    if (NTT == 2) DMB_C2(2, 1, 1);
+    if (NTT == 4) DMB_C2(4, 1, 1);
+  }
+#undef DMB_C2
+  return fail(DMB_EUNSUPPORTED, "conv2d: kernel 1 or 3, dilation 1 or 2 (3x3 only), output channels <= 128");
+}
+
+extern "C" int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int k, int in_channels_total,
+                                 int in_ch_offset, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || H / k <= 0 || W / k <= 0 || in_ch_offset < 0 ||
+      in_ch_offset + C > in_channels_total)
+    return fail(DMB_EINVAL, "avgpool2d: bad argument");
+  const int Ho = H / k, Wo = W / k;
+  const long long n = (long long)B * C * Ho * Wo;
+  hipLaunchKernelGGL(avgpool2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, C, H, W, k,
+                     Ho, Wo, in_channels_total, in_ch_offset);
+  return launch_status("avgpool2d launch failed");
+}
+
+extern "C" int dmb_bilinear_ac_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                   int out_channels_total, int out_ch_offset, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || out_ch_offset < 0 ||
+      out_ch_offset + C > out_channels_total || B > 65535)
+    return fail(DMB_EINVAL, "bilinear: bad argument");
+  const long long n = (long long)C * Ho * Wo;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL(bilinear_ac_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, y, C, Hi,
+                     Wi, Ho, Wo, sh, sw, out_channels_total, out_ch_offset);
+  return launch_status("bilinear launch failed");
+}

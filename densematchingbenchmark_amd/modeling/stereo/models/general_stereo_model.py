@@ -16,6 +16,9 @@ class GeneralizedStereoModel(nn.Module):
         super().__init__()
         self.cfg = cfg.copy()
         self.max_disp = cfg.model.max_disp
+        if backbone == "hip":   # the HIP backbone of this package (PSMNet only so far)
+            from ..backbones import build_backbone
+            backbone = build_backbone(cfg)
         self.backbone = backbone
         self.cost_processor = build_cost_processor(cfg)
         self.cmn = build_cmn(cfg) if 'cmn' in cfg.model else None

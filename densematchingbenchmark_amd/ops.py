@@ -292,3 +292,71 @@ def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
     check(lib.dmb_epe_accum_f64(dev_ptr(est), dev_ptr(gt), dev_ptr(acc), dev_ptr(ws), B, Hp, Wp, int(H0), int(W0),
                                 float(lower_bound), float(upper_bound), stream_ptr(est.device)), "dmb_epe_accum_f64")
     return acc
+
+
+# ---------------------------------------------------------------------------------------------- 2-D backbone ops
+def _window_ptr(t, ch_offset):
+    """Pointer to channel ``ch_offset`` of batch item 0 of a contiguous [B, C, H, W] tensor."""
+    import ctypes
+    dev_ptr(t)  # validates device / dtype / contiguity
+    return ctypes.c_void_p(t.data_ptr() + 4 * ch_offset * t.shape[2] * t.shape[3])
+
+
+def pack_conv2d_weights(w):
+    """nn.Conv2d weight [Co, Ci, k, k] (k in {1, 3}) -> MFMA A-fragment stream."""
+    lib = _lib.load()
+    w = _f32c(w, "weight")
+    Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
+    wp = torch.empty((lib.dmb_conv2d_packed_floats(Co, Ci, k),), dtype=torch.float32, device=w.device)
+    check(lib.dmb_conv2d_pack_weights_f32(dev_ptr(w), dev_ptr(wp), Co, Ci, k, stream_ptr(w.device)),
+          "dmb_conv2d_pack_weights_f32")
+    return wp
+
+
+def conv2d(x, wpack, Co, ksize, stride=1, dilation=1, scale=None, shift=None, residual=None, relu=False,
+           in_window=None, out=None, out_ch_offset=0, res_ch_offset=0):
+    """x: [B, Cx, H, W]; ``in_window=(offset, Ci)`` reads channels [offset, offset + Ci) of it (default: all).
+    ``out``: optional pre-allocated [B, Ctot, Ho, Wo] tensor written at channel ``out_ch_offset``."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Cx, H, W = x.shape
+    coff, Ci = in_window if in_window is not None else (0, Cx)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        out_ch_offset = 0
+    if tuple(out.shape[2:]) != (Ho, Wo) or out.shape[0] != B or out_ch_offset + Co > out.shape[1]:
+        raise _lib.DmbLibraryError("conv2d: output tensor %s does not fit" % (tuple(out.shape),))
+    if residual is not None and (tuple(residual.shape[2:]) != (Ho, Wo) or residual.shape[1] < res_ch_offset + Co):
+        raise _lib.DmbLibraryError("conv2d: residual shape %s" % (tuple(residual.shape),))
+    check(lib.dmb_conv2d_f32(_window_ptr(x, coff), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
+                             dev_ptr(shift, allow_none=True),
+                             _window_ptr(residual, res_ch_offset) if residual is not None else None,
+                             _window_ptr(out, out_ch_offset), B, Ci, Co, H, W, ksize, stride, dilation, int(bool(relu)),
+                             Cx, out.shape[1], residual.shape[1] if residual is not None else 0, stream_ptr(x.device)),
+          "dmb_conv2d_f32")
+    return out
+
+
+def avgpool2d(x, k, in_window=None):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Cx, H, W = x.shape
+    coff, C = in_window if in_window is not None else (0, Cx)
+    y = torch.empty((B, C, H // k, W // k), dtype=torch.float32, device=x.device)
+    check(lib.dmb_avgpool2d_f32(dev_ptr(x), dev_ptr(y), B, C, H, W, int(k), Cx, coff, stream_ptr(x.device)),
+          "dmb_avgpool2d_f32")
+    return y
+
+
+def bilinear_ac(x, out_hw, out=None, out_ch_offset=0):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        out_ch_offset = 0
+    check(lib.dmb_bilinear_ac_f32(dev_ptr(x), dev_ptr(out), B, C, Hi, Wi, Ho, Wo, out.shape[1], out_ch_offset,
+                                  stream_ptr(x.device)), "dmb_bilinear_ac_f32")
+    return out

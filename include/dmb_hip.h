@@ -176,6 +176,34 @@ int dmb_conf_head_f32(const float* cost, const float* w1pack, const float* scale
 int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* workspace, int B, int Hp, int Wp,
                       int H0, int W0, float lb, float ub, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * "Next" row: the 2-D feature backbone that feeds the path.
+ * dmb/modeling/stereo/backbones/PSMNet.py:8-129 with layers/basic_layers.py:31-46,105-123,219-243.
+ * ---------------------------------------------------------------------------------------- */
+
+/* nn.Conv2d weights [Co, Ci, k, k] (k = 1 or 3) -> MFMA A-fragment stream; Co <= 128, any Ci. */
+long long dmb_conv2d_packed_floats(int Co, int Ci, int ksize);
+int dmb_conv2d_pack_weights_f32(const float* w, float* wpack, int Co, int Ci, int ksize, void* stream);
+
+/* Conv2d (kernel 1 or 3, padding = dilation * (k/2), stride 1 or 2, dilation 1 or 2) + folded BatchNorm
+ * (scale/shift, may be NULL) + residual (may be NULL; added after the affine, basic_layers.py:236-241) + ReLU.
+ * x, y and residual may be channel windows of wider tensors: x points at the first input channel of batch item 0 of
+ * a tensor with in_channels_total channels per item (likewise y / out_channels_total, residual / res_channels_total).
+ * x: [B, Ci (of in_channels_total), H, W] -> y: [B, Co (of out_channels_total), Ho, Wo], Ho = (H - 1) / stride + 1. */
+int dmb_conv2d_f32(const float* x, const float* wpack, const float* scale, const float* shift, const float* residual,
+                   float* y, int B, int Ci, int Co, int H, int W, int ksize, int stride, int dilation, int relu,
+                   int in_channels_total, int out_channels_total, int res_channels_total, void* stream);
+
+/* nn.AvgPool2d(k, stride=k) (PSMNet.py:43-58): channels [in_ch_offset, in_ch_offset + C) of x [B, in_channels_total,
+ * H, W] -> y [B, C, H/k, W/k]. */
+int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int k, int in_channels_total,
+                      int in_ch_offset, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=True) (PSMNet.py:95-117): x [B, C, Hi, Wi] -> channels
+ * [out_ch_offset, out_ch_offset + C) of y [B, out_channels_total, Ho, Wo]. */
+int dmb_bilinear_ac_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, int out_channels_total,
+                        int out_ch_offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

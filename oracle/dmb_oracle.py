@@ -344,6 +344,51 @@ def gwcnet_path(ref_fms, tgt_fms, p, max_disp, num_groups=40, scale=4, alpha=1.0
     return disps, costs
 
 
+# ------------------------------------------------------------------------------------------------------------
+# "next" row: PSMNet feature backbone (backbones/PSMNet.py:8-129, layers/basic_layers.py:31-46,105-123,219-243)
+# ------------------------------------------------------------------------------------------------------------
+def conv2d_unit(x, p, prefix, stride=1, dilation=1, ksize=3, batch_norm=True, relu=False):
+    pad = dilation * (ksize // 2)
+    y = F.conv2d(x, p[prefix + ".0.weight"], p.get(prefix + ".0.bias"), stride=stride, padding=pad, dilation=dilation)
+    if batch_norm:
+        y = _bn_eval(y, p, prefix + ".1")
+    return F.relu(y) if relu else y
+
+
+def basic_block(x, p, prefix, stride, dilation, has_down, batch_norm=True):
+    """basic_layers.py:219-243."""
+    out = conv2d_unit(x, p, prefix + ".conv1", stride, dilation, 3, batch_norm, relu=True)
+    out = conv2d_unit(out, p, prefix + ".conv2", 1, dilation, 3, batch_norm)
+    skip = conv2d_unit(x, p, prefix + ".downsample", stride, 1, 1, batch_norm) if has_down else x
+    return out + skip
+
+
+def psmnet_backbone(img, p, prefix="backbone.", batch_norm=True):
+    """PSMNetBackbone._forward (backbones/PSMNet.py:82-123) for one image batch [B, 3, H, W] -> [B, 32, H/4, W/4]."""
+    x = conv2d_unit(img, p, prefix + "firstconv.0", 2, 1, 3, batch_norm, True)
+    x = conv2d_unit(x, p, prefix + "firstconv.1", 1, 1, 3, batch_norm, True)
+    x = conv2d_unit(x, p, prefix + "firstconv.2", 1, 1, 3, batch_norm, True)
+    for i in range(3):
+        x = basic_block(x, p, prefix + "layer1.%d" % i, 1, 1, False, batch_norm)
+    for i in range(16):
+        x = basic_block(x, p, prefix + "layer2.%d" % i, 2 if i == 0 else 1, 1, i == 0, batch_norm)
+    out4 = x
+    for i in range(3):
+        x = basic_block(x, p, prefix + "layer3.%d" % i, 1, 1, i == 0, batch_norm)
+    for i in range(3):
+        x = basic_block(x, p, prefix + "layer4.%d" % i, 1, 2, False, batch_norm)
+    out8 = x
+    H, W = out8.shape[-2:]
+    branches = []
+    for i, k in ((1, 64), (2, 32), (3, 16), (4, 8)):
+        b = F.avg_pool2d(out8, (k, k), stride=(k, k))
+        b = conv2d_unit(b, p, prefix + "branch%d.1" % i, 1, 1, 1, batch_norm, True)
+        branches.append(F.interpolate(b, (H, W), mode="bilinear", align_corners=True))
+    feat = torch.cat((out4, out8, branches[3], branches[2], branches[1], branches[0]), 1)
+    y = conv2d_unit(feat, p, prefix + "lastconv.0", 1, 1, 3, batch_norm, True)
+    return F.conv2d(y, p[prefix + "lastconv.1.weight"])
+
+
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs

@@ -261,3 +261,76 @@ def test_epe_accumulate(dev):
     assert acc[0].item() == 3 and n == 3
     for i, k in enumerate(("epe", "1px", "2px", "3px", "5px")):
         assert abs(acc[1 + i].item() / 3 - ref[k]) <= 1e-5 * max(1.0, abs(ref[k]))
+
+
+# ------------------------------------------------------------------------------------------- 2-D backbone ops
+@pytest.mark.parametrize("Ci,Co,k,stride,dil,shape", [
+    (3, 32, 3, 2, 1, (2, 20, 70)),       # firstconv.0: 3 input channels (zero-padded fragments), stride 2
+    (32, 32, 3, 1, 1, (1, 17, 96)),
+    (32, 64, 3, 2, 1, (1, 18, 50)),      # layer2.0.conv1
+    (32, 64, 1, 2, 1, (1, 18, 50)),      # layer2.0.downsample
+    (64, 128, 3, 1, 1, (2, 9, 48)),
+    (128, 128, 3, 1, 2, (1, 12, 61)),    # layer4: dilation 2
+    (128, 32, 1, 1, 1, (1, 1, 2)),       # SPP branch after 64x64 pooling
+    (320, 128, 3, 1, 1, (1, 8, 30)),     # lastconv.0
+    (20, 32, 3, 1, 1, (1, 6, 13)),
+    (64, 64, 3, 2, 2, (1, 11, 23)),
+])
+def test_conv2d(dev, Ci, Co, k, stride, dil, shape):
+    ops = _ops()
+    B, H, W = shape
+    x = _rand((B, Ci, H, W), 51)
+    w = _rand((Co, Ci, k, k), 52, 1.0 / math.sqrt(Ci * k * k))
+    sc, sh = _affine(Co, 53)
+    pad = dil * (k // 2)
+    ref = F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    res = _rand(ref.shape, 54)
+    wp = ops.pack_conv2d_weights(w.to(dev))
+    got = ops.conv2d(x.to(dev), wp, Co, k, stride, dil, sc.to(dev), sh.to(dev), None, False).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5
+    got = ops.conv2d(x.to(dev), wp, Co, k, stride, dil, sc.to(dev), sh.to(dev), res.to(dev), True).cpu()
+    assert (got - F.relu(ref + res)).abs().max().item() <= 2e-5
+    got = ops.conv2d(x.to(dev), wp, Co, k, stride, dil).cpu()
+    assert (got - F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)).abs().max().item() <= 2e-5
+
+
+def test_conv2d_channel_windows(dev):
+    """Input, output and residual may be channel windows of wider tensors (the 320-channel SPP buffer)."""
+    ops = _ops()
+    xw = _rand((2, 100, 9, 50), 61)
+    w = _rand((64, 32, 3, 3), 62, 1.0 / math.sqrt(32 * 9))
+    sc, sh = _affine(64, 63)
+    resw = _rand((2, 80, 9, 50), 64)
+    out = torch.full((2, 150, 9, 50), 7.0)
+    ref = F.relu(F.conv2d(xw[:, 40:72], w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + resw[:, 10:74])
+    wp = ops.pack_conv2d_weights(w.to(dev))
+    o = out.to(dev)
+    ops.conv2d(xw.to(dev), wp, 64, 3, 1, 1, sc.to(dev), sh.to(dev), resw.to(dev), True, in_window=(40, 32), out=o,
+               out_ch_offset=50, res_ch_offset=10)
+    o = o.cpu()
+    assert (o[:, 50:114] - ref).abs().max().item() <= 2e-5
+    assert torch.equal(o[:, :50], out[:, :50]) and torch.equal(o[:, 114:], out[:, 114:])   # neighbours untouched
+
+
+@pytest.mark.parametrize("k,shape", [(8, (2, 5, 24, 40)), (64, (1, 3, 64, 128)), (16, (1, 4, 40, 50))])
+def test_avgpool2d(dev, k, shape):
+    ops = _ops()
+    x = _rand(shape, 71)
+    got = ops.avgpool2d(x.to(dev), k).cpu()
+    ref = F.avg_pool2d(x, k, k)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 1e-6
+    wide = _rand((shape[0], shape[1] + 5, shape[2], shape[3]), 72)
+    got = ops.avgpool2d(wide.to(dev), k, in_window=(3, shape[1])).cpu()
+    assert (got - F.avg_pool2d(wide[:, 3:3 + shape[1]], k, k)).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("ins,outs", [((1, 2), (64, 128)), ((4, 8), (64, 128)), ((3, 5), (17, 31)), ((2, 2), (2, 2))])
+def test_bilinear_ac(dev, ins, outs):
+    ops = _ops()
+    x = _rand((2, 6) + ins, 81)
+    ref = F.interpolate(x, outs, mode="bilinear", align_corners=True)
+    assert (ops.bilinear_ac(x.to(dev), outs).cpu() - ref).abs().max().item() <= 2e-6
+    out = torch.zeros((2, 10) + outs).to(dev)
+    ops.bilinear_ac(x.to(dev), outs, out=out, out_ch_offset=3)
+    assert (out.cpu()[:, 3:9] - ref).abs().max().item() <= 2e-6 and out.cpu()[:, :3].abs().max().item() == 0

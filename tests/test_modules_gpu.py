@@ -324,3 +324,47 @@ def test_gwcnet_model_vs_oracle(dev):
         assert maxdiff(a, b) <= DISP_TOL
     for a, b in zip(results["costs"], costs):
         assert maxdiff(a, b) <= COST_TOL
+
+
+# -------------------------------------------------------------------------------- "next" row: PSMNet backbone (8-f1)
+def test_psmnet_backbone_vs_reference_golden(dev):
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone
+    g = golden("psmnet_backbone.npz")
+    bb = PSMNetBackbone(3, True).eval()
+    synthetic.init_params_(bb, seed=8, classif_gain=1.0)
+    bb = bb.to(dev)
+    img = rand((1, 3, 256, 512), 441)
+    with torch.no_grad():
+        fl, fr = bb(img.to(dev), rand((1, 3, 256, 512), 442).to(dev))
+    assert fl.shape == (1, 32, 64, 128)
+    assert maxdiff(fl[:, :, ::2, ::2], g["feat"]) <= 5e-6          # features are O(0.1..1) after 50+ FP32 conv layers
+    p = {"backbone." + k: v.cpu() for k, v in bb.state_dict().items()}
+    assert maxdiff(fr, O.psmnet_backbone(rand((1, 3, 256, 512), 442), p)) <= 5e-6   # second view through the 2B batch
+    # odd sizes: H/4, W/4 not multiples of the pooling windows' tiles
+    img = rand((2, 3, 256, 328), 443)
+    with torch.no_grad():
+        fl, _ = bb(img.to(dev), img.to(dev))
+    assert maxdiff(fl, O.psmnet_backbone(img, p)) <= 5e-6
+
+
+def test_psmnet_end_to_end_vs_reference_golden(dev):
+    """Images -> backbone -> cost volume -> hourglass -> soft-argmin, against the reference's whole model."""
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    g = golden("psmnet_e2e_cfg1.npz")
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "PSMNet", "scene_flow.py"))
+    cfg.model.max_disp = 64
+    cfg.model.cost_processor.cost_computation.max_disp = 16
+    cfg.model.cost_processor.cost_aggregator.max_disp = 64
+    cfg.model.disp_predictor.max_disp = 64
+    cfg.model.backbone = dict(type="PSMNet", in_planes=3)
+    model = build_model(cfg, backbone="hip").eval()
+    synthetic.init_params_(model, seed=9, classif_gain=10.0)
+    model = model.to(dev)
+    batch = {"leftImage": rand((1, 3, 256, 512), 451).to(dev), "rightImage": rand((1, 3, 256, 512), 452).to(dev)}
+    with torch.no_grad():
+        result, _ = model(batch)
+    for i, d in enumerate(result["disps"]):
+        assert maxdiff(d[:, :, ::2, ::2], g["disp%d" % (3 - i)]) <= DISP_TOL

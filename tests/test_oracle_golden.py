@@ -165,3 +165,40 @@ def test_stereonet_path_vs_reference():
     disps, costs = O.stereonet_path(lf, rf, p, 192)
     assert maxdiff(costs[0], g["cost"]) <= 1e-5 and maxdiff(disps[0], g["disp"]) <= 2e-5
     assert g["disp"].shape == (2, 1, 20, 36) and g["cost"].shape == (2, 24, 20, 36)
+
+
+def test_psmnet_backbone_and_end_to_end_vs_reference():
+    """"Next" row: the oracle's backbone restatement against the reference's PSMNetBackbone, and the
+    whole reference model (BASELINE configs[0]: 256x512, max_disp 64) against backbone -> path in the oracle."""
+    import os
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone
+    g = golden("psmnet_backbone.npz")
+    bb = PSMNetBackbone(3, True).eval()
+    synthetic.init_params_(bb, seed=8, classif_gain=1.0)
+    p = {"backbone." + k: v.clone() for k, v in bb.state_dict().items()}
+    f = O.psmnet_backbone(rand((1, 3, 256, 512), 441), p)
+    assert maxdiff(f[:, :, ::2, ::2], g["feat"]) <= 2e-6
+    assert abs(float(f.std()) - g["feat_stats"][1]) <= 1e-5 and g["feat_stats"][2] > 0.1   # not a dead network
+
+    g = golden("psmnet_e2e_cfg1.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    cfg.model.max_disp = 64
+    cfg.model.cost_processor.cost_computation.max_disp = 16
+    cfg.model.cost_processor.cost_aggregator.max_disp = 64
+    cfg.model.disp_predictor.max_disp = 64
+    cfg.model.backbone = dict(type="PSMNet", in_planes=3)
+    model = build_model(cfg, backbone="hip").eval()
+    assert sum(p_.numel() for p_ in model.parameters()) == int(g["n_params"][0]) == 5225024
+    synthetic.init_params_(model, seed=9, classif_gain=10.0)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    li, ri = rand((1, 3, 256, 512), 451), rand((1, 3, 256, 512), 452)
+    disps, _ = O.psmnet_path(O.psmnet_backbone(li, p), O.psmnet_backbone(ri, p), p, 64)
+    for i, d in enumerate(disps):
+        assert maxdiff(d[:, :, ::2, ::2], g["disp%d" % (3 - i)]) <= 2e-5
+    want = set(str(s) for s in golden("state_dict_keys.npz")["psmnet_backbone"])
+    got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items() if k.startswith("backbone"))
+    assert got == want and len(got) == 363
