@@ -89,6 +89,32 @@ def cpu_baseline(model, cfg, feat_hw, channels):
                        "%d threads (fastest of a sweep on a %d-thread host), %.1f s" % (cores, os.cpu_count() or 1, dt)), disps
 
 
+def end_to_end(model, dev, B, Hp, Wp, steps):
+    """Secondary figure (not the headline metric): images -> PSMNet backbone (HIP conv2d) -> the path."""
+    from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone
+    bb = PSMNetBackbone(3, True).eval()
+    synthetic.init_params_(bb, seed=8, classif_gain=1.0)
+    bb = bb.to(dev)
+    g = torch.Generator().manual_seed(77)
+    li, ri = (torch.randn((B, 3, Hp, Wp), generator=g).to(dev) for _ in range(2))
+    t_bb = t_all = 0.0
+    with torch.no_grad():
+        for it in range(steps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lf, rf = bb(li, ri)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model(dict(leftFeature=lf, rightFeature=rf))
+            torch.cuda.synchronize()
+            if it:   # first pass packs the weights
+                t_bb += t1 - t0
+                t_all += time.perf_counter() - t0
+    return {"pairs_per_s": round(B * steps / t_all, 2), "ms_per_step": round(t_all / steps * 1e3, 3),
+            "backbone_ms": round(t_bb / steps * 1e3, 3), "steps": steps,
+            "note": "left/right images [%d,3,%d,%d] resident in HBM; backbone runs both views as one batch" % (B, Hp, Wp)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,6 +243,8 @@ def main():
                 diffs = [(a - b).abs().max().item() for a, b in zip(d_gpu, ref_disps)]
                 out["parity_vs_cpu"] = {"max_abs_disp": [round(x, 7) for x in diffs],
                                         "epe_delta": [round((a - b).abs().mean().item(), 8) for a, b in zip(d_gpu, ref_disps)]}
+        if world == 1 and ptype == "Concatenation" and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and not fused:
+            out["end_to_end_with_backbone"] = end_to_end(model, dev, B, Hp, Wp, min(args.steps, 5))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

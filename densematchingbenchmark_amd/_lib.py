@@ -49,6 +49,7 @@ SIGNATURES = {
     "dmb_conv2d_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 12 + [_P]),
     "dmb_avgpool2d_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),
     "dmb_bilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 8 + [_P]),
+    "dmb_bilinear_scale_f32": (_c_int, [_P, _P] + [_c_int] * 6 + [_c_float] + [_c_int] * 2 + [_P]),
     "dmb_epe_accum_f64": (_c_int, [_P, _P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
 }
 

@@ -5,7 +5,8 @@
 // v_mfma_f32_32x32x2_f32, A = prepacked weight fragments, B = row-pair tiles of the haloed LDS tile (lanes 0-15: 16
 // pixels of row r, lanes 16-31: the same columns of row r + 1), LDS-DMA double-buffered chunks of CK input channels
 // (input rows + the chunk's weight fragments), fragments register double-buffered one k-step ahead.
-// One kernel covers kernel size 1 / 3, dilation 1 / 2 (compile time) and stride 1 / 2 (run time: a stride-2 layer
+// One kernel covers kernel size 1 / 3, dilation 1 / 2 / 4 / 8 (compile time; 4 and 8 are StereoNet's edge-aware
+// refinement, disp_refinement/utils/edge_aware.py:33-40) and stride 1 / 2 (run time: a stride-2 layer
 // evaluates the stride-1 grid and stores the even pixels -- only two small layers of the backbone are strided).
 // Input and output may be channel windows of wider tensors (the 320-channel SPP concat is written in place).
 #include "dmb_common.h"
@@ -44,7 +45,8 @@ struct C2Cfg {
   static constexpr int XS = TX / 16;
   static constexpr int MT = (RY / 2) * XS;     // 6 row-pair tiles per wave
   static constexpr int KK = KS * KS;
-  static constexpr int CK = (NTT == 4) ? 4 : 8;   // input channels per chunk (the 128-row weight chunk is 4x larger)
+  static constexpr int CK = (NTT == 4 || DIL >= 4) ? 4 : 8;   // input channels per chunk: halved where the weight chunk
+                                                            // (128 rows) or the halo (dilation 4 / 8) is large
   static constexpr int CH_STRIDE = ROWS * P + 4;
   static constexpr int NK = (CK / 2) * KK;  // k-steps per chunk
   static constexpr int IN_FLOATS = (CK * CH_STRIDE + 3) / 4 * 4;
@@ -213,6 +215,31 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const float* __restric
   y[(((size_t)b * out_ctot + out_coff + c) * Ho + yo) * Wo + xo] = fmaf(a1, ly, a0 * (1.f - ly));
 }
 
+// F.interpolate(mode='bilinear', align_corners=False) * mult (disp_refinement/StereoNet.py:49-50, edge_aware.py:49-50:
+// the coarse disparity map up-sampled to image size and rescaled by the resolution ratio).  ATen's source index:
+// src = max(scale * (dst + 0.5) - 0.5, 0), scale = in / out in FP32.
+__global__ __launch_bounds__(256) void bilinear_hp_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Hi,
+                                                          int Wi, int Ho, int Wo, float sh, float sw, float mult,
+                                                          int out_ctot, int out_coff) {
+#pragma clang fp contract(off)
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= (long long)C * Ho * Wo) return;
+  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), c = (int)(i / ((long long)Wo * Ho));
+  const float sy = fmaxf(sh * ((float)yo + 0.5f) - 0.5f, 0.f), sx = fmaxf(sw * ((float)xo + 0.5f) - 0.5f, 0.f);
+  int y0 = (int)sy, x0 = (int)sx;
+  y0 = y0 > Hi - 1 ? Hi - 1 : y0;
+  x0 = x0 > Wi - 1 ? Wi - 1 : x0;
+  const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+  float ly = sy - (float)y0, lx = sx - (float)x0;
+  ly = fminf(fmaxf(ly, 0.f), 1.f);
+  lx = fminf(fmaxf(lx, 0.f), 1.f);
+  const float* p = x + ((size_t)b * C + c) * Hi * Wi;
+  const float a0 = fmaf(p[(size_t)y0 * Wi + x1], lx, p[(size_t)y0 * Wi + x0] * (1.f - lx));
+  const float a1 = fmaf(p[(size_t)y1 * Wi + x1], lx, p[(size_t)y1 * Wi + x0] * (1.f - lx));
+  y[(((size_t)b * out_ctot + out_coff + c) * Ho + yo) * Wo + xo] = fmaf(a1, ly, a0 * (1.f - ly)) * mult;
+}
+
 template <class C>
 static int launch_conv2d(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                          float* y, int B, int Ci, int Co, int H, int W, int stride, int relu, int in_ctot, int out_ctot,
@@ -274,13 +301,17 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
     if (NTT == 1) DMB_C2(1, 3, 2);
     if (NTT == 2) DMB_C2(2, 3, 2);
     if (NTT == 4) DMB_C2(4, 3, 2);
+  } else if (ksize == 3 && dilation == 4) {
+    if (NTT == 1) DMB_C2(1, 3, 4);
+  } else if (ksize == 3 && dilation == 8) {
+    if (NTT == 1) DMB_C2(1, 3, 8);
   } else if (ksize == 1) {
     if (NTT == 1) DMB_C2(1, 1, 1);
     if (NTT == 2) DMB_C2(2, 1, 1);
     if (NTT == 4) DMB_C2(4, 1, 1);
   }
 #undef DMB_C2
-  return fail(DMB_EUNSUPPORTED, "conv2d: kernel 1 or 3, dilation 1 or 2 (3x3 only), output channels <= 128");
+  return fail(DMB_EUNSUPPORTED, "conv2d: kernel 1 or 3; dilation 1 or 2 (4 or 8 with <= 32 output channels); output channels <= 128");
 }
 
 extern "C" int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int k, int in_channels_total,
@@ -305,4 +336,16 @@ extern "C" int dmb_bilinear_ac_f32(const float* x, float* y, int B, int C, int H
   hipLaunchKernelGGL(bilinear_ac_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, y, C, Hi,
                      Wi, Ho, Wo, sh, sw, out_channels_total, out_ch_offset);
   return launch_status("bilinear launch failed");
+}
+
+extern "C" int dmb_bilinear_scale_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, float mult,
+                                      int out_channels_total, int out_ch_offset, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || out_ch_offset < 0 ||
+      out_ch_offset + C > out_channels_total || B > 65535)
+    return fail(DMB_EINVAL, "bilinear_scale: bad argument");
+  const long long n = (long long)C * Ho * Wo;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  hipLaunchKernelGGL(bilinear_hp_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, y, C, Hi,
+                     Wi, Ho, Wo, sh, sw, mult, out_channels_total, out_ch_offset);
+  return launch_status("bilinear_scale launch failed");
 }

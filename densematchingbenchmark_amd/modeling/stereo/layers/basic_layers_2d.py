@@ -12,15 +12,17 @@ __all__ = ["FusedConv2d", "conv_bn", "conv_bn_relu", "BasicBlock"]
 
 
 class FusedConv2d(nn.Sequential):
-    """Sequential(Conv2d, [BatchNorm2d], [ReLU]) as ONE kernel launch: conv (k 1 or 3, stride 1 or 2, dilation 1 or
-    2) + folded BN + optional residual + ReLU; may read / write channel windows of wider tensors."""
+    """Sequential(Conv2d, [BatchNorm2d], [ReLU]) as ONE kernel launch: conv (k 1 or 3, stride 1 or 2, dilation 1, 2,
+    4 or 8) + folded BN + optional residual + ReLU; may read / write channel windows of wider tensors."""
 
     def __init__(self, batch_norm, in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1, bias=True,
                  relu=False):
         # basic_layers.py:14-28: padding follows the dilation when dilation > 1
         pad = dilation if dilation > 1 else padding
-        if kernel_size not in (1, 3) or stride not in (1, 2) or dilation not in (1, 2) or pad != dilation * (kernel_size // 2):
-            raise NotImplementedError("HIP conv2d: kernel 1|3, stride 1|2, dilation 1|2, 'same' padding")
+        if kernel_size not in (1, 3) or stride not in (1, 2) or dilation not in (1, 2, 4, 8) or pad != dilation * (kernel_size // 2) \
+                or (dilation > 2 and out_planes > 32):
+            raise NotImplementedError("HIP conv2d: kernel 1|3, stride 1|2, dilation 1|2 (4|8 up to 32 output channels), "
+                                      "'same' padding")
         layers = [nn.Conv2d(in_planes, out_planes, kernel_size, stride=stride, padding=pad, dilation=dilation, bias=bias)]
         if batch_norm:
             layers.append(nn.BatchNorm2d(out_planes))

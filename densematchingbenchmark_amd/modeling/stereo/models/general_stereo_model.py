@@ -1,8 +1,9 @@
 """The caller of the hot path: eval-mode contract of models/general_stereo_model.py:14-92.
 
-The 2-D feature backbone is NOT part of this path: pass any ``nn.Module`` with the reference's
-``backbone(left, right) -> (ref_fms, tgt_fms)`` contract (e.g. the reference's own PSMNetBackbone on stock
-PyTorch-ROCm), or feed pre-computed features with ``batch['leftFeature'] / batch['rightFeature']``."""
+The hot path starts at the feature maps: feed pre-computed features with ``batch['leftFeature'] /
+batch['rightFeature']``, pass any ``nn.Module`` with the reference's ``backbone(left, right) -> (ref_fms, tgt_fms)``
+contract, or ``backbone="hip"`` for this package's HIP backbone.  A ``disp_refinement`` entry in the
+config attaches the HIP refinement stage exactly where the reference runs it."""
 import torch
 import torch.nn as nn
 
@@ -23,8 +24,10 @@ class GeneralizedStereoModel(nn.Module):
         self.cost_processor = build_cost_processor(cfg)
         self.cmn = build_cmn(cfg) if 'cmn' in cfg.model else None
         self.disp_predictor = build_disp_predictor(cfg)
-        if 'disp_refinement' in cfg.model and cfg.model.get('require_refinement', False):
-            raise NotImplementedError("disp_refinement is outside the HIP hot path (SURVEY 8-f2)")
+        self.disp_refinement = None
+        if 'disp_refinement' in cfg.model:                           # general_stereo_model.py:35-37
+            from ..disp_refinement import build_disp_refinement
+            self.disp_refinement = build_disp_refinement(cfg)
 
     def forward(self, batch):
         if self.training:
@@ -38,6 +41,10 @@ class GeneralizedStereoModel(nn.Module):
         with torch.no_grad():
             costs = self.cost_processor(ref_fms, tgt_fms)            # general_stereo_model.py:51
             disps = [self.disp_predictor(cost) for cost in costs]    # :54
+            if self.disp_refinement is not None:                     # :57-58
+                if 'leftImage' not in batch:
+                    raise ValueError("disp_refinement needs batch['leftImage'] (full-resolution left view)")
+                disps = self.disp_refinement(disps, ref_fms, tgt_fms, batch['leftImage'], batch.get('rightImage'))
             results = dict(disps=disps, costs=costs)                 # :82-85
             if self.cmn is not None:
                 variance, confs = self.cmn(costs, batch.get('leftDisp'))  # :87-90

@@ -360,3 +360,17 @@ def bilinear_ac(x, out_hw, out=None, out_ch_offset=0):
     check(lib.dmb_bilinear_ac_f32(dev_ptr(x), dev_ptr(out), B, C, Hi, Wi, Ho, Wo, out.shape[1], out_ch_offset,
                                   stream_ptr(x.device)), "dmb_bilinear_ac_f32")
     return out
+
+
+def bilinear_scale(x, out_hw, mult=1.0, out=None, out_ch_offset=0):
+    """F.interpolate(x, out_hw, mode='bilinear', align_corners=False) * mult."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        out_ch_offset = 0
+    check(lib.dmb_bilinear_scale_f32(dev_ptr(x), dev_ptr(out), B, C, Hi, Wi, Ho, Wo, float(mult), out.shape[1],
+                                     out_ch_offset, stream_ptr(x.device)), "dmb_bilinear_scale_f32")
+    return out

@@ -185,7 +185,7 @@ int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* wo
 long long dmb_conv2d_packed_floats(int Co, int Ci, int ksize);
 int dmb_conv2d_pack_weights_f32(const float* w, float* wpack, int Co, int Ci, int ksize, void* stream);
 
-/* Conv2d (kernel 1 or 3, padding = dilation * (k/2), stride 1 or 2, dilation 1 or 2) + folded BatchNorm
+/* Conv2d (kernel 1 or 3, padding = dilation * (k/2), stride 1 or 2, dilation 1 or 2 -- also 4 or 8 when Co <= 32) + folded BatchNorm
  * (scale/shift, may be NULL) + residual (may be NULL; added after the affine, basic_layers.py:236-241) + ReLU.
  * x, y and residual may be channel windows of wider tensors: x points at the first input channel of batch item 0 of
  * a tensor with in_channels_total channels per item (likewise y / out_channels_total, residual / res_channels_total).
@@ -203,6 +203,12 @@ int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int 
  * [out_ch_offset, out_ch_offset + C) of y [B, out_channels_total, Ho, Wo]. */
 int dmb_bilinear_ac_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, int out_channels_total,
                         int out_ch_offset, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=False) * mult: the coarse disparity map brought to image size and
+ * rescaled by the resolution ratio (disp_refinement/StereoNet.py:49-50, disp_refinement/utils/edge_aware.py:49-50).
+ * x [B, C, Hi, Wi] -> channels [out_ch_offset, out_ch_offset + C) of y [B, out_channels_total, Ho, Wo]. */
+int dmb_bilinear_scale_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, float mult,
+                           int out_channels_total, int out_ch_offset, void* stream);
 
 #ifdef __cplusplus
 }

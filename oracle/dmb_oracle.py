@@ -389,6 +389,30 @@ def psmnet_backbone(img, p, prefix="backbone.", batch_norm=True):
     return F.conv2d(y, p[prefix + "lastconv.1.weight"])
 
 
+def edge_aware_refinement(disp, left_image, p, prefix, batch_norm=True):
+    """EdgeAwareRefinement.forward (disp_refinement/utils/edge_aware.py:44-68)."""
+    h, w = left_image.shape[-2:]
+    scale = w / disp.shape[-1]
+    up = F.interpolate(disp, size=(h, w), mode="bilinear", align_corners=False) * scale
+    x = conv2d_unit(torch.cat((up, left_image), 1), p, prefix + "conv_mix", 1, 1, 3, batch_norm, True)
+    for i, d in enumerate((1, 2, 4, 8, 1, 1)):
+        x = basic_block(x, p, prefix + "residual_dilation_blocks.%d" % i, 1, d, False, batch_norm)
+    res = F.conv2d(x, p[prefix + "conv_res.weight"], p[prefix + "conv_res.bias"], padding=1)
+    return F.relu(res + up)
+
+
+def stereonet_refinement(disps, left_image, p, num=1, prefix="disp_refinement.", batch_norm=True):
+    """StereoNetRefinement.forward (disp_refinement/StereoNet.py:39-61): best map first."""
+    h, w = left_image.shape[-2:]
+    init = disps[-1]
+    scale = w / init.shape[-1]
+    out = [F.interpolate(init, size=(h, w), mode="bilinear", align_corners=False) * scale]
+    for i in range(num):
+        out.append(edge_aware_refinement(out[-1], left_image, p, prefix + "refine_blocks.%d." % i, batch_norm))
+    out.reverse()
+    return out
+
+
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs

@@ -334,3 +334,40 @@ def test_bilinear_ac(dev, ins, outs):
     out = torch.zeros((2, 10) + outs).to(dev)
     ops.bilinear_ac(x.to(dev), outs, out=out, out_ch_offset=3)
     assert (out.cpu()[:, 3:9] - ref).abs().max().item() <= 2e-6 and out.cpu()[:, :3].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dil,shape", [(4, (2, 21, 70)), (8, (1, 40, 96)), (8, (1, 5, 7))])
+def test_conv2d_dilation_4_8(dev, dil, shape):
+    ops = _ops()
+    B, H, W = shape
+    x = _rand((B, 32, H, W), 91)
+    w = _rand((32, 32, 3, 3), 92, 1.0 / math.sqrt(32 * 9))
+    sc, sh = _affine(32, 93)
+    ref = F.relu(F.conv2d(x, w, None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wp = ops.pack_conv2d_weights(w.to(dev))
+    got = ops.conv2d(x.to(dev), wp, 32, 3, 1, dil, sc.to(dev), sh.to(dev), None, True).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5
+
+
+def test_conv2d_single_output_channel_with_skip_window(dev):
+    """conv_res of the refinement: 32 -> 1, bias, skip read from channel 0 of the 4-channel mixed input, ReLU."""
+    ops = _ops()
+    x = _rand((2, 32, 19, 50), 95)
+    w = _rand((1, 32, 3, 3), 96, 1.0 / math.sqrt(32 * 9))
+    bias = _rand((1,), 97)
+    mixed = _rand((2, 4, 19, 50), 98)
+    ref = F.relu(F.conv2d(x, w, bias, padding=1) + mixed[:, :1])
+    got = ops.conv2d(x.to(dev), ops.pack_conv2d_weights(w.to(dev)), 1, 3, 1, 1, None, bias.to(dev), mixed.to(dev), True).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("ins,outs,mult", [((24, 40), (192, 320), 8.0), ((5, 7), (13, 30), 30.0 / 7), ((9, 9), (9, 9), 1.0),
+                                            ((48, 156), (384, 1248), 8.0)])
+def test_bilinear_half_pixel_scaled(dev, ins, outs, mult):
+    ops = _ops()
+    x = _rand((2, 1) + ins, 99, 10.0)
+    ref = F.interpolate(x, size=outs, mode="bilinear", align_corners=False) * mult
+    got = ops.bilinear_scale(x.to(dev), outs, mult).cpu()
+    assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item() / 8)
+    if ins == outs:
+        assert torch.equal(got, x)

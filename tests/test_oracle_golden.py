@@ -202,3 +202,32 @@ def test_psmnet_backbone_and_end_to_end_vs_reference():
     want = set(str(s) for s in golden("state_dict_keys.npz")["psmnet_backbone"])
     got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items() if k.startswith("backbone"))
     assert got == want and len(got) == 363
+
+
+def test_stereonet_refinement_vs_reference():
+    """"Next" row: oracle restatement of the edge-aware refinement cascade against the reference's
+    StereoNetRefinement, and the drop-in module's parameter names against the reference's."""
+    import os
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    from densematchingbenchmark_amd.modeling.stereo.disp_refinement import StereoNetRefinement
+    g = golden("stereonet_refinement.npz")
+    rf = StereoNetRefinement(in_planes=4, batch_norm=True, num=2).eval()
+    synthetic.init_params_(rf, seed=10, classif_gain=1.0)
+    p = {"disp_refinement." + k: v.clone() for k, v in rf.state_dict().items()}
+    gen = torch.Generator().manual_seed(461)
+    coarse = torch.rand((2, 1, 24, 40), generator=gen) * 4.0
+    outs = O.stereonet_refinement([coarse], rand((2, 3, 192, 320), 462), p, num=2)
+    assert len(outs) == 3
+    for i, d in enumerate(outs):
+        assert maxdiff(d[:, :, ::2, ::2], g["refined%d" % i]) <= 1e-5
+    assert g["residual_stats"].min() > 0.5      # the blocks really change the map
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "StereoNet", "scene_flow_8x_2stage.py"))
+    cfg.model.disp_refinement = dict(type="StereoNet", in_planes=4, num=1)
+    model = build_model(cfg)
+    want = set(str(s) for s in golden("state_dict_keys.npz")["stereonet_refinement"])
+    got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items() if k.startswith("disp_refinement"))
+    assert got == want and len(got) == 81
