@@ -6,8 +6,9 @@
 // pixels of row r, lanes 16-31: the same columns of row r + 1), LDS-DMA double-buffered chunks of CK input channels
 // (input rows + the chunk's weight fragments), fragments register double-buffered one k-step ahead.
 // One kernel covers kernel size 1 / 3, dilation 1 / 2 / 4 / 8 (compile time; 4 and 8 are StereoNet's edge-aware
-// refinement, disp_refinement/utils/edge_aware.py:33-40) and stride 1 / 2 (run time: a stride-2 layer
-// evaluates the stride-1 grid and stores the even pixels -- only two small layers of the backbone are strided).
+// refinement, disp_refinement/utils/edge_aware.py:33-40), kernel size 5 (StereoNet's down-sampling heads,
+// backbones/StereoNet.py:26-27) and stride 1 / 2 (compile time: a strided tile stages (TX - 1) * 2 + 1 + 2 * HALO input
+// columns and its B fragments walk LDS with stride 2).
 // Input and output may be channel windows of wider tensors (the 320-channel SPP concat is written in place).
 #include "dmb_common.h"
 
@@ -32,45 +33,49 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <int NTT_, int KS_, int DIL_>
+template <int NTT_, int KS_, int DIL_, int S_ = 1>
 struct C2Cfg {
-  static constexpr int NTT = NTT_, KS = KS_, DIL = DIL_;
+  static constexpr int NTT = NTT_, KS = KS_, DIL = DIL_, S = S_;
   static constexpr int WN = NTT;               // one 32-channel row tile per wave column (1, 2 or 4)
   static constexpr int WY = 4 / WN;            // waves stacked along y
-  static constexpr int RY = 4;                 // output rows per wave (two row pairs)
+  static constexpr int RY = (S == 1) ? 4 : 2;  // output rows per wave (row pairs); strided tiles read 2x2 the input
   static constexpr int TY = RY * WY, TX = 48;
   static constexpr int HALO = (KS / 2) * DIL;
-  static constexpr int P = TX + 2 * HALO;
-  static constexpr int ROWS = TY + 2 * HALO;
+  static constexpr int P = (TX - 1) * S + 1 + 2 * HALO;      // staged input row length
+  static constexpr int ROWS = (TY - 1) * S + 1 + 2 * HALO;
+  static constexpr int SEG = (P + 63) / 64;    // one wave stages 64 floats of a tile row per instruction
   static constexpr int XS = TX / 16;
-  static constexpr int MT = (RY / 2) * XS;     // 6 row-pair tiles per wave
+  static constexpr int MT = (RY / 2) * XS;     // row-pair tiles per wave (6, or 3 when strided)
   static constexpr int KK = KS * KS;
-  static constexpr int CK = (NTT == 4 || DIL >= 4) ? 4 : 8;   // input channels per chunk: halved where the weight chunk
-                                                            // (128 rows) or the halo (dilation 4 / 8) is large
   static constexpr int CH_STRIDE = ROWS * P + 4;
+  // input channels per chunk: the largest of 8 / 4 / 2 whose double-buffered chunk (input rows + weight fragments)
+  // lets two workgroups share one CU's 160 KB of LDS
+  static constexpr int lds_bytes(int ck) { return 2 * ((ck * CH_STRIDE + 3) / 4 * 4 + (ck / 2) * KK * NTT * 64) * 4; }
+  static constexpr int CK = lds_bytes(8) <= 80 * 1024 ? 8 : (lds_bytes(4) <= 80 * 1024 ? 4 : 2);
   static constexpr int NK = (CK / 2) * KK;  // k-steps per chunk
   static constexpr int IN_FLOATS = (CK * CH_STRIDE + 3) / 4 * 4;
   static constexpr int W_FLOATS = NK * NTT * 64;
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;
-  static_assert(P <= 64, "one wave stages one tile row per instruction");
-  static_assert((CK * ROWS) % 4 == 0 && C2_CK % CK == 0, "rows are dealt evenly to the 4 waves");
+  static constexpr int UNITS = CK * ROWS * SEG;              // 64-float row segments per chunk
+  static_assert(C2_CK % CK == 0, "chunks tile the padded channel count");
   static_assert(W_FLOATS % 16 == 0, "weights are copied with 16-byte words, evenly over 4 waves");
+  static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
 };
 
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, float* __restrict__ y, int Ci,
-                                                        int Co, int H, int W, int stride, int relu, int in_ctot,
-                                                        int out_ctot, int res_ctot, int ntx, int nty) {
+                                                        int Co, int H, int W, int relu, int in_ctot, int out_ctot,
+                                                        int res_ctot, int ntx, int nty) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
   t /= ntx;
   const int ty = t % nty;
   const int b = t / nty;
-  const int x0 = tx * C::TX, y0 = ty * C::TY;   // stride-1 grid coordinates
+  const int x0 = tx * C::TX, y0 = ty * C::TY;   // output coordinates of the tile
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wy = wave / C::WN, wn = wave % C::WN;
@@ -84,22 +89,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  constexpr int RPW = C::CK * C::ROWS / 4;   // tile rows per wave per chunk
+  constexpr int RPW = (C::UNITS + 3) / 4;    // row segments per wave per chunk
   constexpr int WPW = C::W_FLOATS / 16;      // 16-byte weight words per wave
   constexpr int WI = (WPW + 63) / 64;
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * HW * 4u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)((Cipad / 2) * C::KK * C::NTT * 64) * 4u);
-  const int gx = x0 - C::HALO + lane;
-  const unsigned xvoff = (lane < C::P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+  const int gx0 = x0 * C::S - C::HALO + lane;
   auto stage = [&](int c0, float* buf) {
-    if (lane < C::P) {
 #pragma unroll
-      for (int q = 0; q < RPW; ++q) {
-        const int rid = wave * RPW + q, cl = rid / C::ROWS, yy = rid - cl * C::ROWS;
-        const int gy = y0 - C::HALO + yy;
-        const bool ok = c0 + cl < Ci && gy >= 0 && gy < H;
-        dma4(xrs, ok ? xvoff : DMA_OOB, ok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W) * 4u : 0u,
-             buf + cl * C::CH_STRIDE + yy * C::P);
+    for (int q = 0; q < RPW; ++q) {
+      const int rid = wave * RPW + q;
+      if (C::UNITS % 4 == 0 || rid < C::UNITS) {
+        const int seg = rid % C::SEG, rr = rid / C::SEG, cl = rr / C::ROWS, yy = rr - cl * C::ROWS;
+        const int gy = y0 * C::S - C::HALO + yy, gx = gx0 + seg * 64;
+        const bool rowok = c0 + cl < Ci && gy >= 0 && gy < H;               // wave-uniform: the scalar offset stays an SGPR
+        const bool ok = rowok && seg * 64 + lane < C::P && gx >= 0 && gx < W;
+        if (C::P % 64 == 0 || seg * 64 + lane < C::P)
+          dma4(xrs, ok ? (unsigned)gx * 4u : DMA_OOB, rowok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W) * 4u : 0u,
+               buf + cl * C::CH_STRIDE + yy * C::P + seg * 64);
       }
     }
 #pragma unroll
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
     const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
     if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
     const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + (wy * C::RY) * C::P + (j >> 4) * C::P + (j & 15);
+    const float* bbase = cur + h * C::CH_STRIDE + ((wy * C::RY + (j >> 4)) * C::P + (j & 15)) * C::S;
     float af[2], bf[2][C::MT];
     auto load_frag = [&](int ks, float& a, float (&bq)[C::MT]) {
       const int cp = ks / C::KK, tap = ks % C::KK;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
       a = abase[ks * C::NTT * 64];
       const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::DIL * C::P + dx * C::DIL;
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[2 * (mt / C::XS) * C::P + (mt % C::XS) * 16];
+      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[(2 * (mt / C::XS) * C::P + (mt % C::XS) * 16) * C::S];
     };
     load_frag(0, af[0], bf[0]);
 #pragma unroll
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
   }
 
   // epilogue: BN scale/shift -> + residual -> ReLU (basic_layers.py:219-243 adds the skip AFTER conv2's BN, no ReLU)
-  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
   const unsigned HWo = (unsigned)Ho * Wo;
   float* yb = y + (size_t)b * out_ctot * HWo;
   const float* rb = res ? res + (size_t)b * res_ctot * HWo : nullptr;
@@ -157,9 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
   for (int mt = 0; mt < C::MT; ++mt) {
     const int gy = y0 + wy * C::RY + 2 * (mt / C::XS) + (j >> 4);
     const int gxo = x0 + (mt % C::XS) * 16 + (j & 15);
-    const bool keep = gy < H && gxo < W && (stride == 1 || (((gy | gxo) & 1) == 0));
-    if (keep) {
-      const unsigned o = (unsigned)(gy / stride) * Wo + (unsigned)(gxo / stride);
+    if (gy < Ho && gxo < Wo) {
+      const unsigned o = (unsigned)gy * Wo + (unsigned)gxo;
       float rv[16];
       if (rb) {
 #pragma unroll
@@ -242,9 +248,10 @@ __global__ __launch_bounds__(256) void bilinear_hp_kernel(const float* __restric
 
 template <class C>
 static int launch_conv2d(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                         float* y, int B, int Ci, int Co, int H, int W, int stride, int relu, int in_ctot, int out_ctot,
+                         float* y, int B, int Ci, int Co, int H, int W, int relu, int in_ctot, int out_ctot,
                          int res_ctot, hipStream_t st) {
-  const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY);
+  const int Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
+  const int ntx = cdiv(Wo, C::TX), nty = cdiv(Ho, C::TY);
   const long long nblk = (long long)B * ntx * nty;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
@@ -255,7 +262,7 @@ static int launch_conv2d(const float* x, const float* wp, const float* scale, co
     attr_set = true;
   }
   hipLaunchKernelGGL((conv2d_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, Co, H,
-                     W, stride, relu, in_ctot, out_ctot, res_ctot, ntx, nty);
+                     W, relu, in_ctot, out_ctot, res_ctot, ntx, nty);
   return launch_status("conv2d launch failed");
 }
 
@@ -266,12 +273,13 @@ using namespace dmb;
 static int c2_cipad(int Ci) { return cdiv(Ci, C2_CK) * C2_CK; }
 
 extern "C" long long dmb_conv2d_packed_floats(int Co, int Ci, int ksize) {
-  if (Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3)) return 0;
+  if (Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3 && ksize != 5)) return 0;
   return (long long)(c2_cipad(Ci) / 2) * ksize * ksize * cdiv(Co, 32) * 64;
 }
 
 extern "C" int dmb_conv2d_pack_weights_f32(const float* w, float* wpack, int Co, int Ci, int ksize, void* stream) {
-  if (!w || !wpack || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3)) return fail(DMB_EINVAL, "conv2d_pack: bad argument");
+  if (!w || !wpack || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3 && ksize != 5))
+    return fail(DMB_EINVAL, "conv2d_pack: bad argument");
   const int NTT = cdiv(Co, 32);
   if (NTT != 1 && NTT != 2 && NTT != 4) return fail(DMB_EUNSUPPORTED, "conv2d: output channels must fit 32, 64 or 128");
   hipLaunchKernelGGL(pack_conv2d_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, wpack, Co, Ci, c2_cipad(Ci),
@@ -290,28 +298,41 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
   if ((long long)in_channels_total * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: one batch item must stay below 2 GiB");
   const int NTT = cdiv(Co, 32);
   hipStream_t st = (hipStream_t)stream;
-#define DMB_C2(N, K, DL)                                                                                              \
-  return launch_conv2d<C2Cfg<N, K, DL>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, stride, relu,            \
-                                        in_channels_total, out_channels_total, res_channels_total, st)
-  if (ksize == 3 && dilation == 1) {
-    if (NTT == 1) DMB_C2(1, 3, 1);
-    if (NTT == 2) DMB_C2(2, 3, 1);
-    if (NTT == 4) DMB_C2(4, 3, 1);
-  } else if (ksize == 3 && dilation == 2) {
-    if (NTT == 1) DMB_C2(1, 3, 2);
-    if (NTT == 2) DMB_C2(2, 3, 2);
-    if (NTT == 4) DMB_C2(4, 3, 2);
-  } else if (ksize == 3 && dilation == 4) {
-    if (NTT == 1) DMB_C2(1, 3, 4);
-  } else if (ksize == 3 && dilation == 8) {
-    if (NTT == 1) DMB_C2(1, 3, 8);
-  } else if (ksize == 1) {
-    if (NTT == 1) DMB_C2(1, 1, 1);
-    if (NTT == 2) DMB_C2(2, 1, 1);
-    if (NTT == 4) DMB_C2(4, 1, 1);
+#define DMB_C2(N, K, DL, S)                                                                                           \
+  return launch_conv2d<C2Cfg<N, K, DL, S>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu,                  \
+                                           in_channels_total, out_channels_total, res_channels_total, st)
+  if (stride == 1) {
+    if (ksize == 3 && dilation == 1) {
+      if (NTT == 1) DMB_C2(1, 3, 1, 1);
+      if (NTT == 2) DMB_C2(2, 3, 1, 1);
+      if (NTT == 4) DMB_C2(4, 3, 1, 1);
+    } else if (ksize == 3 && dilation == 2) {
+      if (NTT == 1) DMB_C2(1, 3, 2, 1);
+      if (NTT == 2) DMB_C2(2, 3, 2, 1);
+      if (NTT == 4) DMB_C2(4, 3, 2, 1);
+    } else if (ksize == 3 && dilation == 4) {
+      if (NTT == 1) DMB_C2(1, 3, 4, 1);
+    } else if (ksize == 3 && dilation == 8) {
+      if (NTT == 1) DMB_C2(1, 3, 8, 1);
+    } else if (ksize == 1) {
+      if (NTT == 1) DMB_C2(1, 1, 1, 1);
+      if (NTT == 2) DMB_C2(2, 1, 1, 1);
+      if (NTT == 4) DMB_C2(4, 1, 1, 1);
+    }
+  } else if (dilation == 1) {
+    if (ksize == 3) {
+      if (NTT == 1) DMB_C2(1, 3, 1, 2);
+      if (NTT == 2) DMB_C2(2, 3, 1, 2);
+    } else if (ksize == 1) {
+      if (NTT == 1) DMB_C2(1, 1, 1, 2);
+      if (NTT == 2) DMB_C2(2, 1, 1, 2);
+    } else if (ksize == 5) {
+      if (NTT == 1) DMB_C2(1, 5, 1, 2);
+    }
   }
 #undef DMB_C2
-  return fail(DMB_EUNSUPPORTED, "conv2d: kernel 1 or 3; dilation 1 or 2 (4 or 8 with <= 32 output channels); output channels <= 128");
+  return fail(DMB_EUNSUPPORTED, "conv2d: stride 1 with kernel 1 | 3, dilation 1 | 2 (4 | 8 up to 32 output channels), output channels <= 128; "
+                                "stride 2 with kernel 1 | 3 (<= 64 output channels) or 5 (<= 32), dilation 1");
 }
 
 extern "C" int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int k, int in_channels_total,

@@ -1,14 +1,15 @@
 from .PSMNet import PSMNetBackbone
+from .StereoNet import StereoNetBackbone
 
-BACKBONES = {"PSMNet": PSMNetBackbone}
+BACKBONES = {"PSMNet": PSMNetBackbone, "StereoNet": StereoNetBackbone}
 
 
 def build_backbone(cfg):
-    """dmb/modeling/stereo/backbones/builder.py: only the PSMNet backbone is on the HIP path so far."""
+    """dmb/modeling/stereo/backbones/builder.py: the PSMNet and StereoNet backbones are on the HIP path."""
     b = cfg.model.backbone
     if b.type not in BACKBONES:
         raise NotImplementedError("backbone '%s' is outside the HIP path (attach a stock PyTorch backbone instead)" % b.type)
-    args = b.copy()
+    args = dict(b)
     args.pop("type")
     args.update(batch_norm=cfg.model.batch_norm)
     return BACKBONES[b.type](**args)

@@ -303,7 +303,7 @@ def _window_ptr(t, ch_offset):
 
 
 def pack_conv2d_weights(w):
-    """nn.Conv2d weight [Co, Ci, k, k] (k in {1, 3}) -> MFMA A-fragment stream."""
+    """nn.Conv2d weight [Co, Ci, k, k] (k in {1, 3, 5}) -> MFMA A-fragment stream."""
     lib = _lib.load()
     w = _f32c(w, "weight")
     Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]

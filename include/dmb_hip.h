@@ -177,17 +177,20 @@ int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* wo
                       int H0, int W0, float lb, float ub, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * "Next" row: the 2-D feature backbone that feeds the path.
- * dmb/modeling/stereo/backbones/PSMNet.py:8-129 with layers/basic_layers.py:31-46,105-123,219-243.
+ * "Next" rows: the 2-D networks either side of the path.
+ * dmb/modeling/stereo/backbones/PSMNet.py:8-129 and backbones/StereoNet.py:7-106 with
+ * layers/basic_layers.py:31-46,105-123,219-243; disp_refinement/StereoNet.py:7-62 with
+ * disp_refinement/utils/edge_aware.py:8-70.
  * ---------------------------------------------------------------------------------------- */
 
-/* nn.Conv2d weights [Co, Ci, k, k] (k = 1 or 3) -> MFMA A-fragment stream; Co <= 128, any Ci. */
+/* nn.Conv2d weights [Co, Ci, k, k] (k = 1, 3 or 5) -> MFMA A-fragment stream; Co <= 128, any Ci. */
 long long dmb_conv2d_packed_floats(int Co, int Ci, int ksize);
 int dmb_conv2d_pack_weights_f32(const float* w, float* wpack, int Co, int Ci, int ksize, void* stream);
 
-/* Conv2d (kernel 1 or 3, padding = dilation * (k/2), stride 1 or 2, dilation 1 or 2 -- also 4 or 8 when Co <= 32) + folded BatchNorm
- * (scale/shift, may be NULL) + residual (may be NULL; added after the affine, basic_layers.py:236-241) + ReLU.
- * x, y and residual may be channel windows of wider tensors: x points at the first input channel of batch item 0 of
+/* Conv2d with padding = dilation * (k/2) + folded BatchNorm / bias (scale, shift: each may be NULL).  Supported:
+ * stride 1 with kernel 1 | 3, dilation 1 | 2 (4 | 8 when Co <= 32), Co <= 128; stride 2 with kernel 1 | 3 (Co <= 64) or
+ * 5 (Co <= 32), dilation 1; anything else returns DMB_EUNSUPPORTED.  Then + residual (may be NULL; added after the affine,
+ * basic_layers.py:236-241) + ReLU.  x, y and residual may be channel windows of wider tensors: x points at the first input channel of batch item 0 of
  * a tensor with in_channels_total channels per item (likewise y / out_channels_total, residual / res_channels_total).
  * x: [B, Ci (of in_channels_total), H, W] -> y: [B, Co (of out_channels_total), Ho, Wo], Ho = (H - 1) / stride + 1. */
 int dmb_conv2d_f32(const float* x, const float* wpack, const float* scale, const float* shift, const float* residual,

@@ -389,6 +389,17 @@ def psmnet_backbone(img, p, prefix="backbone.", batch_norm=True):
     return F.conv2d(y, p[prefix + "lastconv.1.weight"])
 
 
+def stereonet_backbone(img, p, prefix="backbone.", batch_norm=True, downsample_num=3, residual_num=6):
+    """StereoNetBackbone._forward (backbones/StereoNet.py:83-93) for one image batch [B, 3, H, W] -> [B, 32, H/8, W/8]."""
+    x = img
+    for i in range(downsample_num):
+        x = F.conv2d(x, p[prefix + "downsample.%d.downsample.weight" % i], p[prefix + "downsample.%d.downsample.bias" % i],
+                     stride=2, padding=2)
+    for i in range(residual_num):
+        x = basic_block(x, p, prefix + "residual_blocks.%d" % i, 1, 1, False, batch_norm)
+    return F.conv2d(x, p[prefix + "lastconv.weight"], p[prefix + "lastconv.bias"], padding=1)
+
+
 def edge_aware_refinement(disp, left_image, p, prefix, batch_norm=True):
     """EdgeAwareRefinement.forward (disp_refinement/utils/edge_aware.py:44-68)."""
     h, w = left_image.shape[-2:]

@@ -274,7 +274,11 @@ def test_epe_accumulate(dev):
     (128, 32, 1, 1, 1, (1, 1, 2)),       # SPP branch after 64x64 pooling
     (320, 128, 3, 1, 1, (1, 8, 30)),     # lastconv.0
     (20, 32, 3, 1, 1, (1, 6, 13)),
-    (64, 64, 3, 2, 2, (1, 11, 23)),
+    (3, 32, 5, 2, 1, (2, 21, 75)),       # StereoNet down-sampling head 0: 5x5, stride 2
+    (32, 32, 5, 2, 1, (1, 48, 156)),
+    (32, 32, 3, 2, 1, (1, 9, 101)),
+    (32, 64, 1, 2, 1, (1, 7, 97)),
+    (16, 32, 1, 2, 1, (1, 1, 1)),
 ])
 def test_conv2d(dev, Ci, Co, k, stride, dil, shape):
     ops = _ops()
@@ -293,6 +297,16 @@ def test_conv2d(dev, Ci, Co, k, stride, dil, shape):
     assert (got - F.relu(ref + res)).abs().max().item() <= 2e-5
     got = ops.conv2d(x.to(dev), wp, Co, k, stride, dil).cpu()
     assert (got - F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)).abs().max().item() <= 2e-5
+
+
+def test_conv2d_unsupported_combinations_fail_loudly(dev):
+    ops = _ops()
+    from densematchingbenchmark_amd._lib import DmbLibraryError
+    x = _rand((1, 64, 8, 8), 1).to(dev)
+    for Co, k, stride, dil in ((64, 3, 2, 2), (128, 3, 2, 1), (64, 3, 1, 4), (64, 5, 2, 1), (32, 5, 1, 1)):
+        wp = ops.pack_conv2d_weights(_rand((Co, 64, k, k), 2).to(dev))
+        with pytest.raises(DmbLibraryError):
+            ops.conv2d(x, wp, Co, k, stride, dil)
 
 
 def test_conv2d_channel_windows(dev):

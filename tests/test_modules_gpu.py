@@ -408,3 +408,26 @@ def test_stereonet_model_with_refinement_vs_oracle(dev):
     assert len(res["disps"]) == 2
     for a, b in zip(res["disps"], want):
         assert maxdiff(a, b) <= DISP_TOL
+
+
+def test_stereonet_end_to_end_vs_reference_golden(dev):
+    """Images -> StereoNet backbone -> difference volume -> aggregator -> soft-argmin -> refinement, all HIP, against
+    the reference's whole model (config scene_flow_8x_2stage)."""
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    g = golden("stereonet_e2e.npz")
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "StereoNet", "scene_flow_8x_2stage.py"))
+    cfg.model.backbone = dict(type="StereoNet", in_planes=3, downsample_num=3, residual_num=6)
+    cfg.model.disp_refinement = dict(type="StereoNet", in_planes=4, num=1)
+    model = build_model(cfg, backbone="hip").eval()
+    synthetic.init_params_(model, seed=12, classif_gain=10.0)
+    model = model.to(dev)
+    li, ri = rand((1, 3, 192, 320), 481).to(dev), rand((1, 3, 192, 320), 482).to(dev)
+    with torch.no_grad():
+        lf, _ = model.backbone(li, ri)
+        res, _ = model(dict(leftImage=li, rightImage=ri))
+    assert maxdiff(lf, g["left_feature"]) <= 2e-5
+    assert len(res["disps"]) == 2
+    for i, d in enumerate(res["disps"]):
+        assert maxdiff(d, g["disp%d" % i]) <= DISP_TOL
