@@ -33,21 +33,30 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <int NTT_, int KS_, int DIL_, int S_ = 1>
+// V16 = the vector path, taken when rows are 16-byte aligned (W, Wo multiples of 4, aligned base pointers): the input
+// tile is staged with 16-byte LDS-DMA words (a tile row starts at the aligned column x0 * S - LP) and the epilogue
+// transposes each 32 x 32 accumulator tile through LDS so that a lane stores 4 consecutive pixels of one channel.
+// Both cut the vector-memory INSTRUCTION count 4x: measured on MI355X these layers are bound by the rate at which a CU
+// issues 64-lane memory instructions (a 3x3 layer has 3x less arithmetic per staged byte than the 3x3x3 ones), not by
+// bytes: 32->32 at 384x1248 ran 1.65 ms with dword copies / stores against 0.97 ms with neither.
+template <int NTT_, int KS_, int DIL_, int S_ = 1, bool V16_ = true>
 struct C2Cfg {
   static constexpr int NTT = NTT_, KS = KS_, DIL = DIL_, S = S_;
+  static constexpr bool V16 = V16_;
   static constexpr int WN = NTT;               // one 32-channel row tile per wave column (1, 2 or 4)
   static constexpr int WY = 4 / WN;            // waves stacked along y
   static constexpr int RY = (S == 1) ? 4 : 2;  // output rows per wave (row pairs); strided tiles read 2x2 the input
   static constexpr int TY = RY * WY, TX = 48;
   static constexpr int HALO = (KS / 2) * DIL;
-  static constexpr int P = (TX - 1) * S + 1 + 2 * HALO;      // staged input row length
+  static constexpr int LP = V16 ? (HALO + 3) / 4 * 4 : HALO;           // staged columns left of the tile origin
+  static constexpr int PMIN = LP + (TX - 1) * S + 1 + HALO;
+  static constexpr int P = V16 ? (PMIN + 3) / 4 * 4 : PMIN;            // staged input row length (LDS row pitch)
   static constexpr int ROWS = (TY - 1) * S + 1 + 2 * HALO;
-  static constexpr int SEG = (P + 63) / 64;    // one wave stages 64 floats of a tile row per instruction
+  static constexpr int SEG = (P + 63) / 64;    // scalar path: one wave stages 64 floats of a tile row per instruction
   static constexpr int XS = TX / 16;
   static constexpr int MT = (RY / 2) * XS;     // row-pair tiles per wave (6, or 3 when strided)
   static constexpr int KK = KS * KS;
-  static constexpr int CH_STRIDE = ROWS * P + 4;
+  static constexpr int CH_STRIDE = V16 ? ROWS * P : ROWS * P + 4;      // vector path: channels are contiguous 16-byte units
   // input channels per chunk: the largest of 8 / 4 / 2 whose double-buffered chunk (input rows + weight fragments)
   // lets two workgroups share one CU's 160 KB of LDS
   static constexpr int lds_bytes(int ck) { return 2 * ((ck * CH_STRIDE + 3) / 4 * 4 + (ck / 2) * KK * NTT * 64) * 4; }
@@ -56,57 +65,89 @@ struct C2Cfg {
   static constexpr int IN_FLOATS = (CK * CH_STRIDE + 3) / 4 * 4;
   static constexpr int W_FLOATS = NK * NTT * 64;
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
-  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;
-  static constexpr int UNITS = CK * ROWS * SEG;              // 64-float row segments per chunk
+  static constexpr int TR_PITCH = 36;                        // transposition scratch: [32 channels][32 pixels + 4]
+  static constexpr int TR_FLOATS = 4 * 32 * TR_PITCH;        // one accumulator tile per wave
+  // the scratch lives in the chunk buffer that was consumed last (free until the next copy lands in it) when that
+  // buffer is large enough, else (1x1 layers) behind the two buffers
+  static constexpr bool TR_OWN = V16 && BUF_FLOATS < TR_FLOATS;
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS + (TR_OWN ? TR_FLOATS : 0);
+  static constexpr int UNITS = CK * ROWS * SEG;              // scalar path: 64-float row segments per chunk
+  static constexpr int UPR = P / 4, UPC = ROWS * UPR;        // vector path: 16-byte units per row / per channel
+  static constexpr int VUNITS = CK * UPC;
   static_assert(C2_CK % CK == 0, "chunks tile the padded channel count");
   static_assert(W_FLOATS % 16 == 0, "weights are copied with 16-byte words, evenly over 4 waves");
   static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
 };
 
+// Persistent workgroups: the grid is two workgroups per CU, workgroup g walks tiles g, g + G, g + 2G, ... (ids remapped so
+// that one XCD owns a contiguous tile range).  The chunk pipeline runs ACROSS tiles: the first chunk of the next tile
+// is in flight while the last chunk of the current one is multiplied, and a tile's stores drain while the next tile's
+// first chunk is multiplied.
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, float* __restrict__ y, int Ci,
                                                         int Co, int H, int W, int relu, int in_ctot, int out_ctot,
-                                                        int res_ctot, int ntx, int nty) {
+                                                        int res_ctot, int ntx, int nty, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = t % ntx;
-  t /= ntx;
-  const int ty = t % nty;
-  const int b = t / nty;
-  const int x0 = tx * C::TX, y0 = ty * C::TY;   // output coordinates of the tile
+  const int G = gridDim.x;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wy = wave / C::WN, wn = wave % C::WN;
   const unsigned HW = (unsigned)H * W;
-  const float* xb = x + (size_t)b * in_ctot * HW;
   const int Cipad = cdiv(Ci, C2_CK) * C2_CK;
+  const int Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
+  const unsigned HWo = (unsigned)Ho * Wo;
 
-  f32x16 acc[C::MT];
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+  struct Tile {
+    int b, x0, y0;   // batch item, output coordinates of the tile origin
+  };
+  auto tile_at = [&](int it) {
+    int t = xcd_remap((int)blockIdx.x + it * G, ntiles);
+    Tile tl;
+    tl.x0 = (t % ntx) * C::TX;
+    t /= ntx;
+    tl.y0 = (t % nty) * C::TY;
+    tl.b = t / nty;
+    return tl;
+  };
 
-  constexpr int RPW = (C::UNITS + 3) / 4;    // row segments per wave per chunk
   constexpr int WPW = C::W_FLOATS / 16;      // 16-byte weight words per wave
   constexpr int WI = (WPW + 63) / 64;
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * HW * 4u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)((Cipad / 2) * C::KK * C::NTT * 64) * 4u);
-  const int gx0 = x0 * C::S - C::HALO + lane;
-  auto stage = [&](int c0, float* buf) {
+  auto stage = [&](const Tile& tl, int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * in_ctot * HW, (unsigned)Ci * HW * 4u);
+    if constexpr (C::V16) {
+      // unit u = 4 consecutive floats of the staged chunk, linear in LDS: u -> (channel, tile row, 16-byte column)
+      constexpr int IPW = (C::VUNITS + 255) / 256;   // instructions per wave
+      const int gxb = tl.x0 * C::S - C::LP, gyb = tl.y0 * C::S - C::HALO;
 #pragma unroll
-    for (int q = 0; q < RPW; ++q) {
-      const int rid = wave * RPW + q;
-      if (C::UNITS % 4 == 0 || rid < C::UNITS) {
-        const int seg = rid % C::SEG, rr = rid / C::SEG, cl = rr / C::ROWS, yy = rr - cl * C::ROWS;
-        const int gy = y0 * C::S - C::HALO + yy, gx = gx0 + seg * 64;
-        const bool rowok = c0 + cl < Ci && gy >= 0 && gy < H;               // wave-uniform: the scalar offset stays an SGPR
-        const bool ok = rowok && seg * 64 + lane < C::P && gx >= 0 && gx < W;
-        if (C::P % 64 == 0 || seg * 64 + lane < C::P)
-          dma4(xrs, ok ? (unsigned)gx * 4u : DMA_OOB, rowok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W) * 4u : 0u,
-               buf + cl * C::CH_STRIDE + yy * C::P + seg * 64);
+      for (int q = 0; q < IPW; ++q) {
+        const int u = (wave * IPW + q) * 64 + lane;
+        const int cl = u / C::UPC, rr = u - cl * C::UPC, yy = rr / C::UPR, sg = rr - yy * C::UPR;
+        const int gy = gyb + yy, gx = gxb + sg * 4;
+        const bool ok = c0 + cl < Ci && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (u < C::VUNITS)   // inactive lanes write nothing: the words behind the last unit belong to the weight fragments
+          dma16(xrs, ok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB, 0u,
+                buf + (wave * IPW + q) * 256);
+      }
+    } else {
+      constexpr int RPW = (C::UNITS + 3) / 4;    // row segments per wave per chunk
+      const int gx0 = tl.x0 * C::S - C::HALO + lane;
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int rid = wave * RPW + q;
+        if (C::UNITS % 4 == 0 || rid < C::UNITS) {
+          const int seg = rid % C::SEG, rr = rid / C::SEG, cl = rr / C::ROWS, yy = rr - cl * C::ROWS;
+          const int gy = tl.y0 * C::S - C::HALO + yy, gx = gx0 + seg * 64;
+          const bool rowok = c0 + cl < Ci && gy >= 0 && gy < H;               // wave-uniform: the scalar offset stays an SGPR
+          const bool ok = rowok && seg * 64 + lane < C::P && gx >= 0 && gx < W;
+          if (C::P % 64 == 0 || seg * 64 + lane < C::P)
+            dma4(xrs, ok ? (unsigned)gx * 4u : DMA_OOB, rowok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W) * 4u : 0u,
+                 buf + cl * C::CH_STRIDE + yy * C::P + seg * 64);
+        }
       }
     }
 #pragma unroll
@@ -117,68 +158,143 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
     }
   };
 
-  const int NC = Cipad / C::CK;
-  stage(0, lds);
-  __syncthreads();
-  for (int ci = 0; ci < NC; ++ci) {
-    const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
-    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
-    const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + ((wy * C::RY + (j >> 4)) * C::P + (j & 15)) * C::S;
-    float af[2], bf[2][C::MT];
-    auto load_frag = [&](int ks, float& a, float (&bq)[C::MT]) {
-      const int cp = ks / C::KK, tap = ks % C::KK;
-      const int dy = tap / C::KS, dx = tap % C::KS;
-      a = abase[ks * C::NTT * 64];
-      const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::DIL * C::P + dx * C::DIL;
+  f32x16 acc[C::MT];
+  auto clear = [&]() {
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[(2 * (mt / C::XS) * C::P + (mt % C::XS) * 16) * C::S];
-    };
-    load_frag(0, af[0], bf[0]);
+    for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-    for (int ks = 0; ks < C::NK; ++ks) {
-      if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(af[ks & 1], bf[ks & 1][mt], acc[mt]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-  }
+      for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+  };
 
   // epilogue: BN scale/shift -> + residual -> ReLU (basic_layers.py:219-243 adds the skip AFTER conv2's BN, no ReLU)
-  const int Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
-  const unsigned HWo = (unsigned)Ho * Wo;
-  float* yb = y + (size_t)b * out_ctot * HWo;
-  const float* rb = res ? res + (size_t)b * res_ctot * HWo : nullptr;
-  float sc[16], sh[16];
-  bool cok[16];
+  auto epilogue = [&](const Tile& tl, float* scratch) {
+    float* yb = y + (size_t)tl.b * out_ctot * HWo;
+    const float* rb = res ? res + (size_t)tl.b * res_ctot * HWo : nullptr;
+    if constexpr (C::V16) {
+      // accumulator tile -> scratch[channel][pixel] -> a lane owns 4 consecutive pixels of one channel
+      float* my = scratch + wave * (32 * C::TR_PITCH);
+      float scv[4], shv[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = wn * 32 + cd_row(r, h);
-    cok[r] = co < Co;
-    sc[r] = (scale && cok[r]) ? scale[co] : 1.f;
-    sh[r] = (shift && cok[r]) ? shift[co] : 0.f;
-  }
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt) {
-    const int gy = y0 + wy * C::RY + 2 * (mt / C::XS) + (j >> 4);
-    const int gxo = x0 + (mt % C::XS) * 16 + (j & 15);
-    if (gy < Ho && gxo < Wo) {
-      const unsigned o = (unsigned)gy * Wo + (unsigned)gxo;
-      float rv[16];
-      if (rb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = cok[r] ? rb[(size_t)(wn * 32 + cd_row(r, h)) * HWo + o] : 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const int co = wn * 32 + k * 8 + (lane >> 3);
+        scv[k] = (scale && co < Co) ? scale[co] : 1.f;
+        shv[k] = (shift && co < Co) ? shift[co] : 0.f;
       }
+      const int px = (lane & 7) * 4;                       // 0..28: pixels 0-15 = first row of the pair, 16-31 = second
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[cd_row(r, h) * C::TR_PITCH + j] = acc[mt][r];
+        const int gy = tl.y0 + wy * C::RY + 2 * (mt / C::XS) + (px >> 4);
+        const int gxo = tl.x0 + (mt % C::XS) * 16 + (px & 15);
+        const bool inb = gy < Ho && gxo < Wo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int cl = k * 8 + (lane >> 3), co = wn * 32 + cl;
+          float4 v = *reinterpret_cast<const float4*>(my + cl * C::TR_PITCH + px);
+          if (inb && co < Co) {
+            const size_t o = (size_t)co * HWo + (unsigned)gy * Wo + (unsigned)gxo;
+            v.x = fmaf(v.x, scv[k], shv[k]);
+            v.y = fmaf(v.y, scv[k], shv[k]);
+            v.z = fmaf(v.z, scv[k], shv[k]);
+            v.w = fmaf(v.w, scv[k], shv[k]);
+            if (rb) {
+              const float4 rv = *reinterpret_cast<const float4*>(rb + o);
+              v.x += rv.x;
+              v.y += rv.y;
+              v.z += rv.z;
+              v.w += rv.w;
+            }
+            if (relu) {
+              v.x = fmaxf(v.x, 0.f);
+              v.y = fmaxf(v.y, 0.f);
+              v.z = fmaxf(v.z, 0.f);
+              v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(yb + o) = v;
+          }
+        }
+      }
+    } else {
+      float sc[16], sh[16];
+      bool cok[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = fmaf(acc[mt][r], sc[r], sh[r]);
-        if (rb) v += rv[r];
-        if (relu) v = fmaxf(v, 0.f);
-        if (cok[r]) yb[(size_t)(wn * 32 + cd_row(r, h)) * HWo + o] = v;
+        const int co = wn * 32 + cd_row(r, h);
+        cok[r] = co < Co;
+        sc[r] = (scale && cok[r]) ? scale[co] : 1.f;
+        sh[r] = (shift && cok[r]) ? shift[co] : 0.f;
+      }
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+        const int gy = tl.y0 + wy * C::RY + 2 * (mt / C::XS) + (j >> 4);
+        const int gxo = tl.x0 + (mt % C::XS) * 16 + (j & 15);
+        if (gy < Ho && gxo < Wo) {
+          const unsigned o = (unsigned)gy * Wo + (unsigned)gxo;
+          float rv[16];
+          if (rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = cok[r] ? rb[(size_t)(wn * 32 + cd_row(r, h)) * HWo + o] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = fmaf(acc[mt][r], sc[r], sh[r]);
+            if (rb) v += rv[r];
+            if (relu) v = fmaxf(v, 0.f);
+            if (cok[r]) yb[(size_t)(wn * 32 + cd_row(r, h)) * HWo + o] = v;
+          }
+        }
       }
     }
+  };
+
+  const int NC = Cipad / C::CK;
+  Tile cur_t = tile_at(0);
+  stage(cur_t, 0, lds);
+  __syncthreads();
+  int g = 0;  // chunks consumed by this workgroup so far: selects the LDS buffer
+  for (int it = 0; it < my_tiles; ++it) {
+    const bool has_next = it + 1 < my_tiles;
+    Tile next_t = cur_t;
+    if (has_next) next_t = tile_at(it + 1);
+    clear();
+    for (int ci = 0; ci < NC; ++ci, ++g) {
+      const float* cur = lds + (g & 1) * C::BUF_FLOATS;
+      float* nxt = lds + ((g + 1) & 1) * C::BUF_FLOATS;
+      {  // ONE inlined copy of the staging code: what to fetch next is data, not control flow
+        const bool same = ci + 1 < NC;
+        Tile st_t;
+        st_t.b = same ? cur_t.b : next_t.b;
+        st_t.x0 = same ? cur_t.x0 : next_t.x0;
+        st_t.y0 = same ? cur_t.y0 : next_t.y0;
+        if (same || has_next) stage(st_t, same ? (ci + 1) * C::CK : 0, nxt);
+      }
+      const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
+      const float* bbase = cur + h * C::CH_STRIDE + ((wy * C::RY + (j >> 4)) * C::P + (j & 15)) * C::S + (C::LP - C::HALO);
+      float af[2], bf[2][C::MT];
+      auto load_frag = [&](int ks, float& a, float (&bq)[C::MT]) {
+        const int cp = ks / C::KK, tap = ks % C::KK;
+        const int dy = tap / C::KS, dx = tap % C::KS;
+        a = abase[ks * C::NTT * 64];
+        const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::DIL * C::P + dx * C::DIL;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[(2 * (mt / C::XS) * C::P + (mt % C::XS) * 16) * C::S];
+      };
+      load_frag(0, af[0], bf[0]);
+#pragma unroll
+      for (int ks = 0; ks < C::NK; ++ks) {
+        if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(af[ks & 1], bf[ks & 1][mt], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+    // the chunk buffer just consumed is free until the next copy lands in it: it doubles as transposition scratch
+    epilogue(cur_t, C::TR_OWN ? lds + 2 * C::BUF_FLOATS : lds + ((g + 1) & 1) * C::BUF_FLOATS);
+    if constexpr (C::V16 && !C::TR_OWN) __syncthreads();
+    cur_t = next_t;
   }
 }
 
@@ -246,14 +362,25 @@ __global__ __launch_bounds__(256) void bilinear_hp_kernel(const float* __restric
   y[(((size_t)b * out_ctot + out_coff + c) * Ho + yo) * Wo + xo] = fmaf(a1, ly, a0 * (1.f - ly)) * mult;
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <class C>
 static int launch_conv2d(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                          float* y, int B, int Ci, int Co, int H, int W, int relu, int in_ctot, int out_ctot,
                          int res_ctot, hipStream_t st) {
   const int Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
   const int ntx = cdiv(Wo, C::TX), nty = cdiv(Ho, C::TY);
-  const long long nblk = (long long)B * ntx * nty;
-  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: grid too large");
+  const long long ntiles = (long long)B * ntx * nty;
+  if (ntiles > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -261,8 +388,10 @@ static int launch_conv2d(const float* x, const float* wp, const float* scale, co
                               (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv2d_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, Co, H,
-                     W, relu, in_ctot, out_ctot, res_ctot, ntx, nty);
+  const long long slots = 2LL * num_cus();   // two workgroups per CU, a multiple of the 8 XCDs
+  const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+  hipLaunchKernelGGL((conv2d_kernel<C>), dim3(grid), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, Co, H, W, relu,
+                     in_ctot, out_ctot, res_ctot, ntx, nty, (int)ntiles);
   return launch_status("conv2d launch failed");
 }
 
@@ -298,9 +427,15 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
   if ((long long)in_channels_total * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: one batch item must stay below 2 GiB");
   const int NTT = cdiv(Co, 32);
   hipStream_t st = (hipStream_t)stream;
+  // vector path: every row of x, y and residual starts on a 16-byte boundary
+  const int Wo_ = (W - 1) / stride + 1;
+  const bool v16 = W % 4 == 0 && Wo_ % 4 == 0 && !g_dev_opts[3] &&
+                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
 #define DMB_C2(N, K, DL, S)                                                                                           \
-  return launch_conv2d<C2Cfg<N, K, DL, S>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu,                  \
-                                           in_channels_total, out_channels_total, res_channels_total, st)
+  return v16 ? launch_conv2d<C2Cfg<N, K, DL, S, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu,     \
+                                                       in_channels_total, out_channels_total, res_channels_total, st)  \
+             : launch_conv2d<C2Cfg<N, K, DL, S, false>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu,    \
+                                                        in_channels_total, out_channels_total, res_channels_total, st)
   if (stride == 1) {
     if (ksize == 3 && dilation == 1) {
       if (NTT == 1) DMB_C2(1, 3, 1, 1);

@@ -299,6 +299,51 @@ def test_conv2d(dev, Ci, Co, k, stride, dil, shape):
     assert (got - F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("Ci,Co,k,stride,dil,shape", [
+    (3, 32, 3, 2, 1, (2, 20, 72)),
+    (32, 32, 3, 1, 1, (1, 17, 96)),
+    (32, 64, 3, 2, 1, (1, 18, 56)),
+    (32, 64, 1, 2, 1, (1, 18, 56)),
+    (64, 64, 3, 1, 1, (2, 19, 100)),
+    (64, 128, 3, 1, 1, (2, 9, 48)),
+    (128, 128, 3, 1, 2, (1, 12, 64)),
+    (128, 32, 1, 1, 1, (1, 3, 4)),
+    (64, 128, 1, 1, 1, (1, 9, 52)),
+    (320, 128, 3, 1, 1, (1, 8, 32)),
+    (20, 32, 3, 1, 1, (1, 6, 12)),
+    (3, 32, 5, 2, 1, (2, 21, 80)),
+    (32, 32, 5, 2, 1, (1, 48, 152)),
+    (32, 32, 3, 1, 4, (2, 21, 72)),
+    (32, 32, 3, 1, 8, (1, 40, 96)),
+    (32, 1, 3, 1, 1, (2, 19, 52)),
+])
+def test_conv2d_vector_path(dev, Ci, Co, k, stride, dil, shape):
+    """Widths that are multiples of 4 take the 16-byte staging + transposed-store path; it must agree bit for bit with the
+    scalar path (same MFMA sequence, same epilogue arithmetic) and with torch within the FP32 tolerance."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, H, W = shape
+    x = _rand((B, Ci, H, W), 151)
+    w = _rand((Co, Ci, k, k), 152, 1.0 / math.sqrt(Ci * k * k))
+    sc, sh = _affine(Co, 153)
+    pad = dil * (k // 2)
+    ref = F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    res = _rand(ref.shape, 154)
+    wp = ops.pack_conv2d_weights(w.to(dev))
+    args = (x.to(dev), wp, Co, k, stride, dil, sc.to(dev), sh.to(dev), res.to(dev), True)
+    got = ops.conv2d(*args)
+    lib = _lib.load()
+    lib.dmb_dev_set_option(3, 1)      # development knob: force the scalar path
+    try:
+        scalar = ops.conv2d(*args)
+    finally:
+        lib.dmb_dev_set_option(3, 0)
+    assert torch.equal(got, scalar)
+    assert (got.cpu() - F.relu(ref + res)).abs().max().item() <= 2e-5
+    got = ops.conv2d(x.to(dev), wp, Co, k, stride, dil).cpu()
+    assert (got - F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)).abs().max().item() <= 2e-5
+
+
 def test_conv2d_unsupported_combinations_fail_loudly(dev):
     ops = _ops()
     from densematchingbenchmark_amd._lib import DmbLibraryError
