@@ -10,6 +10,8 @@
 // backbones/StereoNet.py:26-27) and stride 1 / 2 (compile time: a strided tile stages (TX - 1) * 2 + 1 + 2 * HALO input
 // columns and its B fragments walk LDS with stride 2).
 // Input and output may be channel windows of wider tensors (the 320-channel SPP concat is written in place).
+#include <type_traits>
+
 #include "dmb_common.h"
 
 namespace dmb {
@@ -78,6 +80,11 @@ struct C2Cfg {
   static_assert(W_FLOATS % 16 == 0, "weights are copied with 16-byte words, evenly over 4 waves");
   static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
 };
+
+template <class F>
+__device__ __forceinline__ void noalias_step(const float* __restrict__ cur, float* __restrict__ nxt, F&& f) {
+  f(cur, nxt);
+}
 
 // Persistent workgroups: the grid is two workgroups per CU, workgroup g walks tiles g, g + G, g + 2G, ... (ids remapped so
 // that one XCD owns a contiguous tile range).  The chunk pipeline runs ACROSS tiles: the first chunk of the next tile
@@ -166,65 +173,88 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
       for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
   };
 
+  // Per-channel affine of this lane's output channels, loaded ONCE: a load inside the tile loop that some path leaves
+  // unconsumed stays "pending" in the compiler's wait-count model across the back edge, and the first instruction that
+  // reuses its register then drains vmcnt(0) -- including the chunk copy that was just put in flight.
+  constexpr int NAFF = C::V16 ? 4 : 16;
+  float sc[NAFF], sh[NAFF];
+#pragma unroll
+  for (int k = 0; k < NAFF; ++k) {
+    const int co = wn * 32 + (C::V16 ? k * 8 + (lane >> 3) : cd_row(k, h));
+    sc[k] = (scale && co < Co) ? scale[co] : 1.f;
+    sh[k] = (shift && co < Co) ? shift[co] : 0.f;
+  }
+
   // epilogue: BN scale/shift -> + residual -> ReLU (basic_layers.py:219-243 adds the skip AFTER conv2's BN, no ReLU)
-  auto epilogue = [&](const Tile& tl, float* scratch) {
+  auto epilogue = [&](auto has_res, const Tile& tl, float* scratch) {
+    constexpr bool HAS_RES = decltype(has_res)::value;
     float* yb = y + (size_t)tl.b * out_ctot * HWo;
     const float* rb = res ? res + (size_t)tl.b * res_ctot * HWo : nullptr;
     if constexpr (C::V16) {
-      // accumulator tile -> scratch[channel][pixel] -> a lane owns 4 consecutive pixels of one channel
+      // accumulator tile -> scratch[channel][pixel] -> a lane owns 4 consecutive pixels of one channel.  Loads and
+      // stores go through buffer resources: an out-of-tile lane gets an out-of-range offset (reads 0 / store dropped),
+      // so the epilogue has no divergent branches and the compiler batches the residual loads under counted waits.
       float* my = scratch + wave * (32 * C::TR_PITCH);
-      float scv[4], shv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int co = wn * 32 + k * 8 + (lane >> 3);
-        scv[k] = (scale && co < Co) ? scale[co] : 1.f;
-        shv[k] = (shift && co < Co) ? shift[co] : 0.f;
-      }
+      const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, (unsigned)out_ctot * HWo * 4u);
+      const __amdgpu_buffer_rsrc_t rrs = make_rsrc(rb ? rb : yb, (unsigned)(rb ? res_ctot : out_ctot) * HWo * 4u);
       const int px = (lane & 7) * 4;                       // 0..28: pixels 0-15 = first row of the pair, 16-31 = second
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) my[cd_row(r, h) * C::TR_PITCH + j] = acc[mt][r];
+      const float lo = relu ? 0.f : -__builtin_inff();     // branch-free optional ReLU
+      auto offsets = [&](int mt, unsigned (&off)[4]) {
         const int gy = tl.y0 + wy * C::RY + 2 * (mt / C::XS) + (px >> 4);
         const int gxo = tl.x0 + (mt % C::XS) * 16 + (px & 15);
         const bool inb = gy < Ho && gxo < Wo;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int cl = k * 8 + (lane >> 3), co = wn * 32 + cl;
-          float4 v = *reinterpret_cast<const float4*>(my + cl * C::TR_PITCH + px);
-          if (inb && co < Co) {
-            const size_t o = (size_t)co * HWo + (unsigned)gy * Wo + (unsigned)gxo;
-            v.x = fmaf(v.x, scv[k], shv[k]);
-            v.y = fmaf(v.y, scv[k], shv[k]);
-            v.z = fmaf(v.z, scv[k], shv[k]);
-            v.w = fmaf(v.w, scv[k], shv[k]);
-            if (rb) {
-              const float4 rv = *reinterpret_cast<const float4*>(rb + o);
-              v.x += rv.x;
-              v.y += rv.y;
-              v.z += rv.z;
-              v.w += rv.w;
-            }
-            if (relu) {
-              v.x = fmaxf(v.x, 0.f);
-              v.y = fmaxf(v.y, 0.f);
-              v.z = fmaxf(v.z, 0.f);
-              v.w = fmaxf(v.w, 0.f);
-            }
-            *reinterpret_cast<float4*>(yb + o) = v;
+          const int co = wn * 32 + k * 8 + (lane >> 3);
+          off[k] = (inb && co < Co) ? ((unsigned)co * HWo + (unsigned)gy * Wo + (unsigned)gxo) * 4u : DMA_OOB;
+        }
+      };
+      // residual loads run one accumulator tile ahead of the stores: the counter a load is waited on (vmcnt, in issue
+      // order) then never covers a store
+      unsigned off[2][4];
+      u32x4 rv[2][4];
+      offsets(0, off[0]);
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rv[0][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[0][k], 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+        if (mt + 1 < C::MT) {
+          offsets(mt + 1, off[(mt + 1) & 1]);
+          if constexpr (HAS_RES) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              rv[(mt + 1) & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[(mt + 1) & 1][k], 0, 0);
           }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[cd_row(r, h) * C::TR_PITCH + j] = acc[mt][r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float4 v = *reinterpret_cast<const float4*>(my + (k * 8 + (lane >> 3)) * C::TR_PITCH + px);
+          v.x = fmaf(v.x, sc[k], sh[k]);
+          v.y = fmaf(v.y, sc[k], sh[k]);
+          v.z = fmaf(v.z, sc[k], sh[k]);
+          v.w = fmaf(v.w, sc[k], sh[k]);
+          if constexpr (HAS_RES) {   // (not __builtin_bit_cast on a vector element: this clang reads element 0 for every index)
+            v.x += __uint_as_float(rv[mt & 1][k].x);
+            v.y += __uint_as_float(rv[mt & 1][k].y);
+            v.z += __uint_as_float(rv[mt & 1][k].z);
+            v.w += __uint_as_float(rv[mt & 1][k].w);
+          }
+          u32x4 o;
+          o.x = __float_as_uint(fmaxf(v.x, lo));
+          o.y = __float_as_uint(fmaxf(v.y, lo));
+          o.z = __float_as_uint(fmaxf(v.z, lo));
+          o.w = __float_as_uint(fmaxf(v.w, lo));
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)off[mt & 1][k], 0, 0);
         }
       }
     } else {
-      float sc[16], sh[16];
       bool cok[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = wn * 32 + cd_row(r, h);
-        cok[r] = co < Co;
-        sc[r] = (scale && cok[r]) ? scale[co] : 1.f;
-        sh[r] = (shift && cok[r]) ? shift[co] : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) cok[r] = wn * 32 + cd_row(r, h) < Co;
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) {
         const int gy = tl.y0 + wy * C::RY + 2 * (mt / C::XS) + (j >> 4);
@@ -259,40 +289,50 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
     if (has_next) next_t = tile_at(it + 1);
     clear();
     for (int ci = 0; ci < NC; ++ci, ++g) {
-      const float* cur = lds + (g & 1) * C::BUF_FLOATS;
-      float* nxt = lds + ((g + 1) & 1) * C::BUF_FLOATS;
-      {  // ONE inlined copy of the staging code: what to fetch next is data, not control flow
-        const bool same = ci + 1 < NC;
-        Tile st_t;
-        st_t.b = same ? cur_t.b : next_t.b;
-        st_t.x0 = same ? cur_t.x0 : next_t.x0;
-        st_t.y0 = same ? cur_t.y0 : next_t.y0;
-        if (same || has_next) stage(st_t, same ? (ci + 1) * C::CK : 0, nxt);
-      }
-      const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
-      const float* bbase = cur + h * C::CH_STRIDE + ((wy * C::RY + (j >> 4)) * C::P + (j & 15)) * C::S + (C::LP - C::HALO);
-      float af[2], bf[2][C::MT];
-      auto load_frag = [&](int ks, float& a, float (&bq)[C::MT]) {
-        const int cp = ks / C::KK, tap = ks % C::KK;
-        const int dy = tap / C::KS, dx = tap % C::KS;
-        a = abase[ks * C::NTT * 64];
-        const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::DIL * C::P + dx * C::DIL;
+      // The copy into `nxt` must stay in flight while `cur` is multiplied.  The compiler orders an LDS read after every
+      // outstanding LDS-DMA write it cannot prove disjoint (s_waitcnt vmcnt(0) in front of the first ds_read, which
+      // would serialise copy and arithmetic); the __restrict__ scope of noalias_step() is that proof.  The explicit
+      // vmcnt(0) below is what makes the data visible to the other waves before the barrier.
+      noalias_step(lds + (g & 1) * C::BUF_FLOATS, lds + ((g + 1) & 1) * C::BUF_FLOATS,
+                   [&](const float* cur, float* nxt) __attribute__((always_inline)) {
+        {  // ONE inlined copy of the staging code: what to fetch next is data, not control flow
+          const bool same = ci + 1 < NC;
+          Tile st_t;
+          st_t.b = same ? cur_t.b : next_t.b;
+          st_t.x0 = same ? cur_t.x0 : next_t.x0;
+          st_t.y0 = same ? cur_t.y0 : next_t.y0;
+          if (same || has_next) stage(st_t, same ? (ci + 1) * C::CK : 0, nxt);
+        }
+        const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
+        const float* bbase = cur + h * C::CH_STRIDE + ((wy * C::RY + (j >> 4)) * C::P + (j & 15)) * C::S + (C::LP - C::HALO);
+        float af[2], bf[2][C::MT];
+        auto load_frag = [&](int ks, float& a, float (&bq)[C::MT]) {
+          const int cp = ks / C::KK, tap = ks % C::KK;
+          const int dy = tap / C::KS, dx = tap % C::KS;
+          a = abase[ks * C::NTT * 64];
+          const float* bp = bbase + 2 * cp * C::CH_STRIDE + dy * C::DIL * C::P + dx * C::DIL;
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[(2 * (mt / C::XS) * C::P + (mt % C::XS) * 16) * C::S];
-      };
-      load_frag(0, af[0], bf[0]);
+          for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[(2 * (mt / C::XS) * C::P + (mt % C::XS) * 16) * C::S];
+        };
+        load_frag(0, af[0], bf[0]);
 #pragma unroll
-      for (int ks = 0; ks < C::NK; ++ks) {
-        if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < C::NK; ++ks) {
+          if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(af[ks & 1], bf[ks & 1][mt], acc[mt]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+          for (int mt = 0; mt < C::MT; ++mt) acc[mt] = DMB_MFMA(af[ks & 1], bf[ks & 1][mt], acc[mt]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's copies have landed in LDS
       __syncthreads();
     }
     // the chunk buffer just consumed is free until the next copy lands in it: it doubles as transposition scratch
-    epilogue(cur_t, C::TR_OWN ? lds + 2 * C::BUF_FLOATS : lds + ((g + 1) & 1) * C::BUF_FLOATS);
+    float* scratch = C::TR_OWN ? lds + 2 * C::BUF_FLOATS : lds + ((g + 1) & 1) * C::BUF_FLOATS;
+    if (res)
+      epilogue(std::true_type{}, cur_t, scratch);
+    else
+      epilogue(std::false_type{}, cur_t, scratch);
     if constexpr (C::V16 && !C::TR_OWN) __syncthreads();
     cur_t = next_t;
   }
@@ -424,7 +464,9 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
   if (stride != 1 && stride != 2) return fail(DMB_EUNSUPPORTED, "conv2d: stride must be 1 or 2");
   if (in_channels_total < Ci || out_channels_total < Co || (residual && res_channels_total < Co))
     return fail(DMB_EINVAL, "conv2d: channel window");
-  if ((long long)in_channels_total * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: one batch item must stay below 2 GiB");
+  if ((long long)in_channels_total * H * W * 4 >= 0x7fffffffLL || (long long)out_channels_total * H * W * 4 >= 0x7fffffffLL ||
+      (long long)res_channels_total * H * W * 4 >= 0x7fffffffLL)
+    return fail(DMB_EUNSUPPORTED, "conv2d: one batch item must stay below 2 GiB");
   const int NTT = cdiv(Co, 32);
   hipStream_t st = (hipStream_t)stream;
   // vector path: every row of x, y and residual starts on a 16-byte boundary

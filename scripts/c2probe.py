@@ -19,5 +19,8 @@ for (Ci, Co, h, w, NB) in ((32, 32, 272, 480, 8), (64, 64, 136, 240, 8), (128, 1
     for dbg in (1, 0):
         lib.dmb_dev_set_option(3, dbg)
         ms = timeit(lambda: ops.conv2d(x, wp, Co, 3, 1, 1, sc, sh, None, True))
-        print("%d->%d %dx%d x%d scalar_path=%d: %.3f ms %.1f TF" % (Ci, Co, h, w, NB, dbg, ms, fl / ms / 1e9), flush=True)
+        rs = torch.randn(NB, Co, h, w, device=dev)
+        ms2 = timeit(lambda: ops.conv2d(x, wp, Co, 3, 1, 1, sc, sh, rs, False))
+        del rs
+        print("%d->%d %dx%d x%d scalar_path=%d: %.3f ms %.1f TF | +residual %.3f ms %.1f TF" % (Ci, Co, h, w, NB, dbg, ms, fl / ms / 1e9, ms2, fl / ms2 / 1e9), flush=True)
     lib.dmb_dev_set_option(3, 0)
