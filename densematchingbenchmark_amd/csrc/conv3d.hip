@@ -17,6 +17,8 @@
 //
 // Reference semantics: dmb/modeling/stereo/layers/basic_layers.py:68-100,160-177 (Conv3d/ConvTranspose3d
 // + BatchNorm3d + ReLU factories), cost_processors/utils/hourglass.py:62-86.
+#include <type_traits>
+
 #include "dmb_common.h"
 
 namespace dmb {
@@ -62,10 +64,17 @@ struct S1Cfg {
   static constexpr bool ROWPAIR = ROWPAIR_;
   static constexpr int WZ = 4 / WN;        // waves along z; one output z-slice per wave
   static constexpr int TZ = WZ;
-  static constexpr int P = TX + 2;         // padded row pitch
+  // Row-pair tiles are staged with 16-byte LDS-DMA words: a staged row starts at the 16-byte aligned column x0 - 4
+  // (XOFF = 3 unused floats in front of the halo column) and is a whole number of words long.  A CU retires LDS-DMA
+  // at about one lane per clock whatever the word size, so this is 4x fewer TA cycles for the same bytes.
+  static constexpr int XOFF = ROWPAIR ? 3 : 0;
+  static constexpr int P = ROWPAIR ? (4 + TX + 1 + 3) / 4 * 4 : TX + 2;   // padded row pitch
   static constexpr int ROWS = TY + 2;
   static constexpr int PLANE = ROWS * P;
   static constexpr int ZS = TZ + 2;
+  static constexpr int UPR = P / 4, UPC = ZS * ROWS * UPR;   // row-pair path: 16-byte units per row / per channel
+  static constexpr int IPC = (UPC + 63) / 64;                // copy instructions per channel
+  static constexpr int TR_PITCH = 36;                        // epilogue transposition scratch [32 channels][32 + 4]
   // How the 32 columns (voxels) of an MFMA B tile map onto the LDS tile:
   //  - flattened (default): 32 consecutive positions of the padded (y, x) plane; works for any TX, but the 2 halo
   //    columns per row and the last partial tile are computed and discarded (6 % at TX = 60, TY = 4);
@@ -89,7 +98,7 @@ struct S1Cfg {
   }
   static constexpr int NTT = COUT / 32;          // 32-channel row tiles in total
   static constexpr int NT = NTT / WN;            // ... per wave
-  static constexpr int CH_STRIDE = ZS * PLANE + 36;  // + slack read by discarded columns
+  static constexpr int CH_STRIDE = ZS * PLANE + (ROWPAIR ? 4 : 36);  // + slack read by discarded columns
   static constexpr int NK = (CK / 2) * 27;           // k-steps per chunk
   static constexpr int IN_FLOATS = CK * CH_STRIDE;   // input tile of one chunk
   static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;  // + the chunk's weight fragments
@@ -97,6 +106,7 @@ struct S1Cfg {
   static_assert(P <= 64, "one wave stages one tile row per instruction");
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(!ROWPAIR || (TX % 16 == 0 && TY % 2 == 0), "row-pair tiles need TX % 16 == 0 and an even TY");
+  static_assert(!ROWPAIR || ((CK * IPC) % 4 == 0 && NT == 1 && LDS_FLOATS >= 4 * 32 * TR_PITCH), "row-pair staging / scratch");
 };
 
 // Epilogue shared by the three MFMA kernels: v = acc*scale + shift (+ residual) (relu) for the 16 accumulator
@@ -182,7 +192,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
   const int gx = x0 - 1 + lane;
   const unsigned xvoff = (lane < C::P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
   auto stage = [&](int c0, float* buf) {
-    if (lane < C::P) {
+    if constexpr (C::ROWPAIR) {
+      // unit = 4 consecutive floats of a staged row; the units of one channel are linear in LDS
+      constexpr int IPW = C::CK * C::IPC / 4;   // instructions per wave
+#pragma unroll
+      for (int q = 0; q < IPW; ++q) {
+        const int id = wave * IPW + q, cl = id / C::IPC, qi = id - cl * C::IPC;
+        const int u = qi * 64 + lane;
+        const int zz = u / (C::ROWS * C::UPR), rr = u - zz * (C::ROWS * C::UPR), yy = rr / C::UPR, sg = rr - yy * C::UPR;
+        const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gxs = x0 - 4 + sg * 4;
+        const bool ok = c0 + cl < Ci && gz >= 0 && gz < D && gy >= 0 && gy < H && gxs >= 0 && gxs < W;
+        if (u < C::UPC)
+          dma16(xrs, ok ? ((unsigned)(c0 + cl) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB,
+                0u, buf + cl * C::CH_STRIDE + qi * 256);
+      }
+    } else if (lane < C::P) {
 #pragma unroll
       for (int q = 0; q < PPW; ++q) {
         const int pl = wave * PPW + q, cl = pl / C::ZS, zz = pl - cl * C::ZS;
@@ -216,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
     if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);  // lands while we compute
     // ---- NK k-steps on the current buffer; A and B fragments register double-buffered one k-step ahead ----
     const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + C::lane_off(j);
+    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + C::lane_off(j) + C::XOFF;
     float af[2][C::NT], bf[2][C::MT];
     auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MT]) {
       const int cp = ks / 27, tap = ks % 27;
@@ -243,9 +267,83 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
 
   // ---- epilogue ----
   const int gz = z0 + wz;
-  if (gz >= D) return;
   float* yb = y + (size_t)b * C::COUT * DHW;
   const float* rb = res ? res + (size_t)b * C::COUT * DHW : nullptr;
+  if constexpr (C::ROWPAIR) {
+    // Each 32 x 32 accumulator tile goes through a per-wave LDS scratch (the chunk buffers are free after the last
+    // barrier) so that a lane owns 4 consecutive x of one channel: 16-byte stores / residual loads, 4x fewer
+    // vector-memory instructions.  Buffer addressing with an out-of-range offset for lanes outside the volume keeps
+    // the code branch-free; residual loads run one tile ahead of the stores.
+    float* my = lds + wave * (32 * C::TR_PITCH);
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, (unsigned)C::COUT * DHW * 4u);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(rb ? rb : yb, (unsigned)C::COUT * DHW * 4u);
+    const int px = (lane & 7) * 4;
+    const float lo = relu ? 0.f : -__builtin_inff();
+    float sc4[4], sh4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = wn * 32 + k * 8 + (lane >> 3);
+      sc4[k] = scale ? scale[co] : 1.f;
+      sh4[k] = shift ? shift[co] : 0.f;
+    }
+    auto offsets = [&](int mt, unsigned (&off)[4]) {
+      const int gy = y0 + 2 * (mt / C::XS) + (px >> 4), gxo = x0 + (mt % C::XS) * 16 + (px & 15);
+      const bool inb = gz < D && gy < H && gxo < W;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        off[k] = inb ? ((unsigned)(wn * 32 + k * 8 + (lane >> 3)) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxo) * 4u
+                     : DMA_OOB;
+    };
+    auto run = [&](auto has_res) {
+      constexpr bool HAS_RES = decltype(has_res)::value;
+      unsigned off[2][4];
+      u32x4 rv[2][4];
+      offsets(0, off[0]);
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rv[0][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[0][k], 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+        if (mt + 1 < C::MT) {
+          offsets(mt + 1, off[(mt + 1) & 1]);
+          if constexpr (HAS_RES) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              rv[(mt + 1) & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[(mt + 1) & 1][k], 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[cd_row(r, h) * C::TR_PITCH + j] = acc[mt][0][r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float4 v = *reinterpret_cast<const float4*>(my + (k * 8 + (lane >> 3)) * C::TR_PITCH + px);
+          v.x = fmaf(v.x, sc4[k], sh4[k]);
+          v.y = fmaf(v.y, sc4[k], sh4[k]);
+          v.z = fmaf(v.z, sc4[k], sh4[k]);
+          v.w = fmaf(v.w, sc4[k], sh4[k]);
+          if constexpr (HAS_RES) {   // (not __builtin_bit_cast on a vector element: this clang reads element 0 for every index)
+            v.x += __uint_as_float(rv[mt & 1][k].x);
+            v.y += __uint_as_float(rv[mt & 1][k].y);
+            v.z += __uint_as_float(rv[mt & 1][k].z);
+            v.w += __uint_as_float(rv[mt & 1][k].w);
+          }
+          u32x4 o;
+          o.x = __float_as_uint(fmaxf(v.x, lo));
+          o.y = __float_as_uint(fmaxf(v.y, lo));
+          o.z = __float_as_uint(fmaxf(v.z, lo));
+          o.w = __float_as_uint(fmaxf(v.w, lo));
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)off[mt & 1][k], 0, 0);
+        }
+      }
+    };
+    if (res)
+      run(std::true_type{});
+    else
+      run(std::false_type{});
+    return;
+  }
+  if (gz >= D) return;
 #pragma unroll
   for (int nt = 0; nt < C::NT; ++nt) {
     const int co0 = (wn * C::NT + nt) * 32;
@@ -275,12 +373,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
 // a flattened output index m = ly*(TX+1) + lx maps to LDS offset 2*m + const(tap); the x stride of 2 floats
 // is a harmless 2-way bank conflict (LDS has > 4x headroom next to a 64-cycle MFMA).
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_>
+// V16 (W % 4 == 0, aligned base): rows are staged with 16-byte LDS-DMA words from the aligned column 2*x0 - 4 (XOFF = 3
+// unused floats in front of the halo column), row pitch 64 floats = output-position pitch 32: with dword copies a
+// stride-2 tile (4x the input per output) cost more TA cycles than its MFMAs cost matrix-core cycles.
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false>
 struct S2Cfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_;
+  static constexpr bool V16 = V16_;
   static constexpr int WZ = 4 / WN;
   static constexpr int TZ = WZ;
-  static constexpr int PO = TX + 1;            // output-position pitch
+  static constexpr int XOFF = V16 ? 3 : 0;
+  static constexpr int PO = V16 ? (XOFF + 2 * TX + 1 + 7) / 8 * 4 : TX + 1;   // output-position pitch
   static constexpr int R = 2 * PO;             // LDS row pitch (input columns 2*x0-1 .. 2*x0+2*TX-1, padded)
   static constexpr int PYPL = (TY + 1) * R;    // one y-parity plane
   static constexpr int ZPL = 2 * PYPL;         // one input z-slice
@@ -291,6 +394,8 @@ struct S2Cfg {
   static constexpr int NTT = COUT / 32;
   static constexpr int NT = NTT / WN;
   static constexpr int CH_STRIDE = ZS * ZPL + 72;
+  static constexpr int UPR = R / 4, UPC = ZS * ZPL / 4;      // vector path: 16-byte units per row / per channel
+  static constexpr int IPC = (UPC + 63) / 64;                // copy instructions per channel
   static constexpr int NK = (CK / 2) * 27;
   static constexpr int IN_FLOATS = CK * CH_STRIDE;
   static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;
@@ -342,6 +447,26 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   auto stage = [&](int c0, float* buf) {
+    if constexpr (C::V16) {
+      // unit = 4 consecutive floats of a staged row; the units of one channel ([z][y parity][row][64]) are linear in LDS
+      constexpr int NI = C::CK * C::IPC, IPW = (NI + 3) / 4;
+#pragma unroll
+      for (int q = 0; q < IPW; ++q) {
+        const int id = wave * IPW + q;
+        if (NI % 4 == 0 || id < NI) {
+          const int cl = id / C::IPC, qi = id - cl * C::IPC;
+          const int u = qi * 64 + lane;
+          const int zz = u / (C::ZPL / 4), r1 = u - zz * (C::ZPL / 4), pp = r1 / (C::PYPL / 4), r2 = r1 - pp * (C::PYPL / 4);
+          const int row = r2 / C::UPR, sg = r2 - row * C::UPR;
+          const int ry = 2 * row + pp;
+          const int gz = 2 * z0 - 1 + zz, gy = 2 * y0 - 1 + ry, gxs = 2 * x0 - 4 + sg * 4;
+          const bool ok = c0 + cl < Ci && ry < C::INROWS && gz >= 0 && gz < D && gy >= 0 && gy < H && gxs >= 0 && gxs < W;
+          if (u < C::UPC)
+            dma16(xrs, ok ? ((unsigned)(c0 + cl) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB,
+                  0u, buf + cl * C::CH_STRIDE + qi * 256);
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
       const int uid = wave * UPW + q, pl = uid / NPASS, pass = uid - pl * NPASS;
@@ -362,6 +487,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
         }
       }
     }
+    }
 #pragma unroll
     for (int i = 0; i < WV4; ++i) {
       const int q4 = i * 256 + threadIdx.x;
@@ -377,7 +503,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
     const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
     if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
     const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + (2 * wz) * C::ZPL + 2 * j;
+    const float* bbase = cur + h * C::CH_STRIDE + (2 * wz) * C::ZPL + 2 * j + C::XOFF;
     float af[2][C::NT], bf[2][C::MT];
     auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MT]) {
       const int cp = ks / 27, tap = ks % 27;
@@ -436,27 +562,34 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
 // (input-resolution tile, z parity, y parity); both x parities are accumulated by the same wave so that a
 // lane owns two adjacent outputs and stores them as one 8-byte word.  No zero-insertion, no wasted MACs.
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_>
+// V16: rows are 16-byte aligned (W % 4 == 0, aligned base): the tile is staged with 16-byte LDS-DMA words (row pitch
+// rounded up to 64 floats).  A CU retires LDS-DMA at about one LANE per clock whatever the word size, and with dword
+// copies this kernel spent more TA cycles on staging than matrix-core cycles on arithmetic.
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false>
 struct DCfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_;
+  static constexpr bool V16 = V16_;
   static constexpr int WZ = 4 / WN;
   static constexpr int TZ = WZ;
-  static constexpr int P = TX + 1;
+  static constexpr int P = V16 ? (TX + 1 + 3) / 4 * 4 : TX + 1;
   static constexpr int ROWS = TY + 1;
   static constexpr int PLANE = ROWS * P;
   static constexpr int ZS = TZ + 1;
   static constexpr int MT = (TY * P + 31) / 32;
   static constexpr int NTT = COUT / 32;
   static constexpr int NT = NTT / WN;
-  static constexpr int CH_STRIDE = ZS * PLANE + 36;
+  static constexpr int CH_STRIDE = ZS * PLANE + (V16 ? 4 : 36);   // = 4 (mod 32): the two lane halves hit disjoint banks
   static constexpr int IN_FLOATS = CK * CH_STRIDE;
+  static constexpr int UPR = P / 4, UPC = ZS * ROWS * UPR;    // vector path: 16-byte units per row / per channel
+  static constexpr int IPC = (UPC + 63) / 64;                 // copy instructions per channel
   static constexpr int RUN = 9 * NTT * 64;                    // weight floats of one (channel pair, kz)
   static constexpr int W_FLOATS = (CK / 2) * 2 * RUN;         // worst case: two kz taps (odd output z)
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;           // double buffered
-  static constexpr int WPE = (LDS_FLOATS * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
+  static constexpr int AFF_FLOATS = 2 * COUT;                 // scale / shift table behind the chunk buffers
+  static constexpr int WPE = ((LDS_FLOATS + AFF_FLOATS) * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
   static_assert(P <= 64, "one wave stages one tile row per instruction");
-  static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
+  static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0 && (!V16 || CH_STRIDE % 4 == 0), "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
@@ -505,6 +638,23 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   auto stage = [&](const Tile& tl, int c0, float* buf) {
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * Ci * DHW, (unsigned)Ci * DHW * 4u);
+    if constexpr (C::V16) {
+      // unit = 4 consecutive floats of a staged row; the units of one channel are linear in LDS
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int cl = wave * CPW + cc;
+#pragma unroll
+        for (int q = 0; q < C::IPC; ++q) {
+          const int u = q * 64 + lane;
+          const int zz = u / (C::ROWS * C::UPR), rr = u - zz * (C::ROWS * C::UPR), yy = rr / C::UPR, sg = rr - yy * C::UPR;
+          const int gz = tl.z0 + zz, gy = tl.y0 + yy, gx = tl.x0 + sg * 4;
+          const bool ok = c0 + cl < Ci && gz < D && gy < H && gx < W;
+          if (u < C::UPC)
+            dma16(xrs, ok ? ((unsigned)(c0 + cl) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB,
+                  0u, buf + cl * C::CH_STRIDE + q * 256);
+        }
+      }
+    } else {
     const int gx = tl.x0 + lane;
     const unsigned xvoff = (lane < C::P && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
     if (lane < C::P) {
@@ -525,6 +675,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
         }
       }
     }
+    }
 #pragma unroll
     for (int i = 0; i < WV4; ++i) {
       const int q4 = i * 256 + (int)threadIdx.x;
@@ -537,6 +688,16 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
       }
     }
   };
+
+  // Per-channel affine, staged ONCE into LDS behind the chunk buffers.  (Global loads of scale / shift inside the tile
+  // loop stay "pending" in the compiler's wait-count model on the paths that do not consume them; the first reuse of
+  // their registers in the next tile then drains vmcnt(0) and stalls on the chunk copy that was just put in flight.
+  // LDS reads count on lgkmcnt instead and cost no registers across the loop.)
+  float* aff = lds + C::LDS_FLOATS;
+  if (threadIdx.x < C::COUT) {
+    aff[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
+    aff[C::COUT + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
+  }
 
   const int NC = cdiv(Ci, C::CK);  // a partial last chunk reads zeros (bounds check) against zero-padded weights
   constexpr int NU = (C::CK / 2) * NAZ;  // (channel pair, az) units per chunk
@@ -627,9 +788,8 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
         float sc[16], sh[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = co0 + cd_row(r, h);
-          sc[r] = scale ? scale[co] : 1.f;
-          sh[r] = shift ? shift[co] : 0.f;
+          sc[r] = aff[co0 + cd_row(r, h)];
+          sh[r] = aff[C::COUT + co0 + cd_row(r, h)];
         }
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
@@ -838,7 +998,7 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
   const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long ntiles = (long long)B * ntx * nty * ntz;
   if (ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
-  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)(C::LDS_FLOATS + C::AFF_FLOATS) * sizeof(float);
   static bool attr_set = false;
   static int ncu = 256;
   if (!attr_set) {
@@ -911,7 +1071,8 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
   hipStream_t st = (hipStream_t)stream;
 #define DMB_S1(CO, TX, WN, RP) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, RP>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
   if (stride == 1) {
-    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0;
+    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0 &&
+                    (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path
     const int tx = flat_tx(W);
     if (Co == 32) {
       if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, false>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
@@ -920,6 +1081,8 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     }
     if (Co == 64) return tx == 52 ? DMB_S1(64, 52, 2, false) : DMB_S1(64, 60, 2, false);
   } else if (stride == 2) {
+    const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned input rows
+    if (Co == 64 && v16) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     if (Co == 64) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     if (Co == 32) return launch_s2<S2Cfg<0, 32, 4, 30, 2, 1>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
   }
@@ -934,8 +1097,13 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
   if ((long long)(Ci > 8 * Co ? Ci : 8 * Co) * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "deconv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 64) return launch_deconv<DCfg<0, 64, 1, 60, 4, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
-  if (Co == 32) return launch_deconv<DCfg<0, 32, 1, 60, 8, 1>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+  const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned rows
+  if (Co == 64)
+    return v16 ? launch_deconv<DCfg<0, 64, 1, 60, 4, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
+               : launch_deconv<DCfg<0, 64, 1, 60, 4, 2, false>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+  if (Co == 32)
+    return v16 ? launch_deconv<DCfg<0, 32, 1, 60, 8, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
+               : launch_deconv<DCfg<0, 32, 1, 60, 8, 1, false>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
   return fail(DMB_EUNSUPPORTED, "deconv3d: output channels must be 32 or 64");
 }
 

@@ -81,7 +81,7 @@ def _affine(C, seed):
 
 
 @pytest.mark.parametrize("Ci,Co,stride", [(32, 32, 1), (64, 32, 1), (64, 64, 1), (32, 64, 1), (32, 64, 2), (64, 64, 2)])
-@pytest.mark.parametrize("shape", [(2, 6, 10, 70), (1, 5, 9, 13)])
+@pytest.mark.parametrize("shape", [(2, 6, 10, 70), (1, 5, 9, 13), (1, 6, 11, 96), (2, 3, 5, 48)])
 def test_conv3d_k3(dev, Ci, Co, stride, shape):
     ops = _ops()
     B, D, H, W = shape
@@ -121,7 +121,7 @@ def test_conv3d_any_channels(dev, Ci, Co, stride, shape):
 
 
 @pytest.mark.parametrize("Ci,Co", [(64, 64), (64, 32), (20, 32), (9, 64)])
-@pytest.mark.parametrize("shape", [(2, 3, 5, 35), (1, 4, 6, 61)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 35), (1, 4, 6, 61), (1, 5, 7, 64), (2, 3, 4, 120)])
 def test_deconv3d(dev, Ci, Co, shape):
     ops = _ops()
     B, D, H, W = shape
