@@ -41,6 +41,7 @@ SIGNATURES = {
     "dmb_soft_argmin_sampled_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _P]),
     "dmb_local_soft_argmin_f32": (_c_int, [_P, _P, _P] + [_c_int] * 8 + [_c_float, _P]),
     "dmb_trilinear_soft_argmin_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_c_float, _HF, _P]),
+    "dmb_trilinear_ac_soft_argmin_f32": (_c_int, [_P, _P, _P] + [_c_int] * 7 + [_c_float, _HF, _P]),
     "dmb_conf_head_packed_floats": (_c_ll, [_c_int, _c_int]),
     "dmb_conf_head_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conf_head_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 5 + [_P]),

@@ -254,9 +254,14 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict_
 // reused by every output plane that blends it, so an output costs ~0.4 L1/L2 reads instead of 8; no LDS, no barrier,
 // stores are 16 bytes per lane and 1 KiB contiguous per wave.  Same arithmetic and order as trilinear_kernel
 // (W, then H, then D), hence bit-identical results.
+// WITH_DISP (zsplit == 1): the thread also folds every up-sampled logit of its 4 pixels into the soft-argmin, in the
+// same blocks of SA_BLK planes and the same order as soft_argmin_kernel, and writes the disparity: the regression then
+// costs no second pass over the [B, Do, Ho, Wo] volume (the volume is still written: the reference returns it).
+template <bool WITH_DISP>
 __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __restrict__ x, float* __restrict__ y, int Di,
                                                              int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh,
-                                                             float sw, int zsplit) {
+                                                             float sw, int zsplit, float* __restrict__ disp, float alpha,
+                                                             DispVal dv) {
   const int nxq = cdiv(Wo, 4);
   const int nxb = cdiv(nxq, 256);
   const int xq = (blockIdx.x % nxb) * 256 + threadIdx.x;
@@ -287,6 +292,12 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
   const size_t ostride = (size_t)Ho * Wo;
   float* yp = y + ((size_t)b * Do * Ho + yo) * Wo + xo + (size_t)zbeg * ostride;
   const bool vec = (Wo & 3) == 0;
+  SoftState st[WITH_DISP ? 4 : 1];
+  float vb[WITH_DISP ? 4 : 1][SA_BLK];
+  if constexpr (WITH_DISP) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j].init();
+  }
   for (int zo = zbeg; zo < zend; ++zo) {
     const Lerp lz = lerp_setup(zo, Di, sd);
     if (lz.i0 != cz0) {
@@ -318,6 +329,37 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
         if (xo + j < Wo) yp[j] = o[j];
     }
     yp += ostride;
+    if constexpr (WITH_DISP) {
+      const int full = Do - Do % SA_BLK;   // planes [0, full) fold in blocks, the tail one by one (soft_argmin_kernel)
+      if (zo < full) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int i = 0; i < SA_BLK; ++i)
+            if (i == (zo & (SA_BLK - 1))) vb[j][i] = o[j] * alpha;
+        }
+        if ((zo & (SA_BLK - 1)) == SA_BLK - 1) {
+          float d[SA_BLK];
+#pragma unroll
+          for (int i = 0; i < SA_BLK; ++i) d[i] = dv.v[zo - (SA_BLK - 1) + i];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) st[j].template fold<SA_BLK>(vb[j], d);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v1[1] = {o[j] * alpha};
+          float d1[1] = {dv.v[zo]};
+          st[j].template fold<1>(v1, d1);
+        }
+      }
+    }
+  }
+  if constexpr (WITH_DISP) {
+    float* dp = disp + ((size_t)b * Ho + yo) * Wo + xo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (xo + j < Wo) dp[j] = st[j].result();
   }
 }
 
@@ -554,14 +596,28 @@ extern "C" int dmb_trilinear_ac_f32(const float* x, float* y, int B, int Di, int
     const long long nblk0 = (long long)cdiv(cdiv(Wo, 4), 256) * Ho * B;
     int zsplit = 1;
     while (nblk0 * zsplit < 2048 && zsplit * 2 <= Do && zsplit < 16) zsplit *= 2;
-    hipLaunchKernelGGL(trilinear_zcol_kernel, dim3(cdiv(cdiv(Wo, 4), 256) * zsplit, Ho, B), dim3(256), 0, st, x, y, Di, Hi,
-                       Wi, Do, Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), zsplit);
+    hipLaunchKernelGGL(trilinear_zcol_kernel<false>, dim3(cdiv(cdiv(Wo, 4), 256) * zsplit, Ho, B), dim3(256), 0, st, x, y, Di, Hi,
+                       Wi, Do, Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), zsplit, (float*)nullptr, 1.f,
+                       DispVal{});
   } else {
     dim3 grid(cdiv(cdiv(Wo, 4), 256) * Do * Ho, B);
     hipLaunchKernelGGL(trilinear_kernel, grid, dim3(256), 0, st, x, y, Di, Hi, Wi, Do, Ho, Wo,
                        ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo));
   }
   return launch_status("trilinear launch failed");
+}
+
+extern "C" int dmb_trilinear_ac_soft_argmin_f32(const float* x, float* y, float* disp, int B, int Di, int Hi, int Wi,
+                                                int Do, int Ho, int Wo, float alpha, const float* disp_sample_host,
+                                                void* stream) {
+  if (!x || !y || !disp || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0)
+    return fail(DMB_EINVAL, "trilinear_ac_soft_argmin: bad argument");
+  if (Ho > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "trilinear_ac_soft_argmin: grid too large");
+  DispVal dv;
+  if (int e = fill_samples(disp_sample_host, Do, dv)) return e;
+  hipLaunchKernelGGL(trilinear_zcol_kernel<true>, dim3(cdiv(cdiv(Wo, 4), 256), Ho, B), dim3(256), 0, (hipStream_t)stream, x, y,
+                     Di, Hi, Wi, Do, Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), 1, disp, alpha, dv);
+  return launch_status("trilinear_ac_soft_argmin launch failed");
 }
 
 extern "C" int dmb_trilinear_soft_argmin_f32(const float* x, float* disp, int B, int Di, int Hi, int Wi, int Do,

@@ -41,5 +41,12 @@ class PSMAggregator(nn.Module):
         B, C, D, H, W = raw_cost.shape
         cost1, cost2, cost3 = self.trunk(raw_cost)
         size = (self.max_disp, H * 4, W * 4)                             # PSMNet.py:75-88, align_corners=True
-        up = [ops.trilinear_ac(c.squeeze(1), size) for c in (cost3, cost2, cost1)]
+        # The up-sampling kernel also regresses the standard soft-argmin (alpha 1, samples 0..max_disp-1) of the volume
+        # it writes and leaves it as a hint on the tensor: FasterSoftArgmin / SoftArgmin with exactly those parameters
+        # return it instead of reading the [B, max_disp, H, W] volume again (bit-identical either way).
+        vals = ops.disp_sample_values(self.max_disp, 0, 1)
+        up = []
+        for c in (cost3, cost2, cost1):
+            cost, disp = ops.trilinear_ac_soft_argmin(c.squeeze(1), size, vals, 1.0)
+            up.append(ops.RegressionHint.attach(cost, vals, 1.0, disp))
         return up

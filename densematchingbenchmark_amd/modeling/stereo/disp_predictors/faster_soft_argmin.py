@@ -29,7 +29,11 @@ class FasterSoftArgmin(_SoftArgminBase):
 
     def forward(self, cost_volume, disp_sample=None):
         self._check(cost_volume)
-        return ops.soft_argmin(cost_volume, self._sample_values(), self.alpha, self.normalize)
+        vals = self._sample_values()
+        hint = ops.RegressionHint.lookup(cost_volume, vals, self.alpha, self.normalize)
+        if hint is not None:     # the producing kernel already regressed this very tensor with these parameters
+            return hint
+        return ops.soft_argmin(cost_volume, vals, self.alpha, self.normalize)
 
     @property
     def name(self):

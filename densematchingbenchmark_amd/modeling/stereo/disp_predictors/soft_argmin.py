@@ -40,7 +40,11 @@ class SoftArgmin(_SoftArgminBase):
         D = cost_volume.shape[1]
         if disp_sample is None:
             assert D == self.disp_sample_number, 'The number of disparity samples should be consistent!'
-            return ops.soft_argmin(cost_volume, self.disp_sample.tolist(), self.alpha, self.normalize)
+            vals = self.disp_sample.tolist()
+            hint = ops.RegressionHint.lookup(cost_volume, vals, self.alpha, self.normalize)
+            if hint is not None:     # the producing kernel already regressed this very tensor with these parameters
+                return hint
+            return ops.soft_argmin(cost_volume, vals, self.alpha, self.normalize)
         assert D == disp_sample.shape[1], 'The number of disparity samples should be consistent!'
         return ops.soft_argmin_sampled(cost_volume, disp_sample.float().expand_as(cost_volume).contiguous(),
                                        self.alpha, self.normalize)

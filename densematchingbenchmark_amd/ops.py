@@ -256,6 +256,45 @@ def trilinear_soft_argmin(x, out_size, disp_values, alpha=1.0):
     return disp
 
 
+def trilinear_ac_soft_argmin(x, out_size, disp_values, alpha=1.0):
+    """Up-sampled cost volume AND its soft-argmin (normalize=True) in one pass: returns (cost [B, Do, Ho, Wo],
+    disp [B, 1, Ho, Wo]) with disp == soft_argmin(cost, disp_values, alpha, True) bit for bit."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = out_size
+    y = torch.empty((B, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    disp = torch.empty((B, 1, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib.dmb_trilinear_ac_soft_argmin_f32(dev_ptr(x), dev_ptr(y), dev_ptr(disp), B, Di, Hi, Wi, Do, Ho, Wo,
+                                               float(alpha), host_floats(disp_values), stream_ptr(x.device)),
+          "dmb_trilinear_ac_soft_argmin_f32")
+    return y, disp
+
+
+class RegressionHint:
+    """Side channel from a cost producer to the soft-argmin predictors: a disparity map that the producing kernel
+    already regressed from exactly this cost tensor (same sample values, alpha, normalize=True).  The predictor uses it
+    only if every parameter matches and the tensor has not been modified since (``_version``)."""
+
+    __slots__ = ("values", "alpha", "version", "disp")
+
+    def __init__(self, values, alpha, version, disp):
+        self.values, self.alpha, self.version, self.disp = tuple(values), float(alpha), version, disp
+
+    @staticmethod
+    def attach(cost, values, alpha, disp):
+        cost._dmb_regression_hint = RegressionHint(values, alpha, cost._version, disp)
+        return cost
+
+    @staticmethod
+    def lookup(cost, values, alpha, normalize):
+        hint = getattr(cost, "_dmb_regression_hint", None)
+        if hint is None or not normalize or hint.version != cost._version or hint.alpha != float(alpha) \
+                or hint.values != tuple(values) or hint.disp.shape[0] != cost.shape[0]:
+            return None
+        return hint.disp
+
+
 # ---------------------------------------------------------------------------------------------- conf head / metrics
 def pack_conf_head_weights(w1):
     """Conv2d weight [Cm, D, 3, 3] -> fragment stream."""

@@ -147,6 +147,13 @@ int dmb_local_soft_argmin_f32(const float* cost, float* disp, long long* argidx,
                               int radius, int radius_dilation, int start_disp, int dilation, float alpha,
                               void* stream);
 
+/* Producer-fused form of the two calls above: F.interpolate(..., 'trilinear', align_corners=True) AND the soft-argmin
+ * (normalize=True, disp_sample given per plane) of the up-sampled volume in one pass: y [B, Do, Ho, Wo] is written as
+ * by dmb_trilinear_ac_f32 and disp [B, 1, Ho, Wo] equals dmb_soft_argmin_f32(y) bit for bit, without re-reading y
+ * (aggregators/PSMNet.py:75-88 followed by disp_predictors/faster_soft_argmin.py:51-71). */
+int dmb_trilinear_ac_soft_argmin_f32(const float* x, float* y, float* disp, int B, int Di, int Hi, int Wi, int Do,
+                                     int Ho, int Wo, float alpha, const float* disp_sample_host, void* stream);
+
 /* Opt-in fused fast path: trilinear(align_corners=True) up-sampling of the 1/4-resolution cost
  * [B, Di, Hi, Wi] to [B, Do, Ho, Wo] + soft-argmin, without materialising the full-resolution volume.
  * Legal only when the caller does not need `costs` back (SURVEY 7.3 "costs are part of the return

@@ -430,3 +430,24 @@ def test_bilinear_half_pixel_scaled(dev, ins, outs, mult):
     assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item() / 8)
     if ins == outs:
         assert torch.equal(got, x)
+
+
+@pytest.mark.parametrize("ins,outs", [((6, 9, 20), (24, 36, 80)), ((5, 7, 9), (19, 25, 33)), ((3, 4, 5), (9, 13, 17))])
+def test_trilinear_with_fused_regression_is_bit_identical(dev, ins, outs):
+    """The producer-fused up-sampling writes the same volume as trilinear_ac and the same disparity as a separate
+    soft-argmin pass over that volume (block order of the online soft-max included), bit for bit."""
+    ops = _ops()
+    x = _rand((2,) + ins, 171, 3.0).to(dev)
+    vals = ops.disp_sample_values(outs[0], 0, 1)
+    cost, disp = ops.trilinear_ac_soft_argmin(x, outs, vals, 1.0)
+    ref_cost = ops.trilinear_ac(x, outs)
+    assert torch.equal(cost, ref_cost)
+    assert torch.equal(disp, ops.soft_argmin(ref_cost, vals, 1.0, True))
+    # the hint is honoured only for the exact tensor state and parameters it was computed for
+    ops.RegressionHint.attach(cost, vals, 1.0, disp)
+    assert ops.RegressionHint.lookup(cost, vals, 1.0, True) is disp
+    assert ops.RegressionHint.lookup(cost, vals, 2.0, True) is None
+    assert ops.RegressionHint.lookup(cost, vals[:-1] + [0.0], 1.0, True) is None
+    assert ops.RegressionHint.lookup(cost, vals, 1.0, False) is None
+    cost.add_(1.0)
+    assert ops.RegressionHint.lookup(cost, vals, 1.0, True) is None
