@@ -58,17 +58,20 @@ struct Affine {
 // ---------------------------------------------------------------------------------------------------------
 // Stride-1 kernel.
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, int SCHED_ = 1, bool ROWPAIR_ = false>
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, int SCHED_ = 1, int G_ = 0, int PMIN_ = 0>
 struct S1Cfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_, SCHED = SCHED_;
-  static constexpr bool ROWPAIR = ROWPAIR_;
+  static constexpr int G = G_;                  // row-group width: 0 = flattened tiles, 16 = row pairs, 8 = row quads
+  static constexpr bool ROWPAIR = G_ != 0;     // any row-group mapping (takes the 16-byte vector path)
+  static constexpr int GR = G_ ? 32 / G_ : 1;  // rows per group
   static constexpr int WZ = 4 / WN;        // waves along z; one output z-slice per wave
   static constexpr int TZ = WZ;
   // Row-pair tiles are staged with 16-byte LDS-DMA words: a staged row starts at the 16-byte aligned column x0 - 4
   // (XOFF = 3 unused floats in front of the halo column) and is a whole number of words long.  A CU retires LDS-DMA
   // at about one lane per clock whatever the word size, so this is 4x fewer TA cycles for the same bytes.
   static constexpr int XOFF = ROWPAIR ? 3 : 0;
-  static constexpr int P = ROWPAIR ? (4 + TX + 1 + 3) / 4 * 4 : TX + 2;   // padded row pitch
+  static constexpr int PV = (4 + TX + 1 + 3) / 4 * 4;
+  static constexpr int P = ROWPAIR ? (PV > PMIN_ ? PV : PMIN_) : TX + 2;   // padded row pitch (PMIN: bank-friendly pitch)
   static constexpr int ROWS = TY + 2;
   static constexpr int PLANE = ROWS * P;
   static constexpr int ZS = TZ + 2;
@@ -78,16 +81,16 @@ struct S1Cfg {
   // How the 32 columns (voxels) of an MFMA B tile map onto the LDS tile:
   //  - flattened (default): 32 consecutive positions of the padded (y, x) plane; works for any TX, but the 2 halo
   //    columns per row and the last partial tile are computed and discarded (6 % at TX = 60, TY = 4);
-  //  - row pair (TX % 16 == 0, TY % 2 == 0): 16 columns of row r (lanes 0-15) + the same 16 columns of row r + 1
-  //    (lanes 16-31): every computed voxel is a real output.  Used when W is a multiple of TX.
-  static constexpr int XS = TX / 16;
-  static constexpr int MT = ROWPAIR ? (TY / 2) * XS : (TY * P + 31) / 32;  // 32-voxel column tiles per wave
-  __device__ static constexpr int lane_off(int j) { return ROWPAIR ? (j >> 4) * P + (j & 15) : j; }
-  __device__ static constexpr int tile_off(int mt) { return ROWPAIR ? 2 * (mt / XS) * P + (mt % XS) * 16 : mt * 32; }
+  //  - row group (TX % G == 0, TY % (32 / G) == 0): G columns of 32 / G consecutive rows -- row pairs of 16 (lanes 0-15 =
+  //    row r, 16-31 = row r + 1) or row quads of 8: every computed voxel is a real output.  Used when W % TX == 0.
+  static constexpr int XS = ROWPAIR ? TX / (G_ ? G_ : 1) : 1;
+  static constexpr int MT = ROWPAIR ? (TY / GR) * XS : (TY * P + 31) / 32;  // 32-voxel column tiles per wave
+  __device__ static constexpr int lane_off(int j) { return ROWPAIR ? (j / (G_ ? G_ : 1)) * P + (j % (G_ ? G_ : 1)) : j; }
+  __device__ static constexpr int tile_off(int mt) { return ROWPAIR ? GR * (mt / XS) * P + (mt % XS) * G_ : mt * 32; }
   __device__ static void decode(int mt, int j, int& ly, int& lx, bool& valid) {
     if (ROWPAIR) {
-      ly = 2 * (mt / XS) + (j >> 4);
-      lx = (mt % XS) * 16 + (j & 15);
+      ly = GR * (mt / XS) + j / (G_ ? G_ : 1);
+      lx = (mt % XS) * G_ + j % (G_ ? G_ : 1);
       valid = true;
     } else {
       const int m = mt * 32 + j;
@@ -105,7 +108,7 @@ struct S1Cfg {
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
   static_assert(P <= 64, "one wave stages one tile row per instruction");
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
-  static_assert(!ROWPAIR || (TX % 16 == 0 && TY % 2 == 0), "row-pair tiles need TX % 16 == 0 and an even TY");
+  static_assert(!ROWPAIR || (G_ % 4 == 0 && TX % (G_ ? G_ : 1) == 0 && TY % GR == 0), "row-group tiles need TX % G == 0 and TY % (32 / G) == 0");
   static_assert(!ROWPAIR || ((CK * IPC) % 4 == 0 && NT == 1 && LDS_FLOATS >= 4 * 32 * TR_PITCH), "row-pair staging / scratch");
 };
 
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
       sh4[k] = shift ? shift[co] : 0.f;
     }
     auto offsets = [&](int mt, unsigned (&off)[4]) {
-      const int gy = y0 + 2 * (mt / C::XS) + (px >> 4), gxo = x0 + (mt % C::XS) * 16 + (px & 15);
+      const int gy = y0 + C::GR * (mt / C::XS) + px / C::G, gxo = x0 + (mt % C::XS) * C::G + px % C::G;
       const bool inb = gz < D && gy < H && gxo < W;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -1062,6 +1065,18 @@ static int flat_tx(int W) {
   return e52 > e60 ? 52 : 60;
 }
 
+static long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
+static int s1_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                  const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int stride, int relu, void* stream) {
@@ -1069,17 +1084,31 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
   if ((long long)(Ci > Co ? Ci : Co) * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "conv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-#define DMB_S1(CO, TX, WN, RP) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, RP>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
+#define DMB_S1(CO, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
   if (stride == 1) {
-    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0 &&
-                    (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path
+    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0 && aligned;
     const int tx = flat_tx(W);
     if (Co == 32) {
-      if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, false>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
-      if (rp) return DMB_S1(32, 48, 1, true);
-      return tx == 52 ? DMB_S1(32, 52, 1, false) : DMB_S1(32, 60, 1, false);
+      if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      if (rp) return DMB_S1(32, 48, 1, 16, 0);
+      return tx == 52 ? DMB_S1(32, 52, 1, 0, 0) : DMB_S1(32, 60, 1, 0, 0);
     }
-    if (Co == 64) return tx == 52 ? DMB_S1(64, 52, 2, false) : DMB_S1(64, 60, 2, false);
+    if (Co == 64) {
+      // row quads (8 columns x 4 rows) of 40-column tiles: no discarded halo columns and 5/8 of the flattened tile's
+      // work per workgroup, which at half resolution (W = 120) also quantises better over the 512 workgroup slots
+      // of which two widths exist: 40 and 24.  A launch here is only a few "rounds" of workgroups deep (W = 120, batch
+      // 4: 2448 tiles of 40 columns on 512 slots = 4.8 rounds, measured 128 TF/s; 4080 tiles of 24 = 7.97 rounds, 145
+      // TF/s), so the width is picked per launch by rounds x columns.
+      if (aligned && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0)) {
+        const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 2LL * s1_num_cus();
+        const long long c40 = W % 40 == 0 ? cdiv_ll(per * (W / 40), slots) * 40 : (1LL << 60);
+        const long long c24 = W % 24 == 0 ? cdiv_ll(per * (W / 24), slots) * 24 : (1LL << 60);
+        if (c24 < c40) return DMB_S1(64, 24, 2, 8, 40);
+        return DMB_S1(64, 40, 2, 8, 56);
+      }
+      return tx == 52 ? DMB_S1(64, 52, 2, 0, 0) : DMB_S1(64, 60, 2, 0, 0);
+    }
   } else if (stride == 2) {
     const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned input rows
     if (Co == 64 && v16) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);

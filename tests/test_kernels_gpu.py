@@ -107,6 +107,11 @@ def test_conv3d_k3(dev, Ci, Co, stride, shape):
     (12, 32, 2, (1, 6, 9, 21)),
     (7, 64, 2, (1, 5, 8, 33)),
     (32, 32, 1, (1, 3, 6, 156)),    # StereoNet width: TX = 52 tiles
+    (64, 64, 1, (1, 5, 9, 80)),     # W % 40 == 0 with 64 output channels -> row-quad tiles (8 columns x 4 rows)
+    (20, 64, 1, (2, 3, 6, 120)),
+    (64, 64, 1, (1, 2, 3, 40)),
+    (64, 64, 1, (1, 4, 7, 72)),     # W % 24 == 0 only -> 24-column row-quad tiles
+    (64, 64, 1, (4, 24, 20, 120)),  # both widths possible: picked by the rounds x columns model
 ])
 def test_conv3d_any_channels(dev, Ci, Co, stride, shape):
     ops = _ops()
@@ -118,6 +123,9 @@ def test_conv3d_any_channels(dev, Ci, Co, stride, shape):
     wp = ops.pack_conv3d_weights(w.to(dev))
     got = ops.conv3d_k3(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), None, stride, True).cpu()
     assert (got - F.relu(ref)).abs().max().item() <= 2e-5
+    res = _rand(ref.shape, 34)
+    got = ops.conv3d_k3(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), res.to(dev), stride, False).cpu()
+    assert (got - (ref + res)).abs().max().item() <= 2e-5
 
 
 @pytest.mark.parametrize("Ci,Co", [(64, 64), (64, 32), (20, 32), (9, 64)])
