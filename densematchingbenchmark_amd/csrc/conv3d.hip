@@ -106,7 +106,7 @@ struct S1Cfg {
   static constexpr int IN_FLOATS = CK * CH_STRIDE;   // input tile of one chunk
   static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;  // + the chunk's weight fragments
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
-  static_assert(P <= 64, "one wave stages one tile row per instruction");
+  static_assert(ROWPAIR || P <= 64, "one wave stages one tile row per instruction");
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(!ROWPAIR || (G_ % 4 == 0 && TX % (G_ ? G_ : 1) == 0 && TY % GR == 0), "row-group tiles need TX % G == 0 and TY % (32 / G) == 0");
   static_assert(!ROWPAIR || ((CK * IPC) % 4 == 0 && NT == 1 && LDS_FLOATS >= 4 * 32 * TR_PITCH), "row-pair staging / scratch");
@@ -958,6 +958,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restri
 // The accumulation order above is (dz, dy) outer, dx inner PER channel, i.e. tap-ascending within a channel and
 // channels ascending -- identical to the MFMA kernels' k order up to their channel pairing.
 
+static long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
+static int s1_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <class C>
 static int launch_s1(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                      float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
@@ -1063,18 +1075,6 @@ static int flat_tx(int W) {
   const double e60 = (double)W / w60 * (60.0 / 62.0) * (248.0 / 256.0);
   const double e52 = (double)W / w52 * (52.0 / 54.0) * (216.0 / 224.0);
   return e52 > e60 ? 52 : 60;
-}
-
-static long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
-static int s1_num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
 }
 
 extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,

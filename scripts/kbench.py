@@ -49,8 +49,6 @@ def bw_case(name, fn, nbytes):
 
 
 print("B =", B)
-from densematchingbenchmark_amd import _lib as _l0
-if os.environ.get("KB_OPT5"): _l0.load().dmb_dev_set_option(5, int(os.environ["KB_OPT5"]))
 from densematchingbenchmark_amd import _lib
 _l = _lib.load()
 if hasattr(_l, "dmb_dev_set_option"):
