@@ -30,8 +30,8 @@ namespace dmb {
 // ---------------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Cipad,
                                     int transposed) {
-  const int NTT = Co / 32;
-  const long long total = (long long)Cipad * 27 * Co;
+  const int NTT = cdiv(Co, 32);   // output channels beyond Co are zero rows (1-channel transposed head of GC-Net)
+  const long long total = (long long)Cipad * 27 * NTT * 32;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63);
     long long r = i >> 6;
@@ -42,7 +42,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int co = nt * 32 + (lane & 31);
     const int ci = 2 * kp + (lane >> 5);
     float v = 0.f;  // channels >= Ci are zero padding (the kernels consume Ci rounded up to their chunk size)
-    if (ci < Ci) v = transposed ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap];
+    if (ci < Ci && co < Co) v = transposed ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap];
     wp[i] = v;
   }
 }
@@ -115,14 +115,21 @@ struct S1Cfg {
 // Epilogue shared by the three MFMA kernels: v = acc*scale + shift (+ residual) (relu) for the 16 accumulator
 // registers of one 32x32 tile; `o` is the voxel offset inside one channel plane, `cstride` the channel stride.
 // Residual loads are issued as one batch before the stores (one latency per tile instead of sixteen).
+// relu: 0 none, 1 after the residual add (hourglass.py:67-81), 2 before it (GC-Net adds the skip to the activated
+// output, aggregators/GCNet.py:108-116).  cvalid: channels >= cvalid are padding rows and are neither read nor written.
 template <int VEC>
 __device__ __forceinline__ void store_tile(const f32x16 (&a)[VEC], const float (&sc)[16], const float (&sh)[16],
                                            const float* __restrict__ rb, float* __restrict__ yb, int co0, int h,
-                                           unsigned cstride, unsigned o, int relu) {
+                                           unsigned cstride, unsigned o, int relu, int cvalid = 1 << 30) {
   float rv[16][VEC];
   if (rb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      if (co0 + cd_row(r, h) >= cvalid) {
+        rv[r][0] = 0.f;
+        rv[r][VEC - 1] = 0.f;
+        continue;
+      }
       const float* rp = rb + (size_t)(co0 + cd_row(r, h)) * cstride + o;
       if (VEC == 2) {
         const float2 t = *reinterpret_cast<const float2*>(rp);
@@ -139,9 +146,11 @@ __device__ __forceinline__ void store_tile(const f32x16 (&a)[VEC], const float (
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       v[e] = fmaf(a[e][r], sc[r], sh[r]);
+      if (relu == 2) v[e] = fmaxf(v[e], 0.f);
       if (rb) v[e] += rv[r][e];
-      if (relu) v[e] = fmaxf(v[e], 0.f);
+      if (relu == 1) v[e] = fmaxf(v[e], 0.f);
     }
+    if (co0 + cd_row(r, h) >= cvalid) continue;
     float* yp = yb + (size_t)(co0 + cd_row(r, h)) * cstride + o;
     if (VEC == 2)
       *reinterpret_cast<float2*>(yp) = make_float2(v[0], v[VEC - 1]);
@@ -190,11 +199,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
   static_assert(WCH % 16 == 0, "weights are staged with 16-byte copies, evenly over 4 waves");
   constexpr int WPW = WCH / 16;                 // 16-byte words per wave
   constexpr int WI = (WPW + 63) / 64;           // copy instructions per wave
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   const int gx = x0 - 1 + lane;
   const unsigned xvoff = (lane < C::P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
   auto stage = [&](int c0, float* buf) {
+    // the resource covers only this chunk's channels: 32-bit offsets then never limit the tensor size
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb + (size_t)c0 * DHW, (unsigned)min(C::CK, Ci - c0) * DHW * 4u);
     if constexpr (C::ROWPAIR) {
       // unit = 4 consecutive floats of a staged row; the units of one channel are linear in LDS
       constexpr int IPW = C::CK * C::IPC / 4;   // instructions per wave
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
         const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gxs = x0 - 4 + sg * 4;
         const bool ok = c0 + cl < Ci && gz >= 0 && gz < D && gy >= 0 && gy < H && gxs >= 0 && gxs < W;
         if (u < C::UPC)
-          dma16(xrs, ok ? ((unsigned)(c0 + cl) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB,
+          dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB,
                 0u, buf + cl * C::CH_STRIDE + qi * 256);
       }
     } else if (lane < C::P) {
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
         const int pl = wave * PPW + q, cl = pl / C::ZS, zz = pl - cl * C::ZS;
         const int gz = z0 - 1 + zz;
         const bool zok = gz >= 0 && gz < D && c0 + cl < Ci;
-        const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
+        const unsigned zoff = ((unsigned)cl * DHW + (unsigned)max(gz, 0) * HW) * 4u;
         float* dpl = buf + cl * C::CH_STRIDE + zz * C::PLANE;
 #pragma unroll
         for (int yy = 0; yy < C::ROWS; ++yy) {
@@ -281,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
     const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, (unsigned)C::COUT * DHW * 4u);
     const __amdgpu_buffer_rsrc_t rrs = make_rsrc(rb ? rb : yb, (unsigned)C::COUT * DHW * 4u);
     const int px = (lane & 7) * 4;
-    const float lo = relu ? 0.f : -__builtin_inff();
+    const float lo = relu == 1 ? 0.f : -__builtin_inff();    // ReLU after the residual add
+    const float lo2 = relu == 2 ? 0.f : -__builtin_inff();   // ReLU before it (GC-Net)
     float sc4[4], sh4[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -321,10 +332,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float4 v = *reinterpret_cast<const float4*>(my + (k * 8 + (lane >> 3)) * C::TR_PITCH + px);
-          v.x = fmaf(v.x, sc4[k], sh4[k]);
-          v.y = fmaf(v.y, sc4[k], sh4[k]);
-          v.z = fmaf(v.z, sc4[k], sh4[k]);
-          v.w = fmaf(v.w, sc4[k], sh4[k]);
+          v.x = fmaxf(fmaf(v.x, sc4[k], sh4[k]), lo2);
+          v.y = fmaxf(fmaf(v.y, sc4[k], sh4[k]), lo2);
+          v.z = fmaxf(fmaf(v.z, sc4[k], sh4[k]), lo2);
+          v.w = fmaxf(fmaf(v.w, sc4[k], sh4[k]), lo2);
           if constexpr (HAS_RES) {   // (not __builtin_bit_cast on a vector element: this clang reads element 0 for every index)
             v.x += __uint_as_float(rv[mt & 1][k].x);
             v.y += __uint_as_float(rv[mt & 1][k].y);
@@ -447,9 +458,9 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   constexpr int WCH = C::NK * C::NTT * 64;
   constexpr int WV4 = (WCH / 4 + 255) / 256;
   static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   auto stage = [&](int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb + (size_t)c0 * DHW, (unsigned)min(C::CK, Ci - c0) * DHW * 4u);
     if constexpr (C::V16) {
       // unit = 4 consecutive floats of a staged row; the units of one channel ([z][y parity][row][64]) are linear in LDS
       constexpr int NI = C::CK * C::IPC, IPW = (NI + 3) / 4;
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
           const int gz = 2 * z0 - 1 + zz, gy = 2 * y0 - 1 + ry, gxs = 2 * x0 - 4 + sg * 4;
           const bool ok = c0 + cl < Ci && ry < C::INROWS && gz >= 0 && gz < D && gy >= 0 && gy < H && gxs >= 0 && gxs < W;
           if (u < C::UPC)
-            dma16(xrs, ok ? ((unsigned)(c0 + cl) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB,
+            dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB,
                   0u, buf + cl * C::CH_STRIDE + qi * 256);
         }
       }
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
       const int gz = 2 * z0 - 1 + zz, col = pass * 64 + lane, gx = 2 * x0 - 1 + col;
       const bool zok = gz >= 0 && gz < D && c0 + cl < Ci;
       const unsigned xvoff = (col < C::INCOLS && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
-      const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
+      const unsigned zoff = ((unsigned)cl * DHW + (unsigned)max(gz, 0) * HW) * 4u;
       float* dpl = buf + cl * C::CH_STRIDE + zz * C::ZPL + pass * 64;
       if (col < C::R) {
 #pragma unroll
@@ -608,7 +619,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                             const float* __restrict__ res, float* __restrict__ y, int Ci, int D, int H,
                                             int W, int ntx, int nty, int ntz, int first, int stride, int ntiles,
-                                            int relu) {
+                                            int relu, int cvalid) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wz = wave / C::WN, wn = wave % C::WN;
@@ -640,7 +651,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   constexpr int WV4 = (WCH4 + 255) / 256;
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   auto stage = [&](const Tile& tl, int c0, float* buf) {
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * Ci * DHW, (unsigned)Ci * DHW * 4u);
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)tl.b * Ci + c0) * DHW, (unsigned)min(C::CK, Ci - c0) * DHW * 4u);
     if constexpr (C::V16) {
       // unit = 4 consecutive floats of a staged row; the units of one channel are linear in LDS
 #pragma unroll
@@ -653,7 +664,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
           const int gz = tl.z0 + zz, gy = tl.y0 + yy, gx = tl.x0 + sg * 4;
           const bool ok = c0 + cl < Ci && gz < D && gy < H && gx < W;
           if (u < C::UPC)
-            dma16(xrs, ok ? ((unsigned)(c0 + cl) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB,
+            dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB,
                   0u, buf + cl * C::CH_STRIDE + q * 256);
         }
       }
@@ -668,7 +679,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
 #pragma unroll
         for (int zz = 0; zz < C::ZS; ++zz) {
           const bool zok = tl.z0 + zz < D && c0 + cl < Ci;
-          const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)(tl.z0 + zz) * HW) * 4u;
+          const unsigned zoff = ((unsigned)cl * DHW + (unsigned)(tl.z0 + zz) * HW) * 4u;
 #pragma unroll
           for (int yy = 0; yy < C::ROWS; ++yy) {
             const bool ok = zok && tl.y0 + yy < H;
@@ -698,8 +709,9 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   // LDS reads count on lgkmcnt instead and cost no registers across the loop.)
   float* aff = lds + C::LDS_FLOATS;
   if (threadIdx.x < C::COUT) {
-    aff[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
-    aff[C::COUT + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
+    const bool real = (int)threadIdx.x < cvalid;   // rows >= cvalid are padding (the 1-channel head uses a 32-row tile)
+    aff[threadIdx.x] = (scale && real) ? scale[threadIdx.x] : 1.f;
+    aff[C::COUT + threadIdx.x] = (shift && real) ? shift[threadIdx.x] : 0.f;
   }
 
   const int NC = cdiv(Ci, C::CK);  // a partial last chunk reads zeros (bounds check) against zero-padded weights
@@ -783,8 +795,9 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
     const int gzi = cur_t.z0 + wz;
     if (gzi < D) {
       const unsigned gz = 2 * gzi + PZ;
-      float* yb = y + (size_t)cur_t.b * C::COUT * DHWo;
-      const float* rb = res ? res + (size_t)cur_t.b * C::COUT * DHWo : nullptr;
+      const int cout = cvalid < C::COUT ? cvalid : C::COUT;   // channels the output tensor really has
+      float* yb = y + (size_t)cur_t.b * cout * DHWo;
+      const float* rb = res ? res + (size_t)cur_t.b * cout * DHWo : nullptr;
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) {
         const int co0 = (wn * C::NT + nt) * 32;
@@ -803,7 +816,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
               const f32x16 a2[2] = {acc[py][0][mt][nt], acc[py][1][mt][nt]};
-              store_tile<2>(a2, sc, sh, rb, yb, co0, h, DHWo, gz * HWo + (unsigned)(2 * gyi + py) * Wo + 2u * gxi, relu);
+              store_tile<2>(a2, sc, sh, rb, yb, co0, h, DHWo, gz * HWo + (unsigned)(2 * gyi + py) * Wo + 2u * gxi, relu, cvalid);
             }
           }
         }
@@ -820,13 +833,13 @@ __global__ __launch_bounds__(256, C::WPE) void deconv3d_kernel(const float* __re
                                                                const float* __restrict__ shift,
                                                                const float* __restrict__ res, float* __restrict__ y,
                                                                int Ci, int D, int H, int W, int ntx, int nty, int ntz,
-                                                               int ntiles, int g0, int relu) {
+                                                               int ntiles, int g0, int relu, int cvalid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x < g0)
-    deconv_body<C, 0>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, ntx, nty, ntz, blockIdx.x, g0, ntiles, relu);
+    deconv_body<C, 0>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, ntx, nty, ntz, blockIdx.x, g0, ntiles, relu, cvalid);
   else
     deconv_body<C, 1>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, ntx, nty, ntz, blockIdx.x - g0, gridDim.x - g0,
-                      ntiles, relu);
+                      ntiles, relu, cvalid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -867,19 +880,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_kernel(const float* __restri
   const bool worker = lxq < 15;
   float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb, (unsigned)Ci * DHW * 4u);
   const int gx = x0 - 1 + lane;
   const unsigned xvoff = (lane < C1_P && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
   constexpr int PPW = C1_CK * C1_ZS / 4;  // 5 planes per wave per chunk
   static_assert((C1_CK * C1_ZS) % 4 == 0, "planes are dealt evenly to the 4 waves");
   auto stage = [&](int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb + (size_t)c0 * DHW, (unsigned)min(C1_CK, Ci - c0) * DHW * 4u);
     if (lane < C1_P) {
 #pragma unroll
       for (int q = 0; q < PPW; ++q) {
         const int pl = wave * PPW + q, cl = pl / C1_ZS, zz = pl - cl * C1_ZS;
         const int gz = z0 - 1 + zz;
         const bool zok = gz >= 0 && gz < D && c0 + cl < Ci;
-        const unsigned zoff = ((unsigned)(c0 + cl) * DHW + (unsigned)max(gz, 0) * HW) * 4u;
+        const unsigned zoff = ((unsigned)cl * DHW + (unsigned)max(gz, 0) * HW) * 4u;
         float* dpl = buf + cl * C1_CH + zz * C1_PLANE;
 #pragma unroll
         for (int yy = 0; yy < C1_ROWS; ++yy) {
@@ -1009,7 +1022,7 @@ static int launch_s2(const float* x, const float* wp, const float* scale, const 
 
 template <class C>
 static int launch_deconv(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
-                         float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
+                         float* y, int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st) {
   const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long ntiles = (long long)B * ntx * nty * ntz;
   if (ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
@@ -1038,7 +1051,7 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
     if (g1 > ntiles) g1 = ntiles;
   }
   hipLaunchKernelGGL((deconv3d_kernel<C>), dim3((unsigned)(g0 + g1)), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci,
-                     D, H, W, ntx, nty, ntz, (int)ntiles, (int)g0, relu);
+                     D, H, W, ntx, nty, ntz, (int)ntiles, (int)g0, relu, Co);
   return launch_status("deconv3d launch failed");
 }
 
@@ -1047,13 +1060,13 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
 using namespace dmb;
 
 static int ci_padded(int Ci) { return (Ci + 7) / 8 * 8; }  // covers every kernel's channel-chunk size
-extern "C" long long dmb_conv3d_packed_floats(int Co, int Ci) { return (long long)Co * ci_padded(Ci) * 27; }
-extern "C" long long dmb_deconv3d_packed_floats(int Ci, int Co) { return (long long)Co * ci_padded(Ci) * 27; }
+static int co_padded(int Co) { return cdiv(Co, 32) * 32; }
+extern "C" long long dmb_conv3d_packed_floats(int Co, int Ci) { return (long long)co_padded(Co) * ci_padded(Ci) * 27; }
+extern "C" long long dmb_deconv3d_packed_floats(int Ci, int Co) { return (long long)co_padded(Co) * ci_padded(Ci) * 27; }
 
 static int pack_common(const float* w, float* wp, int Co, int Ci, int transposed, void* stream) {
-  if (!w || !wp || Co <= 0 || Ci <= 0 || Co % 32 != 0)
-    return fail(DMB_EINVAL, "pack_weights: Co must be a multiple of 32");
-  const long long total = (long long)Co * ci_padded(Ci) * 27;
+  if (!w || !wp || Co <= 0 || Ci <= 0) return fail(DMB_EINVAL, "pack_weights: bad argument");
+  const long long total = (long long)co_padded(Co) * ci_padded(Ci) * 27;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci, ci_padded(Ci),
                      transposed);
@@ -1081,13 +1094,14 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
                                  const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int stride, int relu, void* stream) {
   if (!x || !wpack || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d: bad argument");
-  if ((long long)(Ci > Co ? Ci : Co) * D * H * W * 4 >= 0x7fffffffLL)
-    return fail(DMB_EUNSUPPORTED, "conv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
+  if ((long long)8 * D * H * W * 4 >= 0x7fffffffLL)
+    return fail(DMB_EUNSUPPORTED, "conv3d: 8 channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
+  const bool out_small = (long long)Co * D * H * W * 4 < 0x7fffffffLL;   // the vector epilogue addresses the whole output item
   hipStream_t st = (hipStream_t)stream;
 #define DMB_S1(CO, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
   if (stride == 1) {
     const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path
-    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0 && aligned;
+    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0 && aligned && out_small;
     const int tx = flat_tx(W);
     if (Co == 32) {
       if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
@@ -1100,7 +1114,7 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       // of which two widths exist: 40 and 24.  A launch here is only a few "rounds" of workgroups deep (W = 120, batch
       // 4: 2448 tiles of 40 columns on 512 slots = 4.8 rounds, measured 128 TF/s; 4080 tiles of 24 = 7.97 rounds, 145
       // TF/s), so the width is picked per launch by rounds x columns.
-      if (aligned && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0)) {
+      if (aligned && out_small && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0)) {
         const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 2LL * s1_num_cus();
         const long long c40 = W % 40 == 0 ? cdiv_ll(per * (W / 40), slots) * 40 : (1LL << 60);
         const long long c24 = W % 24 == 0 ? cdiv_ll(per * (W / 24), slots) * 24 : (1LL << 60);
@@ -1109,11 +1123,14 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       }
       return tx == 52 ? DMB_S1(64, 52, 2, 0, 0) : DMB_S1(64, 60, 2, 0, 0);
     }
+    if (Co == 128)   // GC-Net's deepest level: 2 waves x 2 row tiles, 2-row tiles keep the accumulators at 160 registers
+      return launch_s1<S1Cfg<0, 128, 2, 60, 2, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
   } else if (stride == 2) {
     const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned input rows
     if (Co == 64 && v16) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     if (Co == 64) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     if (Co == 32) return launch_s2<S2Cfg<0, 32, 4, 30, 2, 1>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+    if (Co == 128) return launch_s2<S2Cfg<0, 128, 4, 30, 2, 4>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
   }
 #undef DMB_S1
   return fail(DMB_EUNSUPPORTED, "conv3d: output channels must be 32 or 64 (or 1: dmb_conv3d_k3_c1_f32), stride 1 or 2");
@@ -1123,17 +1140,17 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
                                      const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                      int relu, void* stream) {
   if (!x || !wpack || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv3d: bad argument");
-  if ((long long)(Ci > 8 * Co ? Ci : 8 * Co) * D * H * W * 4 >= 0x7fffffffLL)
-    return fail(DMB_EUNSUPPORTED, "deconv3d: one batch item must stay below 2 GiB (32-bit buffer offsets)");
+  if ((long long)8 * D * H * W * 4 >= 0x7fffffffLL)
+    return fail(DMB_EUNSUPPORTED, "deconv3d: 8 input channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned rows
   if (Co == 64)
-    return v16 ? launch_deconv<DCfg<0, 64, 1, 60, 4, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
-               : launch_deconv<DCfg<0, 64, 1, 60, 4, 2, false>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
-  if (Co == 32)
-    return v16 ? launch_deconv<DCfg<0, 32, 1, 60, 8, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
-               : launch_deconv<DCfg<0, 32, 1, 60, 8, 1, false>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
-  return fail(DMB_EUNSUPPORTED, "deconv3d: output channels must be 32 or 64");
+    return v16 ? launch_deconv<DCfg<0, 64, 1, 60, 4, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st)
+               : launch_deconv<DCfg<0, 64, 1, 60, 4, 2, false>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
+  if (Co <= 32)   // fewer than 32 channels (GC-Net's 1-channel head): zero-padded weight rows, masked epilogue
+    return v16 ? launch_deconv<DCfg<0, 32, 1, 60, 8, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st)
+               : launch_deconv<DCfg<0, 32, 1, 60, 8, 1, false>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
+  return fail(DMB_EUNSUPPORTED, "deconv3d: output channels must be <= 32 or 64");
 }
 
 extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float* residual, float* y,
@@ -1149,7 +1166,7 @@ extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, 
                               (int)lds);
     attr_set = true;
   }
-  if ((long long)Ci * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: tensor too large for 32-bit offsets");
+  if ((long long)2 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: tensor too large for 32-bit offsets");
   hipLaunchKernelGGL(conv3d_c1_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, x, w, bias, residual, y,
                      Ci, D, H, W, ntx, nty, ntz);
   return launch_status("conv3d_c1 launch failed");

@@ -1,5 +1,6 @@
 """cost_processors/aggregators/builder.py:8-29 for the aggregators on the HIP path."""
 from .AcfNet import AcfAggregator
+from .GCNet import GCAggregator
 from .PSMNet import PSMAggregator
 from .StereoNet import StereoNetAggregator
 
@@ -8,8 +9,9 @@ AGGREGATORS = {
     "GwcNet": PSMAggregator,  # the gwc+concat volume has 64 channels = PSMAggregator(in_planes=64)
     "AcfNet": AcfAggregator,
     "StereoNet": StereoNetAggregator,
+    "GCNet": GCAggregator,
 }
-_OFF_PATH = ("GCNet", "DeepPruner", "AnyNet")
+_OFF_PATH = ("DeepPruner", "AnyNet")
 
 
 def build_cost_aggregator(cfg):

@@ -11,7 +11,8 @@ import torch.nn as nn
 
 from .... import ops
 
-__all__ = ["FusedConv3d", "HeadConv3d", "conv3d_bn", "conv3d_bn_relu", "deconv3d_bn", "fold_batch_norm"]
+__all__ = ["FusedConv3d", "HeadConv3d", "HeadDeconv3d", "conv3d_bn", "conv3d_bn_relu", "deconv3d_bn", "deconv3d_bn_relu",
+           "fold_batch_norm"]
 
 
 def fold_batch_norm(bn, conv_bias, out_planes, device):
@@ -80,11 +81,17 @@ class FusedConv3d(nn.Sequential):
             self._cache_key, self._cache = key, (wp, scale, shift)
         return self._cache
 
-    def forward(self, x, residual=None, relu=None):
+    def forward(self, x, residual=None, relu=None, skip=None):
+        """``residual`` is added BEFORE the activation (hourglass.py:67-81), ``skip`` AFTER it (GC-Net,
+        aggregators/GCNet.py:108-116: ``layer34(cost33 + cost29)`` -- the add runs in layer33's epilogue)."""
         if self.training and torch.is_grad_enabled():
             raise RuntimeError("FusedConv3d is an inference-only HIP path: call model.eval() and run under torch.no_grad()")
         wp, scale, shift = self._prepacked()
         act = self.has_relu if relu is None else relu
+        if skip is not None:
+            if residual is not None:
+                raise ValueError("FusedConv3d: residual and skip are mutually exclusive")
+            residual, act = skip, ("pre" if act else False)
         if self.transposed:
             return ops.deconv3d_k3s2(x, wp, self.out_planes, scale, shift, residual, act)
         return ops.conv3d_k3(x, wp, self.out_planes, scale, shift, residual, self.stride, act)
@@ -110,6 +117,25 @@ class HeadConv3d(nn.Conv3d):
         return ops.conv3d_k3_c1(x, self.weight.detach(), b, residual)
 
 
+class HeadDeconv3d(nn.ConvTranspose3d):
+    """nn.ConvTranspose3d(C, Co<=32, 3, stride 2, padding 1, output_padding 1, bias) without BN / activation (GC-Net's
+    1-channel output layer, aggregators/GCNet.py:63-67) on the MFMA transposed kernel with zero-padded weight rows."""
+
+    def __init__(self, in_planes, out_planes):
+        super().__init__(in_planes, out_planes, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self._key, self._cache = None, None
+
+    def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("HeadDeconv3d is an inference-only HIP path")
+        key = _versions(self.weight, self.bias)
+        if key != self._key:
+            self._key = key
+            self._cache = (ops.pack_deconv3d_weights(self.weight.detach()), self.bias.detach().float().contiguous())
+        wp, bias = self._cache
+        return ops.deconv3d_k3s2(x, wp, self.out_channels, None, bias, None, False)
+
+
 def conv3d_bn(batchNorm, in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1, bias=True):
     """basic_layers.py:68-83."""
     return FusedConv3d(batchNorm, in_planes, out_planes, kernel_size, stride, padding, dilation, bias, relu=False)
@@ -123,4 +149,10 @@ def conv3d_bn_relu(batchNorm, in_planes, out_planes, kernel_size=3, stride=1, pa
 def deconv3d_bn(batchNorm, in_planes, out_planes, kernel_size=4, stride=2, padding=1, output_padding=0, bias=True):
     """basic_layers.py:86-100."""
     return FusedConv3d(batchNorm, in_planes, out_planes, kernel_size, stride, padding, 1, bias, relu=False,
+                       transposed=True, output_padding=output_padding)
+
+
+def deconv3d_bn_relu(batchNorm, in_planes, out_planes, kernel_size=4, stride=2, padding=1, output_padding=0, bias=True):
+    """basic_layers.py:180-197."""
+    return FusedConv3d(batchNorm, in_planes, out_planes, kernel_size, stride, padding, 1, bias, relu=True,
                        transposed=True, output_padding=output_padding)

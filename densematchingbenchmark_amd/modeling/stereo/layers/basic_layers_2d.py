@@ -19,10 +19,11 @@ class FusedConv2d(nn.Sequential):
                  relu=False):
         # basic_layers.py:14-28: padding follows the dilation when dilation > 1
         pad = dilation if dilation > 1 else padding
-        if kernel_size not in (1, 3) or stride not in (1, 2) or dilation not in (1, 2, 4, 8) or pad != dilation * (kernel_size // 2) \
-                or (dilation > 2 and out_planes > 32):
+        if kernel_size not in (1, 3, 5) or stride not in (1, 2) or dilation not in (1, 2, 4, 8) \
+                or pad != dilation * (kernel_size // 2) or (dilation > 2 and out_planes > 32) \
+                or (kernel_size == 5 and (stride != 2 or dilation != 1 or out_planes > 32)):
             raise NotImplementedError("HIP conv2d: kernel 1|3, stride 1|2, dilation 1|2 (4|8 up to 32 output channels), "
-                                      "'same' padding")
+                                      "or kernel 5 with stride 2 (up to 32 output channels); 'same' padding")
         layers = [nn.Conv2d(in_planes, out_planes, kernel_size, stride=stride, padding=pad, dilation=dilation, bias=bias)]
         if batch_norm:
             layers.append(nn.BatchNorm2d(out_planes))

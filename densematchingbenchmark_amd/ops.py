@@ -143,6 +143,13 @@ def pack_deconv3d_weights(w):
     return wp
 
 
+def _relu_mode(relu):
+    """False/0: none; True/1: ReLU after the residual add; 'pre'/2: ReLU before it (GC-Net's skip connections)."""
+    if relu == "pre":
+        return 2
+    return int(relu) if relu in (0, 1, 2) else int(bool(relu))
+
+
 def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, relu=False):
     lib = _lib.load()
     x = _f32c(x, "x")
@@ -156,7 +163,7 @@ def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, rel
         _kernel_timer.start(tag)
     check(lib.dmb_conv3d_k3_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                 dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
-                                B, Ci, Co, D, H, W, stride, int(bool(relu)), stream_ptr(x.device)), "dmb_conv3d_k3_f32")
+                                B, Ci, Co, D, H, W, stride, _relu_mode(relu), stream_ptr(x.device)), "dmb_conv3d_k3_f32")
     if _kernel_timer is not None:
         _kernel_timer.stop(tag)
     return y
@@ -181,7 +188,7 @@ def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=Fals
         raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
     check(lib.dmb_deconv3d_k3s2_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                     dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
-                                    B, Ci, Co, D, H, W, int(bool(relu)), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
+                                    B, Ci, Co, D, H, W, _relu_mode(relu), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
     return y
 
 

@@ -32,7 +32,7 @@ def init_params_(module, seed=0, classif_gain=10.0):
         else:                                                # conv weights: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
             fan_in = v[0].numel() if "deconv" not in k and not _is_transposed(module, k) else v[:, 0].numel()
             t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(max(fan_in, 1))
-            if any(k.endswith("classif%d.1.weight" % i) for i in (1, 2, 3)) or k.endswith("lastconv.weight"):
+            if any(k.endswith("classif%d.1.weight" % i) for i in (1, 2, 3)) or k.endswith(("lastconv.weight", "layer37.weight")):
                 t = t * classif_gain
             if "deconv" in k:                                # AcfNet's learned 4x up-sampling: keep O(1) gain
                 t = t * 8.0

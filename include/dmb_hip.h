@@ -76,8 +76,10 @@ int dmb_cat_fms_into_f32(const float* L, const float* R, float* out, int B, int 
  *
  * Epilogue, in this order (matches the reference's op order):
  *     v = acc * scale[co] + shift[co]      (scale/shift may be NULL -> 1 / 0; BN and bias folded by caller)
+ *     v = max(v, 0)                        (if relu == 2: GC-Net adds its skips to the ACTIVATED output,
+ *                                           aggregators/GCNet.py:108-116)
  *     v = v + residual[...]                (residual may be NULL; same shape as y)
- *     v = max(v, 0)                        (if relu != 0)
+ *     v = max(v, 0)                        (if relu == 1: hourglass.py:67-81 activates after the skip add)
  * acc is an FP32 fma chain over (ci, kd, kh, kw).
  * ---------------------------------------------------------------------------------------- */
 
@@ -92,8 +94,9 @@ int dmb_conv3d_pack_weights_f32(const float* w, float* wpack, int Co, int Ci, vo
 int dmb_deconv3d_pack_weights_f32(const float* w, float* wpack, int Ci, int Co, void* stream);
 
 /* Conv3d, kernel 3, padding 1, stride 1 or 2 (all three axes).  x: [B, Ci, D, H, W];
- * y: [B, Co, Do, Ho, Wo] with Do = (D - 1) / stride + 1 etc.  Co in {32, 64}: MFMA implicit GEMM using
- * wpack from dmb_conv3d_pack_weights_f32.  Any Ci >= 1.  One batch item of x / y must stay below 2 GiB. */
+ * y: [B, Co, Do, Ho, Wo] with Do = (D - 1) / stride + 1 etc.  Co in {32, 64, 128}: MFMA implicit GEMM using
+ * wpack from dmb_conv3d_pack_weights_f32.  Any Ci >= 1.  8 channels of one batch item must stay below 2 GiB
+ * (buffer resources cover one channel chunk at a time, so the tensors themselves may be larger). */
 int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                       const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                       int stride, int relu, void* stream);
@@ -105,7 +108,8 @@ int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float
                          int B, int Ci, int D, int H, int W, void* stream);
 
 /* ConvTranspose3d kernel 3, stride 2, padding 1, output_padding 1 (hourglass.py:52-60):
- * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, 2W];  y[o] += x[i] * w[k] with o = 2i - 1 + k. */
+ * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, 2W];  y[o] += x[i] * w[k] with o = 2i - 1 + k.  Co = 64 or any Co <= 32
+ * (fewer than 32: zero-padded weight rows, e.g. GC-Net's 1-channel output layer, aggregators/GCNet.py:63-67). */
 int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                           const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                           int relu, void* stream);

@@ -400,6 +400,49 @@ def stereonet_backbone(img, p, prefix="backbone.", batch_norm=True, downsample_n
     return F.conv2d(x, p[prefix + "lastconv.weight"], p[prefix + "lastconv.bias"], padding=1)
 
 
+def gc_aggregator(raw_cost, p, prefix="", batch_norm=True):
+    """GCAggregator.forward (aggregators/GCNet.py:70-120): raw [B, 64, D/2, H/2, W/2] -> [cost [B, D, H, W]]."""
+    def conv(x, name, stride=1):
+        return conv3d_unit(x, p, prefix + name, stride, batch_norm, relu=True)
+
+    def deconv(x, name):
+        return F.relu(deconv3d_unit(x, p, prefix + name, batch_norm))
+
+    c18 = raw_cost
+    c20 = conv(conv(c18, "layer19"), "layer20")
+    c21 = conv(torch.cat([c18, c20], 1), "layer21", 2)
+    c23 = conv(conv(c21, "layer22"), "layer23")
+    c24 = conv(torch.cat([c21, c23], 1), "layer24", 2)
+    c26 = conv(conv(c24, "layer25"), "layer26")
+    c27 = conv(torch.cat([c24, c26], 1), "layer27", 2)
+    c29 = conv(conv(c27, "layer28"), "layer29")
+    c30 = conv(torch.cat([c27, c29], 1), "layer30", 2)
+    c32 = conv(conv(c30, "layer31"), "layer32")
+    c33 = deconv(c32, "layer33")
+    c34 = deconv(c33 + c29, "layer34")
+    c35 = deconv(c34 + c26, "layer35")
+    c36 = deconv(c35 + c23, "layer36")
+    c37 = F.conv_transpose3d(c36 + c20, p[prefix + "layer37.weight"], p[prefix + "layer37.bias"], stride=2, padding=1,
+                             output_padding=1)
+    return [c37.squeeze(1)]
+
+
+def gcnet_backbone(img, p, prefix="backbone.", batch_norm=True):
+    """GCNetBackbone (backbones/GCNet.py:26-38) for one image batch [B, 3, H, W] -> [B, 32, H/2, W/2]."""
+    q = prefix + "backbone."
+    x = conv2d_unit(img, p, q + "0", 2, 1, 5, batch_norm, True)
+    for i in range(1, 9):
+        x = basic_block(x, p, q + "%d" % i, 1, 1, False, batch_norm)
+    return F.conv2d(x, p[q + "9.weight"], p[q + "9.bias"], padding=1)
+
+
+def gcnet_path(ref_fms, tgt_fms, p, max_disp, alpha=1.0):
+    """GC-Net after the backbone: cat volume at 1/2 resolution -> GCAggregator -> FasterSoftArgmin."""
+    raw = cat_fms(ref_fms, tgt_fms, max_disp // 2, 0, 1)
+    costs = gc_aggregator(raw, p, "cost_processor.aggregator.")
+    return [faster_soft_argmin(c, max_disp, 0, 1, alpha, True) for c in costs], costs
+
+
 def edge_aware_refinement(disp, left_image, p, prefix, batch_norm=True):
     """EdgeAwareRefinement.forward (disp_refinement/utils/edge_aware.py:44-68)."""
     h, w = left_image.shape[-2:]

@@ -459,3 +459,53 @@ def test_trilinear_with_fused_regression_is_bit_identical(dev, ins, outs):
     assert ops.RegressionHint.lookup(cost, vals, 1.0, False) is None
     cost.add_(1.0)
     assert ops.RegressionHint.lookup(cost, vals, 1.0, True) is None
+
+
+# ------------------------------------------------------------------------------------------- GC-Net primitives
+@pytest.mark.parametrize("Ci,stride,shape", [(128, 1, (1, 3, 5, 21)), (64, 2, (1, 6, 9, 20)), (192, 1, (1, 2, 4, 64))])
+def test_conv3d_128_output_channels(dev, Ci, stride, shape):
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 181)
+    w = _rand((128, Ci, 3, 3, 3), 182, 1.0 / math.sqrt(Ci * 27))
+    sc, sh = _affine(128, 183)
+    ref = F.relu(F.conv3d(x, w, None, stride=stride, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    got = ops.conv3d_k3(x.to(dev), ops.pack_conv3d_weights(w.to(dev)), 128, sc.to(dev), sh.to(dev), None, stride, True).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("Ci,Co,shape", [(32, 1, (2, 3, 5, 24)), (32, 1, (1, 4, 6, 35)), (16, 7, (1, 2, 3, 8))])
+def test_deconv3d_few_output_channels(dev, Ci, Co, shape):
+    """GC-Net's output layer: ConvTranspose3d(32, 1, 3, 2, 1, 1) with bias on zero-padded weight rows."""
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 185)
+    w = _rand((Ci, Co, 3, 3, 3), 186, 1.0 / math.sqrt(Ci * 27 / 8))
+    bias = _rand((Co,), 187)
+    ref = F.conv_transpose3d(x, w, bias, stride=2, padding=1, output_padding=1)
+    got = ops.deconv3d_k3s2(x.to(dev), ops.pack_deconv3d_weights(w.to(dev)), Co, None, bias.to(dev), None, False).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("kind,shape", [("conv", (1, 4, 6, 48)), ("conv", (1, 3, 5, 21)), ("deconv", (1, 3, 4, 24)),
+                                        ("deconv", (2, 2, 3, 13)), ("conv64", (1, 4, 8, 40))])
+def test_conv3d_relu_before_skip(dev, kind, shape):
+    """relu='pre': y = relu(bn(conv(x))) + skip -- GC-Net adds its skip connections to the activated output."""
+    ops = _ops()
+    B, D, H, W = shape
+    Co = 64 if kind == "conv64" else 32
+    x = _rand((B, 32, D, H, W), 191)
+    sc, sh = _affine(Co, 193)
+    if kind == "deconv":
+        w = _rand((32, Co, 3, 3, 3), 192, 0.1)
+        y = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+    else:
+        w = _rand((Co, 32, 3, 3, 3), 192, 1.0 / math.sqrt(32 * 27))
+        y = F.conv3d(x, w, None, padding=1)
+    y = F.relu(y * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    skip = _rand(y.shape, 194)
+    if kind == "deconv":
+        got = ops.deconv3d_k3s2(x.to(dev), ops.pack_deconv3d_weights(w.to(dev)), Co, sc.to(dev), sh.to(dev), skip.to(dev), "pre")
+    else:
+        got = ops.conv3d_k3(x.to(dev), ops.pack_conv3d_weights(w.to(dev)), Co, sc.to(dev), sh.to(dev), skip.to(dev), 1, "pre")
+    assert (got.cpu() - (y + skip)).abs().max().item() <= 2e-5

@@ -431,3 +431,38 @@ def test_stereonet_end_to_end_vs_reference_golden(dev):
     assert len(res["disps"]) == 2
     for i, d in enumerate(res["disps"]):
         assert maxdiff(d, g["disp%d" % i]) <= DISP_TOL
+
+
+# ------------------------------------------------------------------------------------------ GC-Net
+def test_gcnet_aggregator_vs_reference_golden(dev):
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.aggregators import GCAggregator
+    g = golden("gcnet_aggregator.npz")
+    ga = GCAggregator(max_disp=32, in_planes=64, batch_norm=True).eval()
+    synthetic.init_params_(ga, seed=13, classif_gain=30.0)
+    ga = ga.to(dev)
+    with torch.no_grad():
+        cost = ga(rand((1, 64, 16, 16, 32), 491).to(dev))[0]
+    assert cost.shape == (1, 32, 32, 64)
+    assert maxdiff(cost[:, ::2, ::2, ::2], g["cost"]) <= COST_TOL
+
+
+def test_gcnet_end_to_end_vs_reference_golden(dev):
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    g = golden("gcnet_e2e.npz")
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "GCNet", "scene_flow.py"))
+    cfg.model.max_disp = 64
+    cfg.model.cost_processor.cost_computation.max_disp = 32
+    cfg.model.cost_processor.cost_aggregator.max_disp = 64
+    cfg.model.disp_predictor.max_disp = 64
+    model = build_model(cfg, backbone="hip").eval()
+    synthetic.init_params_(model, seed=14, classif_gain=30.0)
+    model = model.to(dev)
+    li, ri = rand((1, 3, 64, 128), 492).to(dev), rand((1, 3, 64, 128), 493).to(dev)
+    with torch.no_grad():
+        lf, _ = model.backbone(li, ri)
+        res, _ = model(dict(leftImage=li, rightImage=ri))
+    assert maxdiff(lf[:, ::2], g["left_feature"]) <= 2e-5
+    assert len(res["disps"]) == 1 and maxdiff(res["disps"][0], g["disp"]) <= DISP_TOL
