@@ -1,3 +1,4 @@
+from ...registry import instantiate
 from .GCNet import GCNetBackbone
 from .PSMNet import PSMNetBackbone
 from .StereoNet import StereoNetBackbone
@@ -6,11 +7,6 @@ BACKBONES = {"PSMNet": PSMNetBackbone, "StereoNet": StereoNetBackbone, "GCNet": 
 
 
 def build_backbone(cfg):
-    """dmb/modeling/stereo/backbones/builder.py: the PSMNet, StereoNet and GC-Net backbones are on the HIP path."""
-    b = cfg.model.backbone
-    if b.type not in BACKBONES:
-        raise NotImplementedError("backbone '%s' is outside the HIP path (attach a stock PyTorch backbone instead)" % b.type)
-    args = dict(b)
-    args.pop("type")
-    args.update(batch_norm=cfg.model.batch_norm)
-    return BACKBONES[b.type](**args)
+    """``cfg.model.backbone`` plus the model-wide ``batch_norm`` flag (reference backbones/builder.py)."""
+    return instantiate(BACKBONES, cfg.model.backbone, "backbone", off_path=("DeepPruner", "AnyNet"),
+                       batch_norm=cfg.model.batch_norm)

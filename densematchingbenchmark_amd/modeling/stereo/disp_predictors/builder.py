@@ -1,19 +1,12 @@
-"""disp_predictors/builder.py:5-23."""
+"""Registry of the disparity predictors on the HIP path (keys as in the reference's disp_predictors/builder.py:5-9)."""
+from ...registry import instantiate
 from .faster_soft_argmin import FasterSoftArgmin
 from .local_soft_argmin import LocalSoftArgmin
 from .soft_argmin import SoftArgmin
 
-PREDICTORS = {
-    'DEFAULT': SoftArgmin,
-    'FASTER': FasterSoftArgmin,
-    'LOCAL': LocalSoftArgmin,
-}
+PREDICTORS = dict(DEFAULT=SoftArgmin, FASTER=FasterSoftArgmin, LOCAL=LocalSoftArgmin)
 
 
 def build_disp_predictor(cfg):
-    pred_type = cfg.model.disp_predictor.get('type', 'FASTER')
-    assert pred_type in PREDICTORS, 'disparity predictor type not found, expected: {},' \
-                                    'but got {}'.format(PREDICTORS.keys(), pred_type)
-    default_args = cfg.model.disp_predictor.copy()
-    default_args.pop('type')
-    return PREDICTORS[pred_type](**default_args)
+    """``cfg.model.disp_predictor``: ``type`` defaults to 'FASTER' (reference builder.py:13), the rest are kwargs."""
+    return instantiate(PREDICTORS, cfg.model.disp_predictor, "disparity predictor", default_type="FASTER")
