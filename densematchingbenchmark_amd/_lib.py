@@ -52,6 +52,12 @@ SIGNATURES = {
     "dmb_bilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 8 + [_P]),
     "dmb_bilinear_scale_f32": (_c_int, [_P, _P] + [_c_int] * 6 + [_c_float] + [_c_int] * 2 + [_P]),
     "dmb_epe_accum_f64": (_c_int, [_P, _P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
+    "dmb_loss_workspace_doubles": (_c_ll, [_c_ll]),
+    "dmb_stereo_focal_loss_fwd_f32": (_c_int, [_P, _P, _P, _c_float, _HF, _P, _P, _P] + [_c_int] * 4 + [_c_float] * 5 + [_P]),
+    "dmb_stereo_focal_loss_bwd_f32": (_c_int, [_P, _P, _P, _c_float, _HF, _P, _P, _P, _c_float, _P, _P] + [_c_int] * 4
+                                      + [_c_float] * 5 + [_P]),
+    "dmb_map_loss_fwd_f32": (_c_int, [_P, _P, _P, _P, _c_ll, _c_float, _c_float, _c_int, _P]),
+    "dmb_map_loss_bwd_f32": (_c_int, [_P, _P, _P, _P, _c_float, _P, _c_ll, _c_float, _c_float, _c_int, _P]),
 }
 
 

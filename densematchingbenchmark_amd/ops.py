@@ -420,3 +420,64 @@ def bilinear_scale(x, out_hw, mult=1.0, out=None, out_ch_offset=0):
     check(lib.dmb_bilinear_scale_f32(dev_ptr(x), dev_ptr(out), B, C, Hi, Wi, Ho, Wo, float(mult), out.shape[1],
                                      out_ch_offset, stream_ptr(x.device)), "dmb_bilinear_scale_f32")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- training-side losses
+def _loss_workspace(n, device):
+    lib = _lib.load()
+    return torch.empty((lib.dmb_loss_workspace_doubles(int(n)),), dtype=torch.float64, device=device)
+
+
+def stereo_focal_loss_fwd(cost, gt, variance, disp_values, lower, upper, start_disp, end_disp, focal_coefficient):
+    """Returns (loss_out [2] = (loss, divisor), stats [B, H, W, 2]); ``variance``: float or [B, 1, H, W] tensor."""
+    lib = _lib.load()
+    cost, gt = _f32c(cost, "cost"), _f32c(gt, "gt")
+    B, D, H, W = cost.shape
+    vmap = _f32c(variance, "variance") if torch.is_tensor(variance) else None
+    stats = torch.empty((B, H, W, 2), dtype=torch.float32, device=cost.device)
+    out = torch.empty((2,), dtype=torch.float32, device=cost.device)
+    check(lib.dmb_stereo_focal_loss_fwd_f32(dev_ptr(cost), dev_ptr(gt), dev_ptr(vmap, allow_none=True),
+                                            1.0 if vmap is not None else float(variance), host_floats(disp_values),
+                                            dev_ptr(stats), dev_ptr(_loss_workspace(B * H * W, cost.device)), dev_ptr(out),
+                                            B, D, H, W, float(lower), float(upper), float(start_disp), float(end_disp),
+                                            float(focal_coefficient), stream_ptr(cost.device)),
+          "dmb_stereo_focal_loss_fwd_f32")
+    return out, stats
+
+
+def stereo_focal_loss_bwd(cost, gt, variance, disp_values, stats, loss_out, grad_out, lower, upper, start_disp, end_disp,
+                          focal_coefficient, want_grad_variance):
+    lib = _lib.load()
+    cost, gt = _f32c(cost, "cost"), _f32c(gt, "gt")
+    B, D, H, W = cost.shape
+    vmap = _f32c(variance, "variance") if torch.is_tensor(variance) else None
+    gcost = torch.empty_like(cost)
+    gvar = torch.empty((B, 1, H, W), dtype=torch.float32, device=cost.device) if (want_grad_variance and vmap is not None) else None
+    go = _f32c(grad_out.reshape(1), "grad_out")
+    check(lib.dmb_stereo_focal_loss_bwd_f32(dev_ptr(cost), dev_ptr(gt), dev_ptr(vmap, allow_none=True),
+                                            1.0 if vmap is not None else float(variance), host_floats(disp_values),
+                                            dev_ptr(stats), dev_ptr(loss_out), dev_ptr(go), 1.0, dev_ptr(gcost),
+                                            dev_ptr(gvar, allow_none=True), B, D, H, W, float(lower), float(upper),
+                                            float(start_disp), float(end_disp), float(focal_coefficient),
+                                            stream_ptr(cost.device)), "dmb_stereo_focal_loss_bwd_f32")
+    return gcost, gvar
+
+
+def map_loss_fwd(x, gt, lower, upper, mode):
+    lib = _lib.load()
+    x, gt = _f32c(x, "x"), _f32c(gt, "gt")
+    out = torch.empty((2,), dtype=torch.float32, device=x.device)
+    check(lib.dmb_map_loss_fwd_f32(dev_ptr(x), dev_ptr(gt), dev_ptr(_loss_workspace(x.numel(), x.device)), dev_ptr(out),
+                                   x.numel(), float(lower), float(upper), int(mode), stream_ptr(x.device)),
+          "dmb_map_loss_fwd_f32")
+    return out
+
+
+def map_loss_bwd(x, gt, loss_out, grad_out, lower, upper, mode):
+    lib = _lib.load()
+    x, gt = _f32c(x, "x"), _f32c(gt, "gt")
+    gx = torch.empty_like(x)
+    go = _f32c(grad_out.reshape(1), "grad_out")
+    check(lib.dmb_map_loss_bwd_f32(dev_ptr(x), dev_ptr(gt), dev_ptr(loss_out), dev_ptr(go), 1.0, dev_ptr(gx), x.numel(),
+                                   float(lower), float(upper), int(mode), stream_ptr(x.device)), "dmb_map_loss_bwd_f32")
+    return gx

@@ -224,6 +224,42 @@ int dmb_bilinear_ac_f32(const float* x, float* y, int B, int C, int Hi, int Wi, 
 int dmb_bilinear_scale_f32(const float* x, float* y, int B, int C, int Hi, int Wi, int Ho, int Wo, float mult,
                            int out_channels_total, int out_ch_offset, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * "Next" row (first part): the training-side loss terms of AcfNet's cost filtering, forward and
+ * backward, each ONE pass over what it reads.  Backward passes of the convolutions are NOT part of this library.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Doubles of reduction workspace for a loss over n_elements pixels (per-block partial sums, deterministic). */
+long long dmb_loss_workspace_doubles(long long n_elements);
+
+/* StereoFocalLoss.loss_per_level with LaplaceDisp2Prob (losses/stereo_focal_loss.py:63-101, losses/utils/
+ * disp2prob.py:107-173) at the cost volume's own resolution:
+ *   m1 = lower < gt < upper;  g = gt*m1;  m2 = start_disp < g < end_disp;  p = softmax_d(-|s_d - g*m2| / variance);
+ *   P = p*m2 + 1e-40;  loss = -sum(P * (1-P)^(-focal_coefficient) * log_softmax_d(cost) * m1) / max(sum(m1), 1).
+ * cost [B, D, H, W]; gt [B, 1, H, W]; variance: per-pixel map [B, 1, H, W] or NULL (then variance_scalar);
+ * disp_sample_host: D host floats (s_d).  stats: 2*B*H*W floats saved for the backward pass; loss_out: 2 floats
+ * (the loss, the divisor). */
+int dmb_stereo_focal_loss_fwd_f32(const float* cost, const float* gt, const float* variance, float variance_scalar,
+                                  const float* disp_sample_host, float* stats, double* workspace, float* loss_out,
+                                  int B, int D, int H, int W, float lower, float upper, float start_disp,
+                                  float end_disp, float focal_coefficient, void* stream);
+/* d loss / d cost [B, D, H, W] and (if grad_variance != NULL) d loss / d variance [B, 1, H, W], scaled by
+ * grad_out[0] (device scalar, may be NULL = 1) * grad_scale. */
+int dmb_stereo_focal_loss_bwd_f32(const float* cost, const float* gt, const float* variance, float variance_scalar,
+                                  const float* disp_sample_host, const float* stats, const float* loss_out,
+                                  const float* grad_out, float grad_scale, float* grad_cost, float* grad_variance,
+                                  int B, int D, int H, int W, float lower, float upper, float start_disp,
+                                  float end_disp, float focal_coefficient, void* stream);
+
+/* Masked mean over a [B, 1, H, W] map, mask = lower < gt < upper.  mode 0: ConfidenceNllLoss, -logsigmoid(x)
+ * (losses/conf_nll_loss.py:35-56, x = confidence logits); mode 1: DispSmoothL1Loss, smooth_l1(x - gt)
+ * (losses/smooth_l1_loss.py:36-58, x = estimated disparity).  loss_out: 2 floats (loss, divisor). */
+int dmb_map_loss_fwd_f32(const float* x, const float* gt, double* workspace, float* loss_out, long long n, float lower,
+                         float upper, int mode, void* stream);
+int dmb_map_loss_bwd_f32(const float* x, const float* gt, const float* loss_out, const float* grad_out,
+                         float grad_scale, float* grad_x, long long n, float lower, float upper, int mode,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

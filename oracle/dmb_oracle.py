@@ -467,6 +467,37 @@ def stereonet_refinement(disps, left_image, p, num=1, prefix="disp_refinement.",
     return out
 
 
+def stereo_focal_loss(cost, gt, variance, max_disp, start_disp=0, dilation=1, coefficient=0.0):
+    """StereoFocalLoss.loss_per_level at the cost volume's resolution with LaplaceDisp2Prob
+    (losses/stereo_focal_loss.py:63-101, losses/utils/disp2prob.py:107-173); differentiable (torch autograd)."""
+    lower, upper = start_disp, start_disp + max_disp
+    end_disp = start_disp + max_disp - 1
+    m1 = ((gt > lower) & (gt < upper)).to(gt.dtype)
+    g = gt * m1
+    n = (max_disp + dilation - 1) // dilation
+    samples = torch.linspace(start_disp, end_disp, n).view(1, n, 1, 1)
+    m2 = ((g > start_disp) & (g < end_disp)).to(gt.dtype)
+    g = g * m2
+    prob = F.softmax(-torch.abs(samples - g) / variance, dim=1) * m2 + 1e-40
+    logq = F.log_softmax(cost, dim=1)
+    weight = (1.0 - prob).pow(-coefficient)
+    return -((prob * logq) * weight * m1).sum() / m1.sum().clamp(min=1.0)
+
+
+def conf_nll_loss(conf_logits, gt, max_disp, start_disp=0):
+    """ConfidenceNllLoss.loss_per_level (losses/conf_nll_loss.py:35-56)."""
+    mask = ((gt > start_disp) & (gt < max_disp)).to(gt.dtype)
+    return (-1.0 * F.logsigmoid(conf_logits) * mask).sum() / mask.sum().clamp(min=1.0)
+
+
+def disp_smooth_l1_loss(est, gt, max_disp, start_disp=0):
+    """DispSmoothL1Loss.loss_per_level (losses/smooth_l1_loss.py:36-58)."""
+    mask = (gt > start_disp) & (gt < max_disp)
+    if mask.sum() < 1:
+        return (torch.abs(est - gt) * mask.float()).mean()
+    return F.smooth_l1_loss(est[mask], gt[mask], reduction="mean")
+
+
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs

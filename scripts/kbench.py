@@ -82,3 +82,11 @@ big = torch.randn(B, 192, 544, 960, device=dev)
 vals = ops.disp_sample_values(192, 0, 1)
 bw_case("soft_argmin D=192", lambda: ops.soft_argmin(big, vals, 1.0, True), big.numel() * 4 + B * 544 * 960 * 4)
 bw_case("fused trilinear+softargmin", lambda: ops.trilinear_soft_argmin(c, (192, 544, 960), vals, 1.0), c.numel() * 4 + B * 544 * 960 * 4)
+
+# training-side losses (first part) at the full cost-volume size
+gt = torch.rand(B, 1, 544, 960, device=dev) * 190 + 1
+var = torch.rand(B, 1, 544, 960, device=dev) + 0.5
+out, stats = ops.stereo_focal_loss_fwd(big, gt, var, vals, 0, 192, 0, 191, 5.0)
+bw_case("focal loss fwd D=192", lambda: ops.stereo_focal_loss_fwd(big, gt, var, vals, 0, 192, 0, 191, 5.0), big.numel() * 4)
+go = torch.ones(1, device=dev)
+bw_case("focal loss bwd D=192", lambda: ops.stereo_focal_loss_bwd(big, gt, var, vals, stats, out, go, 0, 192, 0, 191, 5.0, True), big.numel() * 8)

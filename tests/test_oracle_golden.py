@@ -295,3 +295,26 @@ def test_gcnet_vs_reference():
     want = set(str(s) for s in golden("state_dict_keys.npz")["gcnet"])
     got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items())
     assert got == want and len(got) == 216
+
+
+def test_losses_vs_reference():
+    """SURVEY 8-f3 (first part): the oracle's restatement of StereoFocalLoss + LaplaceDisp2Prob, ConfidenceNllLoss and
+    DispSmoothL1Loss against the reference's values and autograd gradients."""
+    g = golden("losses.npz")
+    gt = torch.from_numpy(g["gt"])
+    for tag, coef, var in (("a", 0.0, 1.2), ("b", 5.0, torch.from_numpy(g["focal_b_var"]).requires_grad_(True))):
+        cost = (rand((2, 48, 12, 20), 512) * 3.0).requires_grad_(True)
+        loss = 0.7 * O.stereo_focal_loss(cost, gt, var, 48, 0, 1, coef)
+        loss.backward()
+        assert abs(float(loss.detach()) - g["focal_%s_loss" % tag][0]) <= 1e-5 * abs(g["focal_%s_loss" % tag][0])
+        assert maxdiff(cost.grad, g["focal_%s_gcost" % tag]) <= 1e-6 * np.abs(g["focal_%s_gcost" % tag]).max() + 1e-9
+        if tag == "b":
+            assert maxdiff(var.grad, g["focal_b_gvar"]) <= 1e-5 * np.abs(g["focal_b_gvar"]).max()
+    conf = (rand((2, 1, 12, 20), 513) * 2.0).requires_grad_(True)
+    l = O.conf_nll_loss(conf, gt, 48)
+    l.backward()
+    assert abs(float(l.detach()) - g["conf_loss"][0]) <= 1e-6 and maxdiff(conf.grad, g["conf_grad"]) <= 1e-8
+    est = (gt + rand((2, 1, 12, 20), 514) * 2.0).detach().requires_grad_(True)
+    l = O.disp_smooth_l1_loss(est, gt, 48)
+    l.backward()
+    assert abs(float(l.detach()) - g["l1_loss"][0]) <= 1e-6 and maxdiff(est.grad, g["l1_grad"]) <= 1e-8
