@@ -94,7 +94,15 @@ class FusedConv3d(nn.Sequential):
             residual, act = skip, ("pre" if act else False)
         if self.transposed:
             return ops.deconv3d_k3s2(x, wp, self.out_planes, scale, shift, residual, act)
+        if ops.conv3d_mode() == "bf16x6" and ops.conv3d_x6_applicable(x, self.out_planes, self.stride):
+            return ops.conv3d_k3_x6(x, self._prepacked_x6(), self.out_planes, scale, shift, residual, act)   # opt-in only
         return ops.conv3d_k3(x, wp, self.out_planes, scale, shift, residual, self.stride, act)
+
+    def _prepacked_x6(self):
+        key = _versions(self[0].weight)
+        if getattr(self, "_x6_key", None) != key:
+            self._x6_key, self._x6 = key, ops.pack_conv3d_x6_weights(self[0].weight.detach())
+        return self._x6
 
 
 class HeadConv3d(nn.Conv3d):

@@ -169,6 +169,56 @@ def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, rel
     return y
 
 
+# Opt-in arithmetic of the 32-channel stride-1 layers: "exact" (default) = FP32 MFMA, bitwise an fmaf chain;
+# "bf16x6" = FP32 operands split exactly into 3 bf16 pieces, 6 cross products on the bf16 matrix cores, FP32 accumulate
+# (EXPERIMENTAL: at least as accurate against FP64, not bit-identical; see csrc/conv3d_x6.hip).  Never changed implicitly.
+_conv3d_mode = "exact"
+
+
+def set_conv3d_mode(mode):
+    global _conv3d_mode
+    if mode not in ("exact", "bf16x6"):
+        raise ValueError("conv3d mode must be 'exact' or 'bf16x6'")
+    _conv3d_mode = mode
+
+
+def conv3d_mode():
+    return _conv3d_mode
+
+
+def conv3d_x6_applicable(x, Co, stride):
+    """The split kernel covers stride 1, 32 output channels, W a multiple of 48."""
+    return stride == 1 and Co == 32 and x.shape[-1] % 48 == 0 and x.data_ptr() % 16 == 0
+
+
+def pack_conv3d_x6_weights(w):
+    lib = _lib.load()
+    w = _f32c(w, "weight")
+    Co, Ci = w.shape[0], w.shape[1]
+    wp = torch.empty((lib.dmb_conv3d_x6_packed_bytes(Co, Ci) // 4,), dtype=torch.float32, device=w.device)
+    check(lib.dmb_conv3d_x6_pack_weights_f32(dev_ptr(w), dev_ptr(wp), Co, Ci, stream_ptr(w.device)),
+          "dmb_conv3d_x6_pack_weights_f32")
+    return wp
+
+
+def conv3d_k3_x6(x, wpack, Co, scale=None, shift=None, residual=None, relu=False):
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Ci, D, H, W = x.shape
+    y = torch.empty((B, Co, D, H, W), dtype=torch.float32, device=x.device)
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    tag = "conv3d_k3_s1_%dto%d" % (Ci, Co)
+    if _kernel_timer is not None:
+        _kernel_timer.start(tag)
+    check(lib.dmb_conv3d_k3_x6_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
+                                   dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
+                                   B, Ci, Co, D, H, W, _relu_mode(relu), stream_ptr(x.device)), "dmb_conv3d_k3_x6_f32")
+    if _kernel_timer is not None:
+        _kernel_timer.stop(tag)
+    return y
+
+
 def conv3d_k3_c1(x, w, bias=0.0, residual=None):
     lib = _lib.load()
     x, w = _f32c(x, "x"), _f32c(w, "weight")

@@ -62,6 +62,13 @@ ms = timeit(lambda: ops.conv3d_k3(x, wp, 32, sc, sh, rs, 1, True))
 print("conv s1 32->32 full +residual   %8.3f ms" % ms, flush=True)
 del x, rs
 conv_case(32, 32, 1, D, H, W, "conv s1 32->32 full")
+for _ci in (32, 64):   # experimental opt-in split kernel (FP32-equivalent TFLOP/s: algorithmic flops / time)
+    _x = torch.randn(B, _ci, D, H, W, device=dev); _w = torch.randn(32, _ci, 3, 3, 3, device=dev) * 0.03
+    _wp = ops.pack_conv3d_x6_weights(_w); _sc = torch.ones(32, device=dev); _sh = torch.zeros(32, device=dev)
+    _ms = timeit(lambda: ops.conv3d_k3_x6(_x, _wp, 32, _sc, _sh, None, True))
+    _fl = 2.0 * 27 * _ci * 32 * B * D * H * W
+    print("%-28s %8.3f ms  %7.2f TFLOP/s FP32-equivalent" % ("conv s1 %d->32 bf16x6 split" % _ci, _ms, _fl / _ms / 1e9), flush=True)
+    del _x
 conv_case(64, 32, 1, D, H, W, "conv s1 64->32 full")
 conv_case(32, 64, 2, D, H, W, "conv s2 32->64 full->half")
 conv_case(64, 64, 1, D // 2, H // 2, W // 2, "conv s1 64->64 half")
