@@ -147,7 +147,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void focal_bwd_kernel(const float* __re
     const float pd = tg.p(dv.v[d]);
     const float P = pd * tg.m2 + eps;
     const float pw = focal_pow(P, fc);
-    gp[(long long)d * HW] = k * (st.y * __expf(c - st.x) - P * pw);
+    __builtin_nontemporal_store(k * (st.y * __expf(c - st.x) - P * pw), gp + (long long)d * HW);   // streaming gradient
     if (grad_var) {
       const float da = fc == 0.f ? 1.f : pw + fc * P * pw / (1.f - P);
       const float dt = fabsf(dv.v[d] - tg.g) * tg.inv_v2;

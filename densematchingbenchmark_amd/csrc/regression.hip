@@ -15,6 +15,8 @@
 
 namespace dmb {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------------------------------------
 // Online soft-argmin state for one pixel.  exp in FP32 (__expf), sum(e) and sum(e*d) in
 // FP64 so that the result is the correctly rounded quotient; the reference's own FP32 evaluation sits up to
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = lerp2(h0[j], lz.w0, h1[j], lz.w1);
     if (vec) {
-      *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+      // streaming store: 1.6 GB per launch that nothing re-reads soon must not wash the L2
+      __builtin_nontemporal_store(f32x4_t{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4_t*>(yp));
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void deconv_k8s4_kernel(const float* __restric
     }
   }
   float* yp = y + (((size_t)b * Do + zo) * Ho + yo) * Wo + 4 * q;
-  *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __builtin_nontemporal_store(f32x4_t{acc[0], acc[1], acc[2], acc[3]}, reinterpret_cast<f32x4_t*>(yp));   // streaming (1.6 GB)
 }
 
 // ---------------------------------------------------------------------------------------------------------
