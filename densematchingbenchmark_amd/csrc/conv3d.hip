@@ -106,6 +106,9 @@ struct S1Cfg {
   static constexpr int IN_FLOATS = CK * CH_STRIDE;   // input tile of one chunk
   static constexpr int BUF_FLOATS = IN_FLOATS + NK * NTT * 64;  // + the chunk's weight fragments
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;  // double buffered
+  // workgroups per CU: three where LDS admits them (row-group tiles: 43-49 KB; the compiler then keeps the kernel inside
+  // 168 registers): 32 -> 32 at full resolution 142 -> 146 TFLOP/s
+  static constexpr int WPE = (ROWPAIR && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2;
   static_assert(ROWPAIR || P <= 64, "one wave stages one tile row per instruction");
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(!ROWPAIR || (G_ % 4 == 0 && TX % (G_ ? G_ : 1) == 0 && TY % GR == 0), "row-group tiles need TX % G == 0 and TY % (32 / G) == 0");
@@ -160,7 +163,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&a)[VEC], const float (
 }
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void conv3d_s1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ res, float* __restrict__ y, int Ci,
@@ -1112,10 +1115,10 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       // row quads (8 columns x 4 rows) of 40-column tiles: no discarded halo columns and 5/8 of the flattened tile's
       // work per workgroup, which at half resolution (W = 120) also quantises better over the 512 workgroup slots
       // of which two widths exist: 40 and 24.  A launch here is only a few "rounds" of workgroups deep (W = 120, batch
-      // 4: 2448 tiles of 40 columns on 512 slots = 4.8 rounds, measured 128 TF/s; 4080 tiles of 24 = 7.97 rounds, 145
+      // 4: 2448 tiles of 40 columns on 2 x 256 slots = 4.8 rounds, measured 128 TF/s; 4080 tiles of 24 = 7.97 rounds, 145
       // TF/s), so the width is picked per launch by rounds x columns.
       if (aligned && out_small && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0)) {
-        const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 2LL * s1_num_cus();
+        const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 3LL * s1_num_cus();   // 3 workgroups per CU
         const long long c40 = W % 40 == 0 ? cdiv_ll(per * (W / 40), slots) * 40 : (1LL << 60);
         const long long c24 = W % 24 == 0 ? cdiv_ll(per * (W / 24), slots) * 24 : (1LL << 60);
         if (c24 < c40) return DMB_S1(64, 24, 2, 8, 40);
