@@ -11,7 +11,7 @@ int g_dev_opts[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // development knobs (kernel vari
 }
 // Development knob, NOT part of the ABI (absent from include/dmb_hip.h): key 0 = conv scheduling variant,
 // key 1 = 1 forces the VALU form of the group-wise correlation, key 2 = 1 forces flattened conv3d tiles,
-// key 3 = 1 forces the scalar (dword) staging / store path of conv2d.
+// key 3 = 1 forces the scalar (dword) staging / store paths (conv2d, stride-2 and transposed conv3d).
 extern "C" void dmb_dev_set_option(int key, int value) {
   if (key >= 0 && key < 8) dmb::g_dev_opts[key] = value;
 }

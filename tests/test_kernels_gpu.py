@@ -533,3 +533,28 @@ def test_conv3d_bf16x6_is_as_accurate_as_fp32(dev, Ci, shape):
     assert e_split.mean().item() <= 1.25 * e_exact.mean().item() + 1e-9
     plain = ops.conv3d_k3_x6(xd, ops.pack_conv3d_x6_weights(w.to(dev)), 32).cpu().double()
     assert (plain - F.conv3d(x.double(), w.double(), None, padding=1)).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("kind,shape", [("s2", (1, 6, 9, 48)), ("s2", (2, 5, 8, 120)), ("deconv", (1, 3, 5, 60)), ("deconv", (2, 2, 3, 24))])
+def test_conv3d_vector_and_scalar_staging_agree(dev, kind, shape):
+    """Rows that are 16-byte aligned are staged with 16-byte LDS-DMA words; the result must be bit-identical to the dword
+    staging path (same MFMA sequence, same epilogue), which stays in use for other widths."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, D, H, W = shape
+    x = _rand((B, 32, D, H, W), 211).to(dev)
+    sc, sh = _affine(64, 213)
+    lib = _lib.load()
+    outs = []
+    for force_scalar in (0, 1):
+        lib.dmb_dev_set_option(3, force_scalar)
+        try:
+            if kind == "s2":
+                w = _rand((64, 32, 3, 3, 3), 212, 0.03).to(dev)
+                outs.append(ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 64, sc.to(dev), sh.to(dev), None, 2, True))
+            else:
+                w = _rand((32, 64, 3, 3, 3), 212, 0.1).to(dev)
+                outs.append(ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(w), 64, sc.to(dev), sh.to(dev), None, True))
+        finally:
+            lib.dmb_dev_set_option(3, 0)
+    assert torch.equal(outs[0], outs[1])
