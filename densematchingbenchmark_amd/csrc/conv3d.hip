@@ -1048,8 +1048,11 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
   if (2 * ntiles <= slots) {
     g0 = g1 = ntiles;
   } else {
-    g0 = slots / 3 > 0 ? slots / 3 : 1;
-    g1 = slots - g0;
+    // twice as many workgroups as resident slots: each walks half as many items, and the dispatcher's dynamic placement
+    // evens out what a static walk cannot (measured 64 -> 32 at half resolution: 0.98 -> 0.82 ms)
+    const long long total = 2 * slots;
+    g0 = total / 3 > 0 ? total / 3 : 1;
+    g1 = total - g0;
     if (g0 > ntiles) g0 = ntiles;
     if (g1 > ntiles) g1 = ntiles;
   }
