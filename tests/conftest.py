@@ -19,3 +19,12 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _library_present():
+    """The C-ABI library is built in-tree and git-ignored: a fresh checkout has none.  Build it once if it is MISSING
+    (hipcc cross-compiles without a GPU); an existing library is used as it is."""
+    from densematchingbenchmark_amd import build
+    if not os.path.exists(build.LIB_PATH):
+        build.build_library(verbose=False)
