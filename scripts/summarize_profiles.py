@@ -46,7 +46,7 @@ if os.path.exists(tr):
     with open(os.path.join(DST, tag + "_kernel_stats.csv"), "a") as f:
         f.write("# split of the shared stride-1 kernel by launch duration (short = Ci 32, long = Ci 64)\n")
         for k, v in d.items():
-            if not (k.startswith("conv3d_s1_kernel") and "true" in k):
+            if not k.startswith("conv3d_s1_kernel<S1Cfg<0, 32, 4, 48"):
                 continue
             lo = min(v)
             for name, sel in (("Ci=32", [t for t in v if t < 1.5 * lo]), ("Ci=64", [t for t in v if t >= 1.5 * lo])):
@@ -83,7 +83,7 @@ with open(os.path.join(DST, tag + "_pmc.csv"), "w") as f:
                                                    ",".join("%.6g" % m[c] for c in counters), hbm, util,
                                                    m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / 1e9,
                                                    sum(dur[k]) / len(dur[k]) if dur[k] else float("nan")))
-dom = [k for k in pmc if k.startswith("conv3d_s1_kernel") and "true" in k]
+dom = [k for k in pmc if k.startswith("conv3d_s1_kernel<S1Cfg<0, 32, 4, 48")]
 dom.sort(key=lambda k: -sum(pmc[k].get("GRBM_GUI_ACTIVE", [0])))
 if dom:
     v = pmc[dom[0]]
