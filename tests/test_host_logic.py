@@ -161,3 +161,37 @@ def test_result_pkl_layout_matches_reference_reader(tmp_path):
     vol = r['Result']['costs'][0][0].cpu().numpy()
     assert est.shape == (6, 10) and vol.shape == (6, 6, 10) and r['OriginalData']['leftDisp'].shape == (6, 10)
     assert np.array_equal(est, res['disps'][0][0, 0, 2:, :10].numpy())   # top/right padding removed (eval.py:24-29)
+
+
+def test_registry_instantiate():
+    from densematchingbenchmark_amd.modeling.registry import UnknownType, instantiate
+
+    class A:
+        def __init__(self, x, batch_norm=False):
+            self.x, self.batch_norm = x, batch_norm
+
+    table = dict(a=A)
+    obj = instantiate(table, dict(type="a", x=3), "thing", batch_norm=True)
+    assert isinstance(obj, A) and obj.x == 3 and obj.batch_norm is True
+    assert instantiate(table, dict(x=1), "thing", default_type="a").x == 1
+    with pytest.raises(NotImplementedError):
+        instantiate(table, dict(type="AnyNet"), "thing", off_path=("AnyNet",))
+    with pytest.raises(UnknownType):
+        instantiate(table, dict(type="zzz"), "thing")
+    node = dict(type="a", x=5)
+    instantiate(table, node, "thing")
+    assert node == dict(type="a", x=5)          # the config node is not consumed
+
+
+def test_opt_in_conv3d_mode_is_explicit():
+    """The split-bf16 convolution is never selected implicitly: the default mode is 'exact' and only the two documented
+    values are accepted."""
+    assert ops.conv3d_mode() == "exact"
+    with pytest.raises(ValueError):
+        ops.set_conv3d_mode("fast")
+    ops.set_conv3d_mode("bf16x6")
+    try:
+        assert ops.conv3d_mode() == "bf16x6"
+    finally:
+        ops.set_conv3d_mode("exact")
+    assert ops.conv3d_mode() == "exact"
