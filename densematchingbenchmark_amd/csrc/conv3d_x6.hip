@@ -1,4 +1,4 @@
-// EXPERIMENTAL, OPT-IN: 3x3x3 stride-1 convolution (32 output channels) with FP32 operands split exactly into three
+// EXPERIMENTAL, OPT-IN: 3x3x3 stride-1 convolution (32 or 64 output channels) with FP32 operands split exactly into three
 // bf16 pieces and the six largest cross products issued on v_mfma_f32_32x32x16_bf16 (FP32 accumulate).
 //
 //   x = x0 + x1 + x2,  w = w0 + w1 + w2  (each piece a bf16, the sum exact: 3 x 8 = 24 significand bits)
@@ -28,22 +28,39 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-namespace x6 {
-constexpr int TX = 48, TY = 4, TZ = 4, CK = 4, NSTEP = 7;
-constexpr int P = 56, ROWS = TY + 2, ZS = TZ + 2, PLANE = ROWS * P, NVOX = ZS * PLANE;   // 2016 staged voxels
-constexpr int XOFF = 3;                                  // the staged row starts at the aligned column x0 - 4
-constexpr int PIECE_BYTES = NVOX * 8;                    // [voxel][4 channels] bf16
-constexpr int ACT_BYTES = 3 * PIECE_BYTES;               // 48384
-constexpr int WSTEP_BYTES = 3 * 64 * 16;                 // one k-step: 3 pieces x 64 lanes x 8 bf16
-constexpr int WGT_BYTES = NSTEP * WSTEP_BYTES;           // 21504
-constexpr int LDS_BYTES = ACT_BYTES + WGT_BYTES;         // 69888: two workgroups per CU
-constexpr int UPR = P / 4, NUNIT = ZS * ROWS * UPR;      // 504 (z, y, 4 columns) units per chunk
-constexpr int XS = TX / 16, MT = (TY / 2) * XS;          // 6 row-pair tiles per wave
-constexpr int TR_PITCH = 36;
-__host__ __device__ constexpr int tapoff(int t) {        // voxel offset of tap t (t = 27 is the zero-weight padding tap)
-  return t >= 27 ? 0 : (t / 9) * PLANE + ((t / 3) % 3) * P + (t % 3);
-}
-}  // namespace x6
+// NT_ 32-channel row tiles per wave (output channels = 32 NT_); G_ = 16: B tiles are row pairs (rows r, r + 2) of 16 columns,
+// G_ = 8: row quads (4 consecutive rows) of 8 columns; P_ = LDS row pitch in voxels, chosen so that the rows of one tile
+// start 32 (pairs) or 16 (quads) banks apart: a ds_read_b64 lane group then covers all 64 banks exactly once.
+template <int NT_, int G_, int TX_, int P_>
+struct X6Cfg {
+  static constexpr int NT = NT_, G = G_, TX = TX_, P = P_;
+  static constexpr int TY = 4, TZ = 4, CK = 4, NSTEP = 7;
+  static constexpr int ROWS = TY + 2, ZS = TZ + 2, PLANE = ROWS * P, NVOX = ZS * PLANE;
+  static constexpr int XOFF = 3;                           // the staged row starts at the aligned column x0 - 4
+  static constexpr int PIECE_BYTES = NVOX * 8;             // [voxel][4 channels] bf16
+  static constexpr int ACT_BYTES = 3 * PIECE_BYTES;
+  static constexpr int WSTEP_BYTES = 3 * NT * 64 * 16;     // one k-step: 3 pieces x NT row tiles x 64 lanes x 8 bf16
+  static constexpr int WGT_BYTES = NSTEP * WSTEP_BYTES;
+  static constexpr int LDS_BYTES = ACT_BYTES + WGT_BYTES;
+  static constexpr int ULOAD = (4 + TX + 1 + 3) / 4;       // 16-byte units loaded per staged row (columns x0 - 4 .. x0 + TX)
+  static constexpr int NUNIT = ZS * ROWS * ULOAD;          // (z, y, 4 columns) units per chunk
+  static constexpr int XS = TX / G, GR = 32 / G;           // tiles per row group, rows per group
+  static constexpr int MT = (G == 16 ? TY / 2 : TY / 4) * XS;
+  static constexpr int TR_PITCH = 36;
+  // lane j of a B tile -> (row, column) inside the tile; tile mt -> (row, column) origin
+  __device__ static constexpr int lane_row(int j) { return G == 16 ? (j >> 4) * 2 : (j >> 3); }
+  __device__ static constexpr int lane_col(int j) { return j & (G - 1); }
+  __device__ static constexpr int tile_row(int mt) { return G == 16 ? mt / XS : 4 * (mt / XS); }
+  __device__ static constexpr int tile_col(int mt) { return (mt % XS) * G; }
+  __host__ __device__ static constexpr int tapoff(int t) {   // voxel offset of tap t (t = 27: the zero-weight padding tap)
+    return t >= 27 ? 0 : (t / 9) * PLANE + ((t / 3) % 3) * P + (t % 3);
+  }
+  static_assert(ULOAD * 4 <= P && NUNIT <= 512 && LDS_BYTES <= 80 * 1024 && ACT_BYTES >= 4 * 32 * TR_PITCH * 4, "tile");
+  static_assert(G == 16 ? (2 * P * 2) % 64 == 32 : (P * 2) % 64 == 16, "rows of a tile must interleave the 64 LDS banks");
+};
+typedef X6Cfg<1, 16, 48, 56> X6C32;   // 32 output channels, W % 48 == 0 (full-resolution layers)
+typedef X6Cfg<2, 8, 24, 40> X6C64;    // 64 output channels, W % 24 == 0 (half-resolution layers)
+constexpr int X6_CK = 4, X6_NSTEP = 7;
 
 // x = hi + mid + lo exactly, each a bf16 (round-to-nearest pieces, exact residuals); two values at a time so that
 // every conversion is one v_cvt_pk_bf16_f32 and the results are already packed pairs.
@@ -56,33 +73,38 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
-// wp[(((chunk * 7 + step) * 3 + piece) * 64 + lane) * 8 + e] = piece(W(co = lane & 31, ci = 4 chunk + (e & 3),
-// tap = 4 step + 2 (lane >> 5) + (e >> 2))), zero for tap >= 27 or ci >= Ci.
-__global__ void pack_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Co, int Ci, int nchunk) {
-  const long long total = (long long)nchunk * x6::NSTEP * 64 * 8;
+// wp[((((chunk * 7 + step) * 3 + piece) * NT + nt) * 64 + lane) * 8 + e] = piece(W(co = 32 nt + (lane & 31),
+// ci = 4 chunk + (e & 3), tap = 4 step + 2 (lane >> 5) + (e >> 2))), zero for tap >= 27 or ci >= Ci.
+__global__ void pack_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Co, int Ci, int nchunk, int NT) {
+  const long long total = (long long)nchunk * X6_NSTEP * NT * 64 * 8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    const long long cs = i >> 9;
-    const int step = (int)(cs % x6::NSTEP), chunk = (int)(cs / x6::NSTEP);
-    const int co = lane & 31, ci = 4 * chunk + (e & 3), tap = 4 * step + 2 * (lane >> 5) + (e >> 2);
+    long long r = i >> 9;
+    const int nt = (int)(r % NT);
+    r /= NT;
+    const int step = (int)(r % X6_NSTEP), chunk = (int)(r / X6_NSTEP);
+    const int co = 32 * nt + (lane & 31), ci = 4 * chunk + (e & 3), tap = 4 * step + 2 * (lane >> 5) + (e >> 2);
     const float v = (co < Co && ci < Ci && tap < 27) ? w[((size_t)co * Ci + ci) * 27 + tap] : 0.f;
     unsigned h, m, l;
     split_pair(v, 0.f, h, m, l);
-    const size_t base = ((size_t)(chunk * x6::NSTEP + step) * 3 * 64 + lane) * 8 + e;
+    const size_t base = ((((size_t)(chunk * X6_NSTEP + step) * 3) * NT + nt) * 64 + lane) * 8 + e;
+    const size_t pstride = (size_t)NT * 64 * 8;
     wp[base] = (unsigned short)(h & 0xffffu);
-    wp[base + 64 * 8] = (unsigned short)(m & 0xffffu);
-    wp[base + 2 * 64 * 8] = (unsigned short)(l & 0xffffu);
+    wp[base + pstride] = (unsigned short)(m & 0xffffu);
+    wp[base + 2 * pstride] = (unsigned short)(l & 0xffffu);
   }
 }
 
+template <class C>
 __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wp,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ res, float* __restrict__ y, int Ci,
                                                               int D, int H, int W, int ntx, int nty, int ntz, int relu) {
-  using namespace x6;
+  constexpr int CK = C::CK, P = C::P, ROWS = C::ROWS, PLANE = C::PLANE, MT = C::MT, NT = C::NT, COUT = 32 * C::NT;
+  constexpr int PIECE_BYTES = C::PIECE_BYTES, WGT_BYTES = C::WGT_BYTES, TR_PITCH = C::TR_PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
   unsigned char* act = lds8;
-  unsigned char* wgt = lds8 + ACT_BYTES;
+  unsigned char* wgt = lds8 + C::ACT_BYTES;
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
   t /= ntx;
@@ -90,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
   t /= nty;
   const int tz = t % ntz;
   const int b = t / ntz;
-  const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
@@ -103,9 +125,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int u = (int)threadIdx.x + q * 256;
-    const int zz = u / (ROWS * UPR), rr = u - zz * (ROWS * UPR), yy = rr / UPR, sg = rr - yy * UPR;
+    const int zz = u / (ROWS * C::ULOAD), rr = u - zz * (ROWS * C::ULOAD), yy = rr / C::ULOAD, sg = rr - yy * C::ULOAD;
     const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 4 + sg * 4;
-    const bool ok = u < NUNIT && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const bool ok = u < C::NUNIT && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
     uoff[q] = ok ? (int)(((unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u) : (int)DMA_OOB;
     uvox[q] = (zz * ROWS + yy) * P + sg * 4;
   }
@@ -114,16 +136,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
     // the resource covers only this chunk's channels: a channel >= Ci is out of range and reads zeros
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb + (size_t)c0 * DHW, (unsigned)min(CK, Ci - c0) * DHW * 4u);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+      if (q == 1 && C::NUNIT <= 256) break;
 #pragma unroll
       for (int c = 0; c < CK; ++c)
         pre[q][c] = __builtin_amdgcn_raw_buffer_load_b128(xrs, uoff[q] == (int)DMA_OOB ? (int)DMA_OOB : uoff[q] + (int)((unsigned)c * DHW * 4u), 0, 0);
+    }
   };
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)nchunk * WGT_BYTES);
   auto split_store = [&](int chunk) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      if (q == 1 && (int)threadIdx.x + 256 >= NUNIT) break;
+      if (q == 1 && (C::NUNIT <= 256 || (int)threadIdx.x + 256 >= C::NUNIT)) break;
       unsigned vals[CK][4];
 #pragma unroll
       for (int c = 0; c < CK; ++c) {
@@ -143,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
         *reinterpret_cast<u32x2*>(dst + 2 * PIECE_BYTES) = u32x2{l01, l23};
       }
     }
-    // this chunk's weight fragments: 21 KB = 1344 16-byte words, LDS-DMA
+    // this chunk's weight fragments (21 KB per 32 output channels), LDS-DMA in 16-byte words
 #pragma unroll
     for (int i = 0; i < (WGT_BYTES / 16 + 255) / 256; ++i) {
       const int q4 = i * 256 + wave * 64 + lane;
@@ -152,42 +176,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
     }
   };
 
-  f32x16 acc[MT];
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-
-  // per-channel affine of this lane's output channels (4 of them after the epilogue's transposition), loaded once
-  float sc4[4], sh4[4];
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int co = k * 8 + (lane >> 3);
-    sc4[k] = scale ? scale[co] : 1.f;
-    sh4[k] = shift ? shift[co] : 0.f;
-  }
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  // a B tile pairs rows r and r + 2 (not r + 1): 2 * P voxels = 224 dwords = 32 (mod 64 banks), so the two 16-lane halves
-  // of a ds_read_b64 group cover all 64 banks exactly once (rows r, r + 1 would collide on 16 banks: 2 cycles per group)
-  const int lane_vox = wave * PLANE + (j >> 4) * 2 * P + (j & 15) + XOFF;
+  const int lane_vox = wave * PLANE + C::lane_row(j) * P + C::lane_col(j) + C::XOFF;
   fetch(0);
   for (int ci = 0; ci < nchunk; ++ci) {
-    split_store(ci);                 // waits for the prefetched registers (vmcnt) as it consumes them
+    split_store(ci);                      // waits for the prefetched registers (vmcnt) as it consumes them
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the weight copy has landed
     __syncthreads();
     if (ci + 1 < nchunk) fetch((ci + 1) * CK);   // in flight under the MFMAs below
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
+    for (int s = 0; s < C::NSTEP; ++s) {
       // lanes 0-31 multiply taps 4s, 4s+1, lanes 32-63 taps 4s+2, 4s+3
-      const int offA = (lane_vox + (h ? tapoff(4 * s + 2) : tapoff(4 * s))) * 8;
-      const int offB = (lane_vox + (h ? tapoff(4 * s + 3) : tapoff(4 * s + 1))) * 8;
-      bf16x8 a[3];
+      const int offA = (lane_vox + (h ? C::tapoff(4 * s + 2) : C::tapoff(4 * s))) * 8;
+      const int offB = (lane_vox + (h ? C::tapoff(4 * s + 3) : C::tapoff(4 * s + 1))) * 8;
+      bf16x8 a[NT][3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(wgt + ((s * 3 + p) * 64 + lane) * 16);
-      // one tile ahead: the next tile's fragments travel from LDS while this tile's six MFMAs run
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          a[nt][p] = *reinterpret_cast<const bf16x8*>(wgt + (((s * 3 + p) * NT + nt) * 64 + lane) * 16);
+      // one tile ahead: the next tile's fragments travel from LDS while this tile's MFMAs run
       bf16x8 bq[2][3];
       auto load_b = [&](int mt, bf16x8 (&d)[3]) {
-        const int to = ((mt / XS) * P + (mt % XS) * 16) * 8;
+        const int to = (C::tile_row(mt) * P + C::tile_col(mt)) * 8;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const u32x2 lo = *reinterpret_cast<const u32x2*>(act + p * PIECE_BYTES + offA + to);
@@ -202,33 +220,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
         if (mt + 1 < MT) load_b(mt + 1, bq[(mt + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         const auto& bb = bq[mt & 1];
-        // smallest cross terms first
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc[mt], 0, 0, 0);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][PA[t6]], bb[PB[t6]], acc[mt][nt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();   // everyone is done reading this chunk: the next split may overwrite it
   }
 
-  // ---- epilogue: as the exact row-pair kernel (transposition through LDS, 16-byte stores, residual one tile ahead)
+  // ---- epilogue: as the exact row-group kernel (transposition through LDS, 16-byte stores, residual one tile ahead)
   float* my = reinterpret_cast<float*>(act) + wave * (32 * TR_PITCH);
-  float* yb = y + (size_t)b * 32 * DHW;
-  const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, 32u * DHW * 4u);
-  const __amdgpu_buffer_rsrc_t rrs = make_rsrc(res ? res + (size_t)b * 32 * DHW : yb, 32u * DHW * 4u);
+  float* yb = y + (size_t)b * COUT * DHW;
+  const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, (unsigned)COUT * DHW * 4u);
+  const __amdgpu_buffer_rsrc_t rrs = make_rsrc(res ? res + (size_t)b * COUT * DHW : yb, (unsigned)COUT * DHW * 4u);
   const int gz = z0 + wave;
   const int px = (lane & 7) * 4;
   const float lo1 = relu == 1 ? 0.f : -__builtin_inff(), lo2 = relu == 2 ? 0.f : -__builtin_inff();
-  auto offsets = [&](int mt, unsigned (&off)[4]) {
-    const int gy = y0 + (mt / XS) + 2 * (px >> 4), gxo = x0 + (mt % XS) * 16 + (px & 15);
+  // tile u of the epilogue = (mt, nt); a lane owns 4 consecutive columns of channel 32 nt + 8 k + lane / 8
+  auto offsets = [&](int u, unsigned (&off)[4]) {
+    const int mt = u / NT, nt = u - mt * NT;
+    const int gy = y0 + C::tile_row(mt) + C::lane_row(px), gxo = x0 + C::tile_col(mt) + C::lane_col(px);
     const bool inb = gz < D && gy < H && gxo < W;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      off[k] = inb ? ((unsigned)(k * 8 + (lane >> 3)) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxo) * 4u : DMA_OOB;
+      off[k] = inb ? ((unsigned)(nt * 32 + k * 8 + (lane >> 3)) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxo) * 4u : DMA_OOB;
   };
   auto run = [&](auto has_res) {
     constexpr bool HAS_RES = decltype(has_res)::value;
@@ -240,36 +259,39 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
       for (int k = 0; k < 4; ++k) rv[0][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[0][k], 0, 0);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (mt + 1 < MT) {
-        offsets(mt + 1, off[(mt + 1) & 1]);
+    for (int u = 0; u < MT * NT; ++u) {
+      const int mt = u / NT, nt = u - mt * NT;
+      if (u + 1 < MT * NT) {
+        offsets(u + 1, off[(u + 1) & 1]);
         if constexpr (HAS_RES) {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            rv[(mt + 1) & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[(mt + 1) & 1][k], 0, 0);
+            rv[(u + 1) & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[(u + 1) & 1][k], 0, 0);
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) my[cd_row(r, h) * TR_PITCH + j] = acc[mt][r];
+      for (int r = 0; r < 16; ++r) my[cd_row(r, h) * TR_PITCH + j] = acc[mt][nt][r];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        const int co = nt * 32 + k * 8 + (lane >> 3);
+        const float sck = scale ? scale[co] : 1.f, shk = shift ? shift[co] : 0.f;
         float4 v = *reinterpret_cast<const float4*>(my + (k * 8 + (lane >> 3)) * TR_PITCH + px);
-        v.x = fmaxf(fmaf(v.x, sc4[k], sh4[k]), lo2);
-        v.y = fmaxf(fmaf(v.y, sc4[k], sh4[k]), lo2);
-        v.z = fmaxf(fmaf(v.z, sc4[k], sh4[k]), lo2);
-        v.w = fmaxf(fmaf(v.w, sc4[k], sh4[k]), lo2);
+        v.x = fmaxf(fmaf(v.x, sck, shk), lo2);
+        v.y = fmaxf(fmaf(v.y, sck, shk), lo2);
+        v.z = fmaxf(fmaf(v.z, sck, shk), lo2);
+        v.w = fmaxf(fmaf(v.w, sck, shk), lo2);
         if constexpr (HAS_RES) {
-          v.x += __uint_as_float(rv[mt & 1][k].x);
-          v.y += __uint_as_float(rv[mt & 1][k].y);
-          v.z += __uint_as_float(rv[mt & 1][k].z);
-          v.w += __uint_as_float(rv[mt & 1][k].w);
+          v.x += __uint_as_float(rv[u & 1][k].x);
+          v.y += __uint_as_float(rv[u & 1][k].y);
+          v.z += __uint_as_float(rv[u & 1][k].z);
+          v.w += __uint_as_float(rv[u & 1][k].w);
         }
         u32x4 o;
         o.x = __float_as_uint(fmaxf(v.x, lo1));
         o.y = __float_as_uint(fmaxf(v.y, lo1));
         o.z = __float_as_uint(fmaxf(v.z, lo1));
         o.w = __float_as_uint(fmaxf(v.w, lo1));
-        __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)off[mt & 1][k], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)off[u & 1][k], 0, 0);
       }
     }
   };
@@ -279,19 +301,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
     run(std::false_type{});
 }
 
+template <class C>
+static int launch_x6(const float* x, const void* wpack, const float* scale, const float* shift, const float* residual,
+                     float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
+  const int ntx = W / C::TX, nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
+  const long long nblk = (long long)B * ntx * nty * ntz;
+  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_x6: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_x6_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3d_s1_x6_kernel<C>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, x,
+                     (const unsigned short*)wpack, scale, shift, residual, y, Ci, D, H, W, ntx, nty, ntz, relu);
+  return launch_status("conv3d_x6 launch failed");
+}
+
 }  // namespace dmb
 
 using namespace dmb;
 
 extern "C" long long dmb_conv3d_x6_packed_bytes(int Co, int Ci) {
-  if (Co <= 0 || Co > 32 || Ci <= 0) return 0;
-  return (long long)cdiv(Ci, x6::CK) * x6::WGT_BYTES;
+  if ((Co != 32 && Co != 64) || Ci <= 0) return 0;
+  return (long long)cdiv(Ci, X6_CK) * X6_NSTEP * 3 * (Co / 32) * 64 * 16;
 }
 
 extern "C" int dmb_conv3d_x6_pack_weights_f32(const float* w, void* wpack, int Co, int Ci, void* stream) {
-  if (!w || !wpack || Co <= 0 || Co > 32 || Ci <= 0) return fail(DMB_EINVAL, "conv3d_x6_pack: 1..32 output channels");
+  if (!w || !wpack || (Co != 32 && Co != 64) || Ci <= 0) return fail(DMB_EINVAL, "conv3d_x6_pack: 32 or 64 output channels");
   hipLaunchKernelGGL(pack_x6_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wpack, Co, Ci,
-                     cdiv(Ci, x6::CK));
+                     cdiv(Ci, X6_CK), Co / 32);
   return launch_status("conv3d_x6_pack launch failed");
 }
 
@@ -299,19 +338,12 @@ extern "C" int dmb_conv3d_k3_x6_f32(const float* x, const void* wpack, const flo
                                     const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                     int relu, void* stream) {
   if (!x || !wpack || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d_x6: bad argument");
-  if (Co != 32 || W % x6::TX != 0 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) != 0 ||
-      (long long)32 * D * H * W * 4 >= 0x7fffffffLL)
-    return fail(DMB_EUNSUPPORTED, "conv3d_x6: 32 output channels, W a multiple of 48, 16-byte aligned tensors, output item < 2 GiB");
-  const int ntx = W / x6::TX, nty = cdiv(H, x6::TY), ntz = cdiv(D, x6::TZ);
-  const long long nblk = (long long)B * ntx * nty * ntz;
-  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_x6: grid too large");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              x6::LDS_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(conv3d_s1_x6_kernel, dim3((unsigned)nblk), dim3(256), x6::LDS_BYTES, (hipStream_t)stream, x,
-                     (const unsigned short*)wpack, scale, shift, residual, y, Ci, D, H, W, ntx, nty, ntz, relu);
-  return launch_status("conv3d_x6 launch failed");
+  const bool ok32 = Co == 32 && W % X6C32::TX == 0, ok64 = Co == 64 && W % X6C64::TX == 0;
+  if ((!ok32 && !ok64) || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) != 0 ||
+      (long long)Co * D * H * W * 4 >= 0x7fffffffLL)
+    return fail(DMB_EUNSUPPORTED, "conv3d_x6: 32 output channels with W % 48 == 0 or 64 with W % 24 == 0, 16-byte aligned "
+                                  "tensors, output item < 2 GiB");
+  hipStream_t st = (hipStream_t)stream;
+  if (ok32) return launch_x6<X6C32>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+  return launch_x6<X6C64>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
 }

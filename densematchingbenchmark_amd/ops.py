@@ -187,8 +187,9 @@ def conv3d_mode():
 
 
 def conv3d_x6_applicable(x, Co, stride):
-    """The split kernel covers stride 1, 32 output channels, W a multiple of 48."""
-    return stride == 1 and Co == 32 and x.shape[-1] % 48 == 0 and x.data_ptr() % 16 == 0
+    """The split kernel covers stride 1 with 32 output channels (W % 48 == 0) or 64 (W % 24 == 0)."""
+    W = x.shape[-1]
+    return stride == 1 and ((Co == 32 and W % 48 == 0) or (Co == 64 and W % 24 == 0)) and x.data_ptr() % 16 == 0
 
 
 def pack_conv3d_x6_weights(w):

@@ -261,11 +261,11 @@ int dmb_map_loss_bwd_f32(const float* x, const float* gt, const float* loss_out,
                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * EXPERIMENTAL, OPT-IN (never selected by the default path): the stride-1 32-output-channel
- * convolution with every FP32 operand split exactly into three bf16 pieces and the six largest cross products issued on
+ * EXPERIMENTAL, OPT-IN (never selected by the default path): the stride-1
+ * convolution (32 or 64 output channels) with every FP32 operand split exactly into three bf16 pieces and the six largest cross products issued on
  * the bf16 matrix cores with FP32 accumulation.  At least as close to the real-number result as the FP32 fma chain of
  * dmb_conv3d_k3_f32 (tests compare both with FP64), but not bit-identical to it.  Same arguments as dmb_conv3d_k3_f32
- * with stride 1; Co must be 32, W a multiple of 48, tensors 16-byte aligned.
+ * with stride 1; Co = 32 with W a multiple of 48, or Co = 64 with W a multiple of 24; tensors 16-byte aligned.
  * ---------------------------------------------------------------------------------------- */
 long long dmb_conv3d_x6_packed_bytes(int Co, int Ci);
 int dmb_conv3d_x6_pack_weights_f32(const float* w, void* wpack, int Co, int Ci, void* stream);

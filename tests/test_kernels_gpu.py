@@ -512,26 +512,28 @@ def test_conv3d_relu_before_skip(dev, kind, shape):
 
 
 # ------------------------------------------------------- experimental, opt-in: FP32 convolution on 3-way bf16 splits
-@pytest.mark.parametrize("Ci,shape", [(32, (1, 6, 10, 96)), (64, (2, 5, 7, 48)), (5, (1, 4, 6, 48)), (32, (1, 9, 13, 240))])
-def test_conv3d_bf16x6_is_as_accurate_as_fp32(dev, Ci, shape):
+@pytest.mark.parametrize("Ci,Co,shape", [(32, 32, (1, 6, 10, 96)), (64, 32, (2, 5, 7, 48)), (5, 32, (1, 4, 6, 48)),
+                                         (32, 32, (1, 9, 13, 240)), (64, 64, (1, 6, 10, 72)), (32, 64, (2, 5, 7, 24)),
+                                         (64, 64, (1, 9, 13, 120))])
+def test_conv3d_bf16x6_is_as_accurate_as_fp32(dev, Ci, Co, shape):
     """The split kernel against an FP64 convolution: its error must not exceed the exact FP32 kernel's by more than
     noise, and both stay inside the FP32 tolerance of the other conv tests."""
     ops = _ops()
     B, D, H, W = shape
     x = _rand((B, Ci, D, H, W), 201)
-    w = _rand((32, Ci, 3, 3, 3), 202, 1.0 / math.sqrt(Ci * 27))
-    sc, sh = _affine(32, 203)
-    res = _rand((B, 32, D, H, W), 204)
+    w = _rand((Co, Ci, 3, 3, 3), 202, 1.0 / math.sqrt(Ci * 27))
+    sc, sh = _affine(Co, 203)
+    res = _rand((B, Co, D, H, W), 204)
     ref = F.relu(F.conv3d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1, 1)
                  + sh.double().view(1, -1, 1, 1, 1) + res.double())
     xd, scd, shd, resd = x.to(dev), sc.to(dev), sh.to(dev), res.to(dev)
-    exact = ops.conv3d_k3(xd, ops.pack_conv3d_weights(w.to(dev)), 32, scd, shd, resd, 1, True).cpu().double()
-    split = ops.conv3d_k3_x6(xd, ops.pack_conv3d_x6_weights(w.to(dev)), 32, scd, shd, resd, True).cpu().double()
+    exact = ops.conv3d_k3(xd, ops.pack_conv3d_weights(w.to(dev)), Co, scd, shd, resd, 1, True).cpu().double()
+    split = ops.conv3d_k3_x6(xd, ops.pack_conv3d_x6_weights(w.to(dev)), Co, scd, shd, resd, True).cpu().double()
     e_exact, e_split = (exact - ref).abs(), (split - ref).abs()
     assert e_split.max().item() <= 2e-5 and e_exact.max().item() <= 2e-5
     assert e_split.max().item() <= 1.5 * e_exact.max().item() + 1e-7
     assert e_split.mean().item() <= 1.25 * e_exact.mean().item() + 1e-9
-    plain = ops.conv3d_k3_x6(xd, ops.pack_conv3d_x6_weights(w.to(dev)), 32).cpu().double()
+    plain = ops.conv3d_k3_x6(xd, ops.pack_conv3d_x6_weights(w.to(dev)), Co).cpu().double()
     assert (plain - F.conv3d(x.double(), w.double(), None, padding=1)).abs().max().item() <= 2e-5
 
 
