@@ -118,6 +118,28 @@ def end_to_end(model, dev, B, Hp, Wp, steps):
             "note": "left/right images [%d,3,%d,%d] resident in HBM; backbone runs both views as one batch" % (B, Hp, Wp)}
 
 
+def split_mode_leg(step, exact_disps, B, steps):
+    """Secondary figure, NOT the headline: the same step with the stride-1 convolutions on exact 3-way bf16 splits of
+    their FP32 operands (csrc/conv3d_x6.hip: FP32-equivalent accuracy, not bit-identical, never selected implicitly)."""
+    ops.set_conv3d_mode("bf16x6")
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                disps = step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                disps = step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        ops.set_conv3d_mode("exact")
+    diff = [round((a - b).abs().max().item(), 7) for a, b in zip(disps, exact_disps)]
+    return {"pairs_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "max_abs_disp_vs_exact_mode": diff,
+            "note": "6 bf16 MFMA products per FP32 product, FP32 accumulate; see DESIGN.md section 8-1"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,6 +283,8 @@ def main():
                                         "epe_delta": [round((a - b).abs().mean().item(), 8) for a, b in zip(d_gpu, ref_disps)]}
         if world == 1 and ptype == "Concatenation" and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and not fused:
             out["end_to_end_with_backbone"] = end_to_end(model, dev, B, Hp, Wp, min(args.steps, 5))
+            if args.conv3d_mode == "exact":
+                out["opt_in_bf16x6"] = split_mode_leg(step, disps, B, min(args.steps, 5))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
