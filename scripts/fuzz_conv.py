@@ -1,0 +1,83 @@
+"""Randomised shape sweep of the convolution entry points against torch CPU (development aid; a failure prints the case)."""
+import sys, os, math, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from densematchingbenchmark_amd import ops
+
+dev = torch.device("cuda:0")
+rng = random.Random(int(os.environ.get("FUZZ_SEED", "1")))
+N = int(os.environ.get("FUZZ_N", "160"))
+bad = 0
+
+
+def rnd(shape, scale=1.0):
+    return torch.randn(shape) * scale
+
+
+for it in range(N):
+    kind = rng.choice(["s1", "s1", "s2", "deconv", "c2d", "c2d", "x6"])
+    B = rng.choice([1, 1, 2])
+    try:
+        if kind in ("s1", "s2", "deconv", "x6"):
+            D, H = rng.randint(1, 9), rng.randint(1, 11)
+            W = rng.choice([rng.randint(1, 70), 24, 40, 48, 72, 80, 96, 120])
+            Ci = rng.choice([1, 3, 7, 8, 16, 32, 33, 64])
+            Co = rng.choice([32, 64] if kind != "s1" else [32, 64, 128])
+            relu = rng.choice([False, True, "pre"])
+            use_res = rng.random() < 0.5
+            sc, sh = 0.5 + torch.rand(Co), torch.rand(Co) - 0.5
+            x = rnd((B, Ci, D, H, W))
+            if kind == "deconv":
+                w = rnd((Ci, Co, 3, 3, 3), 1.0 / math.sqrt(Ci * 27 / 8))
+                y = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+            else:
+                if kind == "x6":
+                    W = rng.choice([24, 48, 72, 96]) if Co == 64 else rng.choice([48, 96])
+                    x = rnd((B, Ci, D, H, W))
+                w = rnd((Co, Ci, 3, 3, 3), 1.0 / math.sqrt(Ci * 27))
+                y = F.conv3d(x, w, None, stride=2 if kind == "s2" else 1, padding=1)
+            y = y * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+            res = rnd(y.shape) if use_res else None
+            if relu == "pre":
+                y = F.relu(y)
+            if res is not None:
+                y = y + res
+            if relu is True:
+                y = F.relu(y)
+            args = (sc.to(dev), sh.to(dev), res.to(dev) if res is not None else None)
+            if kind == "deconv":
+                got = ops.deconv3d_k3s2(x.to(dev), ops.pack_deconv3d_weights(w.to(dev)), Co, *args, relu)
+            elif kind == "x6":
+                got = ops.conv3d_k3_x6(x.to(dev), ops.pack_conv3d_x6_weights(w.to(dev)), Co, *args, relu)
+            else:
+                got = ops.conv3d_k3(x.to(dev), ops.pack_conv3d_weights(w.to(dev)), Co, *args, 2 if kind == "s2" else 1, relu)
+            desc = (kind, B, Ci, Co, D, H, W, relu, use_res)
+        else:
+            H = rng.randint(1, 40)
+            W = rng.choice([rng.randint(1, 100), 16, 48, 52, 96, 100])
+            k, stride, dil = rng.choice([(1, 1, 1), (3, 1, 1), (3, 1, 2), (3, 2, 1), (1, 2, 1), (5, 2, 1), (3, 1, 4), (3, 1, 8)])
+            Co = rng.choice([1, 32] if (dil > 2 or k == 5) else ([32, 64] if stride == 2 else [1, 32, 64, 128]))
+            Ci = rng.choice([1, 3, 4, 8, 20, 32, 64, 128])
+            relu = rng.random() < 0.5
+            use_res = rng.random() < 0.5
+            sc, sh = 0.5 + torch.rand(Co), torch.rand(Co) - 0.5
+            x = rnd((B, Ci, H, W))
+            w = rnd((Co, Ci, k, k), 1.0 / math.sqrt(Ci * k * k))
+            y = F.conv2d(x, w, None, stride=stride, padding=dil * (k // 2), dilation=dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+            res = rnd(y.shape) if use_res else None
+            if res is not None:
+                y = y + res
+            if relu:
+                y = F.relu(y)
+            got = ops.conv2d(x.to(dev), ops.pack_conv2d_weights(w.to(dev)), Co, k, stride, dil, sc.to(dev), sh.to(dev),
+                             res.to(dev) if res is not None else None, relu)
+            desc = (kind, B, Ci, Co, H, W, k, stride, dil, relu, use_res)
+        err = (got.cpu() - y).abs().max().item() if y.numel() else 0.0
+        if got.shape != y.shape or not (err <= 3e-5):
+            bad += 1
+            print("FAIL", desc, "err", err, "shape", tuple(got.shape), tuple(y.shape), flush=True)
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print("EXC", kind, repr(e)[:200], flush=True)
+print("cases", N, "failures", bad)
