@@ -518,3 +518,25 @@ def test_focal_loss_multi_level_and_empty_mask(dev):
 
 def F_avg(x, hw):
     return torch.nn.functional.adaptive_avg_pool2d(x, hw)
+
+
+def test_combined_loss_evaluator_vs_oracle(dev):
+    """make_gsm_loss_evaluator(cfg) with the reference's AcfNet loss block: weighted dict of per-level terms."""
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling.stereo.losses import make_gsm_loss_evaluator
+    cfg = Config(dict(data=dict(sparse=False), model=dict(losses=dict(
+        focal_loss=dict(max_disp=32, start_disp=0, dilation=1, weight=1.0, weights=(1.0, 0.7), coefficient=5.0),
+        l1_loss=dict(max_disp=32, weights=(0.1, 0.05), weight=2.0)))))
+    ev = make_gsm_loss_evaluator(cfg)
+    gen = torch.Generator().manual_seed(531)
+    gt = torch.rand((1, 1, 12, 16), generator=gen) * 30.0 + 1.0
+    costs = [rand((1, 32, 12, 16), 532), rand((1, 32, 12, 16), 533)]
+    disps = [gt + rand((1, 1, 12, 16), 534), gt + rand((1, 1, 12, 16), 535) * 2]
+    var = [0.5 + torch.rand((1, 1, 12, 16), generator=gen) for _ in range(2)]
+    got = ev([d.to(dev) for d in disps], [c.to(dev) for c in costs], gt.to(dev), variance=[v.to(dev) for v in var])
+    assert sorted(got) == ["l1_loss_lvl0", "l1_loss_lvl1", "stereo_focal_loss_lvl0", "stereo_focal_loss_lvl1"]
+    for i, (wf, wl) in enumerate(((1.0, 0.1), (0.7, 0.05))):
+        want_f = wf * 1.0 * float(O.stereo_focal_loss(costs[i], gt, var[i], 32, 0, 1, 5.0))
+        want_l = wl * 2.0 * float(O.disp_smooth_l1_loss(disps[i], gt, 32))
+        assert abs(float(got["stereo_focal_loss_lvl%d" % i]) - want_f) <= 2e-5 * abs(want_f)
+        assert abs(float(got["l1_loss_lvl%d" % i]) - want_l) <= 2e-6
