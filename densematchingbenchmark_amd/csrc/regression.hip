@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) st[j].init();
   }
-  for (int zo = zbeg; zo < zend; ++zo) {
+  // one output plane: blend the two cached input planes, store the 4 columns, return them
+  auto out_plane = [&](int zo, float (&o)[4]) {
     const Lerp lz = lerp_setup(zo, Di, sd);
     if (lz.i0 != cz0) {
       if (lz.i0 == cz1) {
@@ -320,7 +321,6 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
       }
       cz1 = lz.i1;
     }
-    float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = lerp2(h0[j], lz.w0, h1[j], lz.w1);
     if (vec) {
@@ -332,30 +332,37 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
         if (xo + j < Wo) yp[j] = o[j];
     }
     yp += ostride;
-    if constexpr (WITH_DISP) {
-      const int full = Do - Do % SA_BLK;   // planes [0, full) fold in blocks, the tail one by one (soft_argmin_kernel)
-      if (zo < full) {
+  };
+  if constexpr (WITH_DISP) {
+    // planes [0, full) fold in blocks of SA_BLK, the tail one by one -- exactly as soft_argmin_kernel does
+    const int full = Do - Do % SA_BLK;
+    for (int zb = 0; zb < full; zb += SA_BLK) {
+      float d[SA_BLK];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+      for (int i = 0; i < SA_BLK; ++i) {
+        float o[4];
+        out_plane(zb + i, o);
 #pragma unroll
-          for (int i = 0; i < SA_BLK; ++i)
-            if (i == (zo & (SA_BLK - 1))) vb[j][i] = o[j] * alpha;
-        }
-        if ((zo & (SA_BLK - 1)) == SA_BLK - 1) {
-          float d[SA_BLK];
-#pragma unroll
-          for (int i = 0; i < SA_BLK; ++i) d[i] = dv.v[zo - (SA_BLK - 1) + i];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) st[j].template fold<SA_BLK>(vb[j], d);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v1[1] = {o[j] * alpha};
-          float d1[1] = {dv.v[zo]};
-          st[j].template fold<1>(v1, d1);
-        }
+        for (int j = 0; j < 4; ++j) vb[j][i] = o[j] * alpha;
+        d[i] = dv.v[zb + i];
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[j].template fold<SA_BLK>(vb[j], d);
+    }
+    for (int zo = full; zo < Do; ++zo) {
+      float o[4];
+      out_plane(zo, o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v1[1] = {o[j] * alpha};
+        float d1[1] = {dv.v[zo]};
+        st[j].template fold<1>(v1, d1);
+      }
+    }
+  } else {
+    for (int zo = zbeg; zo < zend; ++zo) {
+      float o[4];
+      out_plane(zo, o);
     }
   }
   if constexpr (WITH_DISP) {
