@@ -112,6 +112,7 @@ def test_conv3d_k3(dev, Ci, Co, stride, shape):
     (64, 64, 1, (1, 2, 3, 40)),
     (64, 64, 1, (1, 4, 7, 72)),     # W % 24 == 0 only -> 24-column row-quad tiles
     (64, 64, 1, (4, 24, 20, 120)),  # both widths possible: picked by the rounds x columns model
+    (64, 64, 1, (1, 4, 9, 60)),     # few tiles, W % 30 == 0 -> 30-column flattened tiles
 ])
 def test_conv3d_any_channels(dev, Ci, Co, stride, shape):
     ops = _ops()
