@@ -47,6 +47,7 @@ struct X6Cfg {
   static constexpr int XS = TX / G, GR = 32 / G;           // tiles per row group, rows per group
   static constexpr int MT = (G == 16 ? TY / 2 : TY / 4) * XS;
   static constexpr int TR_PITCH = 36;
+  static constexpr bool A_AHEAD = NT == 1;                 // weight fragments one k-step ahead (register budget)
   // lane j of a B tile -> (row, column) inside the tile; tile mt -> (row, column) origin
   __device__ static constexpr int lane_row(int j) { return G == 16 ? (j >> 4) * 2 : (j >> 3); }
   __device__ static constexpr int lane_col(int j) { return j & (G - 1); }
@@ -191,43 +192,47 @@ __global__ __launch_bounds__(256, 2) void conv3d_s1_x6_kernel(const float* __res
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the weight copy has landed
     __syncthreads();
     if (ci + 1 < nchunk) fetch((ci + 1) * CK);   // in flight under the MFMAs below
-#pragma unroll
-    for (int s = 0; s < C::NSTEP; ++s) {
-      // lanes 0-31 multiply taps 4s, 4s+1, lanes 32-63 taps 4s+2, 4s+3
-      const int offA = (lane_vox + (h ? C::tapoff(4 * s + 2) : C::tapoff(4 * s))) * 8;
-      const int offB = (lane_vox + (h ? C::tapoff(4 * s + 3) : C::tapoff(4 * s + 1))) * 8;
-      bf16x8 a[NT][3];
+    // One flat sequence of (k-step, tile) iterations: lanes 0-31 multiply taps 4s, 4s+1, lanes 32-63 taps 4s+2, 4s+3.
+    // B fragments travel from LDS one tile ahead (also across k-steps), A fragments one k-step ahead.
+    auto load_a = [&](int s, bf16x8 (&d)[NT][3]) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          a[nt][p] = *reinterpret_cast<const bf16x8*>(wgt + (((s * 3 + p) * NT + nt) * 64 + lane) * 16);
-      // one tile ahead: the next tile's fragments travel from LDS while this tile's MFMAs run
-      bf16x8 bq[2][3];
-      auto load_b = [&](int mt, bf16x8 (&d)[3]) {
-        const int to = (C::tile_row(mt) * P + C::tile_col(mt)) * 8;
+          d[nt][p] = *reinterpret_cast<const bf16x8*>(wgt + (((s * 3 + p) * NT + nt) * 64 + lane) * 16);
+    };
+    auto load_b = [&](int s, int mt, bf16x8 (&d)[3]) {
+      const int offA = (lane_vox + (h ? C::tapoff(4 * s + 2) : C::tapoff(4 * s))) * 8;
+      const int offB = (lane_vox + (h ? C::tapoff(4 * s + 3) : C::tapoff(4 * s + 1))) * 8;
+      const int to = (C::tile_row(mt) * P + C::tile_col(mt)) * 8;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const u32x2 lo = *reinterpret_cast<const u32x2*>(act + p * PIECE_BYTES + offA + to);
-          const u32x2 hi = *reinterpret_cast<const u32x2*>(act + p * PIECE_BYTES + offB + to);
-          const u32x4 q = {lo.x, lo.y, hi.x, hi.y};
-          d[p] = __builtin_bit_cast(bf16x8, q);
-        }
-      };
-      load_b(0, bq[0]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (mt + 1 < MT) load_b(mt + 1, bq[(mt + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        const auto& bb = bq[mt & 1];
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
-#pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][PA[t6]], bb[PB[t6]], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int p = 0; p < 3; ++p) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(act + p * PIECE_BYTES + offA + to);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(act + p * PIECE_BYTES + offB + to);
+        const u32x4 q = {lo.x, lo.y, hi.x, hi.y};
+        d[p] = __builtin_bit_cast(bf16x8, q);
       }
+    };
+    constexpr int ADEPTH = C::A_AHEAD ? 2 : 1;
+    bf16x8 a[ADEPTH][NT][3], bq[2][3];
+    load_a(0, a[0]);
+    load_b(0, 0, bq[0]);
+#pragma unroll
+    for (int it = 0; it < C::NSTEP * MT; ++it) {
+      const int s = it / MT, mt = it - s * MT;
+      if (C::A_AHEAD && mt == 0 && s + 1 < C::NSTEP) load_a(s + 1, a[(s + 1) & 1]);
+      if (!C::A_AHEAD && mt == 0 && s > 0) load_a(s, a[0]);
+      if (it + 1 < C::NSTEP * MT) load_b((it + 1) / MT, (it + 1) % MT, bq[(it + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const auto& aa = a[C::A_AHEAD ? (s & 1) : 0];
+      const auto& bb = bq[it & 1];
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[nt][PA[t6]], bb[PB[t6]], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();   // everyone is done reading this chunk: the next split may overwrite it
   }
