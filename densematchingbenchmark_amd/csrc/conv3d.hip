@@ -26,7 +26,8 @@ namespace dmb {
 // ---------------------------------------------------------------------------------------------------------
 // Weight prepack: A fragments in k-step order.
 //   wp[((kp * 27 + tap) * NTT + nt) * 64 + lane] = W(co = nt*32 + (lane & 31), ci = 2*kp + (lane >> 5), tap)
-// For nn.Conv3d W(co, ci, tap) = w[co][ci][tap]; for nn.ConvTranspose3d W(co, ci, tap) = w[ci][co][tap].
+// For nn.Conv3d W(co, ci, tap) = w[co][ci][tap]; for nn.ConvTranspose3d W(co, ci, tap) = w[ci][co][tap]; for the data
+// gradient of a stride-1 nn.Conv3d W(co, ci, tap) = w[ci][co][26 - tap].
 // ---------------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Cipad,
                                     int transposed) {
@@ -42,7 +43,11 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int co = nt * 32 + (lane & 31);
     const int ci = 2 * kp + (lane >> 5);
     float v = 0.f;  // channels >= Ci are zero padding (the kernels consume Ci rounded up to their chunk size)
-    if (ci < Ci && co < Co) v = transposed ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap];
+    // transposed == 2: data gradient of a stride-1 convolution = the same convolution with the channel roles exchanged and
+    // the taps mirrored
+    if (ci < Ci && co < Co)
+      v = transposed == 2 ? w[((size_t)ci * Co + co) * 27 + 26 - tap]
+                          : (transposed ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap]);
     wp[i] = v;
   }
 }
@@ -1084,6 +1089,9 @@ extern "C" int dmb_conv3d_pack_weights_f32(const float* w, float* wpack, int Co,
 }
 extern "C" int dmb_deconv3d_pack_weights_f32(const float* w, float* wpack, int Ci, int Co, void* stream) {
   return pack_common(w, wpack, Co, Ci, 1, stream);
+}
+extern "C" int dmb_conv3d_pack_dgrad_weights_f32(const float* w, float* wpack, int Co, int Ci, void* stream) {
+  return pack_common(w, wpack, Ci, Co, 2, stream);   // a convolution Co -> Ci
 }
 
 // Tile choice for the stride-1 kernel.  Row-pair tiles (TX = 48) when W is a multiple of 48: nothing is discarded.

@@ -1,0 +1,288 @@
+// Weight gradients of the 3x3x3 convolutions (training side) as FP32 implicit GEMMs on the matrix cores.
+//
+//   dW[co, ci, tap] = sum_{b, v} dc[b, co, v] * x[b, ci, S v + tap - 1]      (S = 1 here; M = co, N = ci, K = voxels)
+//
+// (dc = gradient with respect to the raw convolution output: torch.nn.grad.conv3d_weight.)  The GEMM is K-dominated --
+// 25 M voxels against a 32 x 32 x 27 result -- so the result lives in registers for the whole launch and the two input
+// tensors stream through LDS exactly once:
+//   * a workgroup owns one (32 output channels x 32 input channels) block and walks (4 rows x 24 columns) columns of
+//     the volume along z; wave w owns taps 7w .. 7w+6 (112 accumulator registers), every wave reads the same dc
+//     fragment (A) and its taps' shifted x fragments (B) -- 8 ds_read_b32 per 7 MFMAs;
+//   * x planes sit in a ring of four LDS slots (z - 1, z, z + 1 in use, z + 2 landing by LDS-DMA), so every plane is
+//     staged once per column and not three times; dc planes are double buffered;
+//   * an MFMA k-step multiplies two x-adjacent voxels (lanes 0-31: even column, lanes 32-63: odd); channel pitches
+//     (196 / 100 floats) are = 4 mod 64 so that the 2 x 32 lanes of a fragment read fall 2-way on the banks;
+//   * persistent launch (one workgroup per CU): partial results go to a workspace [slot][tap][32][32] and a second
+//     kernel adds the slots in a fixed order -- no atomics, bit-reproducible.
+//
+// Reference semantics: autograd of nn.Conv3d in dmb/modeling/stereo/layers/basic_layers.py:68-83,160-177.
+#include "dmb_common.h"
+
+namespace dmb {
+
+struct WgCfg {
+  static constexpr int TY = 4, TX = 24, ROWS = TY + 2, XOFF = 3;
+  static constexpr int P = (4 + TX + 1 + 3) / 4 * 4;            // staged row: aligned column x0 - 4 .. x0 + TX + 3
+  static constexpr int SX = ROWS * P + 4, SD = TY * TX + 4;     // channel pitches (floats), = 4 mod 64
+  static constexpr int XPLANE = 32 * SX, DPLANE = 32 * SD;
+  static constexpr int NRING = 4;
+  static constexpr int LDS_FLOATS = NRING * XPLANE + 2 * DPLANE;
+  static constexpr int UX = ROWS * P / 4, UD = TY * TX / 4;     // 16-byte units per channel plane
+  static constexpr int KSTEPS = TY * TX / 2;
+  static constexpr int NTAPW = 7;                               // taps per wave (4 x 7 = 28 >= 27; the last one is a dummy)
+  static_assert(SX % 64 == 4 && SD % 64 == 36 % 64 && UX <= 64 && UD <= 64 && LDS_FLOATS * 4 <= 160 * 1024, "tile");
+};
+
+// workspace layout: ws[((blk * nslots + slot) * 27 + tap) * 1024 + m * 32 + n], blk = cob * ncib + cib
+template <bool V16>
+__global__ __launch_bounds__(256, 1) void conv3d_wgrad_s1_kernel(const float* __restrict__ x, const float* __restrict__ dc,
+                                                                 float* __restrict__ ws, int B, int Ci, int Co, int D, int H,
+                                                                 int W, int ntx, int nty, int nzs, int zseg) {
+  typedef WgCfg C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xring = lds;
+  float* dbuf = lds + C::NRING * C::XPLANE;
+  const int ncib = cdiv(Ci, 32);
+  const int cib = blockIdx.y % ncib, cob = blockIdx.y / ncib;
+  const int slot = xcd_remap(blockIdx.x, gridDim.x), nslots = gridDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = lane & 31, kk = lane >> 5;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const int items = B * nzs * nty * ntx;
+  const int nci = min(32, Ci - cib * 32), nco = min(32, Co - cob * 32);   // real channels of this block
+
+  f32x16 acc[C::NTAPW];
+#pragma unroll
+  for (int i = 0; i < C::NTAPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // this wave's taps: B-fragment offsets inside a plane and the plane (dz) they read
+  int tapoff[C::NTAPW], tapdz[C::NTAPW];
+#pragma unroll
+  for (int i = 0; i < C::NTAPW; ++i) {
+    const int t = min(wave * C::NTAPW + i, 26);
+    tapdz[i] = t / 9;
+    tapoff[i] = n * C::SX + kk + C::XOFF + ((t / 3) % 3) * C::P + (t % 3);
+  }
+  const int aoff = n * C::SD + kk;
+
+  for (int it = slot; it < items; it += nslots) {
+    int t = it;
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int zs = t % nzs;
+    const int b = t / nzs;
+    const int x0 = tx * C::TX, y0 = ty * C::TY, za = zs * zseg, zb = min(D, za + zseg);
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)b * Ci + cib * 32) * DHW, (unsigned)nci * DHW * 4u);
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc(dc + ((size_t)b * Co + cob * 32) * DHW, (unsigned)nco * DHW * 4u);
+    // per-lane (row, unit) of the two staging patterns; the plane and the channel are wave-uniform scalar offsets
+    unsigned xvo, dvo;
+    {
+      const int row = lane / (C::P / 4), un = lane % (C::P / 4);
+      const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * un;
+      xvo = (lane < C::UX && gy >= 0 && gy < H && gx >= 0 && gx < W) ? ((unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB;
+      const int drow = lane / (C::TX / 4), dun = lane % (C::TX / 4);
+      const int dgy = y0 + drow, dgx = x0 + 4 * dun;
+      dvo = (lane < C::UD && dgy < H && dgx < W) ? ((unsigned)dgy * W + (unsigned)dgx) * 4u : DMA_OOB;
+    }
+    // (channels >= nci / nco fall outside the resource and read zeros; a plane outside the volume is written as zeros)
+    // One staging step = one channel plane of x or dc (one 16-byte LDS-DMA instruction, or one per row with dword
+    // copies).  Steps are dealt out between the k-steps of the multiply loop: a wave that issues its 16 copies in one go
+    // sits in the address queue for thousands of cycles while its SIMD's matrix core idles (one wave per SIMD here).
+    auto stage_x1 = [&](int gz, int ring, int i) {
+      const bool zok = gz >= 0 && gz < D;
+      const int c = wave * 8 + i;
+      float* dst = xring + ring * C::XPLANE + c * C::SX;
+      if constexpr (V16) {
+        if (lane < C::UX) dma16(xrs, zok ? xvo : DMA_OOB, zok ? ((unsigned)c * DHW + (unsigned)gz * HW) * 4u : 0u, dst);
+      } else {
+        const int gxs = x0 - 4 + lane;
+        if (lane < C::P) {
+#pragma unroll
+          for (int row = 0; row < C::ROWS; ++row) {
+            const int gy = y0 - 1 + row;
+            const bool ok = zok && gy >= 0 && gy < H && gxs >= 0 && gxs < W;
+            dma4(xrs, ok ? ((unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB, ok ? ((unsigned)c * DHW + (unsigned)gz * HW) * 4u : 0u,
+                 dst + row * C::P);
+          }
+        }
+      }
+    };
+    auto stage_d1 = [&](int gz, int buf, int i) {
+      const bool zok = gz >= 0 && gz < zb;
+      const int c = wave * 8 + i;
+      float* dst = dbuf + buf * C::DPLANE + c * C::SD;
+      if constexpr (V16) {
+        if (lane < C::UD) dma16(drs, zok ? dvo : DMA_OOB, zok ? ((unsigned)c * DHW + (unsigned)gz * HW) * 4u : 0u, dst);
+      } else {
+        const int gxs = x0 + lane;
+        if (lane < C::TX) {
+#pragma unroll
+          for (int row = 0; row < C::TY; ++row) {
+            const int gy = y0 + row;
+            const bool ok = zok && gy < H && gxs < W;
+            dma4(drs, ok ? ((unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB, ok ? ((unsigned)c * DHW + (unsigned)gz * HW) * 4u : 0u,
+                 dst + row * C::TX);
+          }
+        }
+      }
+    };
+    auto stage_x = [&](int gz, int ring) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stage_x1(gz, ring, i);
+    };
+    auto stage_d = [&](int gz, int buf) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stage_d1(gz, buf, i);
+    };
+
+    // prologue: planes za - 1, za, za + 1 -> ring slots 0, 1, 2; dc plane za -> buffer 0
+    __syncthreads();   // the previous column's last plane is still being read by slower waves
+    stage_x(za - 1, 0);
+    stage_x(za, 1);
+    stage_x(za + 1, 2);
+    stage_d(za, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+    for (int z = za; z < zb; ++z) {
+      const int rel = z - za;   // plane z + dz - 1 sits in ring slot (rel + dz) % 4
+      const bool more = z + 1 < zb;
+      const float* ap = dbuf + (rel & 1) * C::DPLANE + aoff;
+      const float* bp[C::NTAPW];
+#pragma unroll
+      for (int i = 0; i < C::NTAPW; ++i) bp[i] = xring + ((rel + tapdz[i]) & 3) * C::XPLANE + tapoff[i];
+      float af[2], bf[2][C::NTAPW];
+      auto load_frag = [&](int q, float& a, float (&bq)[C::NTAPW]) {
+        const int r = q / (C::TX / 2), c2 = 2 * (q % (C::TX / 2));
+        a = ap[r * C::TX + c2];
+#pragma unroll
+        for (int i = 0; i < C::NTAPW; ++i) bq[i] = bp[i][r * C::P + c2];
+      };
+      load_frag(0, af[0], bf[0]);
+#pragma unroll
+      for (int q = 0; q < C::KSTEPS; ++q) {
+        if (q + 1 < C::KSTEPS) load_frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < C::NTAPW; ++i) acc[i] = DMB_MFMA(af[q & 1], bf[q & 1][i], acc[i]);
+        if (q % 2 == 0 && q / 2 < 16 && more) {   // the next planes, one copy every other k-step
+          if (q / 2 < 8)
+            stage_x1(z + 2, (rel + 3) & 3, q / 2);
+          else
+            stage_d1(z + 1, (rel + 1) & 1, q / 2 - 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // the next planes have landed
+      __syncthreads();                      // ... and everyone is done with the oldest ones
+    }
+  }
+
+  // partial result of this slot
+  float* wsb = ws + ((size_t)blockIdx.y * nslots + slot) * 27 * 1024;
+#pragma unroll
+  for (int i = 0; i < C::NTAPW; ++i) {
+    const int t = wave * C::NTAPW + i;
+    if (t < 27) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wsb[t * 1024 + cd_row(r, kk) * 32 + n] = acc[i][r];
+    }
+  }
+}
+
+// dw[co][ci][tap] = sum over slots (fixed order, FP32 pairwise by halves of the slot range would not be more accurate than
+// the per-slot chains themselves; a plain ascending sum in double keeps the last step exact to FP32 rounding)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nslots, int transposed) {
+  const int ncib = cdiv(Ci, 32);
+  const long long total = (long long)cdiv(Co, 32) * ncib * 27 * 1024;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int nn = (int)(i & 31), m = (int)((i >> 5) & 31);
+    long long r = i >> 10;
+    const int t = (int)(r % 27);
+    const int blk = (int)(r / 27);
+    const int cib = blk % ncib, cob = blk / ncib;
+    const int co = cob * 32 + m, ci = cib * 32 + nn;
+    if (co >= Co || ci >= Ci) continue;
+    double s = 0.0;
+    const float* p = ws + (size_t)blk * nslots * 27 * 1024 + t * 1024 + m * 32 + nn;
+    for (int sl = 0; sl < nslots; ++sl) s += (double)p[(size_t)sl * 27 * 1024];
+    if (transposed)
+      dw[((size_t)ci * Co + co) * 27 + t] = (float)s;
+    else
+      dw[((size_t)co * Ci + ci) * 27 + t] = (float)s;
+  }
+}
+
+static long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
+static int wgrad_slots() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+// slots per (32 x 32) channel block: the CUs are shared between the blocks of one launch
+static int wgrad_slots_per_block(int Co, int Ci) {
+  const int nblk = cdiv(Co, 32) * cdiv(Ci, 32);
+  const int s = wgrad_slots() / nblk;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" long long dmb_conv3d_wgrad_workspace_floats(int Co, int Ci) {
+  if (Co <= 0 || Ci <= 0) return 0;
+  return (long long)cdiv(Co, 32) * cdiv(Ci, 32) * wgrad_slots_per_block(Co, Ci) * 27 * 1024;
+}
+
+extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co,
+                                       int D, int H, int W, void* stream) {
+  if (!x || !dc || !dw || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(DMB_EINVAL, "conv3d_wgrad: bad argument");
+  if ((long long)32 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_wgrad: 32 channels of one batch item must stay below 2 GiB");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = cdiv(Co, 32) * cdiv(Ci, 32);
+  const int ntx = cdiv(W, WgCfg::TX), nty = cdiv(H, WgCfg::TY);
+  // z segments: the split that minimises rounds x (planes per item + prologue); a round = one item on every slot
+  const int nslots = wgrad_slots_per_block(Co, Ci);
+  int zseg = D;
+  {
+    double best = 1e30;
+    for (int nz = 1; nz <= D; ++nz) {
+      const int zs = cdiv(D, nz);
+      if (zs < 4 && nz > 1) break;
+      const double cost = (double)cdiv_ll((long long)B * ntx * nty * cdiv(D, zs), nslots) * (zs + 0.5);
+      if (cost < best - 1e-9) {
+        best = cost;
+        zseg = zs;
+      }
+    }
+  }
+  if (g_dev_opts[5] > 0) zseg = cdiv(D, g_dev_opts[5]);   // development knob: number of z segments
+  const int nzs = cdiv(D, zseg);
+  const bool v16 = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)dc) & 15) == 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg::LDS_FLOATS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg::LDS_FLOATS * 4);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)nslots, (unsigned)nblk);
+  if (v16)
+    hipLaunchKernelGGL(conv3d_wgrad_s1_kernel<true>, grid, dim3(256), WgCfg::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, ntx, nty, nzs, zseg);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_s1_kernel<false>, grid, dim3(256), WgCfg::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, ntx, nty, nzs, zseg);
+  int rc = launch_status("conv3d_wgrad launch failed");
+  if (rc != DMB_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nslots, 0);
+  return launch_status("conv3d_wgrad reduce launch failed");
+}

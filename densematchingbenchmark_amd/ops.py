@@ -243,6 +243,51 @@ def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=Fals
     return y
 
 
+# ---------------------------------------------------------------------------------------------- conv backward
+# (backward passes of the convolution units.  "dc" = gradient w.r.t. the raw convolution output.)
+def pack_conv3d_dgrad_weights(w):
+    """Stride-1 nn.Conv3d weight [Co, Ci, 3, 3, 3] -> packed weights of its data-gradient convolution (Co -> Ci)."""
+    lib = _lib.load()
+    w = _f32c(w, "weight")
+    Co, Ci = w.shape[0], w.shape[1]
+    wp = torch.empty((lib.dmb_conv3d_packed_floats(Ci, Co),), dtype=torch.float32, device=w.device)
+    check(lib.dmb_conv3d_pack_dgrad_weights_f32(dev_ptr(w), dev_ptr(wp), Co, Ci, stream_ptr(w.device)),
+          "dmb_conv3d_pack_dgrad_weights_f32")
+    return wp
+
+
+def conv3d_k3_dgrad(dc, w, stride=1):
+    """Gradient of nn.Conv3d(k=3, padding=1, stride) w.r.t. its input; w is the layer's weight [Co, Ci, 3, 3, 3].
+    Stride 2 assumes the even input sizes of the hourglass (input = 2 x output)."""
+    Co, Ci = w.shape[0], w.shape[1]
+    if stride == 1:
+        return conv3d_k3(dc, pack_conv3d_dgrad_weights(w), Ci)
+    if stride == 2:
+        # the adjoint of a stride-2 convolution is the transposed convolution with the same weight tensor
+        return deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci)
+    raise _lib.DmbLibraryError("conv3d_k3_dgrad: stride must be 1 or 2")
+
+
+def deconv3d_k3s2_dgrad(dy, w):
+    """Gradient of nn.ConvTranspose3d(k=3, s=2, p=1, output_padding=1) w.r.t. its input; w is [Ci, Co, 3, 3, 3]."""
+    return conv3d_k3(dy, pack_conv3d_weights(w), w.shape[0], stride=2)
+
+
+def conv3d_k3_wgrad(x, dc):
+    """Gradient of a stride-1 nn.Conv3d(k=3, padding=1) w.r.t. its weight: [Co, Ci, 3, 3, 3]."""
+    lib = _lib.load()
+    x, dc = _f32c(x, "x"), _f32c(dc, "dc")
+    B, Ci, D, H, W = x.shape
+    Co = dc.shape[1]
+    if tuple(dc.shape) != (B, Co, D, H, W):
+        raise _lib.DmbLibraryError("conv3d_k3_wgrad: dc shape %s does not match x %s" % (tuple(dc.shape), tuple(x.shape)))
+    dw = torch.empty((Co, Ci, 3, 3, 3), dtype=torch.float32, device=x.device)
+    ws = torch.empty((lib.dmb_conv3d_wgrad_workspace_floats(Co, Ci),), dtype=torch.float32, device=x.device)
+    check(lib.dmb_conv3d_k3_wgrad_f32(dev_ptr(x), dev_ptr(dc), dev_ptr(dw), dev_ptr(ws), B, Ci, Co, D, H, W,
+                                      stream_ptr(x.device)), "dmb_conv3d_k3_wgrad_f32")
+    return dw
+
+
 # ---------------------------------------------------------------------------------------------- upsampling
 def trilinear_ac(x, out_size):
     """x: [B, Di, Hi, Wi] (single channel squeezed) -> [B, Do, Ho, Wo], align_corners=True."""

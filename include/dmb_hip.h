@@ -226,7 +226,7 @@ int dmb_bilinear_scale_f32(const float* x, float* y, int B, int C, int Hi, int W
 
 /* ------------------------------------------------------------------------------------------
  * "Next" row (first part): the training-side loss terms of AcfNet's cost filtering, forward and
- * backward, each ONE pass over what it reads.  Backward passes of the convolutions are NOT part of this library.
+ * backward, each ONE pass over what it reads.
  * ---------------------------------------------------------------------------------------- */
 
 /* Doubles of reduction workspace for a loss over n_elements pixels (per-block partial sums, deterministic). */
@@ -259,6 +259,29 @@ int dmb_map_loss_fwd_f32(const float* x, const float* gt, double* workspace, flo
 int dmb_map_loss_bwd_f32(const float* x, const float* gt, const float* loss_out, const float* grad_out,
                          float grad_scale, float* grad_x, long long n, float lower, float upper, int mode,
                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * "Next" row (second part): backward passes of the 3-D convolution units (autograd of the
+ * nn.Sequential(Conv3d | ConvTranspose3d, BatchNorm3d[, ReLU]) factories, layers/basic_layers.py:68-100,160-177).
+ * "dc" is the gradient with respect to the raw convolution output (before BatchNorm).
+ *
+ * Data gradients reuse the forward kernels (scale = shift = residual = NULL, relu = 0) on re-packed weights:
+ *   stride-1 Conv3d   dx = dmb_conv3d_k3_f32(dc, pack_dgrad(w), stride 1)           (channels Co -> Ci)
+ *   stride-2 Conv3d   dx = dmb_deconv3d_k3s2_f32(dc, dmb_deconv3d_pack_weights_f32(w, Co, Ci))   (even D, H, W of x)
+ *   ConvTranspose3d   dx = dmb_conv3d_k3_f32(dy, dmb_conv3d_pack_weights_f32(w, Ci, Co), stride 2)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Weights of the data-gradient convolution of a stride-1 nn.Conv3d with weight w [Co, Ci, 3, 3, 3]: channel roles
+ * exchanged, taps mirrored.  wpack holds dmb_conv3d_packed_floats(Ci, Co) floats. */
+int dmb_conv3d_pack_dgrad_weights_f32(const float* w, float* wpack, int Co, int Ci, void* stream);
+
+/* Weight gradient of a stride-1 nn.Conv3d (kernel 3, padding 1): dw[co, ci, tap] = sum_{b, v} dc[b, co, v] *
+ * x[b, ci, v + tap - 1] (torch.nn.grad.conv3d_weight).  x [B, Ci, D, H, W], dc [B, Co, D, H, W], dw [Co, Ci, 27].
+ * FP32 MFMA chains per workgroup, partial results added in a fixed order (bit-reproducible, no atomics).
+ * workspace: dmb_conv3d_wgrad_workspace_floats(Co, Ci) floats.  32 channels of one batch item must stay below 2 GiB. */
+long long dmb_conv3d_wgrad_workspace_floats(int Co, int Ci);
+int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int D,
+                            int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * EXPERIMENTAL, OPT-IN (never selected by the default path): the stride-1

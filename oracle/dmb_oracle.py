@@ -498,6 +498,28 @@ def disp_smooth_l1_loss(est, gt, max_disp, start_disp=0):
     return F.smooth_l1_loss(est[mask], gt[mask], reduction="mean")
 
 
+# ---------------------------------------------------------------------------------------------- backward passes
+# The reference trains through torch.autograd of the nn.Sequential(Conv3d | ConvTranspose3d, BatchNorm3d[, ReLU])
+# factories (dmb/modeling/stereo/layers/basic_layers.py:68-100,160-177); the restatement differentiates the same
+# functional ops on the CPU.  "dc" = gradient w.r.t. the raw convolution output.
+def conv3d_backward(x, w, dc, stride=1, dtype=torch.float32):
+    """(dx, dw) of F.conv3d(x, w, stride=stride, padding=1)."""
+    x = x.detach().to(dtype).requires_grad_(True)
+    w = w.detach().to(dtype).requires_grad_(True)
+    y = F.conv3d(x, w, None, stride=stride, padding=1)
+    dx, dw = torch.autograd.grad(y, (x, w), dc.to(dtype))
+    return dx, dw
+
+
+def deconv3d_backward(x, w, dy, dtype=torch.float32):
+    """(dx, dw) of F.conv_transpose3d(x, w, stride=2, padding=1, output_padding=1); w is [Ci, Co, 3, 3, 3]."""
+    x = x.detach().to(dtype).requires_grad_(True)
+    w = w.detach().to(dtype).requires_grad_(True)
+    y = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+    dx, dw = torch.autograd.grad(y, (x, w), dy.to(dtype))
+    return dx, dw
+
+
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs
