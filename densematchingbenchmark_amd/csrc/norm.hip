@@ -1,0 +1,319 @@
+// Training-side BatchNorm(+residual, +ReLU) of the convolution units (second part): batch statistics,
+// the normalising pass, and the two passes of the backward (channel sums, then the gradient w.r.t. the raw convolution
+// output).  nn.BatchNorm3d / nn.BatchNorm2d in training mode as the reference's factories build them
+// (dmb/modeling/stereo/layers/basic_layers.py:68-100,160-177; the skip adds of cost_processors/utils/hourglass.py:62-86).
+//
+//   forward   mean_c, var_c (biased) over (B, voxels);  invstd = 1/sqrt(var + eps);  scale = gamma*invstd,
+//             shift = beta - mean*scale;  y = act(c*scale + shift (+ residual))      (same epilogue as the conv kernels)
+//             running_mean += momentum*(mean - running_mean), running_var likewise with the unbiased variance
+//   backward  dpre = dy * [unit output > 0];  dbeta = sum dpre;  dgamma = sum dpre * xhat,  xhat = (c - mean)*invstd
+//             dc = scale * (dpre - dbeta/N - xhat*dgamma/N)          (eval mode: dc = scale * dpre)
+//
+// All four are HBM-bound single passes with 16-byte accesses; sums are FP64 per block, finished by one block in a fixed
+// order (deterministic, no atomics).  Layout [B, C, S] with S = voxels (or pixels) per channel.
+#include "dmb_common.h"
+
+#pragma clang fp contract(off)
+
+namespace dmb {
+
+constexpr int NB = 256;   // threads per block
+
+__device__ __forceinline__ double norm_block_sum(double v, double* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// Slice s of channel ch: elements [lo, hi) of every batch item's channel plane.  Visit them as float4 where aligned.
+template <class F4, class F1>
+__device__ __forceinline__ void for_slice(long long S, int B, int C, int ch, int s, int nsplit, bool vec, F4 f4, F1 f1) {
+  const long long per = ((S + nsplit - 1) / nsplit + 3) / 4 * 4;
+  const long long lo = (long long)s * per, hi = lo + per < S ? lo + per : S;
+  for (int b = 0; b < B; ++b) {
+    const long long base = ((long long)b * C + ch) * S;
+    if (vec) {
+      for (long long i = lo + 4LL * threadIdx.x; i < hi; i += 4LL * NB) {
+        if (i + 4 <= hi)
+          f4(base + i);
+        else
+          for (long long j = i; j < hi; ++j) f1(base + j);
+      }
+    } else {
+      for (long long i = lo + threadIdx.x; i < hi; i += NB) f1(base + i);
+    }
+  }
+}
+
+// ws[(ch * nsplit + s) * 2 + {0, 1}] = sum, sum of squares (about the channel's first element, for conditioning)
+__global__ __launch_bounds__(NB) void bn_stats_kernel(const float* __restrict__ c, double* __restrict__ ws, int B, int C,
+                                                      long long S, int nsplit, int vec) {
+  __shared__ double sm[4];
+  const int ch = blockIdx.y, s = blockIdx.x;
+  const float pivot = c[(long long)ch * S];
+  // FP32 lane partials over short runs, FP64 across runs
+  double sum = 0.0, sq = 0.0;
+  float ps = 0.f, pq = 0.f;
+  int run = 0;
+  auto add = [&](float v) {
+    const float d = v - pivot;
+    ps += d;
+    pq = fmaf(d, d, pq);
+  };
+  auto flush = [&]() {
+    sum += (double)ps;
+    sq += (double)pq;
+    ps = pq = 0.f;
+    run = 0;
+  };
+  for_slice(S, B, C, ch, s, nsplit, vec != 0,
+            [&](long long o) {
+              const float4 v = *reinterpret_cast<const float4*>(c + o);
+              add(v.x), add(v.y), add(v.z), add(v.w);
+              if (++run == 64) flush();
+            },
+            [&](long long o) {
+              add(c[o]);
+              if (++run == 256) flush();
+            });
+  flush();
+  sum = norm_block_sum(sum, sm);
+  sq = norm_block_sum(sq, sm);
+  if (threadIdx.x == 0) {
+    ws[((long long)ch * nsplit + s) * 2] = sum;
+    ws[((long long)ch * nsplit + s) * 2 + 1] = sq;
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ c, const double* __restrict__ ws, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean_out,
+                                         float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                         int B, int C, long long S, int nsplit) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  double sum = 0.0, sq = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    sum += ws[((long long)ch * nsplit + s) * 2];
+    sq += ws[((long long)ch * nsplit + s) * 2 + 1];
+  }
+  const double n = (double)B * (double)S;
+  const double dm = sum / n;                      // mean - pivot
+  double var = sq / n - dm * dm;
+  if (var < 0.0) var = 0.0;
+  const double mean = (double)c[(long long)ch * S] + dm;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[ch] : 1.f, bta = beta ? beta[ch] : 0.f;
+  const float sc = g * invstd;
+  mean_out[ch] = (float)mean;
+  invstd_out[ch] = invstd;
+  scale_out[ch] = sc;
+  shift_out[ch] = bta - (float)mean * sc;
+  if (running_mean) running_mean[ch] = running_mean[ch] + momentum * ((float)mean - running_mean[ch]);
+  if (running_var) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_var[ch] = running_var[ch] + momentum * ((float)unbiased - running_var[ch]);
+  }
+}
+
+// y = act(c*scale + shift (+ residual));  relu: 0 none, 1 after the residual add, 2 before it
+__global__ __launch_bounds__(NB) void bn_act_kernel(const float* __restrict__ c, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const float* __restrict__ res,
+                                                    float* __restrict__ y, int C, long long S, long long total, int relu, int vec) {
+  const float lo1 = relu == 1 ? 0.f : -INFINITY, lo2 = relu == 2 ? 0.f : -INFINITY;
+  auto one = [&](float v, float r, float sc, float sh) { return fmaxf(fmaxf(fmaf(v, sc, sh), lo2) + r, lo1); };
+  if (vec) {
+    for (long long i = (blockIdx.x * (long long)NB + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * NB * 4) {
+      const int ch = (int)((i / S) % C);
+      const float sc = scale[ch], sh = shift[ch];
+      const float4 v = *reinterpret_cast<const float4*>(c + i);
+      float4 r = {0.f, 0.f, 0.f, 0.f};
+      if (res) r = *reinterpret_cast<const float4*>(res + i);
+      float4 o = {one(v.x, r.x, sc, sh), one(v.y, r.y, sc, sh), one(v.z, r.z, sc, sh), one(v.w, r.w, sc, sh)};
+      *reinterpret_cast<float4*>(y + i) = o;
+    }
+  } else {
+    for (long long i = blockIdx.x * (long long)NB + threadIdx.x; i < total; i += (long long)gridDim.x * NB) {
+      const int ch = (int)((i / S) % C);
+      y[i] = one(c[i], res ? res[i] : 0.f, scale[ch], shift[ch]);
+    }
+  }
+}
+
+// gradient entering the normalisation: dy masked by the unit's ReLU.
+//   relu 1 (activation after the skip add): the mask is the unit's output y > 0
+//   relu 2 (activation before the skip add): the mask is the normalised value c*scale + shift > 0
+__device__ __forceinline__ float dpre_of(float dy, float cv, float yv, float sc, float sh, int relu) {
+  if (relu == 1) return yv > 0.f ? dy : 0.f;
+  if (relu == 2) return fmaf(cv, sc, sh) > 0.f ? dy : 0.f;
+  return dy;
+}
+
+// ws[(ch * nsplit + s) * 2 + {0, 1}] = sum dpre, sum dpre * xhat
+__global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ c,
+                                                           const float* __restrict__ y, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, double* __restrict__ ws, int B, int C,
+                                                           long long S, int nsplit, int relu, int vec) {
+  __shared__ double sm[4];
+  const int ch = blockIdx.y, s = blockIdx.x;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  double s1 = 0.0, s2 = 0.0;
+  float p1 = 0.f, p2 = 0.f;
+  int run = 0;
+  auto add = [&](float g, float cv, float yv) {
+    const float d = dpre_of(g, cv, yv, sc, sh, relu);
+    p1 += d;
+    p2 = fmaf(d, (cv - mu) * is, p2);
+  };
+  auto flush = [&]() {
+    s1 += (double)p1;
+    s2 += (double)p2;
+    p1 = p2 = 0.f;
+    run = 0;
+  };
+  for_slice(S, B, C, ch, s, nsplit, vec != 0,
+            [&](long long o) {
+              const float4 g = *reinterpret_cast<const float4*>(dy + o);
+              const float4 cv = *reinterpret_cast<const float4*>(c + o);
+              float4 yv = {0.f, 0.f, 0.f, 0.f};
+              if (relu == 1) yv = *reinterpret_cast<const float4*>(y + o);
+              add(g.x, cv.x, yv.x), add(g.y, cv.y, yv.y), add(g.z, cv.z, yv.z), add(g.w, cv.w, yv.w);
+              if (++run == 64) flush();
+            },
+            [&](long long o) {
+              add(dy[o], c[o], relu == 1 ? y[o] : 0.f);
+              if (++run == 256) flush();
+            });
+  flush();
+  s1 = norm_block_sum(s1, sm);
+  s2 = norm_block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    ws[((long long)ch * nsplit + s) * 2] = s1;
+    ws[((long long)ch * nsplit + s) * 2 + 1] = s2;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                       int nsplit) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    s1 += ws[((long long)ch * nsplit + s) * 2];
+    s2 += ws[((long long)ch * nsplit + s) * 2 + 1];
+  }
+  dbeta[ch] = (float)s1;
+  dgamma[ch] = (float)s2;
+}
+
+// dc = scale*(dpre - dbeta/N - xhat*dgamma/N) (training) or scale*dpre (eval); dres = dpre (relu 1) when asked for
+__global__ __launch_bounds__(NB) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ c,
+                                                          const float* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ dgamma,
+                                                          const float* __restrict__ dbeta, float* __restrict__ dc,
+                                                          float* __restrict__ dres, int C, long long S, long long total,
+                                                          float inv_n, int relu, int training, int vec) {
+  auto one = [&](float g, float cv, float yv, int ch, float& dr) {
+    const float sc = scale[ch];
+    const float d = dpre_of(g, cv, yv, sc, shift[ch], relu);
+    dr = relu == 2 ? g : d;   // what flows into the skip branch
+    if (!training) return sc * d;
+    const float xh = (cv - mean[ch]) * invstd[ch];
+    return sc * (d - dbeta[ch] * inv_n - xh * (dgamma[ch] * inv_n));
+  };
+  if (vec) {
+    for (long long i = (blockIdx.x * (long long)NB + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * NB * 4) {
+      const int ch = (int)((i / S) % C);
+      const float4 g = *reinterpret_cast<const float4*>(dy + i);
+      const float4 cv = *reinterpret_cast<const float4*>(c + i);
+      float4 yv = {0.f, 0.f, 0.f, 0.f};
+      if (relu == 1) yv = *reinterpret_cast<const float4*>(y + i);
+      float4 o, r;
+      o.x = one(g.x, cv.x, yv.x, ch, r.x);
+      o.y = one(g.y, cv.y, yv.y, ch, r.y);
+      o.z = one(g.z, cv.z, yv.z, ch, r.z);
+      o.w = one(g.w, cv.w, yv.w, ch, r.w);
+      *reinterpret_cast<float4*>(dc + i) = o;
+      if (dres) *reinterpret_cast<float4*>(dres + i) = r;
+    }
+  } else {
+    for (long long i = blockIdx.x * (long long)NB + threadIdx.x; i < total; i += (long long)gridDim.x * NB) {
+      const int ch = (int)((i / S) % C);
+      float r;
+      dc[i] = one(dy[i], c[i], relu == 1 ? y[i] : 0.f, ch, r);
+      if (dres) dres[i] = r;
+    }
+  }
+}
+
+static int bn_nsplit(int C, long long S) {
+  long long n = 4096 / (C > 0 ? C : 1);
+  if (n < 1) n = 1;
+  const long long most = (S + 1023) / 1024;   // at least ~1024 elements per slice and batch item
+  if (n > most) n = most;
+  return (int)(n < 1 ? 1 : n);
+}
+
+static int elementwise_blocks(long long total, int per_thread) {
+  long long b = (total + (long long)NB * per_thread - 1) / ((long long)NB * per_thread);
+  if (b > 16384) b = 16384;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+extern "C" long long dmb_bn_workspace_doubles(int C, long long S) {
+  if (C <= 0 || S <= 0) return 0;
+  return 2LL * C * bn_nsplit(C, S);
+}
+
+extern "C" int dmb_bn_train_stats_f32(const float* c, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float momentum, float eps, float* mean_out, float* invstd_out,
+                                      float* scale_out, float* shift_out, double* workspace, int B, int C, long long S,
+                                      void* stream) {
+  if (!c || !mean_out || !invstd_out || !scale_out || !shift_out || !workspace || B <= 0 || C <= 0 || S <= 0)
+    return fail(DMB_EINVAL, "bn_train_stats: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = bn_nsplit(C, S);
+  const int vec = S % 4 == 0 && ((uintptr_t)c & 15) == 0;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NB), 0, st, c, workspace, B, C, S, nsplit, vec);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, c, workspace, gamma, beta, running_mean,
+                     running_var, momentum, eps, mean_out, invstd_out, scale_out, shift_out, B, C, S, nsplit);
+  return launch_status("bn_train_stats launch failed");
+}
+
+extern "C" int dmb_bn_act_f32(const float* c, const float* scale, const float* shift, const float* residual, float* y, int B,
+                              int C, long long S, int relu, void* stream) {
+  if (!c || !scale || !shift || !y || B <= 0 || C <= 0 || S <= 0 || relu < 0 || relu > 2) return fail(DMB_EINVAL, "bn_act: bad argument");
+  const long long total = (long long)B * C * S;
+  const int vec = S % 4 == 0 && (((uintptr_t)c | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+  hipLaunchKernelGGL(bn_act_kernel, dim3(elementwise_blocks(total, vec ? 8 : 2)), dim3(NB), 0, (hipStream_t)stream, c, scale, shift,
+                     residual, y, C, S, total, relu, vec);
+  return launch_status("bn_act launch failed");
+}
+
+extern "C" int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* y, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, double* workspace, float* dgamma, float* dbeta,
+                                  float* dc, float* dres, int B, int C, long long S, int relu, int training, void* stream) {
+  if (!dy || !c || !scale || !shift || !mean || !invstd || !workspace || !dgamma || !dbeta || !dc || B <= 0 || C <= 0 || S <= 0 ||
+      relu < 0 || relu > 2 || (relu == 1 && !y))
+    return fail(DMB_EINVAL, "bn_act_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = bn_nsplit(C, S);
+  const long long total = (long long)B * C * S;
+  const int vec = S % 4 == 0 && (((uintptr_t)dy | (uintptr_t)c | (uintptr_t)y | (uintptr_t)dc | (uintptr_t)dres) & 15) == 0;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nsplit, C), dim3(NB), 0, st, dy, c, y, scale, shift, mean, invstd, workspace, B, C, S,
+                     nsplit, relu, vec);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, dgamma, dbeta, C, nsplit);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(total, vec ? 8 : 2)), dim3(NB), 0, st, dy, c, y, scale, shift, mean,
+                     invstd, dgamma, dbeta, dc, dres, C, S, total, (float)(1.0 / ((double)B * (double)S)), relu, training, vec);
+  return launch_status("bn_act_bwd launch failed");
+}

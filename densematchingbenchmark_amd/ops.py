@@ -288,6 +288,58 @@ def conv3d_k3_wgrad(x, dc):
     return dw
 
 
+# ---------------------------------------------------------------------------------------------- BatchNorm (training)
+def _bcs(t):
+    """[B, C, *spatial] -> (B, C, S)."""
+    S = 1
+    for d in t.shape[2:]:
+        S *= int(d)
+    return int(t.shape[0]), int(t.shape[1]), S
+
+
+def bn_train_stats(c, gamma=None, beta=None, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """Batch statistics of a raw convolution output; returns (mean, invstd, scale, shift) and updates the running buffers."""
+    lib = _lib.load()
+    c = _f32c(c, "c")
+    B, C, S = _bcs(c)
+    out = [torch.empty((C,), dtype=torch.float32, device=c.device) for _ in range(4)]
+    ws = torch.empty((lib.dmb_bn_workspace_doubles(C, S),), dtype=torch.float64, device=c.device)
+    check(lib.dmb_bn_train_stats_f32(dev_ptr(c), dev_ptr(gamma, allow_none=True), dev_ptr(beta, allow_none=True),
+                                     dev_ptr(running_mean, allow_none=True), dev_ptr(running_var, allow_none=True),
+                                     float(momentum), float(eps), dev_ptr(out[0]), dev_ptr(out[1]), dev_ptr(out[2]),
+                                     dev_ptr(out[3]), dev_ptr(ws), B, C, S, stream_ptr(c.device)), "dmb_bn_train_stats_f32")
+    return tuple(out)
+
+
+def bn_act(c, scale, shift, residual=None, relu=False):
+    """y = act(c*scale + shift (+ residual)); relu as in conv3d_k3 (False / True / 'pre')."""
+    lib = _lib.load()
+    c = _f32c(c, "c")
+    B, C, S = _bcs(c)
+    y = torch.empty_like(c)
+    check(lib.dmb_bn_act_f32(dev_ptr(c), dev_ptr(scale), dev_ptr(shift), dev_ptr(residual, allow_none=True), dev_ptr(y),
+                             B, C, S, _relu_mode(relu), stream_ptr(c.device)), "dmb_bn_act_f32")
+    return y
+
+
+def bn_act_bwd(dy, c, y, scale, shift, mean, invstd, relu=False, training=True, want_dres=False):
+    """Backward of bn_act (+ the batch statistics if training): returns (dc, dgamma, dbeta, dres or None)."""
+    lib = _lib.load()
+    dy, c = _f32c(dy, "dy"), _f32c(c, "c")
+    B, C, S = _bcs(c)
+    mode = _relu_mode(relu)
+    dc = torch.empty_like(c)
+    dres = torch.empty_like(c) if want_dres else None
+    dgamma = torch.empty((C,), dtype=torch.float32, device=c.device)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=c.device)
+    ws = torch.empty((lib.dmb_bn_workspace_doubles(C, S),), dtype=torch.float64, device=c.device)
+    check(lib.dmb_bn_act_bwd_f32(dev_ptr(dy), dev_ptr(c), dev_ptr(y, allow_none=mode != 1), dev_ptr(scale), dev_ptr(shift),
+                                 dev_ptr(mean), dev_ptr(invstd), dev_ptr(ws), dev_ptr(dgamma), dev_ptr(dbeta), dev_ptr(dc),
+                                 dev_ptr(dres, allow_none=True), B, C, S, mode, 1 if training else 0,
+                                 stream_ptr(c.device)), "dmb_bn_act_bwd_f32")
+    return dc, dgamma, dbeta, dres
+
+
 # ---------------------------------------------------------------------------------------------- upsampling
 def trilinear_ac(x, out_size):
     """x: [B, Di, Hi, Wi] (single channel squeezed) -> [B, Do, Ho, Wo], align_corners=True."""

@@ -283,6 +283,27 @@ long long dmb_conv3d_wgrad_workspace_floats(int Co, int Ci);
 int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int D,
                             int H, int W, void* stream);
 
+/* BatchNorm (training mode) + skip add + ReLU of a convolution unit, layout [B, C, S] (S = voxels or pixels per channel).
+ * relu: 0 none, 1 after the skip add, 2 before it -- the same epilogue the inference kernels fuse.
+ *
+ * dmb_bn_train_stats_f32: batch mean / biased variance per channel (FP64 sums, fixed order) ->
+ *   mean_out, invstd_out = 1/sqrt(var + eps), scale_out = gamma*invstd, shift_out = beta - mean*scale_out (C floats each);
+ *   running_mean / running_var (may be NULL) are updated as nn.BatchNorm does (momentum, unbiased variance).
+ *   gamma / beta may be NULL (1 / 0).  workspace: dmb_bn_workspace_doubles(C, S) doubles.
+ * dmb_bn_act_f32: y = act(c*scale + shift (+ residual)).
+ * dmb_bn_act_bwd_f32: dpre = dy * [ReLU mask];  dbeta = sum dpre;  dgamma = sum dpre * (c - mean)*invstd;
+ *   dc = scale*(dpre - dbeta/N - xhat*dgamma/N) if training else scale*dpre;  dres (may be NULL) = the gradient flowing
+ *   into the skip branch (dpre for relu 1, dy otherwise).  y (the unit's output) is only read for relu == 1. */
+long long dmb_bn_workspace_doubles(int C, long long S);
+int dmb_bn_train_stats_f32(const float* c, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, float* mean_out, float* invstd_out,
+                           float* scale_out, float* shift_out, double* workspace, int B, int C, long long S, void* stream);
+int dmb_bn_act_f32(const float* c, const float* scale, const float* shift, const float* residual, float* y, int B, int C,
+                   long long S, int relu, void* stream);
+int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* y, const float* scale, const float* shift,
+                       const float* mean, const float* invstd, double* workspace, float* dgamma, float* dbeta, float* dc,
+                       float* dres, int B, int C, long long S, int relu, int training, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * EXPERIMENTAL, OPT-IN (never selected by the default path): the stride-1
  * convolution (32 or 64 output channels) with every FP32 operand split exactly into three bf16 pieces and the six largest cross products issued on

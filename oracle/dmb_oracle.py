@@ -520,6 +520,32 @@ def deconv3d_backward(x, w, dy, dtype=torch.float32):
     return dx, dw
 
 
+def bn_act_train(c, gamma, beta, residual=None, relu=0, eps=1e-5, dy=None, dtype=torch.float32, training=True,
+                 running_mean=None, running_var=None, momentum=0.1):
+    """nn.BatchNorm (training mode: batch statistics) + skip add + ReLU of a convolution unit, forward and -- when dy is
+    given -- backward.  relu: 0 none, 1 after the skip add (hourglass.py:67-81), 2 before it (aggregators/GCNet.py:108-116).
+    Returns dict(y[, dc, dgamma, dbeta, dres], running_mean, running_var)."""
+    c = c.detach().to(dtype).requires_grad_(True)
+    g = gamma.detach().to(dtype).requires_grad_(True)
+    b = beta.detach().to(dtype).requires_grad_(True)
+    r = residual.detach().to(dtype).requires_grad_(True) if residual is not None else None
+    rm = running_mean.detach().to(dtype).clone() if running_mean is not None else None
+    rv = running_var.detach().to(dtype).clone() if running_var is not None else None
+    v = F.batch_norm(c, rm, rv, g, b, training=training, momentum=momentum, eps=eps)
+    if relu == 2:
+        v = F.relu(v)
+    if r is not None:
+        v = v + r
+    if relu == 1:
+        v = F.relu(v)
+    out = dict(y=v.detach(), running_mean=rm, running_var=rv)
+    if dy is not None:
+        ins = (c, g, b) + ((r,) if r is not None else ())
+        grads = torch.autograd.grad(v, ins, dy.to(dtype))
+        out.update(dc=grads[0], dgamma=grads[1], dbeta=grads[2], dres=grads[3] if r is not None else None)
+    return out
+
+
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs

@@ -84,3 +84,42 @@ def test_deconv3d_dgrad(dev, Ci, Co, shape):
     got = ops.deconv3d_k3s2_dgrad(dy.to(dev), w.to(dev)).cpu()
     assert got.shape == x.shape
     _close(got, dx64, dx32, "dx")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 5, 6, 12), (3, 32, 4, 7, 9), (2, 5, 33, 20)])   # the last one is 2-D, S % 4 != 0 above
+@pytest.mark.parametrize("relu,with_res", [(0, False), (1, False), (1, True), (2, True), (0, True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_train(dev, shape, relu, with_res, training):
+    """Batch statistics, running-buffer update, normalising pass and the backward of one BN(+skip)(+ReLU) epilogue."""
+    ops = _ops()
+    C = shape[1]
+    c = _rand(shape, 1) * 1.5 + 0.3
+    gamma, beta = _rand((C,), 2) * 0.5 + 1.0, _rand((C,), 3) * 0.2
+    res = _rand(shape, 4) if with_res else None
+    dy = _rand(shape, 5)
+    rm, rv = _rand((C,), 6) * 0.1, _rand((C,), 7).abs() + 0.5
+    ref = O.bn_act_train(c, gamma, beta, res, relu, dy=dy, training=training, running_mean=rm, running_var=rv)
+    ref64 = O.bn_act_train(c, gamma, beta, res, relu, dy=dy, dtype=torch.float64, training=training, running_mean=rm, running_var=rv)
+    mode = {0: False, 1: True, 2: "pre"}[relu]
+    cg = c.to(dev)
+    if training:
+        rmg, rvg = rm.to(dev), rv.to(dev)
+        mean, invstd, scale, shift = ops.bn_train_stats(cg, gamma.to(dev), beta.to(dev), rmg, rvg, momentum=0.1, eps=1e-5)
+        # tolerance: FP32 statistics of O(1) data over <= 1e4 elements
+        assert (rmg.cpu() - ref["running_mean"]).abs().max().item() < 1e-5
+        assert (rvg.cpu() - ref["running_var"]).abs().max().item() < 1e-5
+    else:
+        invstd = (1.0 / torch.sqrt(rv + 1e-5)).to(dev)
+        mean = rm.to(dev)
+        scale = gamma.to(dev) * invstd
+        shift = beta.to(dev) - mean * scale
+    y = ops.bn_act(cg, scale, shift, res.to(dev) if with_res else None, relu=mode)
+    assert (y.cpu() - ref["y"]).abs().max().item() < 2e-5
+    dc, dgamma, dbeta, dres = ops.bn_act_bwd(dy.to(dev), cg, y, scale, shift, mean, invstd, relu=mode, training=training,
+                                             want_dres=with_res)
+    # elements whose pre-activation is within rounding of zero may take the other ReLU branch: compare away from them
+    _close(dgamma.cpu(), ref64["dgamma"], ref["dgamma"], "dgamma")
+    _close(dbeta.cpu(), ref64["dbeta"], ref["dbeta"], "dbeta")
+    _close(dc.cpu(), ref64["dc"], ref["dc"], "dc")
+    if with_res:
+        assert torch.equal(dres.cpu(), ref["dres"])
