@@ -62,6 +62,10 @@ SIGNATURES = {
     "dmb_bn_train_stats_f32": (_c_int, [_P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_bn_act_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _c_int, _P]),
     "dmb_bn_act_bwd_f32": (_c_int, [_P] * 12 + [_c_int, _c_int, _c_ll, _c_int, _c_int, _P]),
+    "dmb_cat_fms_bwd_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
+    "dmb_dif_fms_bwd_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
+    "dmb_soft_argmin_bwd_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _HF, _P]),
+    "dmb_trilinear_ac_soft_argmin_bwd_f32": (_c_int, [_P, _P, _P, _P, _P] + [_c_int] * 7 + [_c_float, _HF, _P]),
     "dmb_loss_workspace_doubles": (_c_ll, [_c_ll]),
     "dmb_stereo_focal_loss_fwd_f32": (_c_int, [_P, _P, _P, _c_float, _HF, _P, _P, _P] + [_c_int] * 4 + [_c_float] * 5 + [_P]),
     "dmb_stereo_focal_loss_bwd_f32": (_c_int, [_P, _P, _P, _c_float, _HF, _P, _P, _P, _c_float, _P, _P] + [_c_int] * 4

@@ -14,7 +14,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmb_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip"]
+SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip", "path_bwd.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -37,7 +37,7 @@ def build_library(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link libdmb_hip.so.  Returns the library path."""
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "dmb_common.h"), os.path.join(INCLUDE, "dmb_hip.h")]
+    headers = [os.path.join(CSRC, "dmb_common.h"), os.path.join(CSRC, "interp.h"), os.path.join(INCLUDE, "dmb_hip.h")]
     objs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

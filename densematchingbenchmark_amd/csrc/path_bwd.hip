@@ -1,0 +1,242 @@
+// Backward passes of the HBM-bound ends of the cost path (second part): the cost-volume builders and the
+// disparity regression.  Autograd of
+//   cat_fms / dif_fms                            dmb/modeling/stereo/cost_processors/utils/{cat_fms.py:7-48, dif_fms.py:7-46}
+//   FasterSoftArgmin / SoftArgmin                dmb/modeling/stereo/disp_predictors/{faster_soft_argmin.py:51-75, soft_argmin.py:45-75}
+//   F.interpolate(trilinear, align_corners=True) dmb/modeling/stereo/cost_processors/aggregators/PSMNet.py:74-93
+// Each kernel reads its large operand once; nothing the size of the [B, D, H, W] cost volume is written.
+#include "dmb_common.h"
+#include "interp.h"
+
+#pragma clang fp contract(off)
+
+namespace dmb {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Cost-volume builders.  Forward: vol[:C, k, y, x] = L[y, x], vol[C:, k, y, x] = R[y, x - d_k] on the valid columns
+// x in [max(d_k, 0), min(W, W + d_k)), zero elsewhere.  Backward: dL[y, x] = sum_k [x valid] dvol[c, k, y, x],
+// dR[y, x'] = sum_k [x' + d_k valid] dvol[C + c, k, y, x' + d_k]  (difference volume: one tensor, the second term negated).
+// One thread = one (b, c, y, x) of dL or dR walking the D planes (a wave reads 256 contiguous bytes per plane).
+// ------------------------------------------------------------------------------------------------------------------
+template <bool DIF>
+__global__ __launch_bounds__(256) void volume_bwd_kernel(const float* __restrict__ dvol, float* __restrict__ dL,
+                                                         float* __restrict__ dR, int C, int H, int W, int D, DispIdx idx) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const int y = blockIdx.y % H, side = blockIdx.y / H;   // side 0: dL, 1: dR
+  const int c = blockIdx.z % C, b = blockIdx.z / C;
+  const size_t HW = (size_t)H * W;
+  const int VC = DIF ? C : 2 * C;
+  const float* p = dvol + (((size_t)b * VC + ((DIF || side == 0) ? c : C + c)) * D) * HW + (size_t)y * W;
+  float s = 0.f;
+  for (int k = 0; k < D; ++k) {
+    const int d = idx.d[k];
+    const int xv = side == 0 ? x : x + d;                 // the volume column this plane contributes from
+    const int lo = d > 0 ? d : 0, hi = d < 0 ? W + d : W;
+    if (xv >= lo && xv < hi) s += p[(size_t)k * HW + xv];
+  }
+  float* out = (side == 0 ? dL : dR) + (((size_t)b * C + c) * H + y) * W + x;
+  *out = (DIF && side == 1) ? -s : s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Soft-argmin: disp = sum_k p_k s_k, p = softmax(alpha * cost)  =>  dcost_k = g * alpha * p_k * (s_k - disp).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void soft_argmin_bwd_kernel(const float* __restrict__ cost, const float* __restrict__ disp,
+                                                              const float* __restrict__ g, float* __restrict__ dcost, int D,
+                                                              long long HW, float alpha, DispVal dv) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= HW) return;
+  const int b = blockIdx.y;
+  const float* cp = cost + (size_t)b * D * HW + i;
+  float m = -INFINITY;
+  for (int k = 0; k < D; ++k) m = fmaxf(m, cp[(size_t)k * HW] * alpha);
+  double s = 0.0;
+  for (int k = 0; k < D; ++k) s += (double)__expf(cp[(size_t)k * HW] * alpha - m);
+  const float inv = (float)(1.0 / s);
+  const float dsp = disp[(size_t)b * HW + i], ga = g[(size_t)b * HW + i] * alpha;
+  float* op = dcost + (size_t)b * D * HW + i;
+  for (int k = 0; k < D; ++k) {
+    const float pk = __expf(cp[(size_t)k * HW] * alpha - m) * inv;
+    op[(size_t)k * HW] = ga * pk * (dv.v[k] - dsp);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Up-sampling + soft-argmin, backward, without the [B, Do, Ho, Wo] volume: pass A (one thread per output pixel)
+// re-creates the pixel's up-sampled logits from the low-resolution cost exactly as the forward kernel does, forms
+// dcost_k and folds it along z straight into the (H, W)-interpolated planes it came from:
+//   t[b, zi, yo, xo] = sum_k wz(zi <- k) * dcost_k            ([B, Di, Ho, Wo]: Do/Di times smaller than the volume)
+// pass B contracts t over the (yo, xo) neighbourhood of every low-resolution voxel with the bilinear weights.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_regress_bwd_z_kernel(const float* __restrict__ x, const float* __restrict__ disp,
+                                                                     const float* __restrict__ g, float* __restrict__ t, int Di,
+                                                                     int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh,
+                                                                     float sw, float alpha, DispVal dv) {
+  const int xo = blockIdx.x * 256 + threadIdx.x;
+  if (xo >= Wo) return;
+  const int yo = blockIdx.y, b = blockIdx.z;
+  const Lerp ly = lerp_setup(yo, Hi, sh), lx = lerp_setup(xo, Wi, sw);
+  const float* xb = x + (size_t)b * Di * Hi * Wi;
+  const size_t plane = (size_t)Hi * Wi;
+  const size_t o00 = (size_t)ly.i0 * Wi + lx.i0, o01 = (size_t)ly.i0 * Wi + lx.i1;
+  const size_t o10 = (size_t)ly.i1 * Wi + lx.i0, o11 = (size_t)ly.i1 * Wi + lx.i1;
+  auto hw = [&](int zi) {
+    const float* pz = xb + (size_t)zi * plane;
+    const float a0 = lerp2(pz[o00], lx.w0, pz[o01], lx.w1);
+    const float a1 = lerp2(pz[o10], lx.w0, pz[o11], lx.w1);
+    return lerp2(a0, ly.w0, a1, ly.w1);
+  };
+  // the pixel's up-sampled logit of output plane zo (two cached input planes, as in the forward kernels)
+  int cz0 = -1, cz1 = -1;
+  float h0 = 0.f, h1 = 0.f;
+  auto logit = [&](int zo, Lerp& lz) {
+    lz = lerp_setup(zo, Di, sd);
+    if (lz.i0 != cz0) {
+      h0 = (lz.i0 == cz1) ? h1 : hw(lz.i0);
+      cz0 = lz.i0;
+    }
+    if (lz.i1 != cz1) {
+      h1 = (lz.i1 == cz0) ? h0 : hw(lz.i1);
+      cz1 = lz.i1;
+    }
+    return lerp2(h0, lz.w0, h1, lz.w1) * alpha;
+  };
+  Lerp lz;
+  float m = -INFINITY;
+  for (int zo = 0; zo < Do; ++zo) m = fmaxf(m, logit(zo, lz));
+  cz0 = cz1 = -1;
+  double s = 0.0;
+  for (int zo = 0; zo < Do; ++zo) s += (double)__expf(logit(zo, lz) - m);
+  cz0 = cz1 = -1;
+  const float inv = (float)(1.0 / s);
+  const size_t pix = ((size_t)b * Ho + yo) * Wo + xo;
+  const float dsp = disp[pix], ga = g[pix] * alpha;
+  // fold along z: input planes are visited in ascending order, so two running sums (planes ia, ia + 1) suffice
+  float* tp = t + (size_t)b * Di * Ho * Wo + (size_t)yo * Wo + xo;
+  const size_t tstride = (size_t)Ho * Wo;
+  int ia = 0;
+  float acc_a = 0.f, acc_b = 0.f;
+  for (int zo = 0; zo < Do; ++zo) {
+    const float pk = __expf(logit(zo, lz) - m) * inv;
+    const float dck = ga * pk * (dv.v[zo] - dsp);
+    while (ia < lz.i0) {
+      tp[(size_t)ia * tstride] = acc_a;
+      acc_a = acc_b;
+      acc_b = 0.f;
+      ++ia;
+    }
+    acc_a = fmaf(dck, lz.w0, acc_a);
+    if (lz.i1 != lz.i0)
+      acc_b = fmaf(dck, lz.w1, acc_b);
+    else
+      acc_a = fmaf(dck, lz.w1, acc_a);
+  }
+  while (ia < Di) {
+    tp[(size_t)ia * tstride] = acc_a;
+    acc_a = acc_b;
+    acc_b = 0.f;
+    ++ia;
+  }
+}
+
+// dlow[b, zi, yl, xl] = sum_{yo, xo} wy(yl <- yo) * wx(xl <- xo) * t[b, zi, yo, xo]; one thread per low-resolution voxel.
+// Output rows / columns that blend input index i: src = scale * o in (i - 1, i + 1).
+__global__ __launch_bounds__(256) void upsample_regress_bwd_hw_kernel(const float* __restrict__ t, float* __restrict__ dx, int Di,
+                                                                      int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+  const int xl = blockIdx.x * 256 + threadIdx.x;
+  if (xl >= Wi) return;
+  const int yl = blockIdx.y % Hi, zi = blockIdx.y / Hi, b = blockIdx.z;
+  auto range = [](int i, float scale, int out, int& lo, int& hi) {
+    if (scale <= 0.f) {   // a single output position blends input 0 only
+      lo = 0;
+      hi = i == 0 ? out - 1 : -1;
+      return;
+    }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out - 1 ? out - 1 : hi;
+  };
+  int ylo, yhi, xlo, xhi;
+  range(yl, sh, Ho, ylo, yhi);
+  range(xl, sw, Wo, xlo, xhi);
+  const float* tb = t + ((size_t)b * Di + zi) * Ho * Wo;
+  float acc = 0.f;
+  for (int yo = ylo; yo <= yhi; ++yo) {
+    const Lerp ly = lerp_setup(yo, Hi, sh);
+    const float wy = (ly.i0 == yl ? ly.w0 : 0.f) + (ly.i1 == yl ? ly.w1 : 0.f);
+    if (wy == 0.f) continue;
+    float row = 0.f;
+    for (int xo = xlo; xo <= xhi; ++xo) {
+      const Lerp lx = lerp_setup(xo, Wi, sw);
+      const float wx = (lx.i0 == xl ? lx.w0 : 0.f) + (lx.i1 == xl ? lx.w1 : 0.f);
+      if (wx != 0.f) row = fmaf(tb[(size_t)yo * Wo + xo], wx, row);
+    }
+    acc = fmaf(row, wy, acc);
+  }
+  dx[(((size_t)b * Di + zi) * Hi + yl) * Wi + xl] = acc;
+}
+
+static int fill_idx(const int* host, int D, DispIdx& idx) {
+  if (!host || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
+  for (int k = 0; k < D; ++k) idx.d[k] = host[k];
+  return DMB_OK;
+}
+static int fill_val(const float* host, int D, DispVal& dv) {
+  if (!host || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
+  for (int k = 0; k < D; ++k) dv.v[k] = host[k];
+  return DMB_OK;
+}
+
+template <bool DIF>
+static int launch_volume_bwd(const float* dvol, float* dL, float* dR, int B, int C, int H, int W, int D, const int* disp_idx_host,
+                             void* stream) {
+  if (!dvol || !dL || !dR || B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "volume_bwd: bad argument");
+  if ((long long)B * C > 65535 || 2LL * H > 65535) return fail(DMB_EUNSUPPORTED, "volume_bwd: grid too large");
+  DispIdx idx;
+  if (int e = fill_idx(disp_idx_host, D, idx)) return e;
+  hipLaunchKernelGGL(volume_bwd_kernel<DIF>, dim3(cdiv(W, 256), 2 * H, B * C), dim3(256), 0, (hipStream_t)stream, dvol, dL, dR, C, H,
+                     W, D, idx);
+  return launch_status("volume_bwd launch failed");
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+extern "C" int dmb_cat_fms_bwd_f32(const float* dvol, float* dL, float* dR, int B, int C, int H, int W, int D,
+                                   const int* disp_idx_host, void* stream) {
+  return launch_volume_bwd<false>(dvol, dL, dR, B, C, H, W, D, disp_idx_host, stream);
+}
+extern "C" int dmb_dif_fms_bwd_f32(const float* dvol, float* dL, float* dR, int B, int C, int H, int W, int D,
+                                   const int* disp_idx_host, void* stream) {
+  return launch_volume_bwd<true>(dvol, dL, dR, B, C, H, W, D, disp_idx_host, stream);
+}
+
+extern "C" int dmb_soft_argmin_bwd_f32(const float* cost, const float* disp, const float* grad_disp, float* grad_cost, int B,
+                                       int D, int H, int W, float alpha, const float* disp_sample_host, void* stream) {
+  if (!cost || !disp || !grad_disp || !grad_cost || B <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "soft_argmin_bwd: bad argument");
+  DispVal dv;
+  if (int e = fill_val(disp_sample_host, D, dv)) return e;
+  const long long HW = (long long)H * W;
+  hipLaunchKernelGGL(soft_argmin_bwd_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, cost, disp,
+                     grad_disp, grad_cost, D, HW, alpha, dv);
+  return launch_status("soft_argmin_bwd launch failed");
+}
+
+extern "C" int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, const float* grad_disp, float* scratch,
+                                                    float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                    float alpha, const float* disp_sample_host, void* stream) {
+  if (!x || !disp || !grad_disp || !scratch || !grad_x || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0)
+    return fail(DMB_EINVAL, "trilinear_soft_argmin_bwd: bad argument");
+  if (Ho > 65535 || (long long)Di * Hi > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "trilinear_soft_argmin_bwd: grid too large");
+  DispVal dv;
+  if (int e = fill_val(disp_sample_host, Do, dv)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const float sd = ac_scale(Di, Do), sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+  hipLaunchKernelGGL(upsample_regress_bwd_z_kernel, dim3(cdiv(Wo, 256), Ho, B), dim3(256), 0, st, x, disp, grad_disp, scratch, Di, Hi,
+                     Wi, Do, Ho, Wo, sd, sh, sw, alpha, dv);
+  hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), Di * Hi, B), dim3(256), 0, st, scratch, grad_x, Di, Hi, Wi,
+                     Ho, Wo, sh, sw);
+  return launch_status("trilinear_soft_argmin_bwd launch failed");
+}

@@ -7,6 +7,7 @@
 // faster_soft_argmin.py:51-75, local_soft_argmin.py:48-105}, cost_processors/aggregators/PSMNet.py:74-93,
 // AcfNet.py:55-57,81-83, data/datasets/evaluation/stereo/pixel_error.py:6-73.
 #include "dmb_common.h"
+#include "interp.h"
 
 // No implicit fma contraction in this file: the interpolation index/weight arithmetic must round exactly like the
 // reference's (ATen CPU) float code -- src = scale * dst rounded, THEN lambda = src - floor(src) -- or lambda moves
@@ -191,25 +192,6 @@ __global__ __launch_bounds__(256) void local_soft_argmin_kernel(const float* __r
 // (in-1)/(out-1), src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1;
 // evaluation order W, then H, then D.
 // ---------------------------------------------------------------------------------------------------------
-struct Lerp {
-  int i0, i1;
-  float w0, w1;
-};
-__device__ inline Lerp lerp_setup(int dst, int in, float scale) {
-  const float src = scale * (float)dst;
-  Lerp l;
-  l.i0 = (int)src;
-  l.i1 = l.i0 + ((l.i0 < in - 1) ? 1 : 0);
-  float l1 = src - (float)l.i0;
-  l1 = fminf(fmaxf(l1, 0.f), 1.f);
-  l.w1 = l1;
-  l.w0 = 1.f - l1;
-  return l;
-}
-__host__ __device__ inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
-
-__device__ inline float lerp2(float a, float wa, float b, float wb) { return fmaf(b, wb, a * wa); }
-
 // one thread = 4 consecutive output x of one (b, zo, yo) row
 __global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int Di,
                                                         int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh,

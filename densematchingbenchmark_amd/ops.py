@@ -340,6 +340,53 @@ def bn_act_bwd(dy, c, y, scale, shift, mean, invstd, relu=False, training=True, 
     return dc, dgamma, dbeta, dres
 
 
+# ---------------------------------------------------------------------------------------------- path ends, backward
+def _volume_bwd(fn_name, dvol, disp_idx, C):
+    lib = _lib.load()
+    dvol = _f32c(dvol, "dvol")
+    B, VC, D, H, W = dvol.shape
+    if D != len(disp_idx) or VC != (2 * C if fn_name == "dmb_cat_fms_bwd_f32" else C):
+        raise _lib.DmbLibraryError("%s: gradient shape %s does not match C=%d, D=%d" % (fn_name, tuple(dvol.shape), C, len(disp_idx)))
+    dL = torch.empty((B, C, H, W), dtype=torch.float32, device=dvol.device)
+    dR = torch.empty_like(dL)
+    check(getattr(lib, fn_name)(dev_ptr(dvol), dev_ptr(dL), dev_ptr(dR), B, C, H, W, D, host_ints(disp_idx),
+                                stream_ptr(dvol.device)), fn_name)
+    return dL, dR
+
+
+def cat_fms_bwd(dvol, disp_idx):
+    """Gradient of cat_fms w.r.t. (reference_fm, target_fm); dvol [B, 2C, D, H, W]."""
+    return _volume_bwd("dmb_cat_fms_bwd_f32", dvol, disp_idx, dvol.shape[1] // 2)
+
+
+def dif_fms_bwd(dvol, disp_idx):
+    return _volume_bwd("dmb_dif_fms_bwd_f32", dvol, disp_idx, dvol.shape[1])
+
+
+def soft_argmin_bwd(cost, disp, grad_disp, disp_values, alpha=1.0):
+    lib = _lib.load()
+    cost, disp, grad_disp = _f32c(cost, "cost"), _f32c(disp, "disp"), _f32c(grad_disp, "grad_disp")
+    B, D, H, W = cost.shape
+    out = torch.empty_like(cost)
+    check(lib.dmb_soft_argmin_bwd_f32(dev_ptr(cost), dev_ptr(disp), dev_ptr(grad_disp), dev_ptr(out), B, D, H, W,
+                                      float(alpha), host_floats(disp_values), stream_ptr(cost.device)), "dmb_soft_argmin_bwd_f32")
+    return out
+
+
+def trilinear_ac_soft_argmin_bwd(x, disp, grad_disp, out_size, disp_values, alpha=1.0):
+    """Gradient of trilinear_ac_soft_argmin's disparity w.r.t. the low-resolution cost x [B, Di, Hi, Wi]."""
+    lib = _lib.load()
+    x, disp, grad_disp = _f32c(x, "x"), _f32c(disp, "disp"), _f32c(grad_disp, "grad_disp")
+    B, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = out_size
+    scratch = torch.empty((B, Di, Ho, Wo), dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x)
+    check(lib.dmb_trilinear_ac_soft_argmin_bwd_f32(dev_ptr(x), dev_ptr(disp), dev_ptr(grad_disp), dev_ptr(scratch), dev_ptr(gx),
+                                                   B, Di, Hi, Wi, Do, Ho, Wo, float(alpha), host_floats(disp_values),
+                                                   stream_ptr(x.device)), "dmb_trilinear_ac_soft_argmin_bwd_f32")
+    return gx
+
+
 # ---------------------------------------------------------------------------------------------- upsampling
 def trilinear_ac(x, out_size):
     """x: [B, Di, Hi, Wi] (single channel squeezed) -> [B, Do, Ho, Wo], align_corners=True."""

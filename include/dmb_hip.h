@@ -304,6 +304,25 @@ int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* y, const fl
                        const float* mean, const float* invstd, double* workspace, float* dgamma, float* dbeta, float* dc,
                        float* dres, int B, int C, long long S, int relu, int training, void* stream);
 
+/* Backward of the cost-volume builders: dvol [B, 2C (cat) or C (dif), D, H, W] -> dL, dR [B, C, H, W]; sums over the
+ * valid columns of every disparity plane (cat_fms.py:36-44), FP32 in ascending plane order. */
+int dmb_cat_fms_bwd_f32(const float* dvol, float* dL, float* dR, int B, int C, int H, int W, int D,
+                        const int* disp_idx_host, void* stream);
+int dmb_dif_fms_bwd_f32(const float* dvol, float* dL, float* dR, int B, int C, int H, int W, int D,
+                        const int* disp_idx_host, void* stream);
+
+/* Backward of the soft-argmin (normalize = True): grad_cost[k] = grad_disp * alpha * p_k * (s_k - disp),
+ * p = softmax(alpha * cost).  cost, grad_cost [B, D, H, W]; disp (the forward result), grad_disp [B, 1, H, W]. */
+int dmb_soft_argmin_bwd_f32(const float* cost, const float* disp, const float* grad_disp, float* grad_cost, int B,
+                            int D, int H, int W, float alpha, const float* disp_sample_host, void* stream);
+
+/* Backward of dmb_trilinear_ac_soft_argmin_f32 with respect to the low-resolution cost x [B, Di, Hi, Wi], given the
+ * gradient of the disparity only: the [B, Do, Ho, Wo] volume is re-created per pixel in registers, never stored.
+ * scratch: B*Di*Ho*Wo floats; grad_x [B, Di, Hi, Wi]. */
+int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, const float* grad_disp, float* scratch,
+                                         float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                         float alpha, const float* disp_sample_host, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * EXPERIMENTAL, OPT-IN (never selected by the default path): the stride-1
  * convolution (32 or 64 output channels) with every FP32 operand split exactly into three bf16 pieces and the six largest cross products issued on

@@ -123,3 +123,65 @@ def test_bn_act_train(dev, shape, relu, with_res, training):
     _close(dc.cpu(), ref64["dc"], ref["dc"], "dc")
     if with_res:
         assert torch.equal(dres.cpu(), ref["dres"])
+
+
+@pytest.mark.parametrize("shape,md,sd,dil", [
+    ((2, 8, 6, 40), 12, 0, 1),
+    ((1, 5, 7, 61), 12, -3, 1),
+    ((1, 4, 5, 12), 20, 0, 1),      # disparities beyond the width
+    ((1, 8, 9, 64), 6, 0, 2),
+])
+def test_volume_builders_backward(dev, shape, md, sd, dil):
+    """cat_fms / dif_fms: the adjoint sums; compared with autograd through the oracle's builders.  Tolerance: an FP32 sum
+    of <= 20 terms in a different order (1e-5 on O(1) data)."""
+    ops = _ops()
+    B, C, H, W = shape
+    L, R = _rand(shape, 1), _rand(shape, 2)
+    idx = ops.disp_index_list(md, sd, dil)
+    for name, builder, bwd, VC in (("cat", O.cat_fms, ops.cat_fms_bwd, 2 * C), ("dif", O.dif_fms, ops.dif_fms_bwd, C)):
+        dvol = _rand((B, VC, len(idx), H, W), 3)
+        Lr, Rr = L.clone().requires_grad_(True), R.clone().requires_grad_(True)
+        # the oracle writes slices of leaf-derived tensors into a zero volume: differentiable as is
+        vol = builder(Lr, Rr, md, sd, dil)
+        dLr, dRr = torch.autograd.grad(vol, (Lr, Rr), dvol)
+        dL, dR = bwd(dvol.to(dev), idx)
+        assert (dL.cpu() - dLr).abs().max().item() < 1e-5, name
+        assert (dR.cpu() - dRr).abs().max().item() < 1e-5, name
+
+
+@pytest.mark.parametrize("B,D,H,W,alpha", [(2, 24, 5, 17, 1.0), (1, 192, 3, 8, 1.0), (1, 16, 4, 4, -1.5)])
+def test_soft_argmin_backward(dev, B, D, H, W, alpha):
+    ops = _ops()
+    cost = _rand((B, D, H, W), 1, 2.0)
+    g = _rand((B, 1, H, W), 2)
+    vals = O.disp_sample_values(D).tolist()
+    c = cost.clone().double().requires_grad_(True)
+    p = torch.softmax(c * alpha, dim=1)
+    disp64 = (p * torch.tensor(vals, dtype=torch.float64).view(1, D, 1, 1)).sum(1, keepdim=True)
+    ref, = torch.autograd.grad(disp64, c, g.double())
+    disp = ops.soft_argmin(cost.to(dev), vals, alpha, True)
+    got = ops.soft_argmin_bwd(cost.to(dev), disp, g.to(dev), vals, alpha).cpu()
+    # tolerance: __expf and an FP32 quotient against FP64, relative to the largest gradient entry
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("lo,scale", [((6, 5, 9), 4), ((4, 7, 12), 4), ((8, 4, 6), 2), ((5, 3, 4), 1)])
+def test_upsample_regression_backward(dev, lo, scale):
+    """d disp / d low-resolution cost through F.interpolate(trilinear, align_corners=True) + softmax regression."""
+    import torch.nn.functional as F
+    ops = _ops()
+    Di, Hi, Wi = lo
+    Do, Ho, Wo = Di * scale, Hi * scale, Wi * scale
+    x = _rand((2, Di, Hi, Wi), 1, 2.0)
+    g = _rand((2, 1, Ho, Wo), 2)
+    vals = O.disp_sample_values(Do).tolist()
+    xr = x.clone().double().requires_grad_(True)
+    up = F.interpolate(xr.unsqueeze(1), size=(Do, Ho, Wo), mode="trilinear", align_corners=True).squeeze(1)
+    p = torch.softmax(up, dim=1)
+    disp64 = (p * torch.tensor(vals, dtype=torch.float64).view(1, Do, 1, 1)).sum(1, keepdim=True)
+    ref, = torch.autograd.grad(disp64, xr, g.double())
+    _, disp = ops.trilinear_ac_soft_argmin(x.to(dev), (Do, Ho, Wo), vals, 1.0)
+    got = ops.trilinear_ac_soft_argmin_bwd(x.to(dev), disp, g.to(dev), (Do, Ho, Wo), vals, 1.0).cpu()
+    assert got.shape == x.shape
+    # tolerance: FP32 interpolation weights + __expf against an FP64 evaluation, relative to the largest entry
+    assert (got.double() - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item())
