@@ -193,6 +193,161 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s1_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Stride 2: out[cs, cb, tap] = sum_{b, o} small[b, cs, o] * big[b, cb, 2 o + tap - 1], the weight gradient of both
+//   nn.Conv3d(stride 2):      small = dc [Co], big = x [Ci]   -> out = dW  [Co, Ci, 27]
+//   nn.ConvTranspose3d(s 2):  small = x [Ci],  big = dy [Co]  -> out = dWt [Ci, Co, 27]
+// Same structure as the stride-1 kernel; a small plane z needs big planes 2z - 1, 2z, 2z + 1 (ring of five slots, two
+// landing per step); the tile is 2 rows x 12 columns of the small tensor (5 x 28 staged floats of the big one per
+// channel); fragment reads of the big tile step 2 floats per k lane (bank pattern 12 n + 2 kk: still 2-way).
+// Staging units are linear in LDS across channels (the unit count per channel is made odd: pitch = 4 mod 8 floats), so one LDS-DMA
+// instruction moves 64 units whatever the plane size.
+// ------------------------------------------------------------------------------------------------------------------
+struct Wg2Cfg {
+  static constexpr int TY = 2, TX = 12, ROWS = 2 * TY + 1, XOFF = 3;
+  static constexpr int P = (4 + 2 * TX + 3) / 4 * 4;            // staged row of the big tile: aligned column 2 x0 - 4 ..
+  static constexpr int UBU = ROWS * P / 4, USU = TY * TX / 4;   // 16-byte units per channel plane ...
+  static constexpr int UB = UBU | 1, US = USU | 1;              // ... padded to an odd count (pitch = 4 mod 8 floats)
+  static constexpr int SB = UB * 4, SS = US * 4;                // channel pitches (floats)
+  static constexpr int BPLANE = 32 * SB, SPLANE = 32 * SS;
+  static constexpr int NRING = 5;
+  static constexpr int LDS_FLOATS = NRING * BPLANE + 2 * SPLANE;
+  static constexpr int KSTEPS = TY * TX / 2;
+  static constexpr int NTAPW = 7;
+  static constexpr int IB = (32 * UB + 255) / 256, IS = (32 * US + 255) / 256;   // copy instructions per wave and plane
+  static_assert(SB % 8 == 4 && SS % 8 == 4 && LDS_FLOATS * 4 <= 160 * 1024 && 2 * IB + IS <= KSTEPS, "tile");
+};
+
+__global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __restrict__ sm, const float* __restrict__ bg,
+                                                                 float* __restrict__ ws, int B, int Cs, int Cb, int Ds, int Hs,
+                                                                 int Ws, int Db, int Hb, int Wb, int ntx, int nty, int nzs,
+                                                                 int zseg) {
+  typedef Wg2Cfg C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ring = lds;
+  float* sbuf = lds + C::NRING * C::BPLANE;
+  const int ncbb = cdiv(Cb, 32);
+  const int cbb = blockIdx.y % ncbb, csb = blockIdx.y / ncbb;
+  const int slot = xcd_remap(blockIdx.x, gridDim.x), nslots = gridDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = lane & 31, kk = lane >> 5;
+  const unsigned HWs = (unsigned)Hs * Ws, DHWs = (unsigned)Ds * HWs, HWb = (unsigned)Hb * Wb, DHWb = (unsigned)Db * HWb;
+  const int items = B * nzs * nty * ntx;
+  const int ncs = min(32, Cs - csb * 32), ncb = min(32, Cb - cbb * 32);
+
+  f32x16 acc[C::NTAPW];
+#pragma unroll
+  for (int i = 0; i < C::NTAPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  int tapoff[C::NTAPW], tapdz[C::NTAPW];
+#pragma unroll
+  for (int i = 0; i < C::NTAPW; ++i) {
+    const int t = min(wave * C::NTAPW + i, 26);
+    tapdz[i] = t / 9;
+    tapoff[i] = n * C::SB + 2 * kk + C::XOFF + ((t / 3) % 3) * C::P + (t % 3);
+  }
+  const int aoff = n * C::SS + kk;
+
+  for (int it = slot; it < items; it += nslots) {
+    int t = it;
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int zs = t % nzs;
+    const int b = t / nzs;
+    const int x0 = tx * C::TX, y0 = ty * C::TY, za = zs * zseg, zb = min(Ds, za + zseg);
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(bg + ((size_t)b * Cb + cbb * 32) * DHWb, (unsigned)ncb * DHWb * 4u);
+    const __amdgpu_buffer_rsrc_t srs = make_rsrc(sm + ((size_t)b * Cs + csb * 32) * DHWs, (unsigned)ncs * DHWs * 4u);
+    // per-lane source offsets (channel + in-plane part) of this wave's copy instructions; the plane is a scalar offset
+    unsigned bvo[C::IB], svo[C::IS];
+#pragma unroll
+    for (int j = 0; j < C::IB; ++j) {
+      const int u = (j * 4 + wave) * 64 + lane, ch = u / C::UB, un = u - ch * C::UB;
+      const int row = un / (C::P / 4), cu = un - row * (C::P / 4);
+      const int gy = 2 * y0 - 1 + row, gx = 2 * x0 - 4 + 4 * cu;
+      const bool ok = ch < 32 && un < C::UBU && gy >= 0 && gy < Hb && gx >= 0 && gx < Wb;
+      bvo[j] = ok ? ((unsigned)ch * DHWb + (unsigned)gy * Wb + (unsigned)gx) * 4u : DMA_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < C::IS; ++j) {
+      const int u = (j * 4 + wave) * 64 + lane, ch = u / C::US, un = u - ch * C::US;
+      const int row = un / (C::TX / 4), cu = un - row * (C::TX / 4);
+      const int gy = y0 + row, gx = x0 + 4 * cu;
+      const bool ok = ch < 32 && un < C::USU && gy < Hs && gx < Ws;
+      svo[j] = ok ? ((unsigned)ch * DHWs + (unsigned)gy * Ws + (unsigned)gx) * 4u : DMA_OOB;
+    }
+    auto stage_b1 = [&](int gz, int rslot, int j) {   // copy instruction j of this wave for big plane gz
+      const bool zok = gz >= 0 && gz < Db;
+      const int first = (j * 4 + wave) * 64;
+      if (first + lane < 32 * C::UB) dma16(brs, zok ? bvo[j] : DMA_OOB, zok ? (unsigned)gz * HWb * 4u : 0u, ring + rslot * C::BPLANE + first * 4);
+    };
+    auto stage_s1 = [&](int gz, int buf, int j) {
+      const bool zok = gz >= 0 && gz < zb;
+      const int first = (j * 4 + wave) * 64;
+      if (first + lane < 32 * C::US) dma16(srs, zok ? svo[j] : DMA_OOB, zok ? (unsigned)gz * HWs * 4u : 0u, sbuf + buf * C::SPLANE + first * 4);
+    };
+    // ring slot of big plane p: (p - (2 za - 1)) % 5
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int j = 0; j < C::IB; ++j) stage_b1(2 * za - 1 + q, q, j);
+#pragma unroll
+    for (int j = 0; j < C::IS; ++j) stage_s1(za, 0, j);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    int q0 = 0;   // ring index of plane 2 z - 1
+    for (int z = za; z < zb; ++z) {
+      const int rel = z - za;
+      const bool more = z + 1 < zb;
+      const float* ap = sbuf + (rel & 1) * C::SPLANE + aoff;
+      const float* bp[C::NTAPW];
+#pragma unroll
+      for (int i = 0; i < C::NTAPW; ++i) bp[i] = ring + ((q0 + tapdz[i]) % C::NRING) * C::BPLANE + tapoff[i];
+      const int s3 = (q0 + 3) % C::NRING, s4 = (q0 + 4) % C::NRING;
+      float af[2], bf[2][C::NTAPW];
+      auto load_frag = [&](int q, float& a, float (&bq)[C::NTAPW]) {
+        const int r = q / (C::TX / 2), c = q % (C::TX / 2);
+        a = ap[r * C::TX + 2 * c];
+#pragma unroll
+        for (int i = 0; i < C::NTAPW; ++i) bq[i] = bp[i][2 * r * C::P + 4 * c];
+      };
+      load_frag(0, af[0], bf[0]);
+#pragma unroll
+      for (int q = 0; q < C::KSTEPS; ++q) {
+        if (q + 1 < C::KSTEPS) load_frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < C::NTAPW; ++i) acc[i] = DMB_MFMA(af[q & 1], bf[q & 1][i], acc[i]);
+        if (more) {   // the next planes, one copy per k-step
+          if (q < C::IB)
+            stage_b1(2 * z + 2, s3, q);
+          else if (q < 2 * C::IB)
+            stage_b1(2 * z + 3, s4, q - C::IB);
+          else if (q < 2 * C::IB + C::IS)
+            stage_s1(z + 1, (rel + 1) & 1, q - 2 * C::IB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      q0 = (q0 + 2) % C::NRING;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+  }
+
+  float* wsb = ws + ((size_t)blockIdx.y * nslots + slot) * 27 * 1024;
+#pragma unroll
+  for (int i = 0; i < C::NTAPW; ++i) {
+    const int t = wave * C::NTAPW + i;
+    if (t < 27) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wsb[t * 1024 + cd_row(r, kk) * 32 + n] = acc[i][r];
+    }
+  }
+}
+
 // dw[co][ci][tap] = sum over slots (fixed order, FP32 pairwise by halves of the slot range would not be more accurate than
 // the per-slot chains themselves; a plain ascending sum in double keeps the last step exact to FP32 rounding)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nslots, int transposed) {
@@ -285,4 +440,44 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
   if (rc != DMB_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nslots, 0);
   return launch_status("conv3d_wgrad reduce launch failed");
+}
+
+extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, float* dw, float* workspace, int B, int Cs, int Cb,
+                                         int Ds, int Hs, int Ws, int Db, int Hb, int Wb, void* stream) {
+  if (!small || !big || !dw || !workspace || B <= 0 || Cs <= 0 || Cb <= 0 || Ds <= 0 || Hs <= 0 || Ws <= 0)
+    return fail(DMB_EINVAL, "conv3d_s2_wgrad: bad argument");
+  if ((Db != 2 * Ds && Db != 2 * Ds - 1) || (Hb != 2 * Hs && Hb != 2 * Hs - 1) || (Wb != 2 * Ws && Wb != 2 * Ws - 1))
+    return fail(DMB_EINVAL, "conv3d_s2_wgrad: the big tensor must be 2n or 2n - 1 per axis");
+  if ((long long)32 * Db * Hb * Wb * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_s2_wgrad: 32 channels of one batch item must stay below 2 GiB");
+  if (Ws % 4 != 0 || Wb % 4 != 0 || (((uintptr_t)small | (uintptr_t)big) & 15) != 0)
+    return fail(DMB_EUNSUPPORTED, "conv3d_s2_wgrad: widths must be multiples of 4 and the tensors 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = cdiv(Cs, 32) * cdiv(Cb, 32);
+  const int ntx = cdiv(Ws, Wg2Cfg::TX), nty = cdiv(Hs, Wg2Cfg::TY);
+  const int nslots = wgrad_slots_per_block(Cs, Cb);
+  int zseg = Ds;
+  {
+    double best = 1e30;
+    for (int nz = 1; nz <= Ds; ++nz) {
+      const int zs = cdiv(Ds, nz);
+      if (zs < 4 && nz > 1) break;
+      const double cost = (double)cdiv_ll((long long)B * ntx * nty * cdiv(Ds, zs), nslots) * (zs + 1.0);
+      if (cost < best - 1e-9) {
+        best = cost;
+        zseg = zs;
+      }
+    }
+  }
+  const int nzs = cdiv(Ds, zseg);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2Cfg::LDS_FLOATS * 4);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3d_wgrad_s2_kernel, dim3((unsigned)nslots, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
+                     workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
+  int rc = launch_status("conv3d_s2_wgrad launch failed");
+  if (rc != DMB_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Cs, Cb, nslots, 0);
+  return launch_status("conv3d_s2_wgrad reduce launch failed");
 }

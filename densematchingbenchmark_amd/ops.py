@@ -288,6 +288,30 @@ def conv3d_k3_wgrad(x, dc):
     return dw
 
 
+def _s2_wgrad(small, big, what):
+    lib = _lib.load()
+    small, big = _f32c(small, "small"), _f32c(big, "big")
+    B, Cs, Ds, Hs, Ws = small.shape
+    Bb, Cb, Db, Hb, Wb = big.shape
+    if Bb != B:
+        raise _lib.DmbLibraryError("%s: batch sizes differ" % what)
+    dw = torch.empty((Cs, Cb, 3, 3, 3), dtype=torch.float32, device=small.device)
+    ws = torch.empty((lib.dmb_conv3d_wgrad_workspace_floats(Cs, Cb),), dtype=torch.float32, device=small.device)
+    check(lib.dmb_conv3d_k3s2_wgrad_f32(dev_ptr(small), dev_ptr(big), dev_ptr(dw), dev_ptr(ws), B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb,
+                                        stream_ptr(small.device)), what)
+    return dw
+
+
+def conv3d_k3s2_wgrad(x, dc):
+    """Weight gradient of nn.Conv3d(k=3, stride=2, padding=1): [Co, Ci, 3, 3, 3]."""
+    return _s2_wgrad(dc, x, "dmb_conv3d_k3s2_wgrad_f32 (conv)")
+
+
+def deconv3d_k3s2_wgrad(x, dy):
+    """Weight gradient of nn.ConvTranspose3d(k=3, s=2, p=1, output_padding=1): [Ci, Co, 3, 3, 3]."""
+    return _s2_wgrad(x, dy, "dmb_conv3d_k3s2_wgrad_f32 (transposed conv)")
+
+
 # ---------------------------------------------------------------------------------------------- BatchNorm (training)
 def _bcs(t):
     """[B, C, *spatial] -> (B, C, S)."""

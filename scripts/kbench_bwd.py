@@ -33,3 +33,18 @@ for ci, co, d, h, w in ((32, 32, 48, 136, 240), (64, 32, 48, 136, 240), (64, 64,
     report("wgrad s1 %d->%d %dx%dx%d" % (ci, co, d, h, w), timeit(lambda: ops.conv3d_k3_wgrad(x, dc)), fl)
     wp = ops.pack_conv3d_dgrad_weights(wt)
     report("dgrad s1 %d->%d %dx%dx%d" % (ci, co, d, h, w), timeit(lambda: ops.conv3d_k3(dc, wp, ci)), fl)
+
+for ci, co, d, h, w in ((32, 64, 48, 136, 240), (64, 64, 24, 68, 120)):
+    x = torch.randn(B, ci, d, h, w, device=dev)
+    dc = torch.randn(B, co, d // 2, h // 2, w // 2, device=dev)
+    fl = 2.0 * 27 * ci * co * B * (d // 2) * (h // 2) * (w // 2)
+    report("wgrad s2 conv %d->%d from %dx%dx%d" % (ci, co, d, h, w), timeit(lambda: ops.conv3d_k3s2_wgrad(x, dc)), fl)
+    wt = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.03
+    report("dgrad s2 conv %d->%d" % (ci, co), timeit(lambda: ops.conv3d_k3_dgrad(dc, wt, 2)), fl)
+for ci, co, d, h, w in ((64, 32, 24, 68, 120), (64, 64, 12, 34, 60)):
+    x = torch.randn(B, ci, d, h, w, device=dev)
+    dy = torch.randn(B, co, 2 * d, 2 * h, 2 * w, device=dev)
+    fl = 2.0 * 27 * ci * co * B * d * h * w
+    report("wgrad deconv %d->%d from %dx%dx%d" % (ci, co, d, h, w), timeit(lambda: ops.deconv3d_k3s2_wgrad(x, dy)), fl)
+    wt = torch.randn(ci, co, 3, 3, 3, device=dev) * 0.03
+    report("dgrad deconv %d->%d" % (ci, co), timeit(lambda: ops.deconv3d_k3s2_dgrad(dy, wt)), fl)

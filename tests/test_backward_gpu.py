@@ -185,3 +185,38 @@ def test_upsample_regression_backward(dev, lo, scale):
     assert got.shape == x.shape
     # tolerance: FP32 interpolation weights + __expf against an FP64 evaluation, relative to the largest entry
     assert (got.double() - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("Ci,Co,shape", [
+    (32, 64, (1, 8, 12, 24)),
+    (64, 64, (2, 6, 8, 48)),
+    (32, 32, (1, 7, 9, 40)),        # odd extents of the big tensor (2n - 1)
+    (16, 40, (1, 4, 4, 8)),
+    (32, 64, (1, 24, 20, 56)),
+])
+def test_conv3d_s2_wgrad(dev, Ci, Co, shape):
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 1)
+    w = _rand((Co, Ci, 3, 3, 3), 3, 0.05)
+    dc = _rand((B, Co, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1), 2)
+    if dc.shape[-1] % 4:
+        pytest.skip("output width must be a multiple of 4")
+    _, dw32 = O.conv3d_backward(x, w, dc, 2)
+    _, dw64 = O.conv3d_backward(x, w, dc, 2, dtype=torch.float64)
+    got = ops.conv3d_k3s2_wgrad(x.to(dev), dc.to(dev)).cpu()
+    _close(got, dw64, dw32, "dW (stride 2)")
+
+
+@pytest.mark.parametrize("Ci,Co,shape", [(64, 64, (1, 3, 4, 12)), (64, 32, (2, 4, 6, 20)), (32, 8, (1, 5, 5, 8))])
+def test_deconv3d_wgrad(dev, Ci, Co, shape):
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 1)
+    w = _rand((Ci, Co, 3, 3, 3), 3, 0.05)
+    dy = _rand((B, Co, 2 * D, 2 * H, 2 * W), 2)
+    _, dw32 = O.deconv3d_backward(x, w, dy)
+    _, dw64 = O.deconv3d_backward(x, w, dy, dtype=torch.float64)
+    got = ops.deconv3d_k3s2_wgrad(x.to(dev), dy.to(dev)).cpu()
+    assert got.shape == w.shape
+    _close(got, dw64, dw32, "dW (transposed)")
