@@ -218,6 +218,7 @@ struct Wg2Cfg {
   static_assert(SB % 8 == 4 && SS % 8 == 4 && LDS_FLOATS * 4 <= 160 * 1024 && 2 * IB + IS <= KSTEPS, "tile");
 };
 
+template <bool V16>
 __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __restrict__ sm, const float* __restrict__ bg,
                                                                  float* __restrict__ ws, int B, int Cs, int Cb, int Ds, int Hs,
                                                                  int Ws, int Db, int Hb, int Wb, int ntx, int nty, int nzs,
@@ -288,14 +289,52 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __
       const int first = (j * 4 + wave) * 64;
       if (first + lane < 32 * C::US) dma16(srs, zok ? svo[j] : DMA_OOB, zok ? (unsigned)gz * HWs * 4u : 0u, sbuf + buf * C::SPLANE + first * 4);
     };
+    // widths that are not multiples of 4: whole planes with dword copies, one staged row per instruction (slow path)
+    auto stage_b_rows = [&](int gz, int rslot) {
+      const bool zok = gz >= 0 && gz < Db;
+      const int gx = 2 * x0 - 4 + lane;
+      if (lane < C::P) {
+        for (int i = 0; i < 8; ++i) {
+          const int c = wave * 8 + i;
+#pragma unroll
+          for (int row = 0; row < C::ROWS; ++row) {
+            const int gy = 2 * y0 - 1 + row;
+            const bool ok = zok && gy >= 0 && gy < Hb && gx >= 0 && gx < Wb;
+            dma4(brs, ok ? ((unsigned)gy * Wb + (unsigned)gx) * 4u : DMA_OOB, ok ? ((unsigned)c * DHWb + (unsigned)gz * HWb) * 4u : 0u,
+                 ring + rslot * C::BPLANE + c * C::SB + row * C::P);
+          }
+        }
+      }
+    };
+    auto stage_s_rows = [&](int gz, int buf) {
+      const bool zok = gz >= 0 && gz < zb;
+      const int gx = x0 + lane;
+      if (lane < C::TX) {
+        for (int i = 0; i < 8; ++i) {
+          const int c = wave * 8 + i;
+#pragma unroll
+          for (int row = 0; row < C::TY; ++row) {
+            const int gy = y0 + row;
+            const bool ok = zok && gy < Hs && gx < Ws;
+            dma4(srs, ok ? ((unsigned)gy * Ws + (unsigned)gx) * 4u : DMA_OOB, ok ? ((unsigned)c * DHWs + (unsigned)gz * HWs) * 4u : 0u,
+                 sbuf + buf * C::SPLANE + c * C::SS + row * C::TX);
+          }
+        }
+      }
+    };
     // ring slot of big plane p: (p - (2 za - 1)) % 5
     __syncthreads();
+    if constexpr (V16) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int j = 0; j < C::IB; ++j) stage_b1(2 * za - 1 + q, q, j);
+        for (int j = 0; j < C::IB; ++j) stage_b1(2 * za - 1 + q, q, j);
 #pragma unroll
-    for (int j = 0; j < C::IS; ++j) stage_s1(za, 0, j);
+      for (int j = 0; j < C::IS; ++j) stage_s1(za, 0, j);
+    } else {
+      for (int q = 0; q < 3; ++q) stage_b_rows(2 * za - 1 + q, q);
+      stage_s_rows(za, 0);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     int q0 = 0;   // ring index of plane 2 z - 1
@@ -307,6 +346,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __
 #pragma unroll
       for (int i = 0; i < C::NTAPW; ++i) bp[i] = ring + ((q0 + tapdz[i]) % C::NRING) * C::BPLANE + tapoff[i];
       const int s3 = (q0 + 3) % C::NRING, s4 = (q0 + 4) % C::NRING;
+      if constexpr (!V16) {
+        if (more) {
+          stage_b_rows(2 * z + 2, s3);
+          stage_b_rows(2 * z + 3, s4);
+          stage_s_rows(z + 1, (rel + 1) & 1);
+        }
+      }
       float af[2], bf[2][C::NTAPW];
       auto load_frag = [&](int q, float& a, float (&bq)[C::NTAPW]) {
         const int r = q / (C::TX / 2), c = q % (C::TX / 2);
@@ -321,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < C::NTAPW; ++i) acc[i] = DMB_MFMA(af[q & 1], bf[q & 1][i], acc[i]);
-        if (more) {   // the next planes, one copy per k-step
+        if (V16 && more) {   // the next planes, one copy per k-step
           if (q < C::IB)
             stage_b1(2 * z + 2, s3, q);
           else if (q < 2 * C::IB)
@@ -449,8 +495,7 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
   if ((Db != 2 * Ds && Db != 2 * Ds - 1) || (Hb != 2 * Hs && Hb != 2 * Hs - 1) || (Wb != 2 * Ws && Wb != 2 * Ws - 1))
     return fail(DMB_EINVAL, "conv3d_s2_wgrad: the big tensor must be 2n or 2n - 1 per axis");
   if ((long long)32 * Db * Hb * Wb * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_s2_wgrad: 32 channels of one batch item must stay below 2 GiB");
-  if (Ws % 4 != 0 || Wb % 4 != 0 || (((uintptr_t)small | (uintptr_t)big) & 15) != 0)
-    return fail(DMB_EUNSUPPORTED, "conv3d_s2_wgrad: widths must be multiples of 4 and the tensors 16-byte aligned");
+  const bool v16 = Ws % 4 == 0 && Wb % 4 == 0 && (((uintptr_t)small | (uintptr_t)big) & 15) == 0;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = cdiv(Cs, 32) * cdiv(Cb, 32);
   const int ntx = cdiv(Ws, Wg2Cfg::TX), nty = cdiv(Hs, Wg2Cfg::TY);
@@ -471,11 +516,16 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
   const int nzs = cdiv(Ds, zseg);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2Cfg::LDS_FLOATS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2Cfg::LDS_FLOATS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2Cfg::LDS_FLOATS * 4);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3d_wgrad_s2_kernel, dim3((unsigned)nslots, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
-                     workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
+  if (v16)
+    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<true>, dim3((unsigned)nslots, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
+                       workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
+  else
+    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<false>, dim3((unsigned)nslots, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
+                       workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
   int rc = launch_status("conv3d_s2_wgrad launch failed");
   if (rc != DMB_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Cs, Cb, nslots, 0);

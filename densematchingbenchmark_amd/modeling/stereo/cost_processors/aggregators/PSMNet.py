@@ -2,6 +2,7 @@
 import torch.nn as nn
 
 from ..... import ops
+from ...layers import train_fn
 from ...layers.basic_layers import HeadConv3d, conv3d_bn, conv3d_bn_relu
 from ..utils.hourglass import Hourglass
 
@@ -47,6 +48,9 @@ class PSMAggregator(nn.Module):
         vals = ops.disp_sample_values(self.max_disp, 0, 1)
         up = []
         for c in (cost3, cost2, cost1):
-            cost, disp = ops.trilinear_ac_soft_argmin(c.squeeze(1), size, vals, 1.0)
+            if train_fn.wants_grad(self, c):   # differentiable through the disparity
+                cost, disp = train_fn.UpsampleRegressFn.apply(c.squeeze(1), size, tuple(vals), 1.0)
+            else:
+                cost, disp = ops.trilinear_ac_soft_argmin(c.squeeze(1), size, vals, 1.0)
             up.append(ops.RegressionHint.attach(cost, vals, 1.0, disp))
         return up

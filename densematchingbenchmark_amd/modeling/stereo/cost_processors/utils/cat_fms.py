@@ -1,11 +1,16 @@
 """Concatenation cost volume: drop-in for dmb/modeling/stereo/cost_processors/utils/cat_fms.py (``CAT_FUNCS``)."""
+import torch
+
 from ..... import ops
+from ...layers import train_fn
 
 
 def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
     """[B, C, H, W] x 2 -> [B, 2C, D, H, W]; same arguments and semantics as cat_fms.py:7-48 (``disp_sample`` is
     ignored there too).  One HIP kernel launch instead of 2*D strided slice copies; output is FP32 (cat_fms.py:32)."""
     idx = ops.disp_index_list(max_disp, start_disp, dilation)
+    if torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad):
+        return train_fn.CatFmsFn.apply(reference_fm.float().contiguous(), target_fm.float().contiguous(), tuple(idx))
     return ops.cat_fms(reference_fm.float(), target_fm.float(), idx)
 
 

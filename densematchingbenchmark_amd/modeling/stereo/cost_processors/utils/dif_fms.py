@@ -1,11 +1,16 @@
 """Difference cost volume: drop-in for dmb/modeling/stereo/cost_processors/utils/dif_fms.py (``DIF_FUNCS``)."""
+import torch
+
 from ..... import ops
+from ...layers import train_fn
 
 
 def dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None,
             normalize=False, p=1.0):
     """[B, C, H, W] x 2 -> [B, C, D, H, W] (dif_fms.py:7-46; ``normalize``/``p`` are unused there as well)."""
     idx = ops.disp_index_list(max_disp, start_disp, dilation)
+    if torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad):
+        return train_fn.DifFmsFn.apply(reference_fm.float().contiguous(), target_fm.float().contiguous(), tuple(idx))
     return ops.dif_fms(reference_fm.float(), target_fm.float(), idx)
 
 

@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from ..layers import train_fn
 from .soft_argmin import _SoftArgminBase
 
 
@@ -33,6 +34,8 @@ class FasterSoftArgmin(_SoftArgminBase):
         hint = ops.RegressionHint.lookup(cost_volume, vals, self.alpha, self.normalize)
         if hint is not None:     # the producing kernel already regressed this very tensor with these parameters
             return hint
+        if self.normalize and torch.is_grad_enabled() and cost_volume.requires_grad:
+            return train_fn.SoftArgminFn.apply(cost_volume, tuple(vals), self.alpha)
         return ops.soft_argmin(cost_volume, vals, self.alpha, self.normalize)
 
     @property

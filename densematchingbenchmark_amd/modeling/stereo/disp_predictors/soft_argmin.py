@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from ..layers import train_fn
 
 
 class _SoftArgminBase(nn.Module):
@@ -44,6 +45,8 @@ class SoftArgmin(_SoftArgminBase):
             hint = ops.RegressionHint.lookup(cost_volume, vals, self.alpha, self.normalize)
             if hint is not None:     # the producing kernel already regressed this very tensor with these parameters
                 return hint
+            if self.normalize and torch.is_grad_enabled() and cost_volume.requires_grad:
+                return train_fn.SoftArgminFn.apply(cost_volume, tuple(vals), self.alpha)
             return ops.soft_argmin(cost_volume, vals, self.alpha, self.normalize)
         assert D == disp_sample.shape[1], 'The number of disparity samples should be consistent!'
         return ops.soft_argmin_sampled(cost_volume, disp_sample.float().expand_as(cost_volume).contiguous(),

@@ -4,12 +4,14 @@ Mirrors the factories of dmb/modeling/stereo/layers/basic_layers.py:68-100,160-1
 order, same ``state_dict`` keys (``<unit>.0.weight``, ``<unit>.1.running_mean`` ...) -- but every unit is a
 ``FusedConv3d`` whose forward is ONE kernel launch: convolution with BatchNorm folded into a per-channel
 scale/shift, optional residual add and ReLU in the epilogue.  torch.nn modules are kept only as parameter
-containers so that reference checkpoints load with ``load_state_dict``.  Inference only; no CPU fallback.
+containers so that reference checkpoints load with ``load_state_dict``.  In training mode (or when an input carries a
+gradient) the same units run as autograd Functions on the HIP kernels (train_fn.py).  No CPU fallback.
 """
 import torch
 import torch.nn as nn
 
 from .... import ops
+from . import train_fn
 
 __all__ = ["FusedConv3d", "HeadConv3d", "HeadDeconv3d", "conv3d_bn", "conv3d_bn_relu", "deconv3d_bn", "deconv3d_bn_relu",
            "fold_batch_norm"]
@@ -84,14 +86,16 @@ class FusedConv3d(nn.Sequential):
     def forward(self, x, residual=None, relu=None, skip=None):
         """``residual`` is added BEFORE the activation (hourglass.py:67-81), ``skip`` AFTER it (GC-Net,
         aggregators/GCNet.py:108-116: ``layer34(cost33 + cost29)`` -- the add runs in layer33's epilogue)."""
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("FusedConv3d is an inference-only HIP path: call model.eval() and run under torch.no_grad()")
-        wp, scale, shift = self._prepacked()
         act = self.has_relu if relu is None else relu
         if skip is not None:
             if residual is not None:
                 raise ValueError("FusedConv3d: residual and skip are mutually exclusive")
             residual, act = skip, ("pre" if act else False)
+        if train_fn.wants_grad(self, x, residual):
+            # training / differentiable path (SURVEY 8-f3): conv, BatchNorm statistics, epilogue and their backward
+            # passes as separate HIP launches under torch.autograd
+            return train_fn.conv_unit(self, x, residual, act)
+        wp, scale, shift = self._prepacked()
         if self.transposed:
             return ops.deconv3d_k3s2(x, wp, self.out_planes, scale, shift, residual, act)
         if ops.conv3d_mode() == "bf16x6" and ops.conv3d_x6_applicable(x, self.out_planes, self.stride):
@@ -114,8 +118,8 @@ class HeadConv3d(nn.Conv3d):
         self._bias_key, self._bias_val = None, 0.0
 
     def forward(self, x, residual=None):
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("HeadConv3d is an inference-only HIP path")
+        if train_fn.wants_grad(self, x, residual):
+            return train_fn.HeadConvFn.apply(x, self.weight, self.bias, residual)
         b = 0.0
         if self.bias is not None:
             key = _versions(self.bias)

@@ -1,0 +1,211 @@
+"""Autograd of the cost-path units on the HIP kernels (second part).
+
+What torch.autograd does for the reference's ``nn.Sequential(Conv3d | ConvTranspose3d, BatchNorm3d[, ReLU])`` units
+(dmb/modeling/stereo/layers/basic_layers.py:68-100,160-177), its skip adds (cost_processors/utils/hourglass.py:62-86),
+the cost-volume builders (cost_processors/utils/cat_fms.py:7-48, dif_fms.py:7-46) and the up-sampling + soft-argmin
+tail (aggregators/PSMNet.py:74-93, disp_predictors/faster_soft_argmin.py:51-75), expressed as ``autograd.Function``s
+whose forward and backward are HIP kernel launches:
+
+  forward   raw = conv(x, w) (+ bias)              the inference kernel without its epilogue
+            scale/shift from batch statistics (training) or the running buffers (eval)      bn_train_stats
+            y = act(raw*scale + shift (+ skip))                                             bn_act
+  backward  dc, dgamma, dbeta, dskip <- dy                                                  bn_act_bwd
+            dw = wgrad(x, dc)                                                               conv3d_k3[s2]_wgrad
+            dx = the forward kernel of the adjoint convolution on re-packed weights         conv3d_k3 / deconv3d_k3s2
+
+There is no fallback to torch's convolution backward: without the library these raise like every other op.
+"""
+import torch
+
+from .... import ops
+
+_RELU = {0: False, 1: True, 2: "pre"}
+
+
+def _relu_code(relu):
+    return 2 if relu == "pre" else (1 if relu else 0)
+
+
+def _conv_raw(unit, x, weight, bias):
+    """The unit's convolution without BatchNorm / activation (+ bias through the kernel's shift operand)."""
+    Co = unit.out_planes
+    scale = shift = None
+    if bias is not None:
+        scale, shift = torch.ones_like(bias), bias.detach().contiguous()
+    if unit.transposed:
+        return ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(weight), Co, scale, shift, None, False)
+    return ops.conv3d_k3(x, ops.pack_conv3d_weights(weight), Co, scale, shift, None, unit.stride, False)
+
+
+class ConvUnitFn(torch.autograd.Function):
+    """y = act(BN(conv(x)) (+ skip)) of one FusedConv3d unit; ``unit`` supplies the geometry and the BN buffers."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, skip, unit, relu):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        raw = _conv_raw(unit, x, w, bias)
+        C = unit.out_planes
+        bn = unit[1] if unit.has_bn else None
+        batch_stats = bn is not None and unit.training
+        if batch_stats:
+            rm = bn.running_mean if bn.track_running_stats else None
+            rv = bn.running_var if bn.track_running_stats else None
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            mean, invstd, scale, shift = ops.bn_train_stats(raw, gamma.detach() if gamma is not None else None,
+                                                            beta.detach() if beta is not None else None, rm, rv, momentum, bn.eps)
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        elif bn is not None:
+            mean = bn.running_mean.detach().float()
+            invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+            g = gamma.detach() if gamma is not None else torch.ones_like(mean)
+            b = beta.detach() if beta is not None else torch.zeros_like(mean)
+            scale = g * invstd
+            shift = b - mean * scale
+        else:
+            mean = torch.zeros(C, dtype=torch.float32, device=x.device)
+            invstd = torch.ones_like(mean)
+            scale, shift = torch.ones_like(mean), torch.zeros_like(mean)
+        code = _relu_code(relu)
+        if bn is None and skip is None and code == 0:
+            y = raw
+        else:
+            y = ops.bn_act(raw, scale, shift, skip, _RELU[code])
+        ctx.unit, ctx.code, ctx.batch_stats = unit, code, batch_stats
+        ctx.has = (bias is not None, gamma is not None, beta is not None, skip is not None)
+        ctx.save_for_backward(x, w, raw, y if code == 1 else None, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, raw, y, scale, shift, mean, invstd = ctx.saved_tensors
+        unit, code = ctx.unit, ctx.code
+        has_bias, has_gamma, has_beta, has_skip = ctx.has
+        dy = dy.contiguous()
+        need_dres = has_skip and ctx.needs_input_grad[5]
+        dc, dgamma, dbeta, dres = ops.bn_act_bwd(dy, raw, y, scale, shift, mean, invstd, _RELU[code], ctx.batch_stats,
+                                                 want_dres=need_dres and code == 1)
+        if need_dres and code != 1:
+            dres = dy                       # the skip branch joins after the activation (or there is none)
+        dw = dx = dbias = None
+        if ctx.needs_input_grad[1]:
+            if unit.transposed:
+                dw = ops.deconv3d_k3s2_wgrad(x, dc)
+            elif unit.stride == 2:
+                dw = ops.conv3d_k3s2_wgrad(x, dc)
+            else:
+                dw = ops.conv3d_k3_wgrad(x, dc)
+        if ctx.needs_input_grad[0]:
+            dx = ops.deconv3d_k3s2_dgrad(dc, w) if unit.transposed else ops.conv3d_k3_dgrad(dc, w, unit.stride)
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = dc.sum(dim=(0, 2, 3, 4))
+        return (dx, dw, dbias, dgamma if has_gamma and ctx.needs_input_grad[3] else None,
+                dbeta if has_beta and ctx.needs_input_grad[4] else None, dres if need_dres else None, None, None)
+
+
+def conv_unit(unit, x, residual=None, relu=False):
+    """Differentiable forward of a FusedConv3d unit (``relu``: False / True = after the skip add / 'pre' = before it)."""
+    conv = unit[0]
+    bn = unit[1] if unit.has_bn else None
+    gamma = bn.weight if bn is not None and bn.affine else None
+    beta = bn.bias if bn is not None and bn.affine else None
+    return ConvUnitFn.apply(x, conv.weight, conv.bias, gamma, beta, residual, unit, relu)
+
+
+class HeadConvFn(torch.autograd.Function):
+    """nn.Conv3d(C, 1, 3, 1, 1) (+ bias) (+ the cumulative cost add of PSMNet.py:71-72)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        b = float(bias.detach().cpu()[0]) if bias is not None else 0.0
+        ctx.save_for_backward(x, w)
+        ctx.has = (bias is not None, residual is not None)
+        return ops.conv3d_k3_c1(x, w, b, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = dbias = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3d_k3_dgrad(dy, w, 1)              # a convolution 1 -> C on the mirrored taps
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv3d_k3_wgrad(x, dy)
+        if ctx.has[0] and ctx.needs_input_grad[2]:
+            dbias = dy.sum().reshape(1)
+        return dx, dw, dbias, (dy if ctx.has[1] and ctx.needs_input_grad[3] else None)
+
+
+class CatFmsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, right, disp_idx):
+        ctx.disp_idx = tuple(disp_idx)
+        return ops.cat_fms(left, right, list(disp_idx))
+
+    @staticmethod
+    def backward(ctx, dvol):
+        dL, dR = ops.cat_fms_bwd(dvol.contiguous(), list(ctx.disp_idx))
+        return dL, dR, None
+
+
+class DifFmsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, right, disp_idx):
+        ctx.disp_idx = tuple(disp_idx)
+        return ops.dif_fms(left, right, list(disp_idx))
+
+    @staticmethod
+    def backward(ctx, dvol):
+        dL, dR = ops.dif_fms_bwd(dvol.contiguous(), list(ctx.disp_idx))
+        return dL, dR, None
+
+
+class UpsampleRegressFn(torch.autograd.Function):
+    """(cost [B, Do, Ho, Wo], disp [B, 1, Ho, Wo]) of a low-resolution cost [B, Di, Hi, Wi].  Differentiable through the
+    disparity (the path every PSMNet loss takes); a loss on the up-sampled volume itself is not covered."""
+
+    @staticmethod
+    def forward(ctx, x, size, values, alpha):
+        x = x.contiguous()
+        cost, disp = ops.trilinear_ac_soft_argmin(x, size, values, alpha)
+        ctx.save_for_backward(x, disp)
+        ctx.size, ctx.values, ctx.alpha = tuple(size), tuple(values), float(alpha)
+        ctx.set_materialize_grads(False)
+        return cost, disp
+
+    @staticmethod
+    def backward(ctx, dcost, ddisp):
+        if dcost is not None:
+            raise NotImplementedError("gradient through the up-sampled cost volume itself is not built (only through its "
+                                      "soft-argmin): DESIGN.md section 8")
+        if ddisp is None:
+            return None, None, None, None
+        x, disp = ctx.saved_tensors
+        return ops.trilinear_ac_soft_argmin_bwd(x, disp, ddisp.contiguous(), ctx.size, list(ctx.values), ctx.alpha), None, None, None
+
+
+class SoftArgminFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, values, alpha):
+        cost = cost.contiguous()
+        disp = ops.soft_argmin(cost, list(values), alpha, True)
+        ctx.save_for_backward(cost, disp)
+        ctx.values, ctx.alpha = tuple(values), float(alpha)
+        return disp
+
+    @staticmethod
+    def backward(ctx, ddisp):
+        cost, disp = ctx.saved_tensors
+        return ops.soft_argmin_bwd(cost, disp, ddisp.contiguous(), list(ctx.values), ctx.alpha), None, None
+
+
+def wants_grad(module, *tensors):
+    """True when a forward call must build an autograd graph: gradients are enabled and the module is in training mode or
+    one of its inputs already carries a gradient.  (An eval-mode module fed plain tensors stays on the fused inference
+    kernels even outside torch.no_grad().)"""
+    if not torch.is_grad_enabled():
+        return False
+    return module.training or any(t is not None and t.requires_grad for t in tensors)

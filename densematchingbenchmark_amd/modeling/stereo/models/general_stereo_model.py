@@ -1,4 +1,5 @@
-"""The caller of the hot path: eval-mode contract of models/general_stereo_model.py:14-92.
+"""The caller of the hot path: models/general_stereo_model.py:14-92 (eval-mode contract; training mode = the same cost path
+under autograd on the HIP kernels + the configured disparity losses).
 
 The hot path starts at the feature maps: feed pre-computed features with ``batch['leftFeature'] /
 batch['rightFeature']``, pass any ``nn.Module`` with the reference's ``backbone(left, right) -> (ref_fms, tgt_fms)``
@@ -25,19 +26,39 @@ class GeneralizedStereoModel(nn.Module):
         self.cmn = build_cmn(cfg) if 'cmn' in cfg.model else None
         self.disp_predictor = build_disp_predictor(cfg)
         self.disp_refinement = None
+        self.loss_evaluator = None
         if 'disp_refinement' in cfg.model:                           # general_stereo_model.py:35-37
             from ..disp_refinement import build_disp_refinement
             self.disp_refinement = build_disp_refinement(cfg)
 
+    def _forward_train(self, batch, ref_fms, tgt_fms):
+        """general_stereo_model.py:60-77: the same forward under autograd, then the configured losses.  Built for the
+        cost path (volume builder, aggregator, regression) with the disparity losses; a refinement stage or a
+        confidence network in training mode is not."""
+        if self.disp_refinement is not None or self.cmn is not None:
+            raise NotImplementedError("training through disp_refinement / cmn is outside the HIP path built so far")
+        target = batch.get('leftDisp')
+        costs = self.cost_processor(ref_fms, tgt_fms)
+        disps = [self.disp_predictor(cost) for cost in costs]
+        if self.loss_evaluator is None:
+            if 'losses' not in self.cfg.model:
+                raise ValueError("training mode needs cfg.model.losses (general_stereo_model.py:40)")
+            from ..losses import make_gsm_loss_evaluator
+            self.loss_evaluator = make_gsm_loss_evaluator(self.cfg)
+        variance = None
+        if hasattr(self.cfg.model.losses, 'focal_loss'):
+            variance = self.cfg.model.losses.focal_loss.get('variance', None)
+        return {}, self.loss_evaluator(disps, costs, target, variance=variance)
+
     def forward(self, batch):
-        if self.training:
-            raise NotImplementedError("training (losses, backward) is outside the HIP inference path")
         if 'leftFeature' in batch:
             ref_fms, tgt_fms = batch['leftFeature'], batch['rightFeature']
         else:
             if self.backbone is None:
                 raise ValueError("no backbone attached: provide batch['leftFeature'] and batch['rightFeature']")
             ref_fms, tgt_fms = self.backbone(batch['leftImage'], batch['rightImage'])
+        if self.training:
+            return self._forward_train(batch, ref_fms, tgt_fms)
         with torch.no_grad():
             costs = self.cost_processor(ref_fms, tgt_fms)            # general_stereo_model.py:51
             disps = [self.disp_predictor(cost) for cost in costs]    # :54

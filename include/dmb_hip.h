@@ -285,7 +285,7 @@ int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* w
 /* Weight gradient of the stride-2 units: out[cs, cb, tap] = sum_{b, o} small[b, cs, o] * big[b, cb, 2 o + tap - 1].
  *   nn.Conv3d(k 3, s 2, p 1):                 small = dc [B, Co, Ds, Hs, Ws], big = x  [B, Ci, Db, Hb, Wb] -> dW [Co, Ci, 27]
  *   nn.ConvTranspose3d(k 3, s 2, p 1, op 1):  small = x  [B, Ci, ...],        big = dy [B, Co, 2Ds, ...]  -> dW [Ci, Co, 27]
- * Each big extent is 2n or 2n - 1; Ws and Wb multiples of 4, tensors 16-byte aligned.
+ * Each big extent is 2n or 2n - 1 (16-byte staging when both widths are multiples of 4 and the tensors aligned).
  * workspace: dmb_conv3d_wgrad_workspace_floats(Cs, Cb) floats. */
 int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, float* dw, float* workspace, int B, int Cs, int Cb,
                               int Ds, int Hs, int Ws, int Db, int Hb, int Wb, void* stream);

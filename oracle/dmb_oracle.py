@@ -104,11 +104,26 @@ def gwc_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, num
 # ------------------------------------------------------------------------------------------------------------
 # conv + BN (+ReLU) units: layers/basic_layers.py:68-100,160-177
 # ------------------------------------------------------------------------------------------------------------
+_BN_TRAINING = [False]
+
+
+class bn_training(object):
+    """``with bn_training():`` -- BatchNorm layers use batch statistics and update the running buffers in ``p`` in place
+    (nn.BatchNorm default momentum 0.1), as model.train() does for the reference."""
+
+    def __enter__(self):
+        _BN_TRAINING.append(True)
+
+    def __exit__(self, *exc):
+        _BN_TRAINING.pop()
+
+
 def _bn_eval(x, p, prefix):
-    """Eval-mode BatchNorm with running statistics; prefix names the nn.BatchNorm3d/2d module."""
+    """BatchNorm with running statistics (eval mode; batch statistics inside ``bn_training()``); prefix names the
+    nn.BatchNorm3d/2d module."""
     w, b = p[prefix + ".weight"], p[prefix + ".bias"]
     mean, var = p[prefix + ".running_mean"], p[prefix + ".running_var"]
-    return F.batch_norm(x, mean, var, w, b, training=False, eps=BN_EPS)
+    return F.batch_norm(x, mean, var, w, b, training=_BN_TRAINING[-1], momentum=0.1, eps=BN_EPS)
 
 
 def conv3d_unit(x, p, prefix, stride=1, batch_norm=True, relu=False):
@@ -544,6 +559,36 @@ def bn_act_train(c, gamma, beta, residual=None, relu=0, eps=1e-5, dy=None, dtype
         grads = torch.autograd.grad(v, ins, dy.to(dtype))
         out.update(dc=grads[0], dgamma=grads[1], dbeta=grads[2], dres=grads[3] if r is not None else None)
     return out
+
+
+def psmnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, level_weights=(1.0, 0.7, 0.5), loss_weight=1.0, dtype=torch.float32):
+    """One training forward/backward of the PSMNet cost path as the reference runs it (models/general_stereo_model.py:60-77
+    with losses/smooth_l1_loss.py): cat_fms -> PSMAggregator (BatchNorm in training mode) -> FasterSoftArgmin ->
+    weighted DispSmoothL1Loss per level; gradients by torch.autograd.  Returns (losses, grads, running) where grads maps
+    every learnable parameter (and 'ref_fms' / 'tgt_fms') to its gradient and running holds the updated BN buffers."""
+    q, leaves = dict(), dict()
+    for k, v in p.items():
+        v = v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+            leaves[k] = v
+        q[k] = v
+    L = ref_fms.detach().clone().to(dtype).requires_grad_(True)
+    R = tgt_fms.detach().clone().to(dtype).requires_grad_(True)
+    leaves["ref_fms"], leaves["tgt_fms"] = L, R
+    with bn_training():
+        raw = cat_fms(L, R, max_disp // 4, 0, 1).to(dtype)               # the builder's output is FP32 (cat_fms.py:32)
+        costs = psm_aggregator(raw, q, max_disp, "cost_processor.aggregator.")
+        if dtype == torch.float32:
+            disps = [faster_soft_argmin(c, max_disp, 0, 1, 1.0, True) for c in costs]
+        else:   # the same formula evaluated in `dtype`
+            ds = disp_sample_values(max_disp, 0, 1).to(dtype).view(1, -1, 1, 1)
+            disps = [torch.sum(F.softmax(c, dim=1) * ds, dim=1, keepdim=True) for c in costs]
+    losses = [level_weights[i] * loss_weight * disp_smooth_l1_loss(d, gt.to(dtype), max_disp) for i, d in enumerate(disps)]
+    names = list(leaves)
+    grads = torch.autograd.grad(sum(losses), [leaves[k] for k in names], allow_unused=True)
+    running = {k: v for k, v in q.items() if "running_" in k}
+    return [l.detach() for l in losses], dict(zip(names, grads)), running
 
 
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):

@@ -129,11 +129,11 @@ def test_bn_fold_matches_batch_norm():
     assert (x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) - ref).abs().max().item() <= 1e-6
 
 
-def test_modules_refuse_training_and_cpu():
+def test_modules_refuse_cpu_tensors():
     from densematchingbenchmark_amd.modeling import build_model
     m = build_model(_cfg())
     feats = dict(leftFeature=torch.zeros(1, 32, 16, 16), rightFeature=torch.zeros(1, 32, 16, 16))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.DmbLibraryError):    # training mode runs the same HIP kernels under autograd: no CPU path either
         m.train()(feats)
     with pytest.raises(_lib.DmbLibraryError):
         m.eval()(feats)
