@@ -1120,6 +1120,8 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     if (Co == 32) {
       if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
       if (rp) return DMB_S1(32, 48, 1, 16, 0);
+      // widths of the training crops (512 / 4 = 128) and other multiples of 32: 32-column row-pair tiles, nothing discarded
+      if (W % 32 == 0 && g_dev_opts[2] == 0 && aligned && out_small) return DMB_S1(32, 32, 1, 16, 0);
       return tx == 52 ? DMB_S1(32, 52, 1, 0, 0) : DMB_S1(32, 60, 1, 0, 0);
     }
     if (Co == 64) {
@@ -1128,11 +1130,13 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       // of which two widths exist: 40 and 24.  A launch here is only a few "rounds" of workgroups deep (W = 120, batch
       // 4: 2448 tiles of 40 columns on 2 x 256 slots = 4.8 rounds, measured 128 TF/s; 4080 tiles of 24 = 7.97 rounds, 145
       // TF/s), so the width is picked per launch by rounds x columns.
-      if (aligned && out_small && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0)) {
+      if (aligned && out_small && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0 || W % 32 == 0)) {
         const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 3LL * s1_num_cus();   // 3 workgroups per CU
         const long long c40 = W % 40 == 0 ? cdiv_ll(per * (W / 40), slots) * 40 : (1LL << 60);
+        const long long c32 = W % 32 == 0 ? cdiv_ll(per * (W / 32), slots) * 32 : (1LL << 60);
         const long long c24 = W % 24 == 0 ? cdiv_ll(per * (W / 24), slots) * 24 : (1LL << 60);
-        if (c24 < c40) return DMB_S1(64, 24, 2, 8, 40);
+        if (c24 < c40 && c24 <= c32) return DMB_S1(64, 24, 2, 8, 40);
+        if (c32 < c40) return DMB_S1(64, 32, 2, 8, 40);   // (training crops: W = 64 at half resolution)
         return DMB_S1(64, 40, 2, 8, 56);
       }
       return tx == 52 ? DMB_S1(64, 52, 2, 0, 0) : DMB_S1(64, 60, 2, 0, 0);

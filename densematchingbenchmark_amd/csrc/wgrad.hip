@@ -394,6 +394,60 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One output channel (the classifier heads, nn.Conv3d(C, 1, 3, 1, 1)): dw[ci, tap] = sum_u x[ci, u] * dy[u - tap + 1].
+// 27 x C x voxels multiply-adds is nothing for the vector ALUs; the kernel is one coalesced pass over x (a wave = 64
+// consecutive columns of one channel row) with the 27 dy neighbours from the cache hierarchy (dy is one channel),
+// private sums per lane, one wave reduction at the end, partials per row chunk added in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int C1_CHUNKS = 128;
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ ws, int B, int Ci, int D, int H, int W) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ci = blockIdx.y * 4 + wave;
+  const long long rows = (long long)B * D * H;
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  if (ci < Ci) {
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+    for (long long r = r0; r < r1; ++r) {
+      const int y = (int)(r % H), z = (int)((r / H) % D), b = (int)(r / ((long long)H * D));
+      const float* xr = x + ((size_t)b * Ci + ci) * DHW + (size_t)z * HW + (size_t)y * W;
+      const float* db = dy + (size_t)b * DHW;
+      for (int x0 = 0; x0 < W; x0 += 64) {
+        const int xx = x0 + lane;
+        if (xx >= W) continue;
+        const float xv = xr[xx];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+          const int zz = z - t / 9 + 1, yy = y - (t / 3) % 3 + 1, xn = xx - t % 3 + 1;
+          const bool ok = zz >= 0 && zz < D && yy >= 0 && yy < H && xn >= 0 && xn < W;
+          const float dv = ok ? db[(size_t)zz * HW + (size_t)yy * W + xn] : 0.f;
+          acc[t] = fmaf(xv, dv, acc[t]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    float v = acc[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0 && ci < Ci) ws[((size_t)blockIdx.x * Ci + ci) * 27 + t] = v;
+  }
+}
+
+__global__ void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Ci, int nchunk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Ci * 27) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunk; ++c) s += (double)ws[(size_t)c * Ci * 27 + i];
+  dw[i] = (float)s;
+}
+
 // dw[co][ci][tap] = sum over slots (fixed order, FP32 pairwise by halves of the slot range would not be more accurate than
 // the per-slot chains themselves; a plain ascending sum in double keeps the last step exact to FP32 rounding)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nslots, int transposed) {
@@ -407,9 +461,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     const int cib = blk % ncib, cob = blk / ncib;
     const int co = cob * 32 + m, ci = cib * 32 + nn;
     if (co >= Co || ci >= Ci) continue;
-    double s = 0.0;
+    // eight interleaved partial sums (fixed assignment slot -> partial, fixed final order): the loads of one thread are
+    // independent, a single dependent chain of 256 adds would leave the pass latency-bound
     const float* p = ws + (size_t)blk * nslots * 27 * 1024 + t * 1024 + m * 32 + nn;
-    for (int sl = 0; sl < nslots; ++sl) s += (double)p[(size_t)sl * 27 * 1024];
+    double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int sl = 0;
+    for (; sl + 8 <= nslots; sl += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part[u] += (double)p[(size_t)(sl + u) * 27 * 1024];
+    }
+    for (; sl < nslots; ++sl) part[sl & 7] += (double)p[(size_t)sl * 27 * 1024];
+    const double s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     if (transposed)
       dw[((size_t)ci * Co + co) * 27 + t] = (float)s;
     else
@@ -451,6 +513,11 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
     return fail(DMB_EINVAL, "conv3d_wgrad: bad argument");
   if ((long long)32 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_wgrad: 32 channels of one batch item must stay below 2 GiB");
   hipStream_t st = (hipStream_t)stream;
+  if (Co == 1) {   // classifier heads: the dedicated single-channel kernel (the workspace of the general case is larger)
+    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(C1_CHUNKS, cdiv(Ci, 4)), dim3(256), 0, st, x, dc, workspace, B, Ci, D, H, W);
+    hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(cdiv(Ci * 27, 256)), dim3(256), 0, st, workspace, dw, Ci, C1_CHUNKS);
+    return launch_status("conv3d_wgrad (1 channel) launch failed");
+  }
   const int nblk = cdiv(Co, 32) * cdiv(Ci, 32);
   const int ntx = cdiv(W, WgCfg::TX), nty = cdiv(H, WgCfg::TY);
   // z segments: the split that minimises rounds x (planes per item + prologue); a round = one item on every slot

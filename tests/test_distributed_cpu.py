@@ -68,3 +68,53 @@ def test_two_rank_all_reduce_matches_whole_dataset():
     for rank, mine, count, vals in got:
         assert count == NUM_PAIRS == n          # every rank sees the whole-job image count after the all-reduce
         assert np.allclose(vals, [ref[k] for k in ("epe", "1px", "2px", "3px", "5px")], rtol=1e-9, atol=1e-9)
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from densematchingbenchmark_amd.dist_utils import FlatGradients, all_reduce_grads
+    torch.manual_seed(0)                      # same initial weights on every rank
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    res = {}
+    for mode in ("flat", "coalesced", "one_by_one"):
+        model.zero_grad(set_to_none=True)
+        if hasattr(model, "_dmb_flat_grads"):
+            del model._dmb_flat_grads
+        flat = FlatGradients(model).zero_() if mode == "flat" else None
+        x = torch.randn(4, 5, generator=torch.Generator().manual_seed(100 + rank))   # this rank's shard of the batch
+        model(x).square().mean().backward()
+        if flat is not None:
+            assert flat.attached()            # autograd accumulated into the views, not into fresh tensors
+        all_reduce_grads(model, coalesce=(mode != "one_by_one"))
+        res[mode] = [p.grad.clone() for p in model.parameters()]
+    out.put((rank, {k: [g.numpy() for g in v] for k, v in res.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce():
+    """dist_utils.all_reduce_grads (reference dmb/utils/dist_utils.py:36-48): the averaged gradient of two ranks equals
+    the gradient of the mean of the two shard losses, identically on both ranks and for all three exchange modes."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(WORLD))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    loss = sum(model(torch.randn(4, 5, generator=torch.Generator().manual_seed(100 + r))).square().mean() for r in range(WORLD)) / WORLD
+    ref = [g.numpy() for g in torch.autograd.grad(loss, list(model.parameters()))]
+    for rank in range(WORLD):
+        for mode, grads in got[rank].items():
+            for a, b in zip(grads, ref):
+                assert np.allclose(a, b, rtol=1e-6, atol=1e-7), (rank, mode)

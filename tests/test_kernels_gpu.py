@@ -113,6 +113,10 @@ def test_conv3d_k3(dev, Ci, Co, stride, shape):
     (64, 64, 1, (1, 4, 7, 72)),     # W % 24 == 0 only -> 24-column row-quad tiles
     (64, 64, 1, (4, 24, 20, 120)),  # both widths possible: picked by the rounds x columns model
     (64, 64, 1, (1, 4, 9, 60)),     # few tiles, W % 30 == 0 -> 30-column flattened tiles
+    (32, 32, 1, (2, 5, 7, 128)),    # training-crop widths: 32-column row-pair tiles ...
+    (64, 32, 1, (1, 4, 6, 64)),
+    (64, 64, 1, (1, 5, 9, 64)),     # ... and 32-column row-quad tiles
+    (32, 64, 1, (2, 4, 8, 32)),
 ])
 def test_conv3d_any_channels(dev, Ci, Co, stride, shape):
     ops = _ops()
