@@ -140,6 +140,44 @@ def split_mode_leg(step, exact_disps, B, steps):
             "note": "6 bf16 MFMA products per FP32 product, FP32 accumulate; see DESIGN.md section 8-1"}
 
 
+def training_leg(cfg, dev, steps):
+    """Secondary figure, NOT the headline: one training iteration of the same cost path -- features -> volume ->
+    aggregator with batch-statistics BatchNorm -> fused regression -> weighted smooth-L1, backward through the HIP kernels,
+    Adam step -- at the reference's training shape (256 x 512 crops, configs/PSMNet/scene_flow.py), batch 4."""
+    from densematchingbenchmark_amd.dist_utils import FlatGradients
+    B, H, W = 4, 256, 512
+    model = build_model(cfg).to(dev)
+    synthetic.init_params_(model, seed=0)
+    model.train()
+    flat = FlatGradients(model)
+    opt = torch.optim.Adam(flat.params, lr=1e-3)
+    g = torch.Generator().manual_seed(7)
+    batch = dict(leftFeature=torch.randn((B, 32, H // 4, W // 4), generator=g).to(dev),
+                 rightFeature=torch.randn((B, 32, H // 4, W // 4), generator=g).to(dev),
+                 leftDisp=(torch.rand((B, 1, H, W), generator=g) * 180.0 + 1.0).to(dev))
+
+    def one():
+        flat.zero_()
+        _, losses = model(batch)
+        sum(losses.values()).backward()
+        opt.step()
+
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"pairs_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "workload": "PSMNet cost path, training mode, batch %d x %dx%d crops, max_disp=192, Adam" % (B, H, W),
+           "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+    del model, flat, opt, batch
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -285,6 +323,8 @@ def main():
             out["end_to_end_with_backbone"] = end_to_end(model, dev, B, Hp, Wp, min(args.steps, 5))
             if args.conv3d_mode == "exact":
                 out["opt_in_bf16x6"] = split_mode_leg(step, disps, B, min(args.steps, 5))
+                if "losses" in cfg.model:
+                    out["training_step"] = training_leg(cfg, dev, min(args.steps, 5))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -396,47 +396,60 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __
 
 // ------------------------------------------------------------------------------------------------------------------
 // One output channel (the classifier heads, nn.Conv3d(C, 1, 3, 1, 1)): dw[ci, tap] = sum_u x[ci, u] * dy[u - tap + 1].
-// 27 x C x voxels multiply-adds is nothing for the vector ALUs; the kernel is one coalesced pass over x (a wave = 64
-// consecutive columns of one channel row) with the 27 dy neighbours from the cache hierarchy (dy is one channel),
-// private sums per lane, one wave reduction at the end, partials per row chunk added in a fixed order.
+// 27 x C x voxels multiply-adds is nothing for the vector ALUs; the kernel is one coalesced pass over x with the 27 dy
+// neighbours from the cache hierarchy (dy is one channel), private sums per lane, one block reduction at the end, partials
+// per voxel chunk added in a fixed order.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int C1_CHUNKS = 128;
-__global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ ws, int B, int Ci, int D, int H, int W) {
+constexpr int C1_CHUNKS = 128, C1_CG = 8;   // voxel chunks; channels per thread
+// A thread owns voxels (coalesced along x) and C1_CG channels: the 27 dy neighbours of a voxel are loaded once for all of
+// them (27 loads against 8 x 27 multiply-adds), the 8 x 27 sums live in registers until one block reduction at the end.
+__global__ __launch_bounds__(256, 1) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ ws, int B, int Ci, int D, int H, int W) {
+  __shared__ float red[4][C1_CG * 27];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ci = blockIdx.y * 4 + wave;
-  const long long rows = (long long)B * D * H;
-  const long long per = (rows + gridDim.x - 1) / gridDim.x;
-  const long long r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
-  float acc[27];
+  const int c0 = blockIdx.y * C1_CG;
+  const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+  const long long vox = (long long)B * DHW;
+  const long long per = ((vox + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const long long v0 = blockIdx.x * per, v1 = v0 + per < vox ? v0 + per : vox;
+  float acc[C1_CG][27];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
-  if (ci < Ci) {
-    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
-    for (long long r = r0; r < r1; ++r) {
-      const int y = (int)(r % H), z = (int)((r / H) % D), b = (int)(r / ((long long)H * D));
-      const float* xr = x + ((size_t)b * Ci + ci) * DHW + (size_t)z * HW + (size_t)y * W;
-      const float* db = dy + (size_t)b * DHW;
-      for (int x0 = 0; x0 < W; x0 += 64) {
-        const int xx = x0 + lane;
-        if (xx >= W) continue;
-        const float xv = xr[xx];
+  for (int c = 0; c < C1_CG; ++c)
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-          const int zz = z - t / 9 + 1, yy = y - (t / 3) % 3 + 1, xn = xx - t % 3 + 1;
-          const bool ok = zz >= 0 && zz < D && yy >= 0 && yy < H && xn >= 0 && xn < W;
-          const float dv = ok ? db[(size_t)zz * HW + (size_t)yy * W + xn] : 0.f;
-          acc[t] = fmaf(xv, dv, acc[t]);
-        }
-      }
+    for (int t = 0; t < 27; ++t) acc[c][t] = 0.f;
+  for (long long v = v0 + threadIdx.x; v < v1; v += 256) {
+    const int b = (int)(v / (long long)DHW);
+    const size_t r = (size_t)(v - (long long)b * DHW);
+    const int z = (int)(r / HW), y = (int)((r % HW) / W), xx = (int)(r % W);
+    const float* db = dy + (size_t)b * DHW;
+    float dn[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int zz = z - t / 9 + 1, yy = y - (t / 3) % 3 + 1, xn = xx - t % 3 + 1;
+      const bool ok = zz >= 0 && zz < D && yy >= 0 && yy < H && xn >= 0 && xn < W;
+      dn[t] = ok ? db[(size_t)zz * HW + (size_t)yy * W + xn] : 0.f;
+    }
+    const float* xp = x + ((size_t)b * Ci + c0) * DHW + r;
+#pragma unroll
+    for (int c = 0; c < C1_CG; ++c) {
+      const float xv = c0 + c < Ci ? xp[(size_t)c * DHW] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 27; ++t) acc[c][t] = fmaf(xv, dn[t], acc[c][t]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 27; ++t) {
-    float v = acc[t];
+  for (int c = 0; c < C1_CG; ++c)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0 && ci < Ci) ws[((size_t)blockIdx.x * Ci + ci) * 27 + t] = v;
+    for (int t = 0; t < 27; ++t) {
+      float vsum = acc[c][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
+      if (lane == 0) red[wave][c * 27 + t] = vsum;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C1_CG * 27; i += 256) {
+    const int c = i / 27, t = i - c * 27;
+    if (c0 + c < Ci) ws[((size_t)blockIdx.x * Ci + c0 + c) * 27 + t] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
   }
 }
 
@@ -514,7 +527,7 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
   if ((long long)32 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_wgrad: 32 channels of one batch item must stay below 2 GiB");
   hipStream_t st = (hipStream_t)stream;
   if (Co == 1) {   // classifier heads: the dedicated single-channel kernel (the workspace of the general case is larger)
-    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(C1_CHUNKS, cdiv(Ci, 4)), dim3(256), 0, st, x, dc, workspace, B, Ci, D, H, W);
+    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(C1_CHUNKS, cdiv(Ci, C1_CG)), dim3(256), 0, st, x, dc, workspace, B, Ci, D, H, W);
     hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(cdiv(Ci * 27, 256)), dim3(256), 0, st, workspace, dw, Ci, C1_CHUNKS);
     return launch_status("conv3d_wgrad (1 channel) launch failed");
   }
