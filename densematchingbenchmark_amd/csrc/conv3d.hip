@@ -611,7 +611,7 @@ struct DCfg {
   static constexpr int AFF_FLOATS = 2 * COUT;                 // scale / shift table behind the chunk buffers
   static constexpr int WPE = ((LDS_FLOATS + AFF_FLOATS) * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
   static_assert(P <= 64, "one wave stages one tile row per instruction");
-  static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0 && (!V16 || CH_STRIDE % 4 == 0), "shape");
+  static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0 && (!V16 || (CH_STRIDE % 4 == 0 && TX % 4 == 0)), "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
@@ -1145,7 +1145,14 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       return launch_s1<S1Cfg<0, 128, 2, 60, 2, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
   } else if (stride == 2) {
     const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned input rows
-    if (Co == 64 && v16) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+    if (Co == 64 && v16) {
+      // output positions computed per tile row: 32 with 30-column tiles, 24 with 22-column ones; the narrower tile wins at
+      // the training-crop widths (Wo = 64: 3 x 96 against 3 x 128 positions per 4 rows, Wo = 32: 2 x 96 against 2 x 128)
+      const int Wo = (W - 1) / 2 + 1;
+      if (cdiv(Wo, 22) * 96 < cdiv(Wo, 30) * 128)
+        return launch_s2<S2Cfg<0, 64, 4, 22, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+    }
     if (Co == 64) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     if (Co == 32) return launch_s2<S2Cfg<0, 32, 4, 30, 2, 1>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     if (Co == 128) return launch_s2<S2Cfg<0, 128, 4, 30, 2, 4>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
@@ -1162,6 +1169,11 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
     return fail(DMB_EUNSUPPORTED, "deconv3d: 8 input channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned rows
+  // 2 rows x 28 columns per item instead of 1 x 60 where that computes fewer positions (input W = 64: 3 x 32 against
+  // 2 x 64 per row; the tile width stays a multiple of 4 for the 16-byte staging)
+  const bool narrow = v16 && cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
+  if (Co == 64 && narrow) return launch_deconv<DCfg<0, 64, 2, 28, 4, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
+  if (Co <= 32 && narrow) return launch_deconv<DCfg<0, 32, 2, 28, 8, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
   if (Co == 64)
     return v16 ? launch_deconv<DCfg<0, 64, 1, 60, 4, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st)
                : launch_deconv<DCfg<0, 64, 1, 60, 4, 2, false>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);

@@ -117,6 +117,9 @@ def test_conv3d_k3(dev, Ci, Co, stride, shape):
     (64, 32, 1, (1, 4, 6, 64)),
     (64, 64, 1, (1, 5, 9, 64)),     # ... and 32-column row-quad tiles
     (32, 64, 1, (2, 4, 8, 32)),
+    (32, 64, 2, (1, 6, 8, 128)),    # stride 2 at crop widths: 22-column tiles
+    (64, 64, 2, (2, 4, 9, 64)),
+    (64, 64, 2, (1, 4, 8, 240)),    # ... and the 30-column ones
 ])
 def test_conv3d_any_channels(dev, Ci, Co, stride, shape):
     ops = _ops()
