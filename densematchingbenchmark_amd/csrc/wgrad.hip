@@ -20,8 +20,9 @@
 
 namespace dmb {
 
+template <int TX_>
 struct WgCfg {
-  static constexpr int TY = 4, TX = 24, ROWS = TY + 2, XOFF = 3;
+  static constexpr int TY = 4, TX = TX_, ROWS = TY + 2, XOFF = 3;
   static constexpr int P = (4 + TX + 1 + 3) / 4 * 4;            // staged row: aligned column x0 - 4 .. x0 + TX + 3
   static constexpr int SX = ROWS * P + 4, SD = TY * TX + 4;     // channel pitches (floats), = 4 mod 64
   static constexpr int XPLANE = 32 * SX, DPLANE = 32 * SD;
@@ -30,15 +31,15 @@ struct WgCfg {
   static constexpr int UX = ROWS * P / 4, UD = TY * TX / 4;     // 16-byte units per channel plane
   static constexpr int KSTEPS = TY * TX / 2;
   static constexpr int NTAPW = 7;                               // taps per wave (4 x 7 = 28 >= 27; the last one is a dummy)
-  static_assert(SX % 64 == 4 && SD % 64 == 36 % 64 && UX <= 64 && UD <= 64 && LDS_FLOATS * 4 <= 160 * 1024, "tile");
+  static_assert(SX % 8 == 4 && SD % 8 == 4 && UX <= 64 && UD <= 64 && LDS_FLOATS * 4 <= 160 * 1024, "tile");
 };
 
 // workspace layout: ws[((blk * nslots + slot) * 27 + tap) * 1024 + m * 32 + n], blk = cob * ncib + cib
-template <bool V16>
+template <bool V16, int TX_>
 __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s1_kernel(const float* __restrict__ x, const float* __restrict__ dc,
                                                                  float* __restrict__ ws, int B, int Ci, int Co, int D, int H,
                                                                  int W, int ntx, int nty, int nzs, int zseg) {
-  typedef WgCfg C;
+  typedef WgCfg<TX_> C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xring = lds;
   float* dbuf = lds + C::NRING * C::XPLANE;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s1_kernel(const float* __
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < C::NTAPW; ++i) acc[i] = DMB_MFMA(af[q & 1], bf[q & 1][i], acc[i]);
-        if (q % 2 == 0 && q / 2 < 16 && more) {   // the next planes, one copy every other k-step
+        if (q % 2 == 0 && q / 2 < 16 && more) {   // the next planes, one copy every other k-step (KSTEPS >= 32)
           if (q / 2 < 8)
             stage_x1(z + 2, (rel + 3) & 3, q / 2);
           else
@@ -532,7 +533,10 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
     return launch_status("conv3d_wgrad (1 channel) launch failed");
   }
   const int nblk = cdiv(Co, 32) * cdiv(Ci, 32);
-  const int ntx = cdiv(W, WgCfg::TX), nty = cdiv(H, WgCfg::TY);
+  // 24- or 32-column tiles: whichever covers W with fewer computed columns (W = 128 of the training crops: 128 against 144)
+  const bool wide = cdiv(W, 32) * 32 < cdiv(W, 24) * 24;
+  const int TX = wide ? 32 : 24;
+  const int ntx = cdiv(W, TX), nty = cdiv(H, 4);
   // z segments: the split that minimises rounds x (planes per item + prologue); a round = one item on every slot
   const int nslots = wgrad_slots_per_block(Co, Ci);
   int zseg = D;
@@ -553,15 +557,18 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
   const bool v16 = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)dc) & 15) == 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg::LDS_FLOATS * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg::LDS_FLOATS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<true, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<24>::LDS_FLOATS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<32>::LDS_FLOATS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<false, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<24>::LDS_FLOATS * 4);
     attr_set = true;
   }
   const dim3 grid((unsigned)nslots, (unsigned)nblk);
-  if (v16)
-    hipLaunchKernelGGL(conv3d_wgrad_s1_kernel<true>, grid, dim3(256), WgCfg::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, ntx, nty, nzs, zseg);
+  if (v16 && wide)
+    hipLaunchKernelGGL((conv3d_wgrad_s1_kernel<true, 32>), grid, dim3(256), WgCfg<32>::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, ntx, nty, nzs, zseg);
+  else if (v16)
+    hipLaunchKernelGGL((conv3d_wgrad_s1_kernel<true, 24>), grid, dim3(256), WgCfg<24>::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, ntx, nty, nzs, zseg);
   else
-    hipLaunchKernelGGL(conv3d_wgrad_s1_kernel<false>, grid, dim3(256), WgCfg::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, ntx, nty, nzs, zseg);
+    hipLaunchKernelGGL((conv3d_wgrad_s1_kernel<false, 24>), grid, dim3(256), WgCfg<24>::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, cdiv(W, 24), nty, nzs, zseg);
   int rc = launch_status("conv3d_wgrad launch failed");
   if (rc != DMB_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nslots, 0);

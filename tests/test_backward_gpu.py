@@ -37,6 +37,8 @@ def _close(got, ref64, ref32, what, floor=2e-6):
     (8, 40, (1, 3, 5, 12)),         # channel counts that are not multiples of 32
     (32, 32, (1, 4, 6, 30)),        # W % 4 != 0 -> dword staging
     (32, 32, (1, 20, 12, 48)),
+    (32, 32, (1, 6, 10, 128)),      # 32-column tiles
+    (64, 32, (2, 5, 6, 64)),
     (32, 1, (2, 6, 9, 70)),         # classifier head: the single-output-channel kernel
     (6, 1, (1, 3, 4, 5)),
 ])
