@@ -591,6 +591,31 @@ def psmnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, level_weights=(1.0, 0.7
     return [l.detach() for l in losses], dict(zip(names, grads)), running
 
 
+def stereonet_train_step(ref_fms, tgt_fms, p, max_disp, gt, dtype=torch.float32, num=4):
+    """Training forward/backward of the StereoNet cost path at the volume's own resolution (dif_fms -> StereoNetAggregator
+    with biased convolutions, BatchNorm in training mode -> soft-argmin -> smooth-L1 against ``gt`` [B, 1, H, W] given at
+    that resolution).  ``p``: aggregator-level names.  Returns (loss, grads, running)."""
+    q, leaves = dict(), dict()
+    for k, v in p.items():
+        v = v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+            leaves[k] = v
+        q[k] = v
+    L = ref_fms.detach().clone().to(dtype).requires_grad_(True)
+    R = tgt_fms.detach().clone().to(dtype).requires_grad_(True)
+    leaves["ref_fms"], leaves["tgt_fms"] = L, R
+    with bn_training():
+        raw = dif_fms(L, R, max_disp, 0, 1).to(dtype)
+        cost = stereonet_aggregator(raw, q, "", num=num)[0]
+        ds = disp_sample_values(max_disp, 0, 1).to(dtype).view(1, -1, 1, 1)
+        disp = torch.sum(F.softmax(cost, dim=1) * ds, dim=1, keepdim=True)
+    loss = disp_smooth_l1_loss(disp, gt.to(dtype), max_disp)
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    return loss.detach(), dict(zip(names, grads)), {k: v for k, v in q.items() if "running_" in k}
+
+
 def random_params_psm(seed=0, in_planes=64, classif_gain=10.0, bias=False, acf=False):
     """Seeded default-init parameters with the reference's state_dict names (what nn.Conv3d/BatchNorm3d
     default init produces, drawn with an explicit generator), classifier output convs scaled so that costs
