@@ -1,9 +1,12 @@
 // align_corners=True linear interpolation indices / weights, exactly as the CPU code path the reference's
 // F.interpolate call reaches (area_pixel_compute_scale / compute_indices_weights): FP32 scale (in-1)/(out-1),
 // src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.  Include from translation units
-// that switch fma contraction off (#pragma clang fp contract(off)): src must round before the subtraction.
+// src must round BEFORE the subtraction (an fma there moves lambda by an ulp of src, ~6e-5 at src ~ 900, and the
+// up-sampled costs with it), so this header switches fma contraction off for the rest of the translation unit.
 #pragma once
 #include "dmb_common.h"
+
+#pragma clang fp contract(off)
 
 namespace dmb {
 
