@@ -176,6 +176,26 @@ def test_trilinear(dev, ins, outs):
     assert (got - ref).abs().max().item() <= 2e-6  # same index/weight arithmetic, fma contraction may differ
 
 
+def test_trilinear_weights_round_like_the_reference(dev):
+    """The interpolation weight must be lambda = fl(fl(scale * dst) - i0) -- the product rounded BEFORE the subtraction, as in
+    the ATen CPU path the reference reaches -- not an fma of the two (csrc/interp.h).  A 0/1 comb makes the kernel output the
+    weights themselves, which are compared bit for bit with the same arithmetic done by torch in FP32."""
+    ops = _ops()
+    Wi, Wo = 241, 964
+    x = (torch.arange(Wi) % 2).float().view(1, 1, 1, Wi)
+    got = ops.trilinear_ac(x.to(dev), (1, 1, Wo)).cpu().view(-1)
+    scale = torch.tensor(float(Wi - 1), dtype=torch.float32) / torch.tensor(float(Wo - 1), dtype=torch.float32)
+    src = scale * torch.arange(Wo, dtype=torch.float32)          # rounded FP32 products
+    i0 = src.floor()
+    l1 = (src - i0).clamp(0.0, 1.0)
+    i0 = i0.long()
+    i1 = torch.where(i0 < Wi - 1, i0 + 1, i0)
+    want = torch.where(i1 % 2 == 1, l1, torch.zeros_like(l1)) + torch.where(i0 % 2 == 1, 1.0 - l1, torch.zeros_like(l1))
+    assert torch.equal(got, want)
+    fused, _ = ops.trilinear_ac_soft_argmin(x.to(dev), (1, 1, Wo), [0.0], 1.0)
+    assert torch.equal(fused.cpu().view(-1), want)
+
+
 def test_deconv_k8s4(dev):
     ops = _ops()
     x = _rand((2, 3, 5, 9), 17)
