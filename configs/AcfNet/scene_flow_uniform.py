@@ -1,0 +1,26 @@
+# AcfNet with a fixed (uniform) variance of the target distribution: PSMNet trunk + learned k8/s4 cost up-sampling, no
+# confidence network; trained with the stereo focal loss on the cost volumes and a smooth-L1 term on the disparities.
+import os, runpy
+_c = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_common.py"))
+task = 'stereo'
+max_disp = 192
+model = dict(
+    meta_architecture="GeneralizedStereoModel",
+    max_disp=max_disp,
+    batch_norm=True,
+    cost_processor=dict(
+        type='Concatenation',
+        cost_computation=_c['volume']("default", max_disp, 4),
+        cost_aggregator=dict(type="AcfNet", max_disp=max_disp, in_planes=64),
+    ),
+    disp_predictor=_c['predictor']('FASTER', max_disp),
+    losses=dict(
+        focal_loss=dict(max_disp=max_disp, start_disp=0, dilation=1, weight=1.0, weights=(1.0, 0.7, 0.5), coefficient=5.0,
+                        variance=1.2),
+        l1_loss=dict(max_disp=max_disp, weight=0.1, weights=(1.0, 0.7, 0.5)),
+    ),
+    eval=_c['evaluation'](max_disp),
+)
+data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960]))
+eval_disparity_id = [0, 1, 2]
+dist_params = dict(backend='nccl')

@@ -177,6 +177,112 @@ __global__ __launch_bounds__(256) void upsample_regress_bwd_hw_kernel(const floa
   dx[(((size_t)b * Di + zi) * Hi + yl) * Wi + xl] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// AcfNet's learned up-sampling, nn.ConvTranspose3d(1, 1, 8, 4, 2) (aggregators/AcfNet.py:55-57): y[o] = sum x[i] w[k],
+// o = 4 i - 2 + k per axis.  Backward:
+//   dx[i] = sum_k dy[4 i - 2 + k] w[k]                       (a stride-4 convolution of dy with the same 8 x 8 x 8 taps)
+//   dw[k] = sum_{b, i} x[b, i] dy[b, 4 i - 2 + k]
+// Both walk the 8 x 8 rows of dy that touch an input voxel and read 8 contiguous floats of each; dy is read a few times
+// out of the caches (neighbouring voxels share half of every row segment), 3 x 8 = 24 multiply-adds per 32 bytes.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void k8_row(const float* __restrict__ row, int xi, int Wo, float (&d)[8]) {
+  const int x0 = 4 * xi - 2;   // even: 8-byte aligned pairs
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int xx = x0 + 2 * p;
+    if (xx >= 0 && xx + 1 < Wo) {
+      const float2 v = *reinterpret_cast<const float2*>(row + xx);
+      d[2 * p] = v.x;
+      d[2 * p + 1] = v.y;
+    } else {
+      d[2 * p] = (xx >= 0 && xx < Wo) ? row[xx] : 0.f;
+      d[2 * p + 1] = (xx + 1 >= 0 && xx + 1 < Wo) ? row[xx + 1] : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void deconv_k8s4_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             float* __restrict__ dx, int D, int H, int W) {
+  __shared__ float ws[512];
+  for (int t = threadIdx.x; t < 512; t += 256) ws[t] = w[t];
+  __syncthreads();
+  const int xi = blockIdx.x * 256 + threadIdx.x;
+  if (xi >= W) return;
+  const int yi = blockIdx.y % H, zi = blockIdx.y / H, b = blockIdx.z;
+  const int Do = 4 * D, Ho = 4 * H, Wo = 4 * W;
+  const float* dyb = dy + (size_t)b * Do * Ho * Wo;
+  float acc = 0.f;
+  for (int kz = 0; kz < 8; ++kz) {
+    const int zo = 4 * zi - 2 + kz;
+    if (zo < 0 || zo >= Do) continue;
+    for (int ky = 0; ky < 8; ++ky) {
+      const int yo = 4 * yi - 2 + ky;
+      if (yo < 0 || yo >= Ho) continue;
+      float d[8];
+      k8_row(dyb + ((size_t)zo * Ho + yo) * Wo, xi, Wo, d);
+      const float* wr = ws + (kz * 8 + ky) * 8;
+#pragma unroll
+      for (int kx = 0; kx < 8; ++kx) acc = fmaf(d[kx], wr[kx], acc);
+    }
+  }
+  dx[(((size_t)b * D + zi) * H + yi) * W + xi] = acc;
+}
+
+// one block = one (kz, ky) and a chunk of input rows: 8 private sums per thread, block reduction, partials per chunk
+constexpr int K8_CHUNKS = 32;
+__global__ __launch_bounds__(256) void deconv_k8s4_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             double* __restrict__ ws, int B, int D, int H, int W) {
+  __shared__ double sm[4][8];
+  const int kz = blockIdx.y >> 3, ky = blockIdx.y & 7;
+  const int Do = 4 * D, Ho = 4 * H, Wo = 4 * W;
+  const long long rows = (long long)B * D * H;
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long r = r0; r < r1; ++r) {
+    const int yi = (int)(r % H), zi = (int)((r / H) % D), b = (int)(r / ((long long)H * D));
+    const int zo = 4 * zi - 2 + kz, yo = 4 * yi - 2 + ky;
+    if (zo < 0 || zo >= Do || yo < 0 || yo >= Ho) continue;
+    const float* xr = x + (((size_t)b * D + zi) * H + yi) * W;
+    const float* dr = dy + (((size_t)b * Do + zo) * Ho + yo) * Wo;
+    for (int xi = threadIdx.x; xi < W; xi += 256) {
+      float d[8];
+      k8_row(dr, xi, Wo, d);
+      const float xv = xr[xi];
+#pragma unroll
+      for (int kx = 0; kx < 8; ++kx) acc[kx] = fmaf(xv, d[kx], acc[kx]);
+    }
+    if (((r - r0) & 63) == 63) {   // FP32 runs of at most 64 rows, FP64 across runs
+#pragma unroll
+      for (int kx = 0; kx < 8; ++kx) {
+        tot[kx] += (double)acc[kx];
+        acc[kx] = 0.f;
+      }
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int kx = 0; kx < 8; ++kx) {
+    double v = tot[kx] + (double)acc[kx];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) sm[wave][kx] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8)
+    ws[((size_t)blockIdx.x * 64 + blockIdx.y) * 8 + threadIdx.x] =
+        (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+__global__ void deconv_k8s4_dw_reduce_kernel(const double* __restrict__ ws, float* __restrict__ dw, int nchunk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 512) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunk; ++c) s += ws[(size_t)c * 512 + i];
+  dw[i] = (float)s;
+}
+
 static int fill_idx(const int* host, int D, DispIdx& idx) {
   if (!host || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
   for (int k = 0; k < D; ++k) idx.d[k] = host[k];
@@ -239,4 +345,20 @@ extern "C" int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float*
   hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), Di * Hi, B), dim3(256), 0, st, scratch, grad_x, Di, Hi, Wi,
                      Ho, Wo, sh, sw);
   return launch_status("trilinear_soft_argmin_bwd launch failed");
+}
+
+extern "C" long long dmb_deconv3d_k8s4_bwd_workspace_doubles(void) { return (long long)K8_CHUNKS * 512; }
+
+extern "C" int dmb_deconv3d_k8s4_c1_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                                            double* workspace, int B, int D, int H, int W, void* stream) {
+  if (!x || !w || !dy || (!dx && !dw) || (dw && !workspace) || B <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(DMB_EINVAL, "deconv_k8s4_bwd: bad argument");
+  if ((long long)D * H > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "deconv_k8s4_bwd: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) hipLaunchKernelGGL(deconv_k8s4_dx_kernel, dim3(cdiv(W, 256), D * H, B), dim3(256), 0, st, dy, w, dx, D, H, W);
+  if (dw) {
+    hipLaunchKernelGGL(deconv_k8s4_dw_kernel, dim3(K8_CHUNKS, 64), dim3(256), 0, st, x, dy, workspace, B, D, H, W);
+    hipLaunchKernelGGL(deconv_k8s4_dw_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, dw, K8_CHUNKS);
+  }
+  return launch_status("deconv_k8s4_bwd launch failed");
 }

@@ -2,6 +2,7 @@
 import torch.nn as nn
 
 from ..... import ops
+from ...layers import train_fn
 from ...layers.basic_layers import HeadConv3d, conv3d_bn, conv3d_bn_relu
 from ..utils.hourglass import Hourglass
 from .PSMNet import PSMAggregator
@@ -33,4 +34,6 @@ class AcfAggregator(PSMAggregator):
             raise ValueError("AcfAggregator up-samples exactly 4x: raw volume has %d planes, max_disp=%d" % (D, self.max_disp))
         cost1, cost2, cost3 = self.trunk(raw_cost)
         pairs = ((cost3, self.deconv3), (cost2, self.deconv2), (cost1, self.deconv1))
+        if train_fn.wants_grad(self, cost1):   # differentiable up-sampling
+            return [train_fn.DeconvK8S4Fn.apply(c.squeeze(1), m.weight) for c, m in pairs]
         return [ops.deconv3d_k8s4_c1(c.squeeze(1), m.weight.detach().view(8, 8, 8)) for c, m in pairs]

@@ -187,6 +187,24 @@ class UpsampleRegressFn(torch.autograd.Function):
         return ops.trilinear_ac_soft_argmin_bwd(x, disp, ddisp.contiguous(), ctx.size, list(ctx.values), ctx.alpha), None, None, None
 
 
+class DeconvK8S4Fn(torch.autograd.Function):
+    """AcfNet's learned up-sampling nn.ConvTranspose3d(1, 1, 8, 4, 2) on a squeezed cost [B, D, H, W] (AcfNet.py:55-57,81-83)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        w = weight.detach().contiguous().view(8, 8, 8)
+        ctx.save_for_backward(x, w)
+        ctx.wshape = tuple(weight.shape)
+        return ops.deconv3d_k8s4_c1(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw = ops.deconv3d_k8s4_c1_bwd(x, w, dy.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, (dw.view(ctx.wshape) if dw is not None else None)
+
+
 class SoftArgminFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cost, values, alpha):

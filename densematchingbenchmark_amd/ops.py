@@ -411,6 +411,22 @@ def trilinear_ac_soft_argmin_bwd(x, disp, grad_disp, out_size, disp_values, alph
     return gx
 
 
+def deconv3d_k8s4_c1_bwd(x, w, dy, want_dx=True, want_dw=True):
+    """Backward of deconv3d_k8s4_c1: (dx [B, D, H, W] or None, dw [8, 8, 8] or None)."""
+    lib = _lib.load()
+    x, w, dy = _f32c(x, "x"), _f32c(w, "weight"), _f32c(dy, "dy")
+    B, D, H, W = x.shape
+    if tuple(dy.shape) != (B, 4 * D, 4 * H, 4 * W):
+        raise _lib.DmbLibraryError("deconv3d_k8s4_c1_bwd: dy shape %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.empty((8, 8, 8), dtype=torch.float32, device=x.device) if want_dw else None
+    ws = torch.empty((lib.dmb_deconv3d_k8s4_bwd_workspace_doubles(),), dtype=torch.float64, device=x.device) if want_dw else None
+    check(lib.dmb_deconv3d_k8s4_c1_bwd_f32(dev_ptr(x), dev_ptr(w), dev_ptr(dy), dev_ptr(dx, allow_none=True),
+                                           dev_ptr(dw, allow_none=True), dev_ptr(ws, allow_none=True), B, D, H, W,
+                                           stream_ptr(x.device)), "dmb_deconv3d_k8s4_c1_bwd_f32")
+    return dx, dw
+
+
 # ---------------------------------------------------------------------------------------------- upsampling
 def trilinear_ac(x, out_size):
     """x: [B, Di, Hi, Wi] (single channel squeezed) -> [B, Do, Ho, Wo], align_corners=True."""

@@ -330,6 +330,13 @@ int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, cons
                                          float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                                          float alpha, const float* disp_sample_host, void* stream);
 
+/* Backward of dmb_deconv3d_k8s4_c1_f32 (AcfNet's learned up-sampling, aggregators/AcfNet.py:55-57): dx [B, D, H, W] =
+ * sum_k dy[4 i - 2 + k] w[k], dw [8, 8, 8] = sum_{b, i} x[b, i] dy[b, 4 i - 2 + k]; dy [B, 4D, 4H, 4W].  Either output may be
+ * NULL.  workspace: dmb_deconv3d_k8s4_bwd_workspace_doubles() doubles (needed for dw). */
+long long dmb_deconv3d_k8s4_bwd_workspace_doubles(void);
+int dmb_deconv3d_k8s4_c1_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                                 double* workspace, int B, int D, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * EXPERIMENTAL, OPT-IN (never selected by the default path): the stride-1
  * convolution (32 or 64 output channels) with every FP32 operand split exactly into three bf16 pieces and the six largest cross products issued on
