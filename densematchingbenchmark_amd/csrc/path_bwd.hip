@@ -139,6 +139,37 @@ __global__ __launch_bounds__(256) void upsample_regress_bwd_z_kernel(const float
   }
 }
 
+// The same z fold for a gradient that arrives on the up-sampled volume itself (a loss on the costs, e.g. the focal loss):
+// t[b, zi, yo, xo] (+)= sum_k wz(zi <- k) * dcost[b, k, yo, xo]; accumulate = 1 adds to what pass A of the regression wrote.
+__global__ __launch_bounds__(256) void upsample_bwd_z_kernel(const float* __restrict__ dcost, float* __restrict__ t, int Di, int Do,
+                                                             int Ho, int Wo, float sd, int accumulate) {
+  const int xo = blockIdx.x * 256 + threadIdx.x;
+  if (xo >= Wo) return;
+  const int yo = blockIdx.y, b = blockIdx.z;
+  const size_t tstride = (size_t)Ho * Wo;
+  const float* dp = dcost + (size_t)b * Do * tstride + (size_t)yo * Wo + xo;
+  float* tp = t + (size_t)b * Di * tstride + (size_t)yo * Wo + xo;
+  int ia = 0;
+  float acc_a = 0.f, acc_b = 0.f;
+  auto flush = [&]() {
+    tp[(size_t)ia * tstride] = accumulate ? tp[(size_t)ia * tstride] + acc_a : acc_a;
+    acc_a = acc_b;
+    acc_b = 0.f;
+    ++ia;
+  };
+  for (int zo = 0; zo < Do; ++zo) {
+    const Lerp lz = lerp_setup(zo, Di, sd);
+    const float dck = dp[(size_t)zo * tstride];
+    while (ia < lz.i0) flush();
+    acc_a = fmaf(dck, lz.w0, acc_a);
+    if (lz.i1 != lz.i0)
+      acc_b = fmaf(dck, lz.w1, acc_b);
+    else
+      acc_a = fmaf(dck, lz.w1, acc_a);
+  }
+  while (ia < Di) flush();
+}
+
 // dlow[b, zi, yl, xl] = sum_{yo, xo} wy(yl <- yo) * wx(xl <- xo) * t[b, zi, yo, xo]; one thread per low-resolution voxel.
 // Output rows / columns that blend input index i: src = scale * o in (i - 1, i + 1).
 __global__ __launch_bounds__(256) void upsample_regress_bwd_hw_kernel(const float* __restrict__ t, float* __restrict__ dx, int Di,
@@ -330,9 +361,9 @@ extern "C" int dmb_soft_argmin_bwd_f32(const float* cost, const float* disp, con
   return launch_status("soft_argmin_bwd launch failed");
 }
 
-extern "C" int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, const float* grad_disp, float* scratch,
-                                                    float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                                                    float alpha, const float* disp_sample_host, void* stream) {
+extern "C" int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, const float* grad_disp, const float* grad_y,
+                                                    float* scratch, float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho,
+                                                    int Wo, float alpha, const float* disp_sample_host, void* stream) {
   if (!x || !disp || !grad_disp || !scratch || !grad_x || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0)
     return fail(DMB_EINVAL, "trilinear_soft_argmin_bwd: bad argument");
   if (Ho > 65535 || (long long)Di * Hi > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "trilinear_soft_argmin_bwd: grid too large");
@@ -342,6 +373,8 @@ extern "C" int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float*
   const float sd = ac_scale(Di, Do), sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
   hipLaunchKernelGGL(upsample_regress_bwd_z_kernel, dim3(cdiv(Wo, 256), Ho, B), dim3(256), 0, st, x, disp, grad_disp, scratch, Di, Hi,
                      Wi, Do, Ho, Wo, sd, sh, sw, alpha, dv);
+  if (grad_y)   // a loss on the volume as well: its z fold joins the regression's before the (y, x) contraction
+    hipLaunchKernelGGL(upsample_bwd_z_kernel, dim3(cdiv(Wo, 256), Ho, B), dim3(256), 0, st, grad_y, scratch, Di, Do, Ho, Wo, sd, 1);
   hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), Di * Hi, B), dim3(256), 0, st, scratch, grad_x, Di, Hi, Wi,
                      Ho, Wo, sh, sw);
   return launch_status("trilinear_soft_argmin_bwd launch failed");
@@ -361,4 +394,17 @@ extern "C" int dmb_deconv3d_k8s4_c1_bwd_f32(const float* x, const float* w, cons
     hipLaunchKernelGGL(deconv_k8s4_dw_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, dw, K8_CHUNKS);
   }
   return launch_status("deconv_k8s4_bwd launch failed");
+}
+
+extern "C" int dmb_trilinear_ac_bwd_f32(const float* grad_y, float* scratch, float* grad_x, int B, int Di, int Hi, int Wi, int Do,
+                                        int Ho, int Wo, void* stream) {
+  if (!grad_y || !scratch || !grad_x || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0)
+    return fail(DMB_EINVAL, "trilinear_bwd: bad argument");
+  if (Ho > 65535 || (long long)Di * Hi > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "trilinear_bwd: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  const float sd = ac_scale(Di, Do), sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
+  hipLaunchKernelGGL(upsample_bwd_z_kernel, dim3(cdiv(Wo, 256), Ho, B), dim3(256), 0, st, grad_y, scratch, Di, Do, Ho, Wo, sd, 0);
+  hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), Di * Hi, B), dim3(256), 0, st, scratch, grad_x, Di, Hi, Wi,
+                     Ho, Wo, sh, sw);
+  return launch_status("trilinear_bwd launch failed");
 }

@@ -165,7 +165,7 @@ class DifFmsFn(torch.autograd.Function):
 
 class UpsampleRegressFn(torch.autograd.Function):
     """(cost [B, Do, Ho, Wo], disp [B, 1, Ho, Wo]) of a low-resolution cost [B, Di, Hi, Wi].  Differentiable through the
-    disparity (the path every PSMNet loss takes); a loss on the up-sampled volume itself is not covered."""
+    disparity (the path every PSMNet loss takes, without the full-size gradient volume) and through the volume itself."""
 
     @staticmethod
     def forward(ctx, x, size, values, alpha):
@@ -178,13 +178,13 @@ class UpsampleRegressFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcost, ddisp):
-        if dcost is not None:
-            raise NotImplementedError("gradient through the up-sampled cost volume itself is not built (only through its "
-                                      "soft-argmin): DESIGN.md section 8")
-        if ddisp is None:
+        if dcost is None and ddisp is None:
             return None, None, None, None
         x, disp = ctx.saved_tensors
-        return ops.trilinear_ac_soft_argmin_bwd(x, disp, ddisp.contiguous(), ctx.size, list(ctx.values), ctx.alpha), None, None, None
+        if ddisp is None:   # only a loss on the volume
+            return ops.trilinear_ac_bwd(dcost.contiguous(), tuple(x.shape[1:])), None, None, None
+        return ops.trilinear_ac_soft_argmin_bwd(x, disp, ddisp.contiguous(), ctx.size, list(ctx.values), ctx.alpha,
+                                                grad_cost=dcost.contiguous() if dcost is not None else None), None, None, None
 
 
 class DeconvK8S4Fn(torch.autograd.Function):

@@ -397,17 +397,35 @@ def soft_argmin_bwd(cost, disp, grad_disp, disp_values, alpha=1.0):
     return out
 
 
-def trilinear_ac_soft_argmin_bwd(x, disp, grad_disp, out_size, disp_values, alpha=1.0):
-    """Gradient of trilinear_ac_soft_argmin's disparity w.r.t. the low-resolution cost x [B, Di, Hi, Wi]."""
+def trilinear_ac_soft_argmin_bwd(x, disp, grad_disp, out_size, disp_values, alpha=1.0, grad_cost=None):
+    """Gradient of trilinear_ac_soft_argmin w.r.t. the low-resolution cost x [B, Di, Hi, Wi]: through the disparity
+    (grad_disp) and, if given, through the up-sampled volume itself (grad_cost [B, Do, Ho, Wo])."""
     lib = _lib.load()
     x, disp, grad_disp = _f32c(x, "x"), _f32c(disp, "disp"), _f32c(grad_disp, "grad_disp")
     B, Di, Hi, Wi = x.shape
     Do, Ho, Wo = out_size
+    if grad_cost is not None:
+        grad_cost = _f32c(grad_cost, "grad_cost")
+        if tuple(grad_cost.shape) != (B, Do, Ho, Wo):
+            raise _lib.DmbLibraryError("trilinear_ac_soft_argmin_bwd: grad_cost shape %s" % (tuple(grad_cost.shape),))
     scratch = torch.empty((B, Di, Ho, Wo), dtype=torch.float32, device=x.device)
     gx = torch.empty_like(x)
-    check(lib.dmb_trilinear_ac_soft_argmin_bwd_f32(dev_ptr(x), dev_ptr(disp), dev_ptr(grad_disp), dev_ptr(scratch), dev_ptr(gx),
-                                                   B, Di, Hi, Wi, Do, Ho, Wo, float(alpha), host_floats(disp_values),
-                                                   stream_ptr(x.device)), "dmb_trilinear_ac_soft_argmin_bwd_f32")
+    check(lib.dmb_trilinear_ac_soft_argmin_bwd_f32(dev_ptr(x), dev_ptr(disp), dev_ptr(grad_disp), dev_ptr(grad_cost, allow_none=True),
+                                                   dev_ptr(scratch), dev_ptr(gx), B, Di, Hi, Wi, Do, Ho, Wo, float(alpha),
+                                                   host_floats(disp_values), stream_ptr(x.device)), "dmb_trilinear_ac_soft_argmin_bwd_f32")
+    return gx
+
+
+def trilinear_ac_bwd(grad_y, in_size):
+    """Gradient of trilinear_ac w.r.t. its input: grad_y [B, Do, Ho, Wo] -> [B, Di, Hi, Wi]."""
+    lib = _lib.load()
+    grad_y = _f32c(grad_y, "grad_y")
+    B, Do, Ho, Wo = grad_y.shape
+    Di, Hi, Wi = in_size
+    scratch = torch.empty((B, Di, Ho, Wo), dtype=torch.float32, device=grad_y.device)
+    gx = torch.empty((B, Di, Hi, Wi), dtype=torch.float32, device=grad_y.device)
+    check(lib.dmb_trilinear_ac_bwd_f32(dev_ptr(grad_y), dev_ptr(scratch), dev_ptr(gx), B, Di, Hi, Wi, Do, Ho, Wo,
+                                       stream_ptr(grad_y.device)), "dmb_trilinear_ac_bwd_f32")
     return gx
 
 

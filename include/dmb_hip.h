@@ -323,12 +323,16 @@ int dmb_dif_fms_bwd_f32(const float* dvol, float* dL, float* dR, int B, int C, i
 int dmb_soft_argmin_bwd_f32(const float* cost, const float* disp, const float* grad_disp, float* grad_cost, int B,
                             int D, int H, int W, float alpha, const float* disp_sample_host, void* stream);
 
-/* Backward of dmb_trilinear_ac_soft_argmin_f32 with respect to the low-resolution cost x [B, Di, Hi, Wi], given the
- * gradient of the disparity only: the [B, Do, Ho, Wo] volume is re-created per pixel in registers, never stored.
- * scratch: B*Di*Ho*Wo floats; grad_x [B, Di, Hi, Wi]. */
-int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, const float* grad_disp, float* scratch,
-                                         float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+/* Backward of dmb_trilinear_ac_soft_argmin_f32 with respect to the low-resolution cost x [B, Di, Hi, Wi]: the gradient of
+ * the disparity is propagated without the [B, Do, Ho, Wo] volume (re-created per pixel in registers); grad_y (may be NULL) is
+ * a gradient that arrives on the volume itself (a loss on the costs) and is added.  scratch: B*Di*Ho*Wo floats. */
+int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, const float* grad_disp, const float* grad_y,
+                                         float* scratch, float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                                          float alpha, const float* disp_sample_host, void* stream);
+/* Backward of dmb_trilinear_ac_f32 alone (F.interpolate(trilinear, align_corners=True)): grad_y [B, Do, Ho, Wo] ->
+ * grad_x [B, Di, Hi, Wi].  scratch: B*Di*Ho*Wo floats. */
+int dmb_trilinear_ac_bwd_f32(const float* grad_y, float* scratch, float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho,
+                             int Wo, void* stream);
 
 /* Backward of dmb_deconv3d_k8s4_c1_f32 (AcfNet's learned up-sampling, aggregators/AcfNet.py:55-57): dx [B, D, H, W] =
  * sum_k dy[4 i - 2 + k] w[k], dw [8, 8, 8] = sum_{b, i} x[b, i] dy[b, 4 i - 2 + k]; dy [B, 4D, 4H, 4W].  Either output may be

@@ -183,12 +183,19 @@ def test_upsample_regression_backward(dev, lo, scale):
     up = F.interpolate(xr.unsqueeze(1), size=(Do, Ho, Wo), mode="trilinear", align_corners=True).squeeze(1)
     p = torch.softmax(up, dim=1)
     disp64 = (p * torch.tensor(vals, dtype=torch.float64).view(1, Do, 1, 1)).sum(1, keepdim=True)
-    ref, = torch.autograd.grad(disp64, xr, g.double())
+    ref, = torch.autograd.grad(disp64, xr, g.double(), retain_graph=True)
     _, disp = ops.trilinear_ac_soft_argmin(x.to(dev), (Do, Ho, Wo), vals, 1.0)
     got = ops.trilinear_ac_soft_argmin_bwd(x.to(dev), disp, g.to(dev), (Do, Ho, Wo), vals, 1.0).cpu()
     assert got.shape == x.shape
     # tolerance: FP32 interpolation weights + __expf against an FP64 evaluation, relative to the largest entry
     assert (got.double() - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item())
+    # a gradient on the up-sampled volume itself, alone and together with the disparity's
+    gv = _rand((2, Do, Ho, Wo), 3)
+    refv, = torch.autograd.grad(up, xr, gv.double(), retain_graph=True)
+    gotv = ops.trilinear_ac_bwd(gv.to(dev), (Di, Hi, Wi)).cpu()
+    assert (gotv.double() - refv).abs().max().item() <= 1e-5 * max(1.0, refv.abs().max().item())
+    both = ops.trilinear_ac_soft_argmin_bwd(x.to(dev), disp, g.to(dev), (Do, Ho, Wo), vals, 1.0, grad_cost=gv.to(dev)).cpu()
+    assert (both.double() - (ref + refv)).abs().max().item() <= 5e-5 * max(1.0, (ref + refv).abs().max().item())
 
 
 @pytest.mark.parametrize("Ci,Co,shape", [
