@@ -97,7 +97,7 @@ class ConvUnitFn(torch.autograd.Function):
             else:
                 dw = ops.conv3d_k3_wgrad(x, dc)
         if ctx.needs_input_grad[0]:
-            dx = ops.deconv3d_k3s2_dgrad(dc, w) if unit.transposed else ops.conv3d_k3_dgrad(dc, w, unit.stride)
+            dx = ops.deconv3d_k3s2_dgrad(dc, w) if unit.transposed else ops.conv3d_k3_dgrad(dc, w, unit.stride, tuple(x.shape[2:]))
         if has_bias and ctx.needs_input_grad[2]:
             dbias = dc.sum(dim=(0, 2, 3, 4))
         return (dx, dw, dbias, dgamma if has_gamma and ctx.needs_input_grad[3] else None,

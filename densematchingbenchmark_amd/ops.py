@@ -256,15 +256,22 @@ def pack_conv3d_dgrad_weights(w):
     return wp
 
 
-def conv3d_k3_dgrad(dc, w, stride=1):
+def conv3d_k3_dgrad(dc, w, stride=1, in_size=None):
     """Gradient of nn.Conv3d(k=3, padding=1, stride) w.r.t. its input; w is the layer's weight [Co, Ci, 3, 3, 3].
-    Stride 2 assumes the even input sizes of the hourglass (input = 2 x output)."""
+    ``in_size`` = (D, H, W) of that input; needed for stride 2 when an extent is odd (the adjoint is computed for the even
+    size 2 x output and its last plane / row / column dropped)."""
     Co, Ci = w.shape[0], w.shape[1]
     if stride == 1:
         return conv3d_k3(dc, pack_conv3d_dgrad_weights(w), Ci)
     if stride == 2:
         # the adjoint of a stride-2 convolution is the transposed convolution with the same weight tensor
-        return deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci)
+        dx = deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci)
+        if in_size is not None and tuple(in_size) != tuple(dx.shape[2:]):
+            D, H, W = in_size
+            if any(a not in (b, b - 1) for a, b in zip((D, H, W), dx.shape[2:])):
+                raise _lib.DmbLibraryError("conv3d_k3_dgrad: input size %s does not belong to output size %s" % (tuple(in_size), tuple(dc.shape[2:])))
+            dx = dx[:, :, :D, :H, :W].contiguous()
+        return dx
     raise _lib.DmbLibraryError("conv3d_k3_dgrad: stride must be 1 or 2")
 
 

@@ -62,6 +62,7 @@ def test_conv3d_wgrad(dev, Ci, Co, shape):
     (32, 64, 1, (2, 4, 8, 24)),
     (32, 64, 2, (1, 8, 12, 40)),
     (64, 64, 2, (1, 4, 8, 24)),
+    (32, 64, 2, (1, 7, 9, 21)),     # odd extents: the even-size adjoint with its last plane / row / column dropped
 ])
 def test_conv3d_dgrad(dev, Ci, Co, stride, shape):
     ops = _ops()
@@ -71,7 +72,7 @@ def test_conv3d_dgrad(dev, Ci, Co, stride, shape):
     dc = _rand((B, Co, (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1), 2)
     dx32, _ = O.conv3d_backward(x, w, dc, stride)
     dx64, _ = O.conv3d_backward(x, w, dc, stride, dtype=torch.float64)
-    got = ops.conv3d_k3_dgrad(dc.to(dev), w.to(dev), stride).cpu()
+    got = ops.conv3d_k3_dgrad(dc.to(dev), w.to(dev), stride, (D, H, W)).cpu()
     assert got.shape == x.shape
     _close(got, dx64, dx32, "dx")
 
