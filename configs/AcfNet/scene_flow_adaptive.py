@@ -12,8 +12,13 @@ model = dict(
         cost_computation=_c['volume']("default", max_disp, 4),
         cost_aggregator=dict(type="AcfNet", max_disp=max_disp, in_planes=64),
     ),
-    cmn=dict(num=3, alpha=1.0, beta=1.0, in_planes=max_disp),
+    cmn=dict(num=3, alpha=1.0, beta=1.0, in_planes=max_disp,
+             losses=dict(nll_loss=dict(max_disp=max_disp, start_disp=0, weight=8.0, weights=(1.0, 0.7, 0.5)))),
     disp_predictor=_c['predictor']('FASTER', max_disp),
+    losses=dict(
+        focal_loss=dict(max_disp=max_disp, start_disp=0, dilation=1, weight=1.0, weights=(1.0, 0.7, 0.5), coefficient=5.0),
+        l1_loss=dict(max_disp=max_disp, weight=0.1, weights=(1.0, 0.7, 0.5)),
+    ),
     eval=_c['evaluation'](max_disp),
 )
 data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960]))

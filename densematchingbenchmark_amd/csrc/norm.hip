@@ -252,6 +252,47 @@ __global__ __launch_bounds__(NB) void bn_bwd_apply_kernel(const float* __restric
   }
 }
 
+// out[c] = sum_{b, s} a[b, c, s] * g[b, 0, s]: the weight gradient of a 1x1 convolution with one output channel
+// (the second layer of AcfNet's confidence heads, cmn/cmn.py:30).  ws[ch * nsplit + s] partial sums (FP64).
+__global__ __launch_bounds__(NB) void channel_dot_kernel(const float* __restrict__ a, const float* __restrict__ g,
+                                                         double* __restrict__ ws, int B, int C, long long S, int nsplit, int vec) {
+  __shared__ double sm[4];
+  const int ch = blockIdx.y, s = blockIdx.x;
+  double tot = 0.0;
+  float p = 0.f;
+  int run = 0;
+  auto flush = [&]() {
+    tot += (double)p;
+    p = 0.f;
+    run = 0;
+  };
+  for_slice(S, B, C, ch, s, nsplit, vec != 0,
+            [&](long long o) {
+              // o indexes a ([B, C, S]); the matching element of g ([B, 1, S]) is (b, s) = (o / (C S), o % S)
+              const long long b = o / ((long long)C * S), sp = o % S;
+              const float4 av = *reinterpret_cast<const float4*>(a + o);
+              const float4 gv = *reinterpret_cast<const float4*>(g + b * S + sp);
+              p = fmaf(av.x, gv.x, p), p = fmaf(av.y, gv.y, p), p = fmaf(av.z, gv.z, p), p = fmaf(av.w, gv.w, p);
+              if (++run == 64) flush();
+            },
+            [&](long long o) {
+              const long long b = o / ((long long)C * S), sp = o % S;
+              p = fmaf(a[o], g[b * S + sp], p);
+              if (++run == 256) flush();
+            });
+  flush();
+  tot = norm_block_sum(tot, sm);
+  if (threadIdx.x == 0) ws[(long long)ch * nsplit + s] = tot;
+}
+
+__global__ void channel_dot_finalize_kernel(const double* __restrict__ ws, float* __restrict__ out, int C, int nsplit) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nsplit; ++i) s += ws[(long long)ch * nsplit + i];
+  out[ch] = (float)s;
+}
+
 static int bn_nsplit(int C, long long S) {
   long long n = 4096 / (C > 0 ? C : 1);
   if (n < 1) n = 1;
@@ -316,4 +357,15 @@ extern "C" int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* 
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(total, vec ? 8 : 2)), dim3(NB), 0, st, dy, c, y, scale, shift, mean,
                      invstd, dgamma, dbeta, dc, dres, C, S, total, (float)(1.0 / ((double)B * (double)S)), relu, training, vec);
   return launch_status("bn_act_bwd launch failed");
+}
+
+extern "C" int dmb_channel_dot_f32(const float* a, const float* g, double* workspace, float* out, int B, int C, long long S,
+                                   void* stream) {
+  if (!a || !g || !workspace || !out || B <= 0 || C <= 0 || S <= 0) return fail(DMB_EINVAL, "channel_dot: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = bn_nsplit(C, S);
+  const int vec = S % 4 == 0 && (((uintptr_t)a | (uintptr_t)g) & 15) == 0;
+  hipLaunchKernelGGL(channel_dot_kernel, dim3(nsplit, C), dim3(NB), 0, st, a, g, workspace, B, C, S, nsplit, vec);
+  hipLaunchKernelGGL(channel_dot_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, out, C, nsplit);
+  return launch_status("channel_dot launch failed");
 }

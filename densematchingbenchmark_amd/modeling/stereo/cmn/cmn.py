@@ -1,7 +1,9 @@
-"""AcfNet confidence measurement network, inference side: drop-in for cmn/cmn.py:10-92."""
+"""AcfNet confidence measurement network: drop-in for cmn/cmn.py:10-92 (fused inference kernel; training branch on the 2-D
+convolution / BatchNorm / weight-gradient kernels under autograd)."""
 import torch.nn as nn
 
 from .... import ops
+from ..layers import train_fn
 from ..layers.basic_layers import _versions, fold_batch_norm
 
 
@@ -43,10 +45,18 @@ class ConfHead(nn.Module):
         wp, scale, shift, w2 = self._prepacked()
         return ops.conf_head(cost, wp, scale, shift, w2)
 
+    def logits(self, cost):
+        """The confidence cost BEFORE the sigmoid, differentiable (training side): cmn.py:34-36."""
+        conv1 = self.conf_net[0][0]
+        bn = self.conf_net[0][1] if self.batch_norm else None
+        gamma = bn.weight if bn is not None and bn.affine else None
+        beta = bn.bias if bn is not None and bn.affine else None
+        return train_fn.ConfHeadFn.apply(cost, conv1.weight, gamma, beta, self.conf_net[1].weight, self)
+
 
 class Cmn(nn.Module):
-    """Eval-mode ``forward(costs, target=None) -> (cost_vars, confs)`` (cmn.py:57-84).  The training branch (NLL
-    loss on the confidence logits) is outside the HIP path."""
+    """``forward(costs, target=None)`` -> ``(cost_vars, confs)`` in eval mode, ``(cost_vars, cm_losses)`` in training mode
+    (cmn.py:57-84)."""
 
     def __init__(self, cfg, in_planes, num, alpha, beta):
         super().__init__()
@@ -54,6 +64,7 @@ class Cmn(nn.Module):
         batch_norm = self.cfg.model.batch_norm
         self.conf_heads = nn.ModuleList([ConfHead(in_planes, batch_norm) for _ in range(num)])
         self.alpha, self.beta = alpha, beta
+        self.loss_evaluator = None
 
     def get_confidence(self, costs):
         assert len(self.conf_heads) == len(costs), "NUM of confidence heads({}) must be equal to NUM" \
@@ -64,7 +75,20 @@ class Cmn(nn.Module):
 
     def forward(self, costs, target=None):
         if self.training:
-            raise NotImplementedError("Cmn training (confidence NLL loss) is outside the HIP inference path")
+            # cmn.py:62-84: confidence costs (logits) -> NLL loss; variance = alpha * (1 - sigmoid(logit)) + beta feeds the focal
+            # loss, so the focal loss's d/d variance flows back into the heads.  The sigmoid / affine on the [B, 1, H, W] maps
+            # is left to torch (plumbing-sized); everything on the [B, D, H, W] volumes is HIP.
+            import torch
+            assert len(self.conf_heads) == len(costs)
+            conf_costs = [head.logits(cost) for cost, head in zip(costs, self.conf_heads)]
+            cost_vars = [self.alpha * (1 - torch.sigmoid(c)) + self.beta for c in conf_costs]
+            if self.loss_evaluator is None:
+                from ..losses import ConfidenceNllLoss
+                node = self.cfg.model.cmn.losses.nll_loss
+                self.loss_evaluator = (ConfidenceNllLoss(max_disp=node.max_disp, start_disp=node.get("start_disp", 0),
+                                                         weights=node.get("weights", None), sparse=self.cfg.data.sparse), node.weight)
+            evaluator, weight = self.loss_evaluator
+            return cost_vars, {k: v * weight for k, v in evaluator(conf_costs, target).items()}
         confs, cost_vars = self.get_confidence(costs)
         return cost_vars, confs
 

@@ -205,6 +205,54 @@ class DeconvK8S4Fn(torch.autograd.Function):
         return dx, (dw.view(ctx.wshape) if dw is not None else None)
 
 
+class ConfHeadFn(torch.autograd.Function):
+    """Confidence logits of one AcfNet head (cmn/cmn.py:21-36): Conv2d(D -> D/3, 3x3) + BatchNorm2d + ReLU + Conv2d(-> 1, 1x1),
+    no biases.  Forward and backward are 2-D launches of the same kernel families as the 3-D units."""
+
+    @staticmethod
+    def forward(ctx, cost, w1, gamma, beta, w2, head):
+        cost = cost.contiguous()
+        w1d, w2d = w1.detach().contiguous(), w2.detach().contiguous()
+        Cm = w1d.shape[0]
+        raw = ops.conv2d(cost, ops.pack_conv2d_weights(w1d), Cm, 3)
+        bn = head.conf_net[0][1] if head.batch_norm else None
+        batch_stats = bn is not None and head.training
+        if batch_stats:
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            mean, invstd, scale, shift = ops.bn_train_stats(raw, gamma.detach() if gamma is not None else None,
+                                                            beta.detach() if beta is not None else None,
+                                                            bn.running_mean if bn.track_running_stats else None,
+                                                            bn.running_var if bn.track_running_stats else None, momentum, bn.eps)
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        elif bn is not None:
+            mean = bn.running_mean.detach().float()
+            invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+            scale = (gamma.detach() if gamma is not None else torch.ones_like(mean)) * invstd
+            shift = (beta.detach() if beta is not None else torch.zeros_like(mean)) - mean * scale
+        else:
+            mean = torch.zeros(Cm, dtype=torch.float32, device=cost.device)
+            invstd, scale, shift = torch.ones_like(mean), torch.ones_like(mean), torch.zeros_like(mean)
+        h = ops.bn_act(raw, scale, shift, None, True)
+        logit = ops.conv2d(h, ops.pack_conv2d_weights(w2d), 1, 1)
+        ctx.batch_stats = batch_stats
+        ctx.has = (gamma is not None, beta is not None)
+        ctx.save_for_backward(cost, w1d, w2d, raw, h, scale, shift, mean, invstd)
+        return logit
+
+    @staticmethod
+    def backward(ctx, dlogit):
+        cost, w1, w2, raw, h, scale, shift, mean, invstd = ctx.saved_tensors
+        dlogit = dlogit.contiguous()
+        dh = ops.conv2d_dgrad(dlogit, w2)                                  # 1 -> Cm channels
+        dw2 = ops.channel_dot(h, dlogit).view_as(w2) if ctx.needs_input_grad[4] else None
+        dc, dgamma, dbeta, _ = ops.bn_act_bwd(dh, raw, h, scale, shift, mean, invstd, True, ctx.batch_stats)
+        dw1 = ops.conv2d_k3_wgrad(cost, dc) if ctx.needs_input_grad[1] else None
+        dcost = ops.conv2d_dgrad(dc, w1) if ctx.needs_input_grad[0] else None
+        return (dcost, dw1, dgamma if ctx.has[0] and ctx.needs_input_grad[2] else None,
+                dbeta if ctx.has[1] and ctx.needs_input_grad[3] else None, dw2, None)
+
+
 class SoftArgminFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cost, values, alpha):

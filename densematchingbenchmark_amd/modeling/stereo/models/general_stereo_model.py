@@ -33,10 +33,10 @@ class GeneralizedStereoModel(nn.Module):
 
     def _forward_train(self, batch, ref_fms, tgt_fms):
         """general_stereo_model.py:60-77: the same forward under autograd, then the configured losses.  Built for the
-        cost path (volume builder, aggregator, regression) with the disparity losses; a refinement stage or a
-        confidence network in training mode is not."""
-        if self.disp_refinement is not None or self.cmn is not None:
-            raise NotImplementedError("training through disp_refinement / cmn is outside the HIP path built so far")
+        cost path (volume builder, aggregator, regression, confidence network) with its losses; a refinement
+        stage in training mode is not."""
+        if self.disp_refinement is not None:
+            raise NotImplementedError("training through disp_refinement is outside the HIP path built so far")
         target = batch.get('leftDisp')
         costs = self.cost_processor(ref_fms, tgt_fms)
         disps = [self.disp_predictor(cost) for cost in costs]
@@ -45,10 +45,15 @@ class GeneralizedStereoModel(nn.Module):
                 raise ValueError("training mode needs cfg.model.losses (general_stereo_model.py:40)")
             from ..losses import make_gsm_loss_evaluator
             self.loss_evaluator = make_gsm_loss_evaluator(self.cfg)
+        loss_dict = dict()
         variance = None
         if hasattr(self.cfg.model.losses, 'focal_loss'):
             variance = self.cfg.model.losses.focal_loss.get('variance', None)
-        return {}, self.loss_evaluator(disps, costs, target, variance=variance)
+        if self.cmn is not None:                                     # general_stereo_model.py:66-69
+            variance, cm_losses = self.cmn(costs, target)
+            loss_dict.update(cm_losses)
+        loss_dict.update(self.loss_evaluator(disps, costs, target, variance=variance))
+        return {}, loss_dict
 
     def forward(self, batch):
         if 'leftFeature' in batch:

@@ -319,6 +319,36 @@ def deconv3d_k3s2_wgrad(x, dy):
     return _s2_wgrad(x, dy, "dmb_conv3d_k3s2_wgrad_f32 (transposed conv)")
 
 
+def conv2d_k3_wgrad(x, dc):
+    """Weight gradient of nn.Conv2d(k=3, stride=1, padding=1): x [B, Ci, H, W], dc [B, Co, H, W] -> [Co, Ci, 3, 3]."""
+    lib = _lib.load()
+    x, dc = _f32c(x, "x"), _f32c(dc, "dc")
+    B, Ci, H, W = x.shape
+    Co = dc.shape[1]
+    if tuple(dc.shape) != (B, Co, H, W):
+        raise _lib.DmbLibraryError("conv2d_k3_wgrad: dc shape %s does not match x %s" % (tuple(dc.shape), tuple(x.shape)))
+    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
+    ws = torch.empty((lib.dmb_conv2d_wgrad_workspace_floats(Co, Ci),), dtype=torch.float32, device=x.device)
+    check(lib.dmb_conv2d_k3_wgrad_f32(dev_ptr(x), dev_ptr(dc), dev_ptr(dw), dev_ptr(ws), B, Ci, Co, H, W, stream_ptr(x.device)),
+          "dmb_conv2d_k3_wgrad_f32")
+    return dw
+
+
+def conv2d_dgrad(dc, w):
+    """Gradient of nn.Conv2d(k in {1, 3}, stride 1, padding k//2) w.r.t. its input; w is the layer's weight [Co, Ci, k, k].
+    The same convolution kernel on mirrored, channel-exchanged weights, at most 128 output channels per launch."""
+    w = _f32c(w, "weight")
+    Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
+    wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()           # [Ci, Co, k, k]: a convolution Co -> Ci
+    dc = _f32c(dc, "dc")
+    B, _, H, W = dc.shape
+    dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dc.device)
+    for c0 in range(0, Ci, 128):
+        n = min(128, Ci - c0)
+        conv2d(dc, pack_conv2d_weights(wt[c0:c0 + n].contiguous()), n, k, out=dx, out_ch_offset=c0)
+    return dx
+
+
 # ---------------------------------------------------------------------------------------------- BatchNorm (training)
 def _bcs(t):
     """[B, C, *spatial] -> (B, C, S)."""
@@ -369,6 +399,19 @@ def bn_act_bwd(dy, c, y, scale, shift, mean, invstd, relu=False, training=True, 
                                  dev_ptr(dres, allow_none=True), B, C, S, mode, 1 if training else 0,
                                  stream_ptr(c.device)), "dmb_bn_act_bwd_f32")
     return dc, dgamma, dbeta, dres
+
+
+def channel_dot(a, g):
+    """sum over (batch, space) of a[b, c, s] * g[b, 0, s] -> [C]."""
+    lib = _lib.load()
+    a, g = _f32c(a, "a"), _f32c(g, "g")
+    B, C, S = _bcs(a)
+    if g.shape[0] != B or g.numel() != B * S:
+        raise _lib.DmbLibraryError("channel_dot: g shape %s does not match a %s" % (tuple(g.shape), tuple(a.shape)))
+    out = torch.empty((C,), dtype=torch.float32, device=a.device)
+    ws = torch.empty((lib.dmb_bn_workspace_doubles(C, S),), dtype=torch.float64, device=a.device)
+    check(lib.dmb_channel_dot_f32(dev_ptr(a), dev_ptr(g), dev_ptr(ws), dev_ptr(out), B, C, S, stream_ptr(a.device)), "dmb_channel_dot_f32")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- path ends, backward

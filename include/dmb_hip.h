@@ -290,6 +290,13 @@ int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* w
 int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, float* dw, float* workspace, int B, int Cs, int Cb,
                               int Ds, int Hs, int Ws, int Db, int Hb, int Wb, void* stream);
 
+/* Weight gradient of nn.Conv2d(kernel 3, stride 1, padding 1) (AcfNet's confidence heads, cmn/cmn.py:21-36): x [B, Ci, H, W],
+ * dc [B, Co, H, W] -> dw [Co, Ci, 9].  W a multiple of 4, tensors 16-byte aligned.  The data gradient is dmb_conv2d_f32 on
+ * mirrored, channel-exchanged weights.  workspace: dmb_conv2d_wgrad_workspace_floats(Co, Ci) floats. */
+long long dmb_conv2d_wgrad_workspace_floats(int Co, int Ci);
+int dmb_conv2d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int H, int W,
+                            void* stream);
+
 /* BatchNorm (training mode) + skip add + ReLU of a convolution unit, layout [B, C, S] (S = voxels or pixels per channel).
  * relu: 0 none, 1 after the skip add, 2 before it -- the same epilogue the inference kernels fuse.
  *
@@ -310,6 +317,10 @@ int dmb_bn_act_f32(const float* c, const float* scale, const float* shift, const
 int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* y, const float* scale, const float* shift,
                        const float* mean, const float* invstd, double* workspace, float* dgamma, float* dbeta, float* dc,
                        float* dres, int B, int C, long long S, int relu, int training, void* stream);
+
+/* out[c] = sum_{b, s} a[b, c, s] * g[b, 0, s] (FP64 sums): the weight gradient of a 1x1 convolution with one output channel
+ * (second layer of AcfNet's confidence heads, cmn/cmn.py:30).  workspace: dmb_bn_workspace_doubles(C, S) doubles. */
+int dmb_channel_dot_f32(const float* a, const float* g, double* workspace, float* out, int B, int C, long long S, void* stream);
 
 /* Backward of the cost-volume builders: dvol [B, 2C (cat) or C (dif), D, H, W] -> dL, dR [B, C, H, W]; sums over the
  * valid columns of every disparity plane (cat_fms.py:36-44), FP32 in ascending plane order. */

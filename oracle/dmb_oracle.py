@@ -591,12 +591,15 @@ def psmnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, level_weights=(1.0, 0.7
     return [l.detach() for l in losses], dict(zip(names, grads)), running
 
 
-def acfnet_uniform_train_step(ref_fms, tgt_fms, p, max_disp, gt, variance=1.2, coefficient=5.0, level_weights=(1.0, 0.7, 0.5),
-                              focal_weight=1.0, l1_weight=0.1, dtype=torch.float32):
-    """One training iteration of AcfNet with a fixed variance (configs/AcfNet/scene_flow_uniform.py through
+def acfnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, variance=1.2, coefficient=5.0, level_weights=(1.0, 0.7, 0.5),
+                      focal_weight=1.0, l1_weight=0.1, adaptive=False, cmn_alpha=1.0, cmn_beta=1.0, nll_weight=8.0,
+                      dtype=torch.float32):
+    """One training iteration of AcfNet (configs/AcfNet/scene_flow_{uniform,adaptive}.py through
     models/general_stereo_model.py:60-77): cat_fms -> AcfAggregator (biased convolutions, BatchNorm in training mode, learned
     k8/s4 up-sampling) -> FasterSoftArgmin; StereoFocalLoss on the three cost volumes + DispSmoothL1Loss on the three
-    disparity maps.  Returns (dict of losses, grads, running)."""
+    disparity maps.  ``adaptive``: the confidence network (cmn/cmn.py:62-84) supplies the per-pixel variance
+    alpha * (1 - sigmoid(conf_cost)) + beta and adds ConfidenceNllLoss on the confidence costs; otherwise the variance is the
+    fixed number.  ``p``: model-level names.  Returns (dict of losses, grads, running)."""
     q, leaves = dict(), dict()
     for k, v in p.items():
         v = v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()
@@ -608,18 +611,28 @@ def acfnet_uniform_train_step(ref_fms, tgt_fms, p, max_disp, gt, variance=1.2, c
     R = tgt_fms.detach().clone().to(dtype).requires_grad_(True)
     leaves["ref_fms"], leaves["tgt_fms"] = L, R
     g = gt.to(dtype)
+    losses = dict()
     with bn_training():
         raw = cat_fms(L, R, max_disp // 4, 0, 1).to(dtype)
         costs = acf_aggregator(raw, q, max_disp, "cost_processor.aggregator.")
         ds = disp_sample_values(max_disp, 0, 1).to(dtype).view(1, -1, 1, 1)
         disps = [torch.sum(F.softmax(c, dim=1) * ds, dim=1, keepdim=True) for c in costs]
-    losses = dict()
+        variances = [variance] * len(costs)
+        if adaptive:
+            conf_costs = [conf_head(c, q, "cmn.conf_heads.%d" % i)[1] for i, c in enumerate(costs)]
+            variances = [cmn_alpha * (1 - torch.sigmoid(cc)) + cmn_beta for cc in conf_costs]
+            for i, cc in enumerate(conf_costs):
+                losses["conf_loss_lvl%d" % i] = nll_weight * level_weights[i] * conf_nll_loss(cc, g, max_disp)
     for i, (c, d) in enumerate(zip(costs, disps)):
-        losses["stereo_focal_loss_lvl%d" % i] = focal_weight * level_weights[i] * stereo_focal_loss(c, g, variance, max_disp, 0, 1, coefficient)
+        losses["stereo_focal_loss_lvl%d" % i] = focal_weight * level_weights[i] * stereo_focal_loss(c, g, variances[i], max_disp, 0, 1, coefficient)
         losses["l1_loss_lvl%d" % i] = l1_weight * level_weights[i] * disp_smooth_l1_loss(d, g, max_disp)
     names = list(leaves)
     grads = torch.autograd.grad(sum(losses.values()), [leaves[k] for k in names])
     return {k: v.detach() for k, v in losses.items()}, dict(zip(names, grads)), {k: v for k, v in q.items() if "running_" in k}
+
+
+def acfnet_uniform_train_step(ref_fms, tgt_fms, p, max_disp, gt, **kw):
+    return acfnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, adaptive=False, **kw)
 
 
 def stereonet_train_step(ref_fms, tgt_fms, p, max_disp, gt, dtype=torch.float32, num=4):

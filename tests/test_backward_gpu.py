@@ -404,3 +404,92 @@ def test_acfnet_uniform_training_step(dev):
         assert err <= 3e-2 * scale + zero, "grad of %s: error %.3e of range %.3e" % (k, err, scale)
         tight += err <= 4 * (g32[k].double() - ref).abs().max().item() + 2e-5 * scale + zero
     assert len(g64) == 80 + 7 + 3 and tight >= 0.6 * len(g64)   # PSMNet's 80 + 7 convolution biases + 3 up-sampling kernels
+
+
+@pytest.mark.parametrize("Ci,Co,shape", [
+    (192, 64, (1, 20, 64)),
+    (32, 32, (2, 9, 72)),          # partial strip in x, two batch items
+    (48, 10, (1, 33, 132)),        # channel counts that are not multiples of 32, several row segments
+    (16, 16, (1, 5, 8)),
+])
+def test_conv2d_wgrad_and_dgrad(dev, Ci, Co, shape):
+    """2-D weight / data gradients (AcfNet's confidence heads) against autograd of F.conv2d."""
+    import torch.nn.functional as F
+    ops = _ops()
+    B, H, W = shape
+    x, dc, w = _rand((B, Ci, H, W), 51), _rand((B, Co, H, W), 52), _rand((Co, Ci, 3, 3), 53, 0.05)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        xr, wr = x.to(dt).requires_grad_(True), w.to(dt).requires_grad_(True)
+        res[dt] = torch.autograd.grad(F.conv2d(xr, wr, None, padding=1), (xr, wr), dc.to(dt))
+    dw = ops.conv2d_k3_wgrad(x.to(dev), dc.to(dev)).cpu()
+    _close(dw, res[torch.float64][1], res[torch.float32][1], "dW (2-D)")
+    dx = ops.conv2d_dgrad(dc.to(dev), w.to(dev)).cpu()
+    _close(dx, res[torch.float64][0], res[torch.float32][0], "dx (2-D)")
+
+
+def test_channel_dot(dev):
+    ops = _ops()
+    a, g = _rand((3, 20, 7, 13), 61), _rand((3, 1, 7, 13), 62)
+    ref = (a.double() * g.double()).sum(dim=(0, 2, 3))
+    got = ops.channel_dot(a.to(dev), g.to(dev)).cpu()
+    assert (got.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_acfnet_adaptive_training_step(dev):
+    """AcfNet with its confidence network in training mode (configs/AcfNet/scene_flow_adaptive.py): the heads' NLL loss, the
+    focal loss with the per-pixel variance they supply (whose gradient flows back into them), smooth-L1; every gradient
+    against the oracle.  Tolerances as in test_psmnet_training_step."""
+    import os
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "AcfNet", "scene_flow_adaptive.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 4
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cfg.model.disp_predictor.max_disp = md
+    cfg.model.losses.l1_loss.max_disp = md
+    cfg.model.losses.focal_loss.max_disp = md
+    cfg.model.cmn.in_planes = md
+    cfg.model.cmn.losses.nll_loss.max_disp = md
+    p = O.with_prefix(O.random_params_psm(seed=4, classif_gain=4.0, acf=True), "cost_processor.aggregator.")
+    g = torch.Generator().manual_seed(77)
+    Cm = md // 3
+    for i in range(3):
+        pre = "cmn.conf_heads.%d.conf_net." % i
+        p[pre + "0.0.weight"] = (torch.rand((Cm, md, 3, 3), generator=g) * 2 - 1) / (md * 9) ** 0.5
+        p[pre + "0.1.weight"] = 0.5 + torch.rand(Cm, generator=g)
+        p[pre + "0.1.bias"] = (torch.rand(Cm, generator=g) - 0.5) * 0.2
+        p[pre + "0.1.running_mean"] = torch.zeros(Cm)
+        p[pre + "0.1.running_var"] = torch.ones(Cm)
+        p[pre + "1.weight"] = (torch.rand((1, Cm, 1, 1), generator=g) * 2 - 1) / Cm ** 0.5
+    model = build_model(cfg)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected
+    model = model.to(dev).train()
+    lf, rf = _rand((2, 32, 8, 24), 41), _rand((2, 32, 8, 24), 42)
+    gt = torch.rand((2, 1, 32, 96), generator=torch.Generator().manual_seed(43)) * 40.0 - 4.0
+    l32, g32, run32 = O.acfnet_train_step(lf, rf, p, md, gt, adaptive=True)
+    l64, g64, _ = O.acfnet_train_step(lf, rf, p, md, gt, adaptive=True, dtype=torch.float64)
+    lfg, rfg = lf.to(dev).requires_grad_(True), rf.to(dev).requires_grad_(True)
+    results, loss_dict = model(dict(leftFeature=lfg, rightFeature=rfg, leftDisp=gt.to(dev)))
+    assert results == {} and sorted(loss_dict) == sorted(l64)
+    for k, v in l64.items():
+        assert abs(loss_dict[k].item() - v.item()) <= 1e-4 * max(1.0, abs(v.item())), k
+    sum(loss_dict.values()).backward()
+    named = dict(model.named_parameters())
+    tight = 0
+    zero = 1e-6 * max(v.abs().max().item() for v in g64.values())
+    for k, ref in g64.items():
+        got = lfg.grad if k == "ref_fms" else rfg.grad if k == "tgt_fms" else named[k].grad
+        assert got is not None, k
+        scale = ref.abs().max().item()
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err <= 3e-2 * scale + zero, "grad of %s: error %.3e of range %.3e" % (k, err, scale)
+        tight += err <= 4 * (g32[k].double() - ref).abs().max().item() + 2e-5 * scale + zero
+    assert len(g64) == 90 + 3 * 4 and tight >= 0.6 * len(g64)   # + (conv, gamma, beta, 1x1 conv) per confidence head
+    buffers = dict(model.named_buffers())
+    for k, v in run32.items():
+        assert (buffers[k].cpu() - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
