@@ -271,20 +271,23 @@ __global__ __launch_bounds__(256) void deconv_k8s4_dw_kernel(const float* __rest
   const long long r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long long r = r0; r < r1; ++r) {
+  // threads walk the chunk's (row, column) pairs flattened, so narrow rows still fill the block
+  const long long n = (r1 - r0) * W;
+  int run = 0;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const long long r = r0 + i / W;
+    const int xi = (int)(i % W);
     const int yi = (int)(r % H), zi = (int)((r / H) % D), b = (int)(r / ((long long)H * D));
     const int zo = 4 * zi - 2 + kz, yo = 4 * yi - 2 + ky;
-    if (zo < 0 || zo >= Do || yo < 0 || yo >= Ho) continue;
-    const float* xr = x + (((size_t)b * D + zi) * H + yi) * W;
-    const float* dr = dy + (((size_t)b * Do + zo) * Ho + yo) * Wo;
-    for (int xi = threadIdx.x; xi < W; xi += 256) {
+    if (zo >= 0 && zo < Do && yo >= 0 && yo < Ho) {
       float d[8];
-      k8_row(dr, xi, Wo, d);
-      const float xv = xr[xi];
+      k8_row(dy + (((size_t)b * Do + zo) * Ho + yo) * Wo, xi, Wo, d);
+      const float xv = x[(((size_t)b * D + zi) * H + yi) * W + xi];
 #pragma unroll
       for (int kx = 0; kx < 8; ++kx) acc[kx] = fmaf(xv, d[kx], acc[kx]);
     }
-    if (((r - r0) & 63) == 63) {   // FP32 runs of at most 64 rows, FP64 across runs
+    if (++run == 64) {   // FP32 runs of 64 terms, FP64 across runs
+      run = 0;
 #pragma unroll
       for (int kx = 0; kx < 8; ++kx) {
         tot[kx] += (double)acc[kx];

@@ -99,7 +99,10 @@ class ConvUnitFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.deconv3d_k3s2_dgrad(dc, w) if unit.transposed else ops.conv3d_k3_dgrad(dc, w, unit.stride, tuple(x.shape[2:]))
         if has_bias and ctx.needs_input_grad[2]:
-            dbias = dc.sum(dim=(0, 2, 3, 4))
+            # sum of dc over (batch, voxels) without another pass: dc = scale * (dpre - mean terms), so it is scale * dbeta
+            # with running statistics (or no BatchNorm: scale = 1) and exactly zero behind batch statistics
+            # (sum xhat = 0: the normalisation removes any constant the bias adds)
+            dbias = torch.zeros_like(dbeta) if ctx.batch_stats else scale * dbeta
         return (dx, dw, dbias, dgamma if has_gamma and ctx.needs_input_grad[3] else None,
                 dbeta if has_beta and ctx.needs_input_grad[4] else None, dres if need_dres else None, None, None)
 

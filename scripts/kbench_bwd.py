@@ -48,3 +48,12 @@ for ci, co, d, h, w in ((64, 32, 24, 68, 120), (64, 64, 12, 34, 60)):
     report("wgrad deconv %d->%d from %dx%dx%d" % (ci, co, d, h, w), timeit(lambda: ops.deconv3d_k3s2_wgrad(x, dy)), fl)
     wt = torch.randn(ci, co, 3, 3, 3, device=dev) * 0.03
     report("dgrad deconv %d->%d" % (ci, co), timeit(lambda: ops.deconv3d_k3s2_dgrad(dy, wt)), fl)
+
+# AcfNet confidence head (cmn/cmn.py:21-36): 2-D convolution 192 -> 64 over the full-resolution cost volume
+for ci, co, h, w in ((192, 64, 544, 960),):
+    x = torch.randn(B, ci, h, w, device=dev)
+    dc = torch.randn(B, co, h, w, device=dev)
+    wt = torch.randn(co, ci, 3, 3, device=dev) * 0.03
+    fl = 2.0 * 9 * ci * co * B * h * w
+    report("wgrad 2-D %d->%d %dx%d" % (ci, co, h, w), timeit(lambda: ops.conv2d_k3_wgrad(x, dc)), fl)
+    report("dgrad 2-D %d->%d %dx%d" % (ci, co, h, w), timeit(lambda: ops.conv2d_dgrad(dc, wt)), fl)

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default=os.path.join("PSMNet", "scene_flow.py"), help="relative to configs/ (PSMNet/scene_flow.py, "
+                    "AcfNet/scene_flow_uniform.py, AcfNet/scene_flow_adaptive.py)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -35,7 +37,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    cfg = Config.fromfile(os.path.join(root, "configs", args.config))
     model = build_model(cfg).to(dev)
     synthetic.init_params_(model, seed=0)
     model.train()
@@ -85,7 +87,7 @@ def main():
     ev[3].record()
     torch.cuda.synchronize()
     if local == 0:
-        print("PSMNet cost-path training step: batch %d x %dx%d per GPU, %d GPU(s): %.1f ms/step = %.1f pairs/s; "
+        print(args.config + " cost-path training step: batch %d x %dx%d per GPU, %d GPU(s): %.1f ms/step = %.1f pairs/s; "
               "forward %.1f ms, backward %.1f ms, exchange+optimizer %.1f ms; loss %.4f; peak memory %.1f GB" %
               (B, H, W, world, ms, B * world / ms * 1e3, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]),
                ev[2].elapsed_time(ev[3]), float(loss.detach()), torch.cuda.max_memory_allocated(dev) / 2 ** 30), flush=True)
