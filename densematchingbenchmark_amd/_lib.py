@@ -60,7 +60,7 @@ SIGNATURES = {
     "dmb_conv3d_k3_wgrad_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 6 + [_P]),
     "dmb_conv3d_k3s2_wgrad_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 9 + [_P]),
     "dmb_conv2d_wgrad_workspace_floats": (_c_ll, [_c_int, _c_int]),
-    "dmb_conv2d_k3_wgrad_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 5 + [_P]),
+    "dmb_conv2d_wgrad_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 7 + [_P]),
     "dmb_channel_dot_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_bn_workspace_doubles": (_c_ll, [_c_int, _c_ll]),
     "dmb_bn_train_stats_f32": (_c_int, [_P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),

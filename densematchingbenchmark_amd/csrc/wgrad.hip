@@ -628,26 +628,31 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
 // ------------------------------------------------------------------------------------------------------------------
 namespace dmb {
 
+template <int KS_, int DIL_>
 struct Wg2dCfg {
-  static constexpr int TX = 64, XOFF = 3;
-  static constexpr int P = (4 + TX + 1 + 3) / 4 * 4;           // staged row: aligned column x0 - 4 ..
+  static constexpr int KS = KS_, DIL = DIL_, NTAP = KS * KS;
+  static constexpr int HALO = DIL * (KS / 2);                  // 0, 1 or 2 rows / columns either side
+  static constexpr int TX = 64, XOFF = 4 - HALO;
+  static constexpr int NR = 2 * HALO + 2;                      // ring slots: rows y - HALO .. y + HALO in use, one landing
+  static constexpr int P = (4 + TX + HALO + 3) / 4 * 4;        // staged row: aligned column x0 - 4 ..
   static constexpr int UXU = P / 4, UDU = TX / 4;              // 16-byte units per channel row
   static constexpr int UX = UXU | 1, UD = UDU | 1;             // ... made odd: pitch = 4 mod 8 floats
   static constexpr int SX = UX * 4, SD = UD * 4;
   static constexpr int XROW = 32 * SX, DROW = 32 * SD;
-  static constexpr int LDS_FLOATS = 4 * XROW + 2 * DROW;
+  static constexpr int LDS_FLOATS = NR * XROW + 2 * DROW;
   static constexpr int IX = (32 * UX + 255) / 256, ID = (32 * UD + 255) / 256;   // copy instructions per wave and row
   static constexpr int KSTEPS = TX / 4 / 2;                    // per wave: 16 columns = 8 k-steps
-  static_assert(SX % 8 == 4 && SD % 8 == 4 && IX + ID <= KSTEPS && LDS_FLOATS * 4 * 2 <= 160 * 1024, "tile");
+  static_assert(HALO <= 4 && SX % 8 == 4 && SD % 8 == 4 && IX + ID <= KSTEPS && LDS_FLOATS * 4 * 2 <= 160 * 1024, "tile");
 };
 
+template <int KS_, int DIL_>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dc,
                                                               float* __restrict__ ws, int B, int Ci, int Co, int H, int W, int ntx,
                                                               int nys, int yseg) {
-  typedef Wg2dCfg C;
+  typedef Wg2dCfg<KS_, DIL_> C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xring = lds;
-  float* dbuf = lds + 4 * C::XROW;
+  float* dbuf = lds + C::NR * C::XROW;
   const int ncib = cdiv(Ci, 32);
   const int cib = blockIdx.y % ncib, cob = blockIdx.y / ncib;
   const int slot = xcd_remap(blockIdx.x, gridDim.x), nslots = gridDim.x;
@@ -657,9 +662,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
   const int items = B * nys * ntx;
   const int nci = min(32, Ci - cib * 32), nco = min(32, Co - cob * 32);
 
-  f32x16 acc[9];
+  f32x16 acc[C::NTAP];
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
+  for (int i = 0; i < C::NTAP; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   const int aoff = n * C::SD + wave * 16 + kk;
@@ -697,27 +702,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
       const int first = (j * 4 + wave) * 64;
       if (first + lane < 32 * C::UD) dma16(drs, ok ? dvo[j] : DMA_OOB, ok ? (unsigned)gy * W * 4u : 0u, dbuf + buf * C::DROW + first * 4);
     };
+    // ring slot of image row r: (r - (ya - HALO)) % NR
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < 2 * C::HALO + 1; ++q)
 #pragma unroll
-      for (int j = 0; j < C::IX; ++j) stage_x1(ya - 1 + q, q, j);
+      for (int j = 0; j < C::IX; ++j) stage_x1(ya - C::HALO + q, q, j);
 #pragma unroll
     for (int j = 0; j < C::ID; ++j) stage_d1(ya, 0, j);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    int r0 = 0;   // ring index of row y - HALO
     for (int y = ya; y < yb; ++y) {
-      const int rel = y - ya;   // row y + dy - 1 sits in ring slot (rel + dy) % 4
+      const int rel = y - ya;
       const bool more = y + 1 < yb;
       const float* ap = dbuf + (rel & 1) * C::DROW + aoff;
-      const float* bp[3];
+      const float* bp[C::KS];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) bp[dy] = xring + ((rel + dy) & 3) * C::XROW + boff;
-      float af[2], bf[2][9];
-      auto load_frag = [&](int q, float& a, float (&bq)[9]) {
+      for (int ty = 0; ty < C::KS; ++ty) bp[ty] = xring + ((r0 + ty * C::DIL) % C::NR) * C::XROW + boff;
+      const int rnew = (r0 + 2 * C::HALO + 1) % C::NR;
+      float af[2], bf[2][C::NTAP];
+      auto load_frag = [&](int q, float& a, float (&bq)[C::NTAP]) {
         a = ap[2 * q];
 #pragma unroll
-        for (int tt = 0; tt < 9; ++tt) bq[tt] = bp[tt / 3][2 * q + tt % 3];
+        for (int tt = 0; tt < C::NTAP; ++tt) bq[tt] = bp[tt / C::KS][2 * q + (tt % C::KS) * C::DIL];
       };
       load_frag(0, af[0], bf[0]);
 #pragma unroll
@@ -725,46 +733,47 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
         if (q + 1 < C::KSTEPS) load_frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tt = 0; tt < 9; ++tt) acc[tt] = DMB_MFMA(af[q & 1], bf[q & 1][tt], acc[tt]);
+        for (int tt = 0; tt < C::NTAP; ++tt) acc[tt] = DMB_MFMA(af[q & 1], bf[q & 1][tt], acc[tt]);
         if (more) {
           if (q < C::IX)
-            stage_x1(y + 2, (rel + 3) & 3, q);
+            stage_x1(y + C::HALO + 1, rnew, q);
           else if (q < C::IX + C::ID)
             stage_d1(y + 1, (rel + 1) & 1, q - C::IX);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      r0 = (r0 + 1) % C::NR;
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
   }
-  float* wsb = ws + (((size_t)blockIdx.y * nslots + slot) * 4 + wave) * 9 * 1024;
+  float* wsb = ws + (((size_t)blockIdx.y * nslots + slot) * 4 + wave) * C::NTAP * 1024;
 #pragma unroll
-  for (int tt = 0; tt < 9; ++tt)
+  for (int tt = 0; tt < C::NTAP; ++tt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) wsb[tt * 1024 + cd_row(r, kk) * 32 + n] = acc[tt][r];
 }
 
-__global__ void conv2d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nparts) {
+__global__ void conv2d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nparts, int ntap) {
   const int ncib = cdiv(Ci, 32);
-  const long long total = (long long)cdiv(Co, 32) * ncib * 9 * 1024;
+  const long long total = (long long)cdiv(Co, 32) * ncib * ntap * 1024;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int nn = (int)(i & 31), m = (int)((i >> 5) & 31);
     long long r = i >> 10;
-    const int t = (int)(r % 9);
-    const int blk = (int)(r / 9);
+    const int t = (int)(r % ntap);
+    const int blk = (int)(r / ntap);
     const int cib = blk % ncib, cob = blk / ncib;
     const int co = cob * 32 + m, ci = cib * 32 + nn;
     if (co >= Co || ci >= Ci) continue;
-    const float* p = ws + (size_t)blk * nparts * 9 * 1024 + t * 1024 + m * 32 + nn;
+    const float* p = ws + (size_t)blk * nparts * ntap * 1024 + t * 1024 + m * 32 + nn;
     double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int sl = 0;
     for (; sl + 8 <= nparts; sl += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) part[u] += (double)p[(size_t)(sl + u) * 9 * 1024];
+      for (int u = 0; u < 8; ++u) part[u] += (double)p[(size_t)(sl + u) * ntap * 1024];
     }
-    for (; sl < nparts; ++sl) part[sl & 7] += (double)p[(size_t)sl * 9 * 1024];
-    dw[((size_t)co * Ci + ci) * 9 + t] = (float)(((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7])));
+    for (; sl < nparts; ++sl) part[sl & 7] += (double)p[(size_t)sl * ntap * 1024];
+    dw[((size_t)co * Ci + ci) * ntap + t] = (float)(((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7])));
   }
 }
 
@@ -781,22 +790,18 @@ extern "C" long long dmb_conv2d_wgrad_workspace_floats(int Co, int Ci) {
   return (long long)cdiv(Co, 32) * cdiv(Ci, 32) * wgrad2d_slots_per_block(Co, Ci) * 4 * 9 * 1024;
 }
 
-extern "C" int dmb_conv2d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int H,
-                                       int W, void* stream) {
-  if (!x || !dc || !dw || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv2d_wgrad: bad argument");
-  if ((long long)32 * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d_wgrad: 32 channels of one image must stay below 2 GiB");
-  if (W % 4 != 0 || (((uintptr_t)x | (uintptr_t)dc) & 15) != 0)
-    return fail(DMB_EUNSUPPORTED, "conv2d_wgrad: the width must be a multiple of 4 and the tensors 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
+template <int KS, int DIL>
+static int launch_wgrad2d(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int H, int W, hipStream_t st) {
+  typedef Wg2dCfg<KS, DIL> C;
   const int nblk = cdiv(Co, 32) * cdiv(Ci, 32), nslots = wgrad2d_slots_per_block(Co, Ci);
-  const int ntx = cdiv(W, Wg2dCfg::TX);
+  const int ntx = cdiv(W, C::TX);
   int yseg = H;
   {
     double best = 1e30;
     for (int ny = 1; ny <= H; ++ny) {
       const int ysz = cdiv(H, ny);
       if (ysz < 8 && ny > 1) break;
-      const double cost = (double)cdiv_ll((long long)B * ntx * cdiv(H, ysz), nslots) * (ysz + 1.0);
+      const double cost = (double)cdiv_ll((long long)B * ntx * cdiv(H, ysz), nslots) * (ysz + 1.0 + C::HALO);
       if (cost < best - 1e-9) {
         best = cost;
         yseg = ysz;
@@ -806,13 +811,26 @@ extern "C" int dmb_conv2d_k3_wgrad_f32(const float* x, const float* dc, float* d
   const int nys = cdiv(H, yseg);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2dCfg::LDS_FLOATS * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<KS, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3((unsigned)nslots, (unsigned)nblk), dim3(256), Wg2dCfg::LDS_FLOATS * 4, st, x, dc, workspace, B,
+  hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, DIL>), dim3((unsigned)nslots, (unsigned)nblk), dim3(256), C::LDS_FLOATS * 4, st, x, dc, workspace, B,
                      Ci, Co, H, W, ntx, nys, yseg);
   int rc = launch_status("conv2d_wgrad launch failed");
   if (rc != DMB_OK) return rc;
-  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(nblk * 9 * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nslots * 4);
+  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(nblk * C::NTAP * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nslots * 4, C::NTAP);
   return launch_status("conv2d_wgrad reduce launch failed");
+}
+
+extern "C" int dmb_conv2d_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int H, int W,
+                                    int ksize, int dilation, void* stream) {
+  if (!x || !dc || !dw || !workspace || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv2d_wgrad: bad argument");
+  if ((long long)32 * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d_wgrad: 32 channels of one image must stay below 2 GiB");
+  if (W % 4 != 0 || (((uintptr_t)x | (uintptr_t)dc) & 15) != 0)
+    return fail(DMB_EUNSUPPORTED, "conv2d_wgrad: the width must be a multiple of 4 and the tensors 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 3 && dilation == 1) return launch_wgrad2d<3, 1>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
+  if (ksize == 3 && dilation == 2) return launch_wgrad2d<3, 2>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
+  if (ksize == 1) return launch_wgrad2d<1, 1>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
+  return fail(DMB_EUNSUPPORTED, "conv2d_wgrad: kernel 1, or kernel 3 with dilation 1 or 2 (stride 1)");
 }

@@ -319,24 +319,29 @@ def deconv3d_k3s2_wgrad(x, dy):
     return _s2_wgrad(x, dy, "dmb_conv3d_k3s2_wgrad_f32 (transposed conv)")
 
 
-def conv2d_k3_wgrad(x, dc):
-    """Weight gradient of nn.Conv2d(k=3, stride=1, padding=1): x [B, Ci, H, W], dc [B, Co, H, W] -> [Co, Ci, 3, 3]."""
+def conv2d_wgrad(x, dc, ksize=3, dilation=1):
+    """Weight gradient of a stride-1 nn.Conv2d (k = 1, or k = 3 with dilation 1 | 2, padding = dilation * (k // 2)):
+    x [B, Ci, H, W], dc [B, Co, H, W] -> [Co, Ci, k, k]."""
     lib = _lib.load()
     x, dc = _f32c(x, "x"), _f32c(dc, "dc")
     B, Ci, H, W = x.shape
     Co = dc.shape[1]
     if tuple(dc.shape) != (B, Co, H, W):
-        raise _lib.DmbLibraryError("conv2d_k3_wgrad: dc shape %s does not match x %s" % (tuple(dc.shape), tuple(x.shape)))
-    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
+        raise _lib.DmbLibraryError("conv2d_wgrad: dc shape %s does not match x %s" % (tuple(dc.shape), tuple(x.shape)))
+    dw = torch.empty((Co, Ci, ksize, ksize), dtype=torch.float32, device=x.device)
     ws = torch.empty((lib.dmb_conv2d_wgrad_workspace_floats(Co, Ci),), dtype=torch.float32, device=x.device)
-    check(lib.dmb_conv2d_k3_wgrad_f32(dev_ptr(x), dev_ptr(dc), dev_ptr(dw), dev_ptr(ws), B, Ci, Co, H, W, stream_ptr(x.device)),
-          "dmb_conv2d_k3_wgrad_f32")
+    check(lib.dmb_conv2d_wgrad_f32(dev_ptr(x), dev_ptr(dc), dev_ptr(dw), dev_ptr(ws), B, Ci, Co, H, W, int(ksize), int(dilation),
+                                   stream_ptr(x.device)), "dmb_conv2d_wgrad_f32")
     return dw
 
 
-def conv2d_dgrad(dc, w):
-    """Gradient of nn.Conv2d(k in {1, 3}, stride 1, padding k//2) w.r.t. its input; w is the layer's weight [Co, Ci, k, k].
-    The same convolution kernel on mirrored, channel-exchanged weights, at most 128 output channels per launch."""
+def conv2d_k3_wgrad(x, dc):
+    return conv2d_wgrad(x, dc, 3, 1)
+
+
+def conv2d_dgrad(dc, w, dilation=1):
+    """Gradient of a stride-1 nn.Conv2d (k in {1, 3}, padding = dilation * (k // 2)) w.r.t. its input; w is the layer's weight
+    [Co, Ci, k, k].  The same convolution kernel on mirrored, channel-exchanged weights, at most 128 output channels per launch."""
     w = _f32c(w, "weight")
     Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
     wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()           # [Ci, Co, k, k]: a convolution Co -> Ci
@@ -345,7 +350,7 @@ def conv2d_dgrad(dc, w):
     dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dc.device)
     for c0 in range(0, Ci, 128):
         n = min(128, Ci - c0)
-        conv2d(dc, pack_conv2d_weights(wt[c0:c0 + n].contiguous()), n, k, out=dx, out_ch_offset=c0)
+        conv2d(dc, pack_conv2d_weights(wt[c0:c0 + n].contiguous()), n, k, dilation=dilation, out=dx, out_ch_offset=c0)
     return dx
 
 

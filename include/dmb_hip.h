@@ -290,12 +290,13 @@ int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* w
 int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, float* dw, float* workspace, int B, int Cs, int Cb,
                               int Ds, int Hs, int Ws, int Db, int Hb, int Wb, void* stream);
 
-/* Weight gradient of nn.Conv2d(kernel 3, stride 1, padding 1) (AcfNet's confidence heads, cmn/cmn.py:21-36): x [B, Ci, H, W],
- * dc [B, Co, H, W] -> dw [Co, Ci, 9].  W a multiple of 4, tensors 16-byte aligned.  The data gradient is dmb_conv2d_f32 on
+/* Weight gradient of a stride-1 nn.Conv2d with kernel 1, or kernel 3 with dilation 1 | 2 (padding = dilation * (k / 2)):
+ * AcfNet's confidence heads (cmn/cmn.py:21-36) and the stride-1 layers of the 2-D networks.  x [B, Ci, H, W],
+ * dc [B, Co, H, W] -> dw [Co, Ci, k*k].  W a multiple of 4, tensors 16-byte aligned.  The data gradient is dmb_conv2d_f32 on
  * mirrored, channel-exchanged weights.  workspace: dmb_conv2d_wgrad_workspace_floats(Co, Ci) floats. */
 long long dmb_conv2d_wgrad_workspace_floats(int Co, int Ci);
-int dmb_conv2d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int H, int W,
-                            void* stream);
+int dmb_conv2d_wgrad_f32(const float* x, const float* dc, float* dw, float* workspace, int B, int Ci, int Co, int H, int W,
+                         int ksize, int dilation, void* stream);
 
 /* BatchNorm (training mode) + skip add + ReLU of a convolution unit, layout [B, C, S] (S = voxels or pixels per channel).
  * relu: 0 none, 1 after the skip add, 2 before it -- the same epilogue the inference kernels fuse.

@@ -406,25 +406,30 @@ def test_acfnet_uniform_training_step(dev):
     assert len(g64) == 80 + 7 + 3 and tight >= 0.6 * len(g64)   # PSMNet's 80 + 7 convolution biases + 3 up-sampling kernels
 
 
-@pytest.mark.parametrize("Ci,Co,shape", [
-    (192, 64, (1, 20, 64)),
-    (32, 32, (2, 9, 72)),          # partial strip in x, two batch items
-    (48, 10, (1, 33, 132)),        # channel counts that are not multiples of 32, several row segments
-    (16, 16, (1, 5, 8)),
+@pytest.mark.parametrize("Ci,Co,k,dil,shape", [
+    (192, 64, 3, 1, (1, 20, 64)),
+    (32, 32, 3, 1, (2, 9, 72)),          # partial strip in x, two batch items
+    (48, 10, 3, 1, (1, 33, 132)),        # channel counts that are not multiples of 32, several row segments
+    (16, 16, 3, 1, (1, 5, 8)),
+    (128, 128, 3, 2, (1, 17, 68)),       # dilation 2 (backbone layer4): six ring slots
+    (20, 40, 3, 2, (2, 6, 12)),
+    (64, 128, 1, 1, (1, 12, 64)),        # 1x1 convolutions (down-sampling shortcuts, SPP branches, lastconv)
+    (320, 32, 1, 1, (2, 7, 20)),
 ])
-def test_conv2d_wgrad_and_dgrad(dev, Ci, Co, shape):
-    """2-D weight / data gradients (AcfNet's confidence heads) against autograd of F.conv2d."""
+def test_conv2d_wgrad_and_dgrad(dev, Ci, Co, k, dil, shape):
+    """2-D weight / data gradients (AcfNet's confidence heads, the stride-1 layers of the 2-D networks) against autograd of
+    F.conv2d."""
     import torch.nn.functional as F
     ops = _ops()
     B, H, W = shape
-    x, dc, w = _rand((B, Ci, H, W), 51), _rand((B, Co, H, W), 52), _rand((Co, Ci, 3, 3), 53, 0.05)
+    x, dc, w = _rand((B, Ci, H, W), 51), _rand((B, Co, H, W), 52), _rand((Co, Ci, k, k), 53, 0.05)
     res = {}
     for dt in (torch.float32, torch.float64):
         xr, wr = x.to(dt).requires_grad_(True), w.to(dt).requires_grad_(True)
-        res[dt] = torch.autograd.grad(F.conv2d(xr, wr, None, padding=1), (xr, wr), dc.to(dt))
-    dw = ops.conv2d_k3_wgrad(x.to(dev), dc.to(dev)).cpu()
+        res[dt] = torch.autograd.grad(F.conv2d(xr, wr, None, padding=dil * (k // 2), dilation=dil), (xr, wr), dc.to(dt))
+    dw = ops.conv2d_wgrad(x.to(dev), dc.to(dev), k, dil).cpu()
     _close(dw, res[torch.float64][1], res[torch.float32][1], "dW (2-D)")
-    dx = ops.conv2d_dgrad(dc.to(dev), w.to(dev)).cpu()
+    dx = ops.conv2d_dgrad(dc.to(dev), w.to(dev), dil).cpu()
     _close(dx, res[torch.float64][0], res[torch.float32][0], "dx (2-D)")
 
 
