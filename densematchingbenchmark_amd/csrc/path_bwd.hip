@@ -317,6 +317,18 @@ __global__ void deconv_k8s4_dw_reduce_kernel(const double* __restrict__ ws, floa
   dw[i] = (float)s;
 }
 
+// nn.AvgPool2d(k, stride k) backward (the SPP branches, backbones/PSMNet.py:43-58): every input element of a pooled window gets
+// dy / k^2, the rows / columns the pooling dropped get zero.
+__global__ __launch_bounds__(256) void avgpool2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long total,
+                                                            int H, int W, int k, int Ho, int Wo) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const long long bc = i / ((long long)W * H);
+  const int yo = y / k, xo = x / k;
+  dx[i] = (yo < Ho && xo < Wo) ? dy[(bc * Ho + yo) * Wo + xo] / (float)(k * k) : 0.f;
+}
+
 static int fill_idx(const int* host, int D, DispIdx& idx) {
   if (!host || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
   for (int k = 0; k < D; ++k) idx.d[k] = host[k];
@@ -410,4 +422,21 @@ extern "C" int dmb_trilinear_ac_bwd_f32(const float* grad_y, float* scratch, flo
   hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), Di * Hi, B), dim3(256), 0, st, scratch, grad_x, Di, Hi, Wi,
                      Ho, Wo, sh, sw);
   return launch_status("trilinear_bwd launch failed");
+}
+
+extern "C" int dmb_avgpool2d_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int H, int W, int k, void* stream) {
+  if (!grad_y || !grad_x || B <= 0 || C <= 0 || k <= 0 || H < k || W < k) return fail(DMB_EINVAL, "avgpool2d_bwd: bad argument");
+  const long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(avgpool2d_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_y, grad_x, total,
+                     H, W, k, H / k, W / k);
+  return launch_status("avgpool2d_bwd launch failed");
+}
+
+extern "C" int dmb_bilinear_ac_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  if (!grad_y || !grad_x || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return fail(DMB_EINVAL, "bilinear_bwd: bad argument");
+  if ((long long)C * Hi > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "bilinear_bwd: grid too large");
+  // the (y, x) contraction of the up-sampling backward, one "plane" per channel
+  hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), C * Hi, B), dim3(256), 0, (hipStream_t)stream, grad_y, grad_x, C,
+                     Hi, Wi, Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  return launch_status("bilinear_bwd launch failed");
 }

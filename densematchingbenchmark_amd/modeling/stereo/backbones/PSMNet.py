@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from ..layers import train_fn
 from ..layers.basic_layers_2d import BasicBlock, conv_bn, conv_bn_relu
 
 
@@ -62,10 +63,30 @@ class PSMNetBackbone(nn.Module):
             ops.bilinear_ac(branch[1](pooled), (H4, W4), out=feat, out_ch_offset=off)
         return self.lastconv[1](self.lastconv[0](feat))
 
+    def _forward_train(self, x):
+        """The same network on plain tensors under autograd (SURVEY 8-f3 widened to the backbone): PSMNet.py:64-125."""
+        x = self.firstconv(x)
+        x = self.layer1(x)
+        out2 = self.layer2(x)
+        x = self.layer3(out2)
+        out4 = self.layer4(x)
+        H4, W4 = out4.shape[2:]
+        ups = []
+        for i in (4, 3, 2, 1):
+            branch = getattr(self, "branch%d" % i)
+            pooled = train_fn.AvgPool2dFn.apply(out4, branch[0].kernel_size[0])
+            ups.append(train_fn.BilinearAcFn.apply(branch[1](pooled), (H4, W4)))
+        feat = torch.cat([out2, out4] + ups, 1)                             # PSMNet.py:119-121
+        return self.lastconv[1](self.lastconv[0](feat))
+
     def forward(self, *input):
         if len(input) != 2:
             raise ValueError('expected input length 2 (got {} length input)'.format(len(input)))
         l_img, r_img = input
+        if train_fn.wants_grad(self, l_img, r_img):
+            # one view after the other, as the reference does (PSMNet.py:127-131): in training mode the BatchNorm statistics
+            # are those of each call, and the running buffers are updated twice
+            return self._forward_train(l_img), self._forward_train(r_img)
         # shared weights (PSMNet.py:127-131): both views go through as one batch of 2B images -- per-image results are
         # unchanged, the launches are half as many and twice as wide
         B = l_img.shape[0]
@@ -82,6 +103,8 @@ class _BareConv1x1(nn.Conv2d):
 
     def forward(self, x):
         from ..layers.basic_layers import _versions
+        if train_fn.wants_grad(self, x):
+            return train_fn.BareConv1x1Fn.apply(x, self.weight)
         key = _versions(self.weight)
         if key != self._key:
             self._key, self._wp = key, ops.pack_conv2d_weights(self.weight.detach())

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from . import train_fn
 from .basic_layers import _versions, fold_batch_norm
 
 __all__ = ["FusedConv2d", "conv_bn", "conv_bn_relu", "BasicBlock"]
@@ -47,8 +48,11 @@ class FusedConv2d(nn.Sequential):
         return self._cache
 
     def forward(self, x, residual=None, relu=None, in_window=None, out=None, out_ch_offset=0, res_ch_offset=0):
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("FusedConv2d is an inference-only HIP path: call model.eval() and run under torch.no_grad()")
+        if train_fn.wants_grad(self, x, residual):
+            # training / differentiable path: plain tensors (no channel windows), separate launches under torch.autograd
+            if in_window is not None or out is not None or res_ch_offset:
+                raise ValueError("FusedConv2d: channel windows are an inference-path feature")
+            return train_fn.conv2d_unit(self, x, residual, self.has_relu if relu is None else relu)
         wp, scale, shift = self._prepacked()
         return ops.conv2d(x, wp, self.out_planes, self.kernel_size, self.stride, self.dilation, scale, shift, residual,
                           self.has_relu if relu is None else relu, in_window, out, out_ch_offset, res_ch_offset)

@@ -256,6 +256,144 @@ class ConfHeadFn(torch.autograd.Function):
                 dbeta if ctx.has[1] and ctx.needs_input_grad[3] else None, dw2, None)
 
 
+def _bn_forward(bn, training, raw, gamma, beta, C, device):
+    """Shared by the 2-D / 3-D units: (mean, invstd, scale, shift, batch_stats) for this call, running buffers updated."""
+    batch_stats = bn is not None and training
+    if batch_stats:
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        mean, invstd, scale, shift = ops.bn_train_stats(raw, gamma.detach() if gamma is not None else None,
+                                                        beta.detach() if beta is not None else None,
+                                                        bn.running_mean if bn.track_running_stats else None,
+                                                        bn.running_var if bn.track_running_stats else None, momentum, bn.eps)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    elif bn is not None:
+        mean = bn.running_mean.detach().float()
+        invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        scale = (gamma.detach() if gamma is not None else torch.ones_like(mean)) * invstd
+        shift = (beta.detach() if beta is not None else torch.zeros_like(mean)) - mean * scale
+    else:
+        mean = torch.zeros(C, dtype=torch.float32, device=device)
+        invstd, scale, shift = torch.ones_like(mean), torch.ones_like(mean), torch.zeros_like(mean)
+    return mean, invstd, scale, shift, batch_stats
+
+
+def _as3d_weight(w):
+    """[Co, Ci, 3, 3] -> [Co, Ci, 3, 3, 3] with the 2-D taps on the middle plane: a 2-D layer seen by the 3-D stride-2 kernels."""
+    w3 = torch.zeros(w.shape[:2] + (3, 3, 3), dtype=w.dtype, device=w.device)
+    w3[:, :, 1] = w
+    return w3
+
+
+class Conv2dUnitFn(torch.autograd.Function):
+    """y = act(BN(conv2d(x)) (+ skip)) of one FusedConv2d unit of the 2-D networks (layers/basic_layers.py:31-46,105-123):
+    kernel 1 | 3, stride 1 | 2, dilation 1 | 2.  Stride-1 gradients run on the 2-D kernels; the few stride-2 layers borrow the
+    3-D stride-2 kernels with a depth of one."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, skip, unit, relu):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        C, k, s, d = unit.out_planes, unit.kernel_size, unit.stride, unit.dilation
+        if k not in (1, 3) or d not in (1, 2) or (s == 2 and d != 1):
+            raise NotImplementedError("training path of FusedConv2d: kernel 1|3, dilation 1|2, stride 2 only without dilation")
+        sc = sh = None
+        if bias is not None:
+            sc, sh = torch.ones_like(bias), bias.detach().contiguous()
+        raw = ops.conv2d(x, ops.pack_conv2d_weights(w), C, k, s, d, sc, sh, None, False)
+        bn = unit[1] if unit.has_bn else None
+        mean, invstd, scale, shift, batch_stats = _bn_forward(bn, unit.training, raw, gamma, beta, C, x.device)
+        code = _relu_code(relu)
+        y = raw if (bn is None and skip is None and code == 0) else ops.bn_act(raw, scale, shift, skip, _RELU[code])
+        ctx.unit, ctx.code, ctx.batch_stats = unit, code, batch_stats
+        ctx.has = (bias is not None, gamma is not None, beta is not None, skip is not None)
+        ctx.save_for_backward(x, w, raw, y if code == 1 else None, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, raw, y, scale, shift, mean, invstd = ctx.saved_tensors
+        unit, code = ctx.unit, ctx.code
+        k, s, d = unit.kernel_size, unit.stride, unit.dilation
+        has_bias, has_gamma, has_beta, has_skip = ctx.has
+        dy = dy.contiguous()
+        need_dres = has_skip and ctx.needs_input_grad[5]
+        dc, dgamma, dbeta, dres = ops.bn_act_bwd(dy, raw, y, scale, shift, mean, invstd, _RELU[code], ctx.batch_stats,
+                                                 want_dres=need_dres and code == 1)
+        if need_dres and code != 1:
+            dres = dy
+        dw = dx = dbias = None
+        if ctx.needs_input_grad[1]:
+            if s == 1:
+                dw = ops.conv2d_wgrad(x, dc, k, d)
+            elif k == 3:   # stride 2: the 3-D stride-2 weight gradient at depth 1, middle plane of its taps
+                dw = ops.conv3d_k3s2_wgrad(x.unsqueeze(2), dc.unsqueeze(2))[:, :, 1].contiguous()
+            else:          # 1x1, stride 2: a 1x1 layer on the even positions
+                dw = ops.conv2d_wgrad(x[:, :, ::2, ::2].contiguous(), dc, 1, 1)
+        if ctx.needs_input_grad[0]:
+            if s == 1:
+                dx = ops.conv2d_dgrad(dc, w, d)
+            elif k == 3:
+                dx = ops.conv3d_k3_dgrad(dc.unsqueeze(2), _as3d_weight(w), 2, (1,) + tuple(x.shape[2:])).squeeze(2)
+            else:
+                dx = torch.zeros_like(x)
+                dx[:, :, ::2, ::2] = ops.conv2d_dgrad(dc, w, 1)
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = torch.zeros_like(dbeta) if ctx.batch_stats else scale * dbeta
+        return (dx, dw, dbias, dgamma if has_gamma and ctx.needs_input_grad[3] else None,
+                dbeta if has_beta and ctx.needs_input_grad[4] else None, dres if need_dres else None, None, None)
+
+
+def conv2d_unit(unit, x, residual=None, relu=False):
+    conv = unit[0]
+    bn = unit[1] if unit.has_bn else None
+    gamma = bn.weight if bn is not None and bn.affine else None
+    beta = bn.bias if bn is not None and bn.affine else None
+    return Conv2dUnitFn.apply(x, conv.weight, conv.bias, gamma, beta, residual, unit, relu)
+
+
+class BareConv1x1Fn(torch.autograd.Function):
+    """nn.Conv2d(C, Co, 1, bias=False) (the last layer of the PSMNet backbone, backbones/PSMNet.py:61-62)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        ctx.save_for_backward(x, w)
+        return ops.conv2d(x, ops.pack_conv2d_weights(w), w.shape[0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        return (ops.conv2d_dgrad(dy, w) if ctx.needs_input_grad[0] else None,
+                ops.conv2d_wgrad(x, dy, 1, 1) if ctx.needs_input_grad[1] else None)
+
+
+class AvgPool2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        x = x.contiguous()
+        ctx.k, ctx.hw = int(k), tuple(x.shape[2:])
+        return ops.avgpool2d(x, k)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool2d_bwd(dy.contiguous(), ctx.hw, ctx.k), None
+
+
+class BilinearAcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        x = x.contiguous()
+        ctx.hw = tuple(x.shape[2:])
+        return ops.bilinear_ac(x, tuple(out_hw))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bilinear_ac_bwd(dy.contiguous(), ctx.hw), None
+
+
 class SoftArgminFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cost, values, alpha):

@@ -328,6 +328,11 @@ def conv2d_wgrad(x, dc, ksize=3, dilation=1):
     Co = dc.shape[1]
     if tuple(dc.shape) != (B, Co, H, W):
         raise _lib.DmbLibraryError("conv2d_wgrad: dc shape %s does not match x %s" % (tuple(dc.shape), tuple(x.shape)))
+    if W % 4:
+        # the kernel stages 16-byte units: zero columns on the right change nothing (dc is zero there, x reads as padding)
+        pad = 4 - W % 4
+        x, dc = torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(dc, (0, pad))
+        W += pad
     dw = torch.empty((Co, Ci, ksize, ksize), dtype=torch.float32, device=x.device)
     ws = torch.empty((lib.dmb_conv2d_wgrad_workspace_floats(Co, Ci),), dtype=torch.float32, device=x.device)
     check(lib.dmb_conv2d_wgrad_f32(dev_ptr(x), dev_ptr(dc), dev_ptr(dw), dev_ptr(ws), B, Ci, Co, H, W, int(ksize), int(dilation),
@@ -481,6 +486,26 @@ def trilinear_ac_bwd(grad_y, in_size):
     gx = torch.empty((B, Di, Hi, Wi), dtype=torch.float32, device=grad_y.device)
     check(lib.dmb_trilinear_ac_bwd_f32(dev_ptr(grad_y), dev_ptr(scratch), dev_ptr(gx), B, Di, Hi, Wi, Do, Ho, Wo,
                                        stream_ptr(grad_y.device)), "dmb_trilinear_ac_bwd_f32")
+    return gx
+
+
+def avgpool2d_bwd(grad_y, in_hw, k):
+    lib = _lib.load()
+    grad_y = _f32c(grad_y, "grad_y")
+    B, C = grad_y.shape[0], grad_y.shape[1]
+    H, W = in_hw
+    gx = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_y.device)
+    check(lib.dmb_avgpool2d_bwd_f32(dev_ptr(grad_y), dev_ptr(gx), B, C, H, W, int(k), stream_ptr(grad_y.device)), "dmb_avgpool2d_bwd_f32")
+    return gx
+
+
+def bilinear_ac_bwd(grad_y, in_hw):
+    lib = _lib.load()
+    grad_y = _f32c(grad_y, "grad_y")
+    B, C, Ho, Wo = grad_y.shape
+    Hi, Wi = in_hw
+    gx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=grad_y.device)
+    check(lib.dmb_bilinear_ac_bwd_f32(dev_ptr(grad_y), dev_ptr(gx), B, C, Hi, Wi, Ho, Wo, stream_ptr(grad_y.device)), "dmb_bilinear_ac_bwd_f32")
     return gx
 
 

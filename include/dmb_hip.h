@@ -346,6 +346,11 @@ int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float* disp, cons
 int dmb_trilinear_ac_bwd_f32(const float* grad_y, float* scratch, float* grad_x, int B, int Di, int Hi, int Wi, int Do, int Ho,
                              int Wo, void* stream);
 
+/* Backward of dmb_avgpool2d_f32 and dmb_bilinear_ac_f32 on plain [B, C, ., .] tensors (the SPP branches of the PSMNet
+ * backbone under training): grad_y -> grad_x. */
+int dmb_avgpool2d_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int H, int W, int k, void* stream);
+int dmb_bilinear_ac_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+
 /* Backward of dmb_deconv3d_k8s4_c1_f32 (AcfNet's learned up-sampling, aggregators/AcfNet.py:55-57): dx [B, D, H, W] =
  * sum_k dy[4 i - 2 + k] w[k], dw [8, 8, 8] = sum_{b, i} x[b, i] dy[b, 4 i - 2 + k]; dy [B, 4D, 4H, 4W].  Either output may be
  * NULL.  workspace: dmb_deconv3d_k8s4_bwd_workspace_doubles() doubles (needed for dw). */

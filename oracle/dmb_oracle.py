@@ -635,6 +635,25 @@ def acfnet_uniform_train_step(ref_fms, tgt_fms, p, max_disp, gt, **kw):
     return acfnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, adaptive=False, **kw)
 
 
+def psmnet_backbone_train_step(l_img, r_img, p, dl, dr, dtype=torch.float32, prefix="backbone."):
+    """Training-mode forward / backward of the PSMNet backbone as the reference runs it (backbones/PSMNet.py:127-131: the left
+    view, then the right view through the shared weights, BatchNorm statistics per call): gradients of sum(fl * dl) + sum(fr * dr)
+    w.r.t. every learnable parameter.  Returns ((fl, fr), grads, running)."""
+    q, leaves = dict(), dict()
+    for k, v in p.items():
+        v = v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+            leaves[k] = v
+        q[k] = v
+    with bn_training():
+        fl = psmnet_backbone(l_img.to(dtype), q, prefix)
+        fr = psmnet_backbone(r_img.to(dtype), q, prefix)
+    names = list(leaves)
+    grads = torch.autograd.grad((fl * dl.to(dtype)).sum() + (fr * dr.to(dtype)).sum(), [leaves[k] for k in names])
+    return (fl.detach(), fr.detach()), dict(zip(names, grads)), {k: v for k, v in q.items() if "running_" in k}
+
+
 def stereonet_train_step(ref_fms, tgt_fms, p, max_disp, gt, dtype=torch.float32, num=4):
     """Training forward/backward of the StereoNet cost path at the volume's own resolution (dif_fms -> StereoNetAggregator
     with biased convolutions, BatchNorm in training mode -> soft-argmin -> smooth-L1 against ``gt`` [B, 1, H, W] given at

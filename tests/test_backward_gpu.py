@@ -415,6 +415,8 @@ def test_acfnet_uniform_training_step(dev):
     (20, 40, 3, 2, (2, 6, 12)),
     (64, 128, 1, 1, (1, 12, 64)),        # 1x1 convolutions (down-sampling shortcuts, SPP branches, lastconv)
     (320, 32, 1, 1, (2, 7, 20)),
+    (128, 32, 1, 1, (2, 2, 3)),          # SPP branch sizes: width not a multiple of 4 (padded by the wrapper)
+    (24, 24, 3, 1, (1, 6, 10)),
 ])
 def test_conv2d_wgrad_and_dgrad(dev, Ci, Co, k, dil, shape):
     """2-D weight / data gradients (AcfNet's confidence heads, the stride-1 layers of the 2-D networks) against autograd of
@@ -498,3 +500,55 @@ def test_acfnet_adaptive_training_step(dev):
     buffers = dict(model.named_buffers())
     for k, v in run32.items():
         assert (buffers[k].cpu() - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
+
+
+def test_avgpool_and_bilinear_backward(dev):
+    import torch.nn.functional as F
+    ops = _ops()
+    x = _rand((2, 5, 20, 37), 71)
+    for k in (8, 16):
+        xr = x.clone().double().requires_grad_(True)
+        y = F.avg_pool2d(xr, (k, k), stride=(k, k))
+        dy = _rand(tuple(y.shape), 72)
+        ref, = torch.autograd.grad(y, xr, dy.double())
+        got = ops.avgpool2d_bwd(dy.to(dev), (20, 37), k).cpu()
+        assert (got.double() - ref).abs().max().item() <= 1e-7
+    lo = _rand((2, 6, 3, 4), 73)
+    lr = lo.clone().double().requires_grad_(True)
+    up = F.interpolate(lr, (17, 30), mode="bilinear", align_corners=True)
+    dy = _rand(tuple(up.shape), 74)
+    ref, = torch.autograd.grad(up, lr, dy.double())
+    got = ops.bilinear_ac_bwd(dy.to(dev), (3, 4)).cpu()
+    assert (got.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_psmnet_backbone_training(dev):
+    """The PSMNet backbone in train() mode (both views, BatchNorm statistics per view, SPP branches): features and the gradient
+    of every parameter against the oracle's autograd.  Tolerances as in test_psmnet_training_step."""
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone
+    bb = PSMNetBackbone(3, True)
+    synthetic.init_params_(bb, seed=8, classif_gain=1.0)
+    p = {"backbone." + k: v.clone() for k, v in bb.state_dict().items()}
+    bb = bb.to(dev).train()
+    li, ri = _rand((2, 3, 256, 320), 81), _rand((2, 3, 256, 320), 82)   # (2 images per view: BatchNorm needs > 1 value after the 64x64 pooling)
+    dl, dr = _rand((2, 32, 64, 80), 83), _rand((2, 32, 64, 80), 84)
+    (fl32, fr32), g32, run32 = O.psmnet_backbone_train_step(li, ri, p, dl, dr)
+    (fl64, fr64), g64, _ = O.psmnet_backbone_train_step(li, ri, p, dl, dr, dtype=torch.float64)
+    fl, fr = bb(li.to(dev), ri.to(dev))
+    assert (fl.detach().cpu().double() - fl64).abs().max().item() <= 2e-5 and (fr.detach().cpu().double() - fr64).abs().max().item() <= 2e-5
+    ((fl * dl.to(dev)).sum() + (fr * dr.to(dev)).sum()).backward()
+    named = dict(bb.named_parameters())
+    tight = 0
+    zero = 1e-6 * max(v.abs().max().item() for v in g64.values())
+    for k, ref in g64.items():
+        got = named[k[len("backbone."):]].grad
+        assert got is not None, k
+        scale = ref.abs().max().item()
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err <= 3e-2 * scale + zero, "grad of %s: error %.3e of range %.3e" % (k, err, scale)
+        tight += err <= 4 * (g32[k].double() - ref).abs().max().item() + 2e-5 * scale + zero
+    assert tight >= 0.6 * len(g64), "only %d of %d gradients within the tight tolerance" % (tight, len(g64))
+    buffers = dict(bb.named_buffers())
+    for k, v in run32.items():
+        assert (buffers[k[len("backbone."):]].cpu() - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
