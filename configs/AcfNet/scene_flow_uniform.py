@@ -8,6 +8,7 @@ model = dict(
     meta_architecture="GeneralizedStereoModel",
     max_disp=max_disp,
     batch_norm=True,
+    backbone=dict(type="PSMNet", in_planes=3),
     cost_processor=dict(
         type='Concatenation',
         cost_computation=_c['volume']("default", max_disp, 4),

@@ -329,6 +329,41 @@ __global__ __launch_bounds__(256) void avgpool2d_bwd_kernel(const float* __restr
   dx[i] = (yo < Ho && xo < Wo) ? dy[(bc * Ho + yo) * Wo + xo] / (float)(k * k) : 0.f;
 }
 
+// Bilinear (align_corners) adjoint for SMALL inputs (the SPP branches: 1x2 .. 8x16 maps blown up to the feature size): one
+// wave per input element gathers its whole footprint in parallel (the one-thread-per-element form above walks up to the
+// whole output image serially).
+__global__ __launch_bounds__(64) void bilinear_ac_bwd_small_kernel(const float* __restrict__ t, float* __restrict__ dx, int C, int Hi,
+                                                                   int Wi, int Ho, int Wo, float sh, float sw) {
+  const int xl = blockIdx.x % Wi, yl = blockIdx.x / Wi, c = blockIdx.y, b = blockIdx.z;
+  auto range = [](int i, float scale, int out, int& lo, int& hi) {
+    if (scale <= 0.f) {
+      lo = 0;
+      hi = i == 0 ? out - 1 : -1;
+      return;
+    }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out - 1 ? out - 1 : hi;
+  };
+  int ylo, yhi, xlo, xhi;
+  range(yl, sh, Ho, ylo, yhi);
+  range(xl, sw, Wo, xlo, xhi);
+  const float* tb = t + ((size_t)b * C + c) * Ho * Wo;
+  const int nx = xhi - xlo + 1, total = (yhi - ylo + 1) * (nx > 0 ? nx : 0);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < total; i += 64) {
+    const int yo = ylo + i / nx, xo = xlo + i % nx;
+    const Lerp ly = lerp_setup(yo, Hi, sh), lx = lerp_setup(xo, Wi, sw);
+    const float wy = (ly.i0 == yl ? ly.w0 : 0.f) + (ly.i1 == yl ? ly.w1 : 0.f);
+    const float wx = (lx.i0 == xl ? lx.w0 : 0.f) + (lx.i1 == xl ? lx.w1 : 0.f);
+    acc = fmaf(tb[(size_t)yo * Wo + xo], wy * wx, acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (threadIdx.x == 0) dx[(((size_t)b * C + c) * Hi + yl) * Wi + xl] = acc;
+}
+
 static int fill_idx(const int* host, int D, DispIdx& idx) {
   if (!host || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
   for (int k = 0; k < D; ++k) idx.d[k] = host[k];
@@ -434,7 +469,12 @@ extern "C" int dmb_avgpool2d_bwd_f32(const float* grad_y, float* grad_x, int B, 
 
 extern "C" int dmb_bilinear_ac_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
   if (!grad_y || !grad_x || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return fail(DMB_EINVAL, "bilinear_bwd: bad argument");
-  if ((long long)C * Hi > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "bilinear_bwd: grid too large");
+  if ((long long)C * Hi > 65535 || B > 65535 || C > 65535) return fail(DMB_EUNSUPPORTED, "bilinear_bwd: grid too large");
+  if ((long long)Hi * Wi * 64 <= (long long)Ho * Wo) {   // footprints of >= 64 output pixels: one wave per input element
+    hipLaunchKernelGGL(bilinear_ac_bwd_small_kernel, dim3(Hi * Wi, C, B), dim3(64), 0, (hipStream_t)stream, grad_y, grad_x, C, Hi, Wi, Ho,
+                       Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+    return launch_status("bilinear_bwd launch failed");
+  }
   // the (y, x) contraction of the up-sampling backward, one "plane" per channel
   hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), C * Hi, B), dim3(256), 0, (hipStream_t)stream, grad_y, grad_x, C,
                      Hi, Wi, Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo));

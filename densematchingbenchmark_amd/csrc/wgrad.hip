@@ -624,7 +624,7 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
 // heads (cmn/cmn.py:21-36: 192 -> 64 over the full-resolution cost volume).  Same idea as the 3-D kernel, one dimension down:
 // a workgroup owns a (32 x 32) channel block and walks strips of 64 columns along y; x rows sit in a ring of four LDS slots,
 // dc rows are double buffered; the four waves split the strip's columns (16 each) and each holds all nine taps (144
-// accumulator registers), so their partial results are added together with the slots' by the reduction kernel.
+// accumulator registers); their partial results are added through LDS at the end, the slots' by the reduction kernel.
 // ------------------------------------------------------------------------------------------------------------------
 namespace dmb {
 
@@ -747,11 +747,26 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
       __syncthreads();
     }
   }
-  float* wsb = ws + (((size_t)blockIdx.y * nslots + slot) * 4 + wave) * C::NTAP * 1024;
+  // the four waves' partial results are added through LDS (wave 0 stores, the others add in turn) before one copy per
+  // workgroup goes to the workspace
+  __syncthreads();
+  float* red = lds;   // NTAP x 1024 floats <= the ring
+  static_assert(C::NTAP * 1024 <= C::LDS_FLOATS, "reduction scratch");
 #pragma unroll
-  for (int tt = 0; tt < C::NTAP; ++tt)
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) wsb[tt * 1024 + cd_row(r, kk) * 32 + n] = acc[tt][r];
+      for (int tt = 0; tt < C::NTAP; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* q = red + tt * 1024 + cd_row(r, kk) * 32 + n;
+          *q = wv == 0 ? acc[tt][r] : *q + acc[tt][r];
+        }
+    }
+    __syncthreads();
+  }
+  float* wsb = ws + ((size_t)blockIdx.y * nslots + slot) * C::NTAP * 1024;
+  for (int i = threadIdx.x; i < C::NTAP * 1024; i += 256) wsb[i] = red[i];
 }
 
 __global__ void conv2d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nparts, int ntap) {
@@ -787,7 +802,7 @@ static int wgrad2d_slots_per_block(int Co, int Ci) {
 
 extern "C" long long dmb_conv2d_wgrad_workspace_floats(int Co, int Ci) {
   if (Co <= 0 || Ci <= 0) return 0;
-  return (long long)cdiv(Co, 32) * cdiv(Ci, 32) * wgrad2d_slots_per_block(Co, Ci) * 4 * 9 * 1024;
+  return (long long)cdiv(Co, 32) * cdiv(Ci, 32) * wgrad2d_slots_per_block(Co, Ci) * 9 * 1024;
 }
 
 template <int KS, int DIL>
@@ -814,11 +829,13 @@ static int launch_wgrad2d(const float* x, const float* dc, float* dw, float* wor
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<KS, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, DIL>), dim3((unsigned)nslots, (unsigned)nblk), dim3(256), C::LDS_FLOATS * 4, st, x, dc, workspace, B,
+  const long long items = (long long)B * ntx * nys;
+  const int nused = (int)(items < nslots ? items : nslots);   // small layers: no idle slots to write and add zeros for
+  hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, DIL>), dim3((unsigned)nused, (unsigned)nblk), dim3(256), C::LDS_FLOATS * 4, st, x, dc, workspace, B,
                      Ci, Co, H, W, ntx, nys, yseg);
   int rc = launch_status("conv2d_wgrad launch failed");
   if (rc != DMB_OK) return rc;
-  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(nblk * C::NTAP * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nslots * 4, C::NTAP);
+  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(cdiv(nblk * C::NTAP * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nused, C::NTAP);
   return launch_status("conv2d_wgrad reduce launch failed");
 }
 

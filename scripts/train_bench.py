@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", action="store_true", help="start from images: the HIP backbone trains too")
     ap.add_argument("--config", default=os.path.join("PSMNet", "scene_flow.py"), help="relative to configs/ (PSMNet/scene_flow.py, "
                     "AcfNet/scene_flow_uniform.py, AcfNet/scene_flow_adaptive.py)")
     args = ap.parse_args()
@@ -38,7 +39,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = Config.fromfile(os.path.join(root, "configs", args.config))
-    model = build_model(cfg).to(dev)
+    model = build_model(cfg, backbone="hip" if args.images else None).to(dev)
     synthetic.init_params_(model, seed=0)
     model.train()
     flat = FlatGradients(model)
@@ -49,6 +50,9 @@ def main():
     rf = torch.randn((B, 32, H // 4, W // 4), generator=g).to(dev)
     gt = (torch.rand((B, 1, H, W), generator=g) * 180.0 + 1.0).to(dev)
     batch = dict(leftFeature=lf, rightFeature=rf, leftDisp=gt)
+    if args.images:
+        batch = dict(leftImage=torch.randn((B, 3, H, W), generator=g).to(dev), rightImage=torch.randn((B, 3, H, W), generator=g).to(dev),
+                     leftDisp=gt)
 
     def step():
         flat.zero_()
@@ -87,7 +91,7 @@ def main():
     ev[3].record()
     torch.cuda.synchronize()
     if local == 0:
-        print(args.config + " cost-path training step: batch %d x %dx%d per GPU, %d GPU(s): %.1f ms/step = %.1f pairs/s; "
+        print(args.config + (" images -> loss" if args.images else " cost-path") + " training step: batch %d x %dx%d per GPU, %d GPU(s): %.1f ms/step = %.1f pairs/s; "
               "forward %.1f ms, backward %.1f ms, exchange+optimizer %.1f ms; loss %.4f; peak memory %.1f GB" %
               (B, H, W, world, ms, B * world / ms * 1e3, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]),
                ev[2].elapsed_time(ev[3]), float(loss.detach()), torch.cuda.max_memory_allocated(dev) / 2 ** 30), flush=True)
