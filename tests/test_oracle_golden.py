@@ -318,3 +318,60 @@ def test_losses_vs_reference():
     l = O.disp_smooth_l1_loss(est, gt, 48)
     l.backward()
     assert abs(float(l.detach()) - g["l1_loss"][0]) <= 1e-6 and maxdiff(est.grad, g["l1_grad"]) <= 1e-8
+
+
+def _fingerprint(t):
+    f = t.detach().double().reshape(-1)
+    step = max(1, f.numel() // 16)
+    return np.concatenate([[f.sum().item(), (f * f).sum().item()], f[::step][:16].numpy()])
+
+
+def _check_fingerprints(g, prefix, grads, strip=""):
+    """Every gradient of the oracle's training step against the fingerprint (sum, sum of squares, 16 strided samples) of the
+    REAL reference's autograd gradient.  Both are torch CPU FP32 evaluations of the same graph up to operator fusion: 1e-4 of
+    each tensor's scale (sum of squares: 2e-4)."""
+    n = 0
+    keys = [k for k in g.files if k.startswith(prefix + "_g_")]
+    # gradients that are exactly zero in exact arithmetic (a bias in front of a batch-statistics BatchNorm) are rounding noise
+    # in both evaluations: an absolute floor of 1e-6 of the largest gradient entry of the step
+    zero = 1e-6 * max(np.abs(g[k][2:]).max() for k in keys)
+    for key in keys:
+        name = key[len(prefix) + 3:]
+        t = grads[strip + name if name not in ("ref_fms", "tgt_fms") else name]
+        want, got = g[key], _fingerprint(t)
+        scale = max(np.abs(want[2:]).max(), np.sqrt(want[1] / max(1, t.numel())))
+        assert np.abs(got[2:] - want[2:]).max() <= 1e-4 * scale + zero, name
+        assert abs(got[1] - want[1]) <= 2e-4 * want[1] + zero * zero * t.numel(), name
+        n += 1
+    return n
+
+
+def test_training_step_matches_reference_autograd():
+    """oracle.psmnet_train_step / acfnet_train_step against ONE TRAINING ITERATION OF THE REFERENCE'S OWN MODULES (train() mode,
+    its loss classes, torch.autograd; oracle/gen_golden.py section 4h): losses, every gradient, updated BatchNorm buffers."""
+    g = golden("training.npz")
+    gt = torch.rand((2, 1, 32, 96), generator=torch.Generator().manual_seed(13)) * 40.0 - 4.0
+    lf, rf = rand((2, 32, 8, 24), 11), rand((2, 32, 8, 24), 12)
+    p = O.with_prefix(O.random_params_psm(seed=7, classif_gain=4.0), "cost_processor.aggregator.")
+    losses, grads, running = O.psmnet_train_step(lf, rf, p, 32, gt)
+    assert np.allclose([float(x) for x in losses], g["psm_losses"], rtol=1e-5)
+    assert _check_fingerprints(g, "psm", grads, "cost_processor.aggregator.") == 80
+    assert np.allclose(running["cost_processor.aggregator.dres0.0.1.running_mean"].numpy(), g["psm_rm"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(running["cost_processor.aggregator.dres0.0.1.running_var"].numpy(), g["psm_rv"], rtol=1e-5, atol=1e-7)
+
+    p = O.with_prefix(O.random_params_psm(seed=4, classif_gain=4.0, acf=True), "cost_processor.aggregator.")
+    gq = torch.Generator().manual_seed(77)
+    md, Cm = 32, 32 // 3
+    for i in range(3):
+        pre = "cmn.conf_heads.%d.conf_net." % i
+        p[pre + "0.0.weight"] = (torch.rand((Cm, md, 3, 3), generator=gq) * 2 - 1) / (md * 9) ** 0.5
+        p[pre + "0.1.weight"] = 0.5 + torch.rand(Cm, generator=gq)
+        p[pre + "0.1.bias"] = (torch.rand(Cm, generator=gq) - 0.5) * 0.2
+        p[pre + "0.1.running_mean"], p[pre + "0.1.running_var"] = torch.zeros(Cm), torch.ones(Cm)
+        p[pre + "1.weight"] = (torch.rand((1, Cm, 1, 1), generator=gq) * 2 - 1) / Cm ** 0.5
+    lf, rf = rand((2, 32, 8, 24), 41), rand((2, 32, 8, 24), 42)
+    gt = torch.rand((2, 1, 32, 96), generator=torch.Generator().manual_seed(43)) * 40.0 - 4.0
+    losses, grads, _ = O.acfnet_train_step(lf, rf, p, 32, gt, adaptive=True)
+    assert sorted(losses) == [str(k) for k in g["acf_loss_keys"]]
+    assert np.allclose([float(losses[k]) for k in sorted(losses)], g["acf_losses"], rtol=1e-5)
+    assert _check_fingerprints(g, "acf", grads) == 102
