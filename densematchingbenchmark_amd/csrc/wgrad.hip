@@ -562,7 +562,9 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<false, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<24>::LDS_FLOATS * 4);
     attr_set = true;
   }
-  const dim3 grid((unsigned)nslots, (unsigned)nblk);
+  const long long items3 = (long long)B * ntx * nty * nzs;
+  const int nused = (int)(items3 < nslots ? items3 : nslots);   // small layers: no idle slots to write and add zeros for
+  const dim3 grid((unsigned)nused, (unsigned)nblk);
   if (v16 && wide)
     hipLaunchKernelGGL((conv3d_wgrad_s1_kernel<true, 32>), grid, dim3(256), WgCfg<32>::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, ntx, nty, nzs, zseg);
   else if (v16)
@@ -571,7 +573,7 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
     hipLaunchKernelGGL((conv3d_wgrad_s1_kernel<false, 24>), grid, dim3(256), WgCfg<24>::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, cdiv(W, 24), nty, nzs, zseg);
   int rc = launch_status("conv3d_wgrad launch failed");
   if (rc != DMB_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nslots, 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nused, 0);
   return launch_status("conv3d_wgrad reduce launch failed");
 }
 
@@ -607,15 +609,17 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2Cfg::LDS_FLOATS * 4);
     attr_set = true;
   }
+  const long long items2 = (long long)B * ntx * nty * nzs;
+  const int nused = (int)(items2 < nslots ? items2 : nslots);
   if (v16)
-    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<true>, dim3((unsigned)nslots, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
+    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<true>, dim3((unsigned)nused, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
                        workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
   else
-    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<false>, dim3((unsigned)nslots, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
+    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<false>, dim3((unsigned)nused, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
                        workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
   int rc = launch_status("conv3d_s2_wgrad launch failed");
   if (rc != DMB_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Cs, Cb, nslots, 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Cs, Cb, nused, 0);
   return launch_status("conv3d_s2_wgrad reduce launch failed");
 }
 
