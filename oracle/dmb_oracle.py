@@ -561,7 +561,16 @@ def bn_act_train(c, gamma, beta, residual=None, relu=0, eps=1e-5, dy=None, dtype
     return out
 
 
-def psmnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, level_weights=(1.0, 0.7, 0.5), loss_weight=1.0, dtype=torch.float32):
+class _no_context(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def psmnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, level_weights=(1.0, 0.7, 0.5), loss_weight=1.0, dtype=torch.float32,
+                      training=True):
     """One training forward/backward of the PSMNet cost path as the reference runs it (models/general_stereo_model.py:60-77
     with losses/smooth_l1_loss.py): cat_fms -> PSMAggregator (BatchNorm in training mode) -> FasterSoftArgmin ->
     weighted DispSmoothL1Loss per level; gradients by torch.autograd.  Returns (losses, grads, running) where grads maps
@@ -576,7 +585,7 @@ def psmnet_train_step(ref_fms, tgt_fms, p, max_disp, gt, level_weights=(1.0, 0.7
     L = ref_fms.detach().clone().to(dtype).requires_grad_(True)
     R = tgt_fms.detach().clone().to(dtype).requires_grad_(True)
     leaves["ref_fms"], leaves["tgt_fms"] = L, R
-    with bn_training():
+    with (bn_training() if training else _no_context()):   # training=False: eval-mode BatchNorm (running statistics), same graph
         raw = cat_fms(L, R, max_disp // 4, 0, 1).to(dtype)               # the builder's output is FP32 (cat_fms.py:32)
         costs = psm_aggregator(raw, q, max_disp, "cost_processor.aggregator.")
         if dtype == torch.float32:
