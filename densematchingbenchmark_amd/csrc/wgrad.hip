@@ -626,7 +626,8 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
 // ------------------------------------------------------------------------------------------------------------------
 // 2-D: dW[co, ci, tap] = sum_{b, p} dc[b, co, p] * x[b, ci, p + tap - 1] for nn.Conv2d(k 3, s 1, p 1) -- AcfNet's confidence
 // heads (cmn/cmn.py:21-36: 192 -> 64 over the full-resolution cost volume).  Same idea as the 3-D kernel, one dimension down:
-// a workgroup owns a (32 x 32) channel block and walks strips of 64 columns along y; x rows sit in a ring of four LDS slots,
+// a workgroup owns a (32 x 32) channel block and walks strips of 64 columns along y (in steps of the dilation: the image is
+// `dilation` interleaved row classes, so a tap's rows are neighbours inside the class); x rows sit in a ring of four LDS slots,
 // dc rows are double buffered; the four waves split the strip's columns (16 each) and each holds all nine taps (144
 // accumulator registers); their partial results are added through LDS at the end, the slots' by the reduction kernel.
 // ------------------------------------------------------------------------------------------------------------------
@@ -635,10 +636,13 @@ namespace dmb {
 template <int KS_, int DIL_>
 struct Wg2dCfg {
   static constexpr int KS = KS_, DIL = DIL_, NTAP = KS * KS;
-  static constexpr int HALO = DIL * (KS / 2);                  // 0, 1 or 2 rows / columns either side
-  static constexpr int TX = 64, XOFF = 4 - HALO;
-  static constexpr int NR = 2 * HALO + 2;                      // ring slots: rows y - HALO .. y + HALO in use, one landing
-  static constexpr int P = (4 + TX + HALO + 3) / 4 * 4;        // staged row: aligned column x0 - 4 ..
+  static constexpr int HALO = DIL * (KS / 2);                  // columns either side
+  static constexpr int PAD = HALO <= 4 ? 4 : 8;                // the staged row starts at the aligned column x0 - PAD
+  static constexpr int TX = 64, XOFF = PAD - HALO;
+  // Rows are walked in steps of DIL (the image is DIL interleaved row classes; taps reach rows y - DIL, y, y + DIL = the
+  // neighbours INSIDE the class), so the ring is four slots whatever the dilation: three in use, one landing.
+  static constexpr int NR = KS == 1 ? 2 : 4;
+  static constexpr int P = (PAD + TX + HALO + 3) / 4 * 4;
   static constexpr int UXU = P / 4, UDU = TX / 4;              // 16-byte units per channel row
   static constexpr int UX = UXU | 1, UD = UDU | 1;             // ... made odd: pitch = 4 mod 8 floats
   static constexpr int SX = UX * 4, SD = UD * 4;
@@ -646,9 +650,10 @@ struct Wg2dCfg {
   static constexpr int LDS_FLOATS = NR * XROW + 2 * DROW;
   static constexpr int IX = (32 * UX + 255) / 256, ID = (32 * UD + 255) / 256;   // copy instructions per wave and row
   static constexpr int KSTEPS = TX / 4 / 2;                    // per wave: 16 columns = 8 k-steps
-  static_assert(HALO <= 4 && SX % 8 == 4 && SD % 8 == 4 && IX + ID <= KSTEPS && LDS_FLOATS * 4 * 2 <= 160 * 1024, "tile");
+  static_assert(HALO <= 8 && SX % 8 == 4 && SD % 8 == 4 && IX + ID <= KSTEPS && LDS_FLOATS * 4 * 2 <= 160 * 1024, "tile");
 };
 
+// nys: segments per row class; yseg: class rows per segment.  An item = (batch item, column strip, row class, segment).
 template <int KS_, int DIL_>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dc,
                                                               float* __restrict__ ws, int B, int Ci, int Co, int H, int W, int ntx,
@@ -663,8 +668,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = lane & 31, kk = lane >> 5;
   const unsigned HW = (unsigned)H * W;
-  const int items = B * nys * ntx;
+  const int items = B * nys * C::DIL * ntx;
   const int nci = min(32, Ci - cib * 32), nco = min(32, Co - cob * 32);
+  constexpr int RH = C::KS / 2;   // class rows either side (0 or 1)
 
   f32x16 acc[C::NTAP];
 #pragma unroll
@@ -678,16 +684,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
     int t = it;
     const int tx = t % ntx;
     t /= ntx;
+    const int rc = t % C::DIL;        // row class: image rows rc, rc + DIL, rc + 2 DIL, ...
+    t /= C::DIL;
     const int ys = t % nys;
     const int b = t / nys;
-    const int x0 = tx * C::TX, ya = ys * yseg, yb = min(H, ya + yseg);
+    const int x0 = tx * C::TX, ia = ys * yseg, ib = ia + yseg;   // class-row range [ia, ib); rows past H read as zeros
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)b * Ci + cib * 32) * HW, (unsigned)nci * HW * 4u);
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(dc + ((size_t)b * Co + cob * 32) * HW, (unsigned)nco * HW * 4u);
     unsigned xvo[C::IX], dvo[C::ID];   // channel + column part of this wave's copy instructions; the row is a scalar offset
 #pragma unroll
     for (int j = 0; j < C::IX; ++j) {
       const int u = (j * 4 + wave) * 64 + lane, ch = u / C::UX, un = u - ch * C::UX;
-      const int gx = x0 - 4 + 4 * un;
+      const int gx = x0 - C::PAD + 4 * un;
       xvo[j] = (ch < 32 && un < C::UXU && gx >= 0 && gx < W) ? ((unsigned)ch * HW + (unsigned)gx) * 4u : DMA_OOB;
     }
 #pragma unroll
@@ -696,35 +704,37 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
       const int gx = x0 + 4 * un;
       dvo[j] = (ch < 32 && un < C::UDU && gx < W) ? ((unsigned)ch * HW + (unsigned)gx) * 4u : DMA_OOB;
     }
-    auto stage_x1 = [&](int gy, int rslot, int j) {
-      const bool ok = gy >= 0 && gy < H;
+    auto stage_x1 = [&](int ci_row, int rslot, int j) {   // class row -> image row rc + DIL * ci_row
+      const int gy = rc + C::DIL * ci_row;
+      const bool ok = ci_row >= 0 && gy < H;
       const int first = (j * 4 + wave) * 64;
       if (first + lane < 32 * C::UX) dma16(xrs, ok ? xvo[j] : DMA_OOB, ok ? (unsigned)gy * W * 4u : 0u, xring + rslot * C::XROW + first * 4);
     };
-    auto stage_d1 = [&](int gy, int buf, int j) {
-      const bool ok = gy >= 0 && gy < yb;
+    auto stage_d1 = [&](int ci_row, int buf, int j) {
+      const int gy = rc + C::DIL * ci_row;
+      const bool ok = ci_row < ib && gy < H;
       const int first = (j * 4 + wave) * 64;
       if (first + lane < 32 * C::UD) dma16(drs, ok ? dvo[j] : DMA_OOB, ok ? (unsigned)gy * W * 4u : 0u, dbuf + buf * C::DROW + first * 4);
     };
-    // ring slot of image row r: (r - (ya - HALO)) % NR
+    // ring slot of class row j: (j - (ia - RH)) % NR
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 2 * C::HALO + 1; ++q)
+    for (int q = 0; q < 2 * RH + 1; ++q)
 #pragma unroll
-      for (int j = 0; j < C::IX; ++j) stage_x1(ya - C::HALO + q, q, j);
+      for (int j = 0; j < C::IX; ++j) stage_x1(ia - RH + q, q, j);
 #pragma unroll
-    for (int j = 0; j < C::ID; ++j) stage_d1(ya, 0, j);
+    for (int j = 0; j < C::ID; ++j) stage_d1(ia, 0, j);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    int r0 = 0;   // ring index of row y - HALO
-    for (int y = ya; y < yb; ++y) {
-      const int rel = y - ya;
-      const bool more = y + 1 < yb;
+    int r0 = 0;   // ring index of class row i - RH
+    for (int i = ia; i < ib; ++i) {
+      const int rel = i - ia;
+      const bool more = i + 1 < ib;
       const float* ap = dbuf + (rel & 1) * C::DROW + aoff;
       const float* bp[C::KS];
 #pragma unroll
-      for (int ty = 0; ty < C::KS; ++ty) bp[ty] = xring + ((r0 + ty * C::DIL) % C::NR) * C::XROW + boff;
-      const int rnew = (r0 + 2 * C::HALO + 1) % C::NR;
+      for (int ty = 0; ty < C::KS; ++ty) bp[ty] = xring + ((r0 + ty) % C::NR) * C::XROW + boff;
+      const int rnew = (r0 + 2 * RH + 1) % C::NR;
       float af[2], bf[2][C::NTAP];
       auto load_frag = [&](int q, float& a, float (&bq)[C::NTAP]) {
         a = ap[2 * q];
@@ -740,9 +750,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const float* __res
         for (int tt = 0; tt < C::NTAP; ++tt) acc[tt] = DMB_MFMA(af[q & 1], bf[q & 1][tt], acc[tt]);
         if (more) {
           if (q < C::IX)
-            stage_x1(y + C::HALO + 1, rnew, q);
+            stage_x1(i + RH + 1, rnew, q);
           else if (q < C::IX + C::ID)
-            stage_d1(y + 1, (rel + 1) & 1, q - C::IX);
+            stage_d1(i + 1, (rel + 1) & 1, q - C::IX);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -814,26 +824,27 @@ static int launch_wgrad2d(const float* x, const float* dc, float* dw, float* wor
   typedef Wg2dCfg<KS, DIL> C;
   const int nblk = cdiv(Co, 32) * cdiv(Ci, 32), nslots = wgrad2d_slots_per_block(Co, Ci);
   const int ntx = cdiv(W, C::TX);
-  int yseg = H;
+  const int HC = cdiv(H, DIL);   // rows of one row class
+  int yseg = HC;
   {
     double best = 1e30;
-    for (int ny = 1; ny <= H; ++ny) {
-      const int ysz = cdiv(H, ny);
+    for (int ny = 1; ny <= HC; ++ny) {
+      const int ysz = cdiv(HC, ny);
       if (ysz < 8 && ny > 1) break;
-      const double cost = (double)cdiv_ll((long long)B * ntx * cdiv(H, ysz), nslots) * (ysz + 1.0 + C::HALO);
+      const double cost = (double)cdiv_ll((long long)B * ntx * DIL * cdiv(HC, ysz), nslots) * (ysz + 2.0);
       if (cost < best - 1e-9) {
         best = cost;
         yseg = ysz;
       }
     }
   }
-  const int nys = cdiv(H, yseg);
+  const int nys = cdiv(HC, yseg);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<KS, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
     attr_set = true;
   }
-  const long long items = (long long)B * ntx * nys;
+  const long long items = (long long)B * ntx * DIL * nys;
   const int nused = (int)(items < nslots ? items : nslots);   // small layers: no idle slots to write and add zeros for
   hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, DIL>), dim3((unsigned)nused, (unsigned)nblk), dim3(256), C::LDS_FLOATS * 4, st, x, dc, workspace, B,
                      Ci, Co, H, W, ntx, nys, yseg);
@@ -852,6 +863,8 @@ extern "C" int dmb_conv2d_wgrad_f32(const float* x, const float* dc, float* dw, 
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 3 && dilation == 1) return launch_wgrad2d<3, 1>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
   if (ksize == 3 && dilation == 2) return launch_wgrad2d<3, 2>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
+  if (ksize == 3 && dilation == 4) return launch_wgrad2d<3, 4>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
+  if (ksize == 3 && dilation == 8) return launch_wgrad2d<3, 8>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
   if (ksize == 1) return launch_wgrad2d<1, 1>(x, dc, dw, workspace, B, Ci, Co, H, W, st);
-  return fail(DMB_EUNSUPPORTED, "conv2d_wgrad: kernel 1, or kernel 3 with dilation 1 or 2 (stride 1)");
+  return fail(DMB_EUNSUPPORTED, "conv2d_wgrad: kernel 1, or kernel 3 with dilation 1, 2, 4 or 8 (stride 1)");
 }

@@ -290,7 +290,7 @@ int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* dw, float* w
 int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, float* dw, float* workspace, int B, int Cs, int Cb,
                               int Ds, int Hs, int Ws, int Db, int Hb, int Wb, void* stream);
 
-/* Weight gradient of a stride-1 nn.Conv2d with kernel 1, or kernel 3 with dilation 1 | 2 (padding = dilation * (k / 2)):
+/* Weight gradient of a stride-1 nn.Conv2d with kernel 1, or kernel 3 with dilation 1 | 2 | 4 | 8 (padding = dilation * (k / 2)):
  * AcfNet's confidence heads (cmn/cmn.py:21-36) and the stride-1 layers of the 2-D networks.  x [B, Ci, H, W],
  * dc [B, Co, H, W] -> dw [Co, Ci, k*k].  W a multiple of 4, tensors 16-byte aligned.  The data gradient is dmb_conv2d_f32 on
  * mirrored, channel-exchanged weights.  workspace: dmb_conv2d_wgrad_workspace_floats(Co, Ci) floats. */

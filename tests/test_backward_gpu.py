@@ -413,6 +413,9 @@ def test_acfnet_uniform_training_step(dev):
     (16, 16, 3, 1, (1, 5, 8)),
     (128, 128, 3, 2, (1, 17, 68)),       # dilation 2 (backbone layer4): six ring slots
     (20, 40, 3, 2, (2, 6, 12)),
+    (32, 32, 3, 4, (1, 19, 72)),         # dilations of the refinement blocks: rows walked in interleaved classes
+    (32, 32, 3, 8, (2, 21, 64)),
+    (32, 16, 3, 8, (1, 6, 20)),          # fewer rows than the dilation
     (64, 128, 1, 1, (1, 12, 64)),        # 1x1 convolutions (down-sampling shortcuts, SPP branches, lastconv)
     (320, 32, 1, 1, (2, 7, 20)),
     (128, 32, 1, 1, (2, 2, 3)),          # SPP branch sizes: width not a multiple of 4 (padded by the wrapper)
