@@ -73,6 +73,7 @@ SIGNATURES = {
     "dmb_trilinear_ac_bwd_f32": (_c_int, [_P, _P, _P] + [_c_int] * 7 + [_P]),
     "dmb_avgpool2d_bwd_f32": (_c_int, [_P, _P] + [_c_int] * 5 + [_P]),
     "dmb_bilinear_ac_bwd_f32": (_c_int, [_P, _P] + [_c_int] * 6 + [_P]),
+    "dmb_bilinear_scale_bwd_f32": (_c_int, [_P, _P] + [_c_int] * 6 + [_c_float, _P]),
     "dmb_deconv3d_k8s4_bwd_workspace_doubles": (_c_ll, []),
     "dmb_deconv3d_k8s4_c1_bwd_f32": (_c_int, [_P] * 6 + [_c_int] * 4 + [_P]),
     "dmb_loss_workspace_doubles": (_c_ll, [_c_ll]),

@@ -364,6 +364,44 @@ __global__ __launch_bounds__(64) void bilinear_ac_bwd_small_kernel(const float* 
   if (threadIdx.x == 0) dx[(((size_t)b * C + c) * Hi + yl) * Wi + xl] = acc;
 }
 
+// Adjoint of F.interpolate(mode='bilinear', align_corners=False) * mult (the refinement's disparity up-sampling,
+// disp_refinement/utils/edge_aware.py:49-50): one wave per input element gathers its footprint; the weights are recomputed
+// with the forward kernel's arithmetic (src = max(scale * (dst + 0.5) - 0.5, 0), conv2d.hip::bilinear_hp_kernel).
+__global__ __launch_bounds__(64) void bilinear_hp_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int C, int Hi, int Wi,
+                                                             int Ho, int Wo, float sh, float sw, float mult) {
+  const int xl = blockIdx.x % Wi, yl = blockIdx.x / Wi, c = blockIdx.y, b = blockIdx.z;
+  auto range = [](int i, float scale, int out, int& lo, int& hi) {
+    lo = (int)floorf((float)(i - 1) / scale) - 2;
+    hi = (int)ceilf((float)(i + 2) / scale) + 2;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out - 1 ? out - 1 : hi;
+  };
+  auto weight = [](int o, int i, int in, float scale) {   // weight of input index i in output index o
+    const float s = fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+    int i0 = (int)s;
+    i0 = i0 > in - 1 ? in - 1 : i0;
+    const int i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    float l = s - (float)i0;
+    l = fminf(fmaxf(l, 0.f), 1.f);
+    return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+  };
+  int ylo, yhi, xlo, xhi;
+  range(yl, sh, Ho, ylo, yhi);
+  range(xl, sw, Wo, xlo, xhi);
+  const float* tb = dy + ((size_t)b * C + c) * Ho * Wo;
+  const int nx = xhi - xlo + 1, total = (yhi - ylo + 1) * (nx > 0 ? nx : 0);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < total; i += 64) {
+    const int yo = ylo + i / nx, xo = xlo + i % nx;
+    const float wy = weight(yo, yl, Hi, sh);
+    if (wy == 0.f) continue;
+    acc = fmaf(tb[(size_t)yo * Wo + xo], wy * weight(xo, xl, Wi, sw), acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (threadIdx.x == 0) dx[(((size_t)b * C + c) * Hi + yl) * Wi + xl] = acc * mult;
+}
+
 static int fill_idx(const int* host, int D, DispIdx& idx) {
   if (!host || D <= 0 || D > DMB_MAX_DISP_SAMPLES) return fail(DMB_EINVAL, "disparity sample count out of range");
   for (int k = 0; k < D; ++k) idx.d[k] = host[k];
@@ -479,4 +517,13 @@ extern "C" int dmb_bilinear_ac_bwd_f32(const float* grad_y, float* grad_x, int B
   hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), C * Hi, B), dim3(256), 0, (hipStream_t)stream, grad_y, grad_x, C,
                      Hi, Wi, Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
   return launch_status("bilinear_bwd launch failed");
+}
+
+extern "C" int dmb_bilinear_scale_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int Hi, int Wi, int Ho, int Wo, float mult,
+                                          void* stream) {
+  if (!grad_y || !grad_x || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return fail(DMB_EINVAL, "bilinear_scale_bwd: bad argument");
+  if (C > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "bilinear_scale_bwd: grid too large");
+  hipLaunchKernelGGL(bilinear_hp_bwd_kernel, dim3(Hi * Wi, C, B), dim3(64), 0, (hipStream_t)stream, grad_y, grad_x, C, Hi, Wi, Ho, Wo,
+                     (float)Hi / (float)Ho, (float)Wi / (float)Wo, mult);
+  return launch_status("bilinear_scale_bwd launch failed");
 }

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from ..layers import train_fn
 from ..layers.basic_layers import _versions
 from ..layers.basic_layers_2d import BasicBlock
 
@@ -19,6 +20,8 @@ class _HipConv2d(nn.Conv2d):
         self._key, self._cache = None, None
 
     def forward(self, x):
+        if train_fn.wants_grad(self, x):
+            return train_fn.BareConv2dFn.apply(x, self.weight, self.bias, None, False)
         key = _versions(self.weight, self.bias)
         if key != self._key:
             self._key = key
@@ -64,6 +67,9 @@ class StereoNetBackbone(nn.Module):
         if len(input) != 2:
             raise ValueError('expected input length 2 (got {} length input)'.format(len(input)))
         l_img, r_img = input
+        if train_fn.wants_grad(self, l_img, r_img):
+            # one view after the other, as the reference does (backbones/StereoNet.py:95-99): BatchNorm statistics per call
+            return self._forward(l_img), self._forward(r_img)
         B = l_img.shape[0]
         f = self._forward(torch.cat((l_img, r_img), 0))   # shared weights: one batch of 2B images
         return f[:B], f[B:]

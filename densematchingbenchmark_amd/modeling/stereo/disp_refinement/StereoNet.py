@@ -2,6 +2,7 @@
 import torch.nn as nn
 
 from .... import ops
+from ..layers import train_fn
 from .utils.edge_aware import EdgeAwareRefinement
 
 
@@ -15,7 +16,10 @@ class StereoNetRefinement(nn.Module):
         init_disp = disps[-1]
         h, w = leftImage.shape[-2:]
         scale = w / init_disp.shape[-1]
-        init_disp = ops.bilinear_scale(init_disp, (h, w), scale)
+        if train_fn.wants_grad(self, init_disp):
+            init_disp = train_fn.BilinearScaleFn.apply(init_disp, (h, w), scale)
+        else:
+            init_disp = ops.bilinear_scale(init_disp, (h, w), scale)
         refine_disps = [init_disp]
         for block in self.refine_blocks:
             refine_disps.append(block(refine_disps[-1], leftImage))

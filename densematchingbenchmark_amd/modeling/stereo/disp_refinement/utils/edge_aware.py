@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from ..... import ops
+from ...layers import train_fn
 from ...layers.basic_layers import _versions
 from ...layers.basic_layers_2d import BasicBlock, conv_bn_relu
 
@@ -20,6 +21,10 @@ class _ResidualHead(nn.Conv2d):
         self._key, self._cache = None, None
 
     def forward(self, x, skip, res_ch_offset=0):
+        if train_fn.wants_grad(self, x, skip):
+            if res_ch_offset or skip.shape[1] != 1:
+                raise ValueError("_ResidualHead training path: the skip is the 1-channel up-sampled disparity")
+            return train_fn.BareConv2dFn.apply(x, self.weight, self.bias, skip, True)
         key = _versions(self.weight, self.bias)
         if key != self._key:
             self._key = key
@@ -42,6 +47,12 @@ class EdgeAwareRefinement(nn.Module):
         h, w = leftImage.shape[-2:]
         scale = w / disp.shape[-1]
         B = disp.shape[0]
+        if train_fn.wants_grad(self, disp):   # training: plain tensors under autograd (edge_aware.py:45-66)
+            up = train_fn.BilinearScaleFn.apply(disp, (h, w), scale)
+            feat = self.conv_mix(torch.cat((up, leftImage), 1))
+            for block in self.residual_dilation_blocks:
+                feat = block(feat)
+            return self.conv_res(feat, up)
         # cat(up_disp, leftImage) (edge_aware.py:53): the up-sampling kernel writes channel 0 of the mixed input in place
         mixed = torch.empty((B, 1 + leftImage.shape[1], h, w), dtype=torch.float32, device=disp.device)
         ops.bilinear_scale(disp, (h, w), scale, out=mixed, out_ch_offset=0)

@@ -295,8 +295,8 @@ class Conv2dUnitFn(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().contiguous()
         C, k, s, d = unit.out_planes, unit.kernel_size, unit.stride, unit.dilation
-        if k not in (1, 3) or d not in (1, 2) or (s == 2 and d != 1):
-            raise NotImplementedError("training path of FusedConv2d: kernel 1|3, dilation 1|2, stride 2 only without dilation")
+        if k not in (1, 3) or d not in (1, 2, 4, 8) or (s == 2 and d != 1):
+            raise NotImplementedError("training path of FusedConv2d: kernel 1|3, dilation 1|2|4|8, stride 2 only without dilation")
         sc = sh = None
         if bias is not None:
             sc, sh = torch.ones_like(bias), bias.detach().contiguous()
@@ -368,6 +368,94 @@ class BareConv1x1Fn(torch.autograd.Function):
         dy = dy.contiguous()
         return (ops.conv2d_dgrad(dy, w) if ctx.needs_input_grad[0] else None,
                 ops.conv2d_wgrad(x, dy, 1, 1) if ctx.needs_input_grad[1] else None)
+
+
+def _space_to_depth(x):
+    """[B, C, H, W] (even H, W) -> [B, 4C, H/2, W/2], channel order (c, row parity, column parity)."""
+    B, C, H, W = x.shape
+    return x.view(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, 4 * C, H // 2, W // 2)
+
+
+def _depth_to_space(x):
+    B, C4, H2, W2 = x.shape
+    C = C4 // 4
+    return x.view(B, C, 2, 2, H2, W2).permute(0, 1, 4, 2, 5, 3).reshape(B, C, 2 * H2, 2 * W2)
+
+
+def _k5s2_as_k3(w):
+    """A 5x5 stride-2 convolution (padding 2) IS a 3x3 stride-1 convolution (padding 1) on the space-to-depth input:
+    x[2(o + A - 1) + r] meets w[2A + r] (A in 0..2, r in 0..1; the sixth tap is zero).  [Co, Ci, 5, 5] -> [Co, 4Ci, 3, 3]."""
+    Co, Ci = w.shape[:2]
+    w6 = torch.nn.functional.pad(w, (0, 1, 0, 1))
+    return w6.view(Co, Ci, 3, 2, 3, 2).permute(0, 1, 3, 5, 2, 4).reshape(Co, 4 * Ci, 3, 3).contiguous()
+
+
+def _k3_as_k5s2_grad(dw3, Ci):
+    Co = dw3.shape[0]
+    return dw3.view(Co, Ci, 2, 2, 3, 3).permute(0, 1, 4, 2, 5, 3).reshape(Co, Ci, 6, 6)[:, :, :5, :5].contiguous()
+
+
+class BareConv2dFn(torch.autograd.Function):
+    """A bare nn.Conv2d with bias (backbones/StereoNet.py:26-27,76: 5x5 stride 2 or 3x3 stride 1; edge_aware.py:42 with its skip
+    add and ReLU): y = act(conv(x) + bias (+ skip)).  The 5x5 stride-2 layers take their gradients through the equivalent 3x3
+    stride-1 layer on the space-to-depth input."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, skip, relu):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        Co, k = w.shape[0], w.shape[2]
+        stride = 2 if k == 5 else 1
+        if k == 5 and (x.shape[2] % 2 or x.shape[3] % 2):
+            raise NotImplementedError("training path of the 5x5 stride-2 layers: even input sizes")
+        b = bias.detach().contiguous() if bias is not None else None
+        raw = ops.conv2d(x, ops.pack_conv2d_weights(w), Co, k, stride, 1, None, b, None, False)
+        one, zero = torch.ones(Co, device=x.device), torch.zeros(Co, device=x.device)
+        if relu:
+            y = ops.bn_act(raw, one, zero, skip, True)
+        elif skip is not None:
+            y = ops.bn_act(raw, one, zero, skip, False)
+        else:
+            y = raw
+        ctx.relu, ctx.has = bool(relu), (bias is not None, skip is not None)
+        ctx.save_for_backward(x, w, raw, y if relu else None, one, zero)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, raw, y, one, zero = ctx.saved_tensors
+        has_bias, has_skip = ctx.has
+        dy = dy.contiguous()
+        need_dres = has_skip and ctx.needs_input_grad[3]
+        dc, _, dsum, dres = ops.bn_act_bwd(dy, raw, y, one, zero, zero, one, ctx.relu, False, want_dres=need_dres and ctx.relu)
+        if need_dres and not ctx.relu:
+            dres = dy
+        k, Ci = w.shape[2], w.shape[1]
+        dx = dw = None
+        if k == 5:
+            w3 = _k5s2_as_k3(w)
+            if ctx.needs_input_grad[1]:
+                dw = _k3_as_k5s2_grad(ops.conv2d_wgrad(_space_to_depth(x).contiguous(), dc, 3, 1), Ci)
+            if ctx.needs_input_grad[0]:
+                dx = _depth_to_space(ops.conv2d_dgrad(dc, w3)).contiguous()
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv2d_wgrad(x, dc, k, 1)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv2d_dgrad(dc, w)
+        return dx, dw, (dsum if has_bias and ctx.needs_input_grad[2] else None), (dres if need_dres else None), None
+
+
+class BilinearScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_hw, mult):
+        x = x.contiguous()
+        ctx.hw, ctx.mult = tuple(x.shape[2:]), float(mult)
+        return ops.bilinear_scale(x, tuple(out_hw), mult)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bilinear_scale_bwd(dy.contiguous(), ctx.hw, ctx.mult), None, None
 
 
 class AvgPool2dFn(torch.autograd.Function):

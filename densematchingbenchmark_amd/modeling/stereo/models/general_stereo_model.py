@@ -33,13 +33,15 @@ class GeneralizedStereoModel(nn.Module):
 
     def _forward_train(self, batch, ref_fms, tgt_fms):
         """general_stereo_model.py:60-77: the same forward under autograd, then the configured losses.  Built for the
-        cost path (volume builder, aggregator, regression, confidence network) with its losses; a refinement
-        stage in training mode is not."""
-        if self.disp_refinement is not None:
-            raise NotImplementedError("training through disp_refinement is outside the HIP path built so far")
+        cost path (volume builder, aggregator, regression, confidence network), the refinement stage and their losses
+        (SURVEY 8-f3)."""
         target = batch.get('leftDisp')
         costs = self.cost_processor(ref_fms, tgt_fms)
         disps = [self.disp_predictor(cost) for cost in costs]
+        if self.disp_refinement is not None:                         # general_stereo_model.py:57-58
+            if 'leftImage' not in batch:
+                raise ValueError("disp_refinement needs batch['leftImage'] (full-resolution left view)")
+            disps = self.disp_refinement(disps, ref_fms, tgt_fms, batch['leftImage'], batch.get('rightImage'))
         if self.loss_evaluator is None:
             if 'losses' not in self.cfg.model:
                 raise ValueError("training mode needs cfg.model.losses (general_stereo_model.py:40)")

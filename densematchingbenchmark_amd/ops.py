@@ -509,6 +509,17 @@ def bilinear_ac_bwd(grad_y, in_hw):
     return gx
 
 
+def bilinear_scale_bwd(grad_y, in_hw, mult):
+    lib = _lib.load()
+    grad_y = _f32c(grad_y, "grad_y")
+    B, C, Ho, Wo = grad_y.shape
+    Hi, Wi = in_hw
+    gx = torch.empty((B, C, Hi, Wi), dtype=torch.float32, device=grad_y.device)
+    check(lib.dmb_bilinear_scale_bwd_f32(dev_ptr(grad_y), dev_ptr(gx), B, C, Hi, Wi, Ho, Wo, float(mult), stream_ptr(grad_y.device)),
+          "dmb_bilinear_scale_bwd_f32")
+    return gx
+
+
 def deconv3d_k8s4_c1_bwd(x, w, dy, want_dx=True, want_dw=True):
     """Backward of deconv3d_k8s4_c1: (dx [B, D, H, W] or None, dw [8, 8, 8] or None)."""
     lib = _lib.load()

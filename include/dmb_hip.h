@@ -350,6 +350,9 @@ int dmb_trilinear_ac_bwd_f32(const float* grad_y, float* scratch, float* grad_x,
  * backbone under training): grad_y -> grad_x. */
 int dmb_avgpool2d_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int H, int W, int k, void* stream);
 int dmb_bilinear_ac_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* Backward of dmb_bilinear_scale_f32 (half-pixel bilinear * mult, edge_aware.py:49-50) on plain tensors. */
+int dmb_bilinear_scale_bwd_f32(const float* grad_y, float* grad_x, int B, int C, int Hi, int Wi, int Ho, int Wo, float mult,
+                               void* stream);
 
 /* Backward of dmb_deconv3d_k8s4_c1_f32 (AcfNet's learned up-sampling, aggregators/AcfNet.py:55-57): dx [B, D, H, W] =
  * sum_k dy[4 i - 2 + k] w[k], dw [8, 8, 8] = sum_{b, i} x[b, i] dy[b, 4 i - 2 + k]; dy [B, 4D, 4H, 4W].  Either output may be

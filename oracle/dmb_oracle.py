@@ -663,6 +663,34 @@ def psmnet_backbone_train_step(l_img, r_img, p, dl, dr, dtype=torch.float32, pre
     return (fl.detach(), fr.detach()), dict(zip(names, grads)), {k: v for k, v in q.items() if "running_" in k}
 
 
+def stereonet_e2e_train_step(l_img, r_img, p, max_disp, gt, level_weights=(1.0, 0.5), dtype=torch.float32, num_refine=1):
+    """One training iteration of the WHOLE StereoNet-8x model (configs/StereoNet/scene_flow_8x_2stage.py through
+    models/general_stereo_model.py:42-77): backbone on each view (BatchNorm statistics per call), difference volume at 1/8,
+    StereoNetAggregator, FasterSoftArgmin, edge-aware refinement cascade, weighted DispSmoothL1Loss on [refined..., up-sampled
+    coarse] (sparse ground truth: data.sparse=True -> no interpolation of gt; all maps here are full-size).
+    ``p``: model-level names.  Returns (losses, grads, running)."""
+    q, leaves = dict(), dict()
+    for k, v in p.items():
+        v = v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and "running_" not in k and "disp_regression" not in k:
+            v.requires_grad_(True)
+            leaves[k] = v
+        q[k] = v
+    li, ri, g = l_img.to(dtype), r_img.to(dtype), gt.to(dtype)
+    with bn_training():
+        fl = stereonet_backbone(li, q)
+        fr = stereonet_backbone(ri, q)
+        raw = dif_fms(fl, fr, max_disp // 8, 0, 1).to(dtype)
+        cost = stereonet_aggregator(raw, q, "cost_processor.aggregator.")[0]
+        ds = disp_sample_values(max_disp // 8, 0, 1).to(dtype).view(1, -1, 1, 1)
+        disp = torch.sum(F.softmax(cost, dim=1) * ds, dim=1, keepdim=True)
+        disps = stereonet_refinement([disp], li, q, num=num_refine)
+    losses = [level_weights[i] * disp_smooth_l1_loss(d, g, max_disp) for i, d in enumerate(disps)]
+    names = list(leaves)
+    grads = torch.autograd.grad(sum(losses), [leaves[k] for k in names], allow_unused=True)
+    return [l.detach() for l in losses], dict(zip(names, grads)), {k: v for k, v in q.items() if "running_" in k}
+
+
 def stereonet_train_step(ref_fms, tgt_fms, p, max_disp, gt, dtype=torch.float32, num=4):
     """Training forward/backward of the StereoNet cost path at the volume's own resolution (dif_fms -> StereoNetAggregator
     with biased convolutions, BatchNorm in training mode -> soft-argmin -> smooth-L1 against ``gt`` [B, 1, H, W] given at
