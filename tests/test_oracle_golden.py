@@ -395,3 +395,28 @@ def test_backbone_training_matches_reference_autograd():
     assert _check_fingerprints(g, "bb", grads) == len(grads)
     assert np.allclose(running["backbone.firstconv.0.1.running_mean"].numpy(), g["bb_rm"], rtol=1e-5, atol=1e-7)
     assert np.allclose(running["backbone.firstconv.0.1.running_var"].numpy(), g["bb_rv"], rtol=1e-5, atol=1e-7)
+
+
+def test_stereonet_training_matches_reference_autograd():
+    """oracle.stereonet_e2e_train_step against one training iteration of the reference's WHOLE StereoNet model (build_model(cfg)
+    .train(), its own loss evaluator and autograd; gen_golden.py section 4h)."""
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    import os
+    g = golden("training.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "StereoNet", "scene_flow_8x_2stage.py"))
+    cfg.model.disp_refinement = dict(type="StereoNet", in_planes=4, num=1)
+    cfg.model.backbone = dict(type="StereoNet", in_planes=3)
+    model = build_model(cfg, backbone="hip")          # parameter container only: same names / shapes as the reference's model
+    synthetic.init_params_(model, seed=12, classif_gain=4.0)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    li, ri = rand((2, 3, 64, 96), 97), rand((2, 3, 64, 96), 98)
+    gt = torch.rand((2, 1, 64, 96), generator=torch.Generator().manual_seed(99)) * 30.0 + 0.5
+    losses, grads, _ = O.stereonet_e2e_train_step(li, ri, p, 192, gt)
+    assert [str(k) for k in g["sn_loss_keys"]] == ["l1_loss_lvl0", "l1_loss_lvl1"]
+    assert np.allclose([float(x) for x in losses], g["sn_losses"], rtol=1e-5)
+    grads = {k: v for k, v in grads.items() if v is not None}
+    n = _check_fingerprints(g, "sn", grads)
+    assert n == len(grads) and n >= 100
