@@ -1,0 +1,25 @@
+# StereoNet-8x, the whole model: backbone (three 5x5 stride-2 heads + 6 residual blocks), difference volume at 1/8 resolution,
+# 4 conv units + 1-channel head, soft-argmin at 1/8, one edge-aware refinement block at full resolution; smooth-L1 on the
+# refined and on the up-sampled coarse map.  (scene_flow_8x_2stage.py in this directory is the cost path alone.)
+import os, runpy
+_c = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_common.py"))
+task = 'stereo'
+max_disp = 192
+model = dict(
+    meta_architecture="GeneralizedStereoModel",
+    max_disp=max_disp,
+    batch_norm=True,
+    backbone=dict(type="StereoNet", in_planes=3),
+    cost_processor=dict(
+        type='Difference',
+        cost_computation=_c['volume']("default", max_disp, 8),
+        cost_aggregator=dict(type="StereoNet", max_disp=max_disp, in_planes=32),
+    ),
+    disp_predictor=_c['predictor']('FASTER', max_disp // 8),
+    disp_refinement=dict(type='StereoNet', in_planes=4, num=1),
+    losses=dict(l1_loss=dict(max_disp=max_disp, weights=(1.0, 0.5), weight=1.0)),
+    eval=_c['evaluation'](max_disp),
+)
+data = dict(sparse=True, eval=dict(input_shape=[384, 1248], original_shape=[375, 1242]))
+eval_disparity_id = [0]
+dist_params = dict(backend='nccl')
