@@ -142,6 +142,28 @@ class HeadConvFn(torch.autograd.Function):
         return dx, dw, dbias, (dy if ctx.has[1] and ctx.needs_input_grad[3] else None)
 
 
+class HeadDeconvFn(torch.autograd.Function):
+    """nn.ConvTranspose3d(C, Co <= 32, 3, stride 2, padding 1, output_padding 1, bias) without BatchNorm / activation: GC-Net's
+    output layer (aggregators/GCNet.py:63-67)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(w), w.shape[1], None,
+                                 bias.detach().float().contiguous() if bias is not None else None, None, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        return (ops.deconv3d_k3s2_dgrad(dy, w) if ctx.needs_input_grad[0] else None,
+                ops.deconv3d_k3s2_wgrad(x, dy) if ctx.needs_input_grad[1] else None,
+                dy.sum(dim=(0, 2, 3, 4)) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+
+
 class CatFmsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, left, right, disp_idx):
@@ -295,7 +317,10 @@ class Conv2dUnitFn(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().contiguous()
         C, k, s, d = unit.out_planes, unit.kernel_size, unit.stride, unit.dilation
-        if k not in (1, 3) or d not in (1, 2, 4, 8) or (s == 2 and d != 1):
+        if k == 5:
+            if s != 2 or d != 1 or x.shape[2] % 2 or x.shape[3] % 2:
+                raise NotImplementedError("training path of FusedConv2d: 5x5 layers are stride 2 on even input sizes")
+        elif k not in (1, 3) or d not in (1, 2, 4, 8) or (s == 2 and d != 1):
             raise NotImplementedError("training path of FusedConv2d: kernel 1|3, dilation 1|2|4|8, stride 2 only without dilation")
         sc = sh = None
         if bias is not None:
@@ -324,14 +349,18 @@ class Conv2dUnitFn(torch.autograd.Function):
             dres = dy
         dw = dx = dbias = None
         if ctx.needs_input_grad[1]:
-            if s == 1:
+            if k == 5:     # 5x5 stride 2 = 3x3 stride 1 on the space-to-depth input (GC-Net's first layer)
+                dw = _k3_as_k5s2_grad(ops.conv2d_wgrad(_space_to_depth(x).contiguous(), dc, 3, 1), x.shape[1])
+            elif s == 1:
                 dw = ops.conv2d_wgrad(x, dc, k, d)
             elif k == 3:   # stride 2: the 3-D stride-2 weight gradient at depth 1, middle plane of its taps
                 dw = ops.conv3d_k3s2_wgrad(x.unsqueeze(2), dc.unsqueeze(2))[:, :, 1].contiguous()
             else:          # 1x1, stride 2: a 1x1 layer on the even positions
                 dw = ops.conv2d_wgrad(x[:, :, ::2, ::2].contiguous(), dc, 1, 1)
         if ctx.needs_input_grad[0]:
-            if s == 1:
+            if k == 5:
+                dx = _depth_to_space(ops.conv2d_dgrad(dc, _k5s2_as_k3(w))).contiguous()
+            elif s == 1:
                 dx = ops.conv2d_dgrad(dc, w, d)
             elif k == 3:
                 dx = ops.conv3d_k3_dgrad(dc.unsqueeze(2), _as3d_weight(w), 2, (1,) + tuple(x.shape[2:])).squeeze(2)

@@ -264,8 +264,17 @@ def conv3d_k3_dgrad(dc, w, stride=1, in_size=None):
     if stride == 1:
         return conv3d_k3(dc, pack_conv3d_dgrad_weights(w), Ci)
     if stride == 2:
-        # the adjoint of a stride-2 convolution is the transposed convolution with the same weight tensor
-        dx = deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci)
+        # the adjoint of a stride-2 convolution is the transposed convolution with the same weight tensor; the transposed kernel
+        # takes 64 or <= 32 output channels per launch, so wider inputs (GC-Net: 96, 128) are done in channel chunks
+        if Ci == 64 or Ci <= 32:
+            dx = deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci)
+        else:
+            parts, c0 = [], 0
+            while c0 < Ci:
+                n = 64 if Ci - c0 >= 64 else min(32, Ci - c0)
+                parts.append(deconv3d_k3s2(dc, pack_deconv3d_weights(w[:, c0:c0 + n].contiguous()), n))
+                c0 += n
+            dx = torch.cat(parts, 1)
         if in_size is not None and tuple(in_size) != tuple(dx.shape[2:]):
             D, H, W = in_size
             if any(a not in (b, b - 1) for a, b in zip((D, H, W), dx.shape[2:])):

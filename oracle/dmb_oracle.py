@@ -691,6 +691,30 @@ def stereonet_e2e_train_step(l_img, r_img, p, max_disp, gt, level_weights=(1.0, 
     return [l.detach() for l in losses], dict(zip(names, grads)), {k: v for k, v in q.items() if "running_" in k}
 
 
+def gcnet_e2e_train_step(l_img, r_img, p, max_disp, gt, dtype=torch.float32, training=True):
+    """One training iteration of the whole GC-Net model (configs/GCNet/scene_flow.py through models/general_stereo_model.py:42-77):
+    backbone on each view (BatchNorm statistics per call), concatenation volume at 1/2 resolution, GCAggregator, FasterSoftArgmin,
+    DispSmoothL1Loss.  ``p``: model-level names.  Returns (loss, grads, running)."""
+    q, leaves = dict(), dict()
+    for k, v in p.items():
+        v = v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and "running_" not in k and "disp_regression" not in k:
+            v.requires_grad_(True)
+            leaves[k] = v
+        q[k] = v
+    with (bn_training() if training else _no_context()):   # training=False: the same graph with running statistics
+        fl = gcnet_backbone(l_img.to(dtype), q)
+        fr = gcnet_backbone(r_img.to(dtype), q)
+        raw = cat_fms(fl, fr, max_disp // 2, 0, 1).to(dtype)
+        cost = gc_aggregator(raw, q, "cost_processor.aggregator.")[0]
+        ds = disp_sample_values(max_disp, 0, 1).to(dtype).view(1, -1, 1, 1)
+        disp = torch.sum(F.softmax(cost, dim=1) * ds, dim=1, keepdim=True)
+    loss = disp_smooth_l1_loss(disp, gt.to(dtype), max_disp)
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    return loss.detach(), dict(zip(names, grads)), {k: v for k, v in q.items() if "running_" in k}
+
+
 def stereonet_train_step(ref_fms, tgt_fms, p, max_disp, gt, dtype=torch.float32, num=4):
     """Training forward/backward of the StereoNet cost path at the volume's own resolution (dif_fms -> StereoNetAggregator
     with biased convolutions, BatchNorm in training mode -> soft-argmin -> smooth-L1 against ``gt`` [B, 1, H, W] given at

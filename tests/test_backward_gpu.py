@@ -647,3 +647,77 @@ def test_stereonet_end_to_end_training(dev):
         tight += err <= 4 * (g32[k].double() - ref).abs().max().item() + 2e-5 * scale + zero
         checked += 1
     assert checked >= 100 and tight >= 0.6 * checked
+
+
+def test_gcnet_end_to_end_training(dev):
+    """The whole GC-Net model, images -> loss -> gradients: 5x5 stride-2 first layer (space-to-depth form), BasicBlocks,
+    concatenation volume at 1/2 resolution, the 3-D encoder / decoder with 64 / 128-channel units (chunked stride-2 data
+    gradients), ReLU-before-skip transposed units, the 1-channel transposed head.
+
+    At a size the CPU oracle can differentiate in FP64, GC-Net's deepest level holds 1 x 2 x 3 voxels per channel: batch
+    statistics over 12 values make the training-mode gradients ill-conditioned (the FP32 oracle itself sits up to 1e-1 of the
+    range from its FP64 evaluation).  So the per-gradient bound is checked on the SAME graph with running statistics
+    (eval mode, input requiring a gradient), and training mode is checked for its loss and for the direction of every
+    gradient (cosine similarity with the FP64 oracle)."""
+    import os
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "GCNet", "scene_flow.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 2
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cfg.model.disp_predictor.max_disp = md
+    cfg.model.losses = dict(l1_loss=dict(max_disp=md, weights=(1.0,), weight=1.0))
+    model = build_model(cfg, backbone="hip")
+    synthetic.init_params_(model, seed=14, classif_gain=4.0)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    li, ri = _rand((2, 3, 64, 96), 101), _rand((2, 3, 64, 96), 102)
+    gt = torch.rand((2, 1, 64, 96), generator=torch.Generator().manual_seed(103)) * 28.0 + 0.5
+    named = dict(model.named_parameters())
+
+    # (a) running statistics: the per-gradient bounds of test_psmnet_training_step
+    _, g32, _ = O.gcnet_e2e_train_step(li, ri, p, md, gt, training=False)
+    l64, g64, _ = O.gcnet_e2e_train_step(li, ri, p, md, gt, training=False, dtype=torch.float64)
+    model.eval()
+    from densematchingbenchmark_amd.modeling.stereo.losses import DispSmoothL1Loss
+    # (an eval-mode module builds a graph only for inputs that carry a gradient: both views must)
+    lig, rig = li.to(dev).requires_grad_(True), ri.to(dev).requires_grad_(True)
+    fl, fr = model.backbone(lig, rig)
+    disp = model.disp_predictor(model.cost_processor(fl, fr)[0])
+    loss = DispSmoothL1Loss(max_disp=md, weights=(1.0,))(disp, gt.to(dev))["l1_loss_lvl0"]
+    assert abs(loss.item() - l64.item()) <= 1e-4 * max(1.0, abs(l64.item()))
+    loss.backward()
+    tight, checked = 0, 0
+    # (the head's bias shifts every cost of a pixel alike: its gradient is exactly zero, rounding noise in any evaluation)
+    zero = 1e-5 * max(v.abs().max().item() for v in g64.values() if v is not None)
+    for k, ref in g64.items():
+        if ref is None:
+            continue
+        got = named[k].grad
+        assert got is not None, k
+        scale = ref.abs().max().item()
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err <= 3e-2 * scale + zero, "grad of %s: error %.3e of range %.3e" % (k, err, scale)
+        tight += err <= 4 * (g32[k].double() - ref).abs().max().item() + 2e-5 * scale + zero
+        checked += 1
+    assert checked >= 100 and tight >= 0.6 * checked
+
+    # (b) batch statistics: loss and gradient directions
+    model.zero_grad(set_to_none=True)
+    model.train()
+    l64, g64, _ = O.gcnet_e2e_train_step(li, ri, p, md, gt, dtype=torch.float64)
+    results, loss_dict = model(dict(leftImage=li.to(dev), rightImage=ri.to(dev), leftDisp=gt.to(dev)))
+    assert results == {} and list(loss_dict) == ["l1_loss_lvl0"]
+    assert abs(loss_dict["l1_loss_lvl0"].item() - l64.item()) <= 1e-4 * max(1.0, abs(l64.item()))
+    sum(loss_dict.values()).backward()
+    for k, ref in g64.items():
+        if ref is None or ref.abs().max().item() < 1e-12:
+            continue
+        got = named[k].grad.cpu().double().reshape(-1)
+        assert torch.isfinite(got).all(), k
+        cos = torch.dot(got, ref.reshape(-1)) / (got.norm() * ref.norm() + 1e-300)
+        assert cos.item() >= 0.98, "grad of %s: cosine %.4f" % (k, cos.item())
