@@ -20,6 +20,16 @@ import torch
 from .... import ops
 
 _RELU = {0: False, 1: True, 2: "pre"}
+_CONST = {}
+
+
+def _const(value, C, device):
+    """Cached [C] tensor of ones / zeros (identity scale / shift of units without BatchNorm): no fill launch per call."""
+    key = (float(value), int(C), str(device))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((C,), float(value), dtype=torch.float32, device=device)
+    return t
 
 
 def _relu_code(relu):
@@ -31,7 +41,7 @@ def _conv_raw(unit, x, weight, bias):
     Co = unit.out_planes
     scale = shift = None
     if bias is not None:
-        scale, shift = torch.ones_like(bias), bias.detach().contiguous()
+        scale, shift = _const(1.0, bias.numel(), bias.device), bias.detach().contiguous()
     if unit.transposed:
         return ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(weight), Co, scale, shift, None, False)
     return ops.conv3d_k3(x, ops.pack_conv3d_weights(weight), Co, scale, shift, None, unit.stride, False)
@@ -64,9 +74,8 @@ class ConvUnitFn(torch.autograd.Function):
             scale = g * invstd
             shift = b - mean * scale
         else:
-            mean = torch.zeros(C, dtype=torch.float32, device=x.device)
-            invstd = torch.ones_like(mean)
-            scale, shift = torch.ones_like(mean), torch.zeros_like(mean)
+            mean = shift = _const(0.0, C, x.device)
+            invstd = scale = _const(1.0, C, x.device)
         code = _relu_code(relu)
         if bn is None and skip is None and code == 0:
             y = raw
@@ -123,10 +132,12 @@ class HeadConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual):
         x = x.contiguous()
         w = weight.detach().contiguous()
-        b = float(bias.detach().cpu()[0]) if bias is not None else 0.0
         ctx.save_for_backward(x, w)
         ctx.has = (bias is not None, residual is not None)
-        return ops.conv3d_k3_c1(x, w, b, residual)
+        y = ops.conv3d_k3_c1(x, w, 0.0, residual)
+        # the kernel takes its bias as a host scalar; reading the parameter back every step would stall the stream, so the
+        # 1-channel result gets it from the device tensor
+        return y + bias.detach().view(1, 1, 1, 1, 1) if bias is not None else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -295,8 +306,8 @@ def _bn_forward(bn, training, raw, gamma, beta, C, device):
         scale = (gamma.detach() if gamma is not None else torch.ones_like(mean)) * invstd
         shift = (beta.detach() if beta is not None else torch.zeros_like(mean)) - mean * scale
     else:
-        mean = torch.zeros(C, dtype=torch.float32, device=device)
-        invstd, scale, shift = torch.ones_like(mean), torch.ones_like(mean), torch.zeros_like(mean)
+        mean = shift = _const(0.0, C, device)
+        invstd = scale = _const(1.0, C, device)
     return mean, invstd, scale, shift, batch_stats
 
 
@@ -324,7 +335,7 @@ class Conv2dUnitFn(torch.autograd.Function):
             raise NotImplementedError("training path of FusedConv2d: kernel 1|3, dilation 1|2|4|8, stride 2 only without dilation")
         sc = sh = None
         if bias is not None:
-            sc, sh = torch.ones_like(bias), bias.detach().contiguous()
+            sc, sh = _const(1.0, bias.numel(), bias.device), bias.detach().contiguous()
         raw = ops.conv2d(x, ops.pack_conv2d_weights(w), C, k, s, d, sc, sh, None, False)
         bn = unit[1] if unit.has_bn else None
         mean, invstd, scale, shift, batch_stats = _bn_forward(bn, unit.training, raw, gamma, beta, C, x.device)
@@ -439,7 +450,7 @@ class BareConv2dFn(torch.autograd.Function):
             raise NotImplementedError("training path of the 5x5 stride-2 layers: even input sizes")
         b = bias.detach().contiguous() if bias is not None else None
         raw = ops.conv2d(x, ops.pack_conv2d_weights(w), Co, k, stride, 1, None, b, None, False)
-        one, zero = torch.ones(Co, device=x.device), torch.zeros(Co, device=x.device)
+        one, zero = _const(1.0, Co, x.device), _const(0.0, Co, x.device)
         if relu:
             y = ops.bn_act(raw, one, zero, skip, True)
         elif skip is not None:
