@@ -401,34 +401,36 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __
 // neighbours from the cache hierarchy (dy is one channel), private sums per lane, one block reduction at the end, partials
 // per voxel chunk added in a fixed order.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int C1_CHUNKS = 128, C1_CG = 8;   // voxel chunks; channels per thread
+constexpr int C1_CHUNKS = 256, C1_CG = 4;   // voxel chunks; channels per thread
 // A thread owns voxels (coalesced along x) and C1_CG channels: the 27 dy neighbours of a voxel are loaded once for all of
 // them (27 loads against 8 x 27 multiply-adds), the 8 x 27 sums live in registers until one block reduction at the end.
-__global__ __launch_bounds__(256, 1) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 2) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  float* __restrict__ ws, int B, int Ci, int D, int H, int W) {
   __shared__ float red[4][C1_CG * 27];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c0 = blockIdx.y * C1_CG;
-  const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
-  const long long vox = (long long)B * DHW;
-  const long long per = ((vox + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
-  const long long v0 = blockIdx.x * per, v1 = v0 + per < vox ? v0 + per : vox;
+  // 32-bit index arithmetic throughout (the launcher checks B * D * H * W < 2^31): 64-bit divisions per voxel cost more than
+  // the 27 loads and the multiply-adds together
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const unsigned vox = (unsigned)B * DHW;
+  const unsigned per = ((vox + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const unsigned v0 = blockIdx.x * per, v1 = v0 + per < vox ? v0 + per : vox;
   float acc[C1_CG][27];
 #pragma unroll
   for (int c = 0; c < C1_CG; ++c)
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[c][t] = 0.f;
-  for (long long v = v0 + threadIdx.x; v < v1; v += 256) {
-    const int b = (int)(v / (long long)DHW);
-    const size_t r = (size_t)(v - (long long)b * DHW);
-    const int z = (int)(r / HW), y = (int)((r % HW) / W), xx = (int)(r % W);
+  for (unsigned v = v0 + threadIdx.x; v < v1; v += 256) {
+    const unsigned b = v / DHW, r = v - b * DHW;
+    const unsigned zu = r / HW, r2 = r - zu * HW, yu = r2 / W;
+    const int z = (int)zu, y = (int)yu, xx = (int)(r2 - yu * W);
     const float* db = dy + (size_t)b * DHW;
     float dn[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) {
       const int zz = z - t / 9 + 1, yy = y - (t / 3) % 3 + 1, xn = xx - t % 3 + 1;
       const bool ok = zz >= 0 && zz < D && yy >= 0 && yy < H && xn >= 0 && xn < W;
-      dn[t] = ok ? db[(size_t)zz * HW + (size_t)yy * W + xn] : 0.f;
+      dn[t] = ok ? db[(unsigned)zz * HW + (unsigned)yy * W + (unsigned)xn] : 0.f;
     }
     const float* xp = x + ((size_t)b * Ci + c0) * DHW + r;
 #pragma unroll
@@ -527,7 +529,7 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
     return fail(DMB_EINVAL, "conv3d_wgrad: bad argument");
   if ((long long)32 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_wgrad: 32 channels of one batch item must stay below 2 GiB");
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 1) {   // classifier heads: the dedicated single-channel kernel (the workspace of the general case is larger)
+  if (Co == 1 && (long long)B * D * H * W < 0x7fffffffLL) {   // classifier heads: the dedicated single-channel kernel
     hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(C1_CHUNKS, cdiv(Ci, C1_CG)), dim3(256), 0, st, x, dc, workspace, B, Ci, D, H, W);
     hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(cdiv(Ci * 27, 256)), dim3(256), 0, st, workspace, dw, Ci, C1_CHUNKS);
     return launch_status("conv3d_wgrad (1 channel) launch failed");
