@@ -57,25 +57,7 @@ class ConvUnitFn(torch.autograd.Function):
         raw = _conv_raw(unit, x, w, bias)
         C = unit.out_planes
         bn = unit[1] if unit.has_bn else None
-        batch_stats = bn is not None and unit.training
-        if batch_stats:
-            rm = bn.running_mean if bn.track_running_stats else None
-            rv = bn.running_var if bn.track_running_stats else None
-            momentum = 0.1 if bn.momentum is None else bn.momentum
-            mean, invstd, scale, shift = ops.bn_train_stats(raw, gamma.detach() if gamma is not None else None,
-                                                            beta.detach() if beta is not None else None, rm, rv, momentum, bn.eps)
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
-        elif bn is not None:
-            mean = bn.running_mean.detach().float()
-            invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
-            g = gamma.detach() if gamma is not None else torch.ones_like(mean)
-            b = beta.detach() if beta is not None else torch.zeros_like(mean)
-            scale = g * invstd
-            shift = b - mean * scale
-        else:
-            mean = shift = _const(0.0, C, x.device)
-            invstd = scale = _const(1.0, C, x.device)
+        mean, invstd, scale, shift, batch_stats = _bn_forward(bn, unit.training, raw, gamma, beta, C, x.device)
         code = _relu_code(relu)
         if bn is None and skip is None and code == 0:
             y = raw
@@ -252,23 +234,7 @@ class ConfHeadFn(torch.autograd.Function):
         Cm = w1d.shape[0]
         raw = ops.conv2d(cost, ops.pack_conv2d_weights(w1d), Cm, 3)
         bn = head.conf_net[0][1] if head.batch_norm else None
-        batch_stats = bn is not None and head.training
-        if batch_stats:
-            momentum = 0.1 if bn.momentum is None else bn.momentum
-            mean, invstd, scale, shift = ops.bn_train_stats(raw, gamma.detach() if gamma is not None else None,
-                                                            beta.detach() if beta is not None else None,
-                                                            bn.running_mean if bn.track_running_stats else None,
-                                                            bn.running_var if bn.track_running_stats else None, momentum, bn.eps)
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
-        elif bn is not None:
-            mean = bn.running_mean.detach().float()
-            invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
-            scale = (gamma.detach() if gamma is not None else torch.ones_like(mean)) * invstd
-            shift = (beta.detach() if beta is not None else torch.zeros_like(mean)) - mean * scale
-        else:
-            mean = torch.zeros(Cm, dtype=torch.float32, device=cost.device)
-            invstd, scale, shift = torch.ones_like(mean), torch.ones_like(mean), torch.zeros_like(mean)
+        mean, invstd, scale, shift, batch_stats = _bn_forward(bn, head.training, raw, gamma, beta, Cm, cost.device)
         h = ops.bn_act(raw, scale, shift, None, True)
         logit = ops.conv2d(h, ops.pack_conv2d_weights(w2d), 1, 1)
         ctx.batch_stats = batch_stats
