@@ -195,3 +195,49 @@ def test_opt_in_conv3d_mode_is_explicit():
     finally:
         ops.set_conv3d_mode("exact")
     assert ops.conv3d_mode() == "exact"
+
+
+def _keys(tag):
+    return set(str(s) for s in golden("state_dict_keys.npz")[tag])
+
+
+@pytest.mark.parametrize("rel,want", [
+    ("PSMNet/scene_flow.py", ("psmnet", "psmnet_backbone")),
+    ("AcfNet/scene_flow_uniform.py", ("acfnet-cmn", "psmnet_backbone")),
+    ("StereoNet/scene_flow_8x_refined.py", ("stereonet", "stereonet_backbone", "stereonet_refinement")),
+])
+def test_whole_model_configs_match_reference_keys(rel, want):
+    """build_model(cfg, backbone="hip") on the whole-model configs: the union of the reference's key lists (checkpoint interop
+    for the training / end-to-end entry points; constructing the modules needs no GPU)."""
+    from densematchingbenchmark_amd.modeling import build_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", rel))
+    model = build_model(cfg, backbone="hip")
+    got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items())
+    expect = set()
+    for tag in want:
+        if tag == "acfnet-cmn":     # the fixed-variance config has no confidence network
+            expect |= set(k for k in _keys("acfnet") if not k.startswith("cmn."))
+        else:
+            expect |= _keys(tag)
+    assert got == expect, (sorted(got - expect)[:5], sorted(expect - got)[:5])
+    assert "losses" in cfg.model     # the training branch of the model needs them
+
+
+def test_flat_gradients_views():
+    """dist_utils.FlatGradients without a process group: every grad is a view into one buffer, autograd accumulates into the
+    views, zero_() clears them in place and re-attaches views an optimizer dropped."""
+    from densematchingbenchmark_amd.dist_utils import FlatGradients
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    flat = FlatGradients(model)
+    assert flat.attached() and flat.flat.numel() >= sum(p.numel() for p in model.parameters())
+    model(torch.randn(4, 5)).sum().backward()
+    assert flat.attached() and flat.flat.abs().sum().item() > 0
+    ref = [p.grad.clone() for p in model.parameters()]
+    model(torch.randn(4, 5)).sum().backward()                 # accumulates in place
+    assert all(not torch.equal(p.grad, r) for p, r in zip(model.parameters(), ref))
+    model.zero_grad(set_to_none=True)
+    assert not flat.attached()
+    flat.zero_()
+    assert flat.attached() and flat.flat.abs().sum().item() == 0
