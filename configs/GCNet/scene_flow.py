@@ -14,6 +14,7 @@ model = dict(
         cost_aggregator=dict(type="GCNet", max_disp=max_disp, in_planes=64),
     ),
     disp_predictor=_c['predictor']('FASTER', max_disp),
+    losses=dict(l1_loss=dict(max_disp=max_disp, weights=(1.0,), weight=1.0)),
     eval=_c['evaluation'](max_disp),
 )
 data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960]))
