@@ -1,0 +1,31 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from densematchingbenchmark_amd.config import Config
+from densematchingbenchmark_amd.dist_utils import FlatGradients
+from densematchingbenchmark_amd.modeling import build_model
+from densematchingbenchmark_amd import synthetic
+dev = torch.device("cuda:0")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+model = build_model(cfg).to(dev)
+synthetic.init_params_(model, seed=0, classif_gain=1.0)
+model.train()
+flat = FlatGradients(model)
+opt = torch.optim.Adam(flat.params, lr=1e-3)
+g = torch.Generator().manual_seed(3)
+B, H, W = 2, 256, 512
+lf = torch.randn((B, 32, H // 4, W // 4), generator=g).to(dev)
+rf = torch.randn((B, 32, H // 4, W // 4), generator=g).to(dev)
+gt = (torch.rand((B, 1, H, W), generator=g) * 100.0 + 20.0).to(dev)
+batch = dict(leftFeature=lf, rightFeature=rf, leftDisp=gt)
+hist = []
+for it in range(60):
+    flat.zero_()
+    _, losses = model(batch)
+    loss = sum(losses.values())
+    loss.backward()
+    opt.step()
+    if it % 10 == 0 or it == 59:
+        hist.append((it, round(float(loss), 3)))
+print("PSMNet cost path, fixed synthetic batch, Adam lr 1e-3: total loss by iteration", hist)
