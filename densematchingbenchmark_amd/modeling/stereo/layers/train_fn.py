@@ -256,8 +256,12 @@ class ConfHeadFn(torch.autograd.Function):
 
 
 def _bn_forward(bn, training, raw, gamma, beta, C, device):
-    """Shared by the 2-D / 3-D units: (mean, invstd, scale, shift, batch_stats) for this call, running buffers updated."""
-    batch_stats = bn is not None and training
+    """Shared by the 2-D / 3-D units: (mean, invstd, scale, shift, batch_stats) for this call, running buffers updated.
+    Batch statistics are used when the BatchNorm module ITSELF is in training mode (as nn.BatchNorm decides): a model in
+    train() whose BatchNorm layers were put in eval() -- fine-tuning with frozen statistics -- normalises with the running
+    buffers and leaves them alone."""
+    del training   # the enclosing unit's flag is not what decides
+    batch_stats = bn is not None and bn.training
     if batch_stats:
         momentum = 0.1 if bn.momentum is None else bn.momentum
         mean, invstd, scale, shift = ops.bn_train_stats(raw, gamma.detach() if gamma is not None else None,

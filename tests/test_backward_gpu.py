@@ -583,15 +583,32 @@ def test_eval_mode_gradients(dev):
     for k, v in agg.named_buffers():
         assert torch.equal(v, before[k]), k      # eval mode: no running-statistics update
     named = dict(agg.named_parameters())
-    tight = 0
-    for k, ref in g64.items():
-        got = lfg.grad if k == "ref_fms" else rfg.grad if k == "tgt_fms" else named[k[len("cost_processor.aggregator."):]].grad
-        assert got is not None, k
-        scale = ref.abs().max().item()
-        err = (got.cpu().double() - ref).abs().max().item()
-        assert err <= 3e-2 * scale, "grad of %s: error %.3e of range %.3e" % (k, err, scale)
-        tight += err <= 4 * (g32[k].double() - ref).abs().max().item() + 2e-5 * scale
-    assert tight >= 0.6 * len(g64)
+
+    def check():
+        tight = 0
+        for k, ref in g64.items():
+            got = lfg.grad if k == "ref_fms" else rfg.grad if k == "tgt_fms" else named[k[len("cost_processor.aggregator."):]].grad
+            assert got is not None, k
+            scale = ref.abs().max().item()
+            err = (got.cpu().double() - ref).abs().max().item()
+            assert err <= 3e-2 * scale, "grad of %s: error %.3e of range %.3e" % (k, err, scale)
+            tight += err <= 4 * (g32[k].double() - ref).abs().max().item() + 2e-5 * scale
+        assert tight >= 0.6 * len(g64)
+
+    check()
+    # fine-tuning with frozen statistics: the model in train(), its BatchNorm layers in eval() -- the same graph again, from
+    # plain inputs this time (a training-mode unit builds the graph for its parameters)
+    agg.zero_grad(set_to_none=True)
+    agg.train()
+    for m in agg.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    lfg, rfg = lf.to(dev).requires_grad_(True), rf.to(dev).requires_grad_(True)
+    costs = agg(cat_fms(lfg, rfg, md // 4, 0, 1))
+    sum(DispSmoothL1Loss(max_disp=md, weights=(1.0, 0.7, 0.5))([pred(c) for c in costs], gt.to(dev)).values()).backward()
+    for k, v in agg.named_buffers():
+        assert torch.equal(v, before[k]), k
+    check()
 
 
 def test_bilinear_scale_backward(dev):
