@@ -508,9 +508,10 @@ class SoftArgminFn(torch.autograd.Function):
 
 
 def wants_grad(module, *tensors):
-    """True when a forward call must build an autograd graph: gradients are enabled and the module is in training mode or
-    one of its inputs already carries a gradient.  (An eval-mode module fed plain tensors stays on the fused inference
-    kernels even outside torch.no_grad().)"""
-    if not torch.is_grad_enabled():
-        return False
-    return module.training or any(t is not None and t.requires_grad for t in tensors)
+    """True when a forward call must take the unit-by-unit path of this file instead of the fused inference kernels: the
+    module is in training mode (batch statistics and running-buffer updates are training-mode semantics with or without
+    autograd, e.g. a validation pass under torch.no_grad() inside train()), or gradients are enabled and one of its inputs
+    already carries one.  An eval-mode module fed plain tensors stays on the fused kernels even outside torch.no_grad()."""
+    if module.training:
+        return True
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

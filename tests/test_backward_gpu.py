@@ -738,3 +738,27 @@ def test_gcnet_end_to_end_training(dev):
         assert torch.isfinite(got).all(), k
         cos = torch.dot(got, ref.reshape(-1)) / (got.norm() * ref.norm() + 1e-300)
         assert cos.item() >= 0.98, "grad of %s: cosine %.4f" % (k, cos.item())
+
+
+def test_train_mode_without_autograd_uses_batch_statistics(dev):
+    """train() under torch.no_grad() (a forward-only pass in training mode): batch statistics and running-buffer updates are
+    training-mode semantics, not autograd's -- the result must be the training-mode forward, not the folded inference one."""
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.aggregators import AGGREGATORS
+    from tests._util import golden
+    g = golden("aggregators.npz")
+    p = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("snp_")}
+    agg = AGGREGATORS["StereoNet"](max_disp=12, in_planes=32, batch_norm=True, num=4)
+    agg.load_state_dict(p, strict=False)
+    agg = agg.to(dev).train()
+    raw = _rand((2, 32, 12, 10, 28), 111)
+    q = {k: v.clone() for k, v in p.items()}
+    with O.bn_training():
+        want = O.stereonet_aggregator(raw, q, "", num=4)[0]
+    with torch.no_grad():
+        got = agg(raw.to(dev))[0]
+    assert not got.requires_grad
+    assert (got.cpu() - want).abs().max().item() <= 2e-5
+    buffers = dict(agg.named_buffers())
+    for k, v in q.items():
+        if "running_" in k:
+            assert (buffers[k].cpu() - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), k
