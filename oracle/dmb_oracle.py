@@ -15,6 +15,12 @@ those vectors, including the reference's own known-answer cases (tests/.../test_
 test_disp_predictors.py:42-102).  The group-wise correlation volume has NO reference implementation
 (README.md:16 only names GwcNet): for that one function parity is UNPINNED and the spec is SURVEY 8-a4.
 
+Training side: the ``*_train_step`` / ``*_backward`` functions differentiate the same restatements with
+torch.autograd in training mode (``bn_training()``); they are pinned too -- gen_golden.py section 4h runs one training
+iteration of the reference's OWN modules (PSMNet cost path, AcfNet with its confidence network, the PSMNet backbone, the
+whole StereoNet model; ``train()`` mode, its loss classes, its autograd) and ``tests/golden/training.npz`` holds the losses
+and a fingerprint of every gradient.
+
 The primitive index formulas (conv / transposed conv / trilinear) are additionally restated as plain C loop
 nests in ``oracle/dmb_oracle_c.c`` and cross-checked against this file on small shapes.
 """
