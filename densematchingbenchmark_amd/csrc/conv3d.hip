@@ -21,6 +21,13 @@
 
 #include "dmb_common.h"
 
+#ifndef DMB_EPI_LD
+#define DMB_EPI_LD 0   // buffer cache policy of the transposed kernel's epilogue: bit 1 = nt (streaming)
+#endif
+#ifndef DMB_EPI_ST
+#define DMB_EPI_ST 0
+#endif
+
 namespace dmb {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -443,6 +450,8 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   const int tz = t % ntz;
   const int b = t / ntz;
   const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;  // output coordinates
+  const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
+  relu &= 0xff;
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
@@ -467,25 +476,36 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   constexpr int WV4 = (WCH / 4 + 255) / 256;
   static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
+  // Vector path: the per-lane source offsets of a chunk's copies depend on the tile only, not on the chunk (the chunk's
+  // channels are selected by the resource base), so they are computed ONCE here.  Recomputing the unit -> (z, parity, row,
+  // column) decode and the bounds tests for every copy of every chunk cost about two vector instructions per MFMA.
+  constexpr int S_NI = C::CK * C::IPC, S_IPW = (S_NI + 3) / 4;
+  unsigned xoff[C::V16 ? S_IPW : 1];
+  if constexpr (C::V16) {
+#pragma unroll
+    for (int q = 0; q < S_IPW; ++q) {
+      const int id = wave * S_IPW + q;
+      const int cl = id / C::IPC, qi = id - cl * C::IPC;
+      const int u = qi * 64 + lane;
+      const int zz = u / (C::ZPL / 4), r1 = u - zz * (C::ZPL / 4), pp = r1 / (C::PYPL / 4), r2 = r1 - pp * (C::PYPL / 4);
+      const int row = r2 / C::UPR, sg = r2 - row * C::UPR;
+      const int ry = 2 * row + pp;
+      const int gz = 2 * z0 - 1 + zz, gy = 2 * y0 - 1 + ry, gxs = 2 * x0 - 4 + sg * 4;
+      const bool ok = ry < C::INROWS && gz >= 0 && gz < D && gy >= 0 && gy < H && gxs >= 0 && gxs < W;
+      // (a channel past Ci lies beyond the chunk's resource: the bounds check returns zeros for it)
+      xoff[q] = ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB;
+    }
+  }
   auto stage = [&](int c0, float* buf) {
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb + (size_t)c0 * DHW, (unsigned)min(C::CK, Ci - c0) * DHW * 4u);
     if constexpr (C::V16) {
       // unit = 4 consecutive floats of a staged row; the units of one channel ([z][y parity][row][64]) are linear in LDS
-      constexpr int NI = C::CK * C::IPC, IPW = (NI + 3) / 4;
 #pragma unroll
-      for (int q = 0; q < IPW; ++q) {
-        const int id = wave * IPW + q;
-        if (NI % 4 == 0 || id < NI) {
+      for (int q = 0; q < S_IPW; ++q) {
+        const int id = wave * S_IPW + q;
+        if (S_NI % 4 == 0 || id < S_NI) {
           const int cl = id / C::IPC, qi = id - cl * C::IPC;
-          const int u = qi * 64 + lane;
-          const int zz = u / (C::ZPL / 4), r1 = u - zz * (C::ZPL / 4), pp = r1 / (C::PYPL / 4), r2 = r1 - pp * (C::PYPL / 4);
-          const int row = r2 / C::UPR, sg = r2 - row * C::UPR;
-          const int ry = 2 * row + pp;
-          const int gz = 2 * z0 - 1 + zz, gy = 2 * y0 - 1 + ry, gxs = 2 * x0 - 4 + sg * 4;
-          const bool ok = c0 + cl < Ci && ry < C::INROWS && gz >= 0 && gz < D && gy >= 0 && gy < H && gxs >= 0 && gxs < W;
-          if (u < C::UPC)
-            dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxs) * 4u : DMA_OOB,
-                  0u, buf + cl * C::CH_STRIDE + qi * 256);
+          if (qi * 64 + lane < C::UPC) dma16(xrs, xoff[q], 0u, buf + cl * C::CH_STRIDE + qi * 256);
         }
       }
     } else {
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   __syncthreads();
   for (int ci = 0; ci < NC; ++ci) {
     const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
-    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
+    if (ci + 1 < NC && !(dbg & 2)) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
     const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
     const float* bbase = cur + h * C::CH_STRIDE + (2 * wz) * C::ZPL + 2 * j + C::XOFF;
     float af[2][C::NT], bf[2][C::MT];
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   }
 
   const int gz = z0 + wz;
-  if (gz >= Do) return;
+  if (gz >= Do || (dbg & 1)) return;
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = (unsigned)Do * HWo;
   float* yb = y + (size_t)b * C::COUT * DHWo;
   const float* rb = res ? res + (size_t)b * C::COUT * DHWo : nullptr;
@@ -609,10 +629,19 @@ struct DCfg {
   static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;           // double buffered
   static constexpr int AFF_FLOATS = 2 * COUT;                 // scale / shift table behind the chunk buffers
-  static constexpr int WPE = ((LDS_FLOATS + AFF_FLOATS) * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
+  // Vector epilogue (V16): PCH channels x 64 output columns of one output row go through a per-wave LDS scratch so that
+  // a lane stores 4 consecutive x.  The scratch is the part of the just-consumed chunk buffer that only this wave's own
+  // copies write (its CK/4 channels), or a dedicated region behind the affine table where that part is too small.
+  static constexpr int SCR_PITCH = 68;
+  static constexpr int PRIV_FLOATS = (CK / 4) * CH_STRIDE;
+  static constexpr int PCH = PRIV_FLOATS >= 16 * SCR_PITCH ? 16 : 8;
+  static constexpr bool SCR_PRIVATE = PRIV_FLOATS >= PCH * SCR_PITCH;
+  static constexpr int SCR_FLOATS = (V16 && !SCR_PRIVATE) ? 4 * PCH * SCR_PITCH : 0;
+  static constexpr int WPE = ((LDS_FLOATS + AFF_FLOATS + SCR_FLOATS) * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
   static_assert(P <= 64, "one wave stages one tile row per instruction");
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0 && (!V16 || (CH_STRIDE % 4 == 0 && TX % 4 == 0)), "shape");
-  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+  static_assert((LDS_FLOATS + AFF_FLOATS + SCR_FLOATS) * 4 <= 160 * 1024, "LDS budget");
+  static_assert(!V16 || P == 32 || P == 64, "a 32-position tile of the vector epilogue is part of one input row");
 };
 
 // Body for one z parity PZ.  A work item = (input-resolution tile, z parity): the outputs of z parity PZ for BOTH y
@@ -634,6 +663,9 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + stride - 1) / stride;
+  const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
+  const bool vec_epi = (relu >> 4) & 1;   // 16-byte stores through the LDS scratch (set by the host when the shapes allow)
+  relu &= 0xf;
 
   struct Tile {
     int b, x0, y0, z0;
@@ -658,10 +690,21 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   constexpr int WCH4 = (C::CK / 2) * NAZ * C::RUN / 4;  // 16-byte copies per chunk
   constexpr int WV4 = (WCH4 + 255) / 256;
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
-  auto stage = [&](const Tile& tl, int c0, float* buf) {
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)tl.b * Ci + c0) * DHW, (unsigned)min(C::CK, Ci - c0) * DHW * 4u);
+  // Vector path: a copy's per-lane source offset depends on the tile only (the chunk's channels are selected by the
+  // resource base), so the unit -> (z, row, column) decode and the bounds tests run once per tile (tile_offsets), not once
+  // per copy and chunk: they cost more vector-instruction issue slots than the chunk's MFMAs left free.
+  unsigned woff[WV4];   // weight copies: per-lane source offset inside a chunk's block (the chunk goes into the scalar offset)
+#pragma unroll
+  for (int i = 0; i < WV4; ++i) {
+    const int q4 = i * 256 + (int)threadIdx.x;
+    const int run = q4 / (C::RUN / 4), off = q4 - run * (C::RUN / 4);
+    const int cp = run / NAZ, az = run - cp * NAZ;
+    const int kz = PZ ? (az ? 0 : 2) : 1;
+    woff[i] = (unsigned)(((cp * 27 + kz * 9) * C::NTT * 64) * 4 + off * 16);
+  }
+  constexpr int NQ = C::V16 ? CPW * C::IPC : 1;
+  auto tile_offsets = [&](const Tile& tl, unsigned (&o)[NQ]) {
     if constexpr (C::V16) {
-      // unit = 4 consecutive floats of a staged row; the units of one channel are linear in LDS
 #pragma unroll
       for (int cc = 0; cc < CPW; ++cc) {
         const int cl = wave * CPW + cc;
@@ -670,13 +713,30 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
           const int u = q * 64 + lane;
           const int zz = u / (C::ROWS * C::UPR), rr = u - zz * (C::ROWS * C::UPR), yy = rr / C::UPR, sg = rr - yy * C::UPR;
           const int gz = tl.z0 + zz, gy = tl.y0 + yy, gx = tl.x0 + sg * 4;
-          const bool ok = c0 + cl < Ci && gz < D && gy < H && gx < W;
-          if (u < C::UPC)
-            dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB,
-                  0u, buf + cl * C::CH_STRIDE + q * 256);
+          // (a channel past Ci lies beyond the chunk's resource: the bounds check returns zeros for it)
+          o[cc * C::IPC + q] = (gz < D && gy < H && gx < W)
+                                   ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB;
         }
       }
-    } else {
+    }
+  };
+  // A chunk's copies are numbered: pieces [0, NQ) = the input tile (vector path), [NQ, NQ + WV4) = the weights; stage()
+  // issues pieces [lo, hi) so that the main loop can deal them out between its MFMA groups (a wave that queues a dozen
+  // 1-KiB copies back to back sits in the address queue for a few thousand cycles with its matrix pipe idle).
+  constexpr int NPIECE = NQ + WV4;
+  auto stage = [&](const Tile& tl, const unsigned (&toff)[NQ], int c0, float* buf, int lo = 0, int hi = 1 << 20) {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)tl.b * Ci + c0) * DHW, (unsigned)min(C::CK, Ci - c0) * DHW * 4u);
+    if constexpr (C::V16) {
+      // unit = 4 consecutive floats of a staged row; the units of one channel are linear in LDS
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int cl = wave * CPW + cc;
+#pragma unroll
+        for (int q = 0; q < C::IPC; ++q)
+          if (cc * C::IPC + q >= lo && cc * C::IPC + q < hi && q * 64 + lane < C::UPC)
+            dma16(xrs, toff[cc * C::IPC + q], 0u, buf + cl * C::CH_STRIDE + q * 256);
+      }
+    } else if (lo == 0) {
     const int gx = tl.x0 + lane;
     const unsigned xvoff = (lane < C::P && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
     if (lane < C::P) {
@@ -699,16 +759,9 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
     }
     }
 #pragma unroll
-    for (int i = 0; i < WV4; ++i) {
-      const int q4 = i * 256 + (int)threadIdx.x;
-      if (q4 < WCH4) {
-        const int run = q4 / (C::RUN / 4), off = q4 - run * (C::RUN / 4);
-        const int cp = run / NAZ, az = run - cp * NAZ;
-        const int kz = PZ ? (az ? 0 : 2) : 1;
-        dma16(wrs, (unsigned)((((c0 / 2 + cp) * 27 + kz * 9) * C::NTT * 64) * 4 + off * 16), 0u,
-              buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
-      }
-    }
+    for (int i = 0; i < WV4; ++i)
+      if (NQ + i >= lo && NQ + i < hi && i * 256 + (int)threadIdx.x < WCH4)
+        dma16(wrs, woff[i], (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
   };
 
   // Per-channel affine, staged ONCE into LDS behind the chunk buffers.  (Global loads of scale / shift inside the tile
@@ -727,13 +780,18 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   const int Ho = 2 * H, Wo = 2 * W;
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = 2u * D * HWo;
   Tile cur_t = tile_at(0);
-  stage(cur_t, 0, lds);
+  unsigned coff[NQ], noff[NQ];
+  tile_offsets(cur_t, coff);
+  stage(cur_t, coff, 0, lds);
   __syncthreads();
   int g = 0;  // chunks consumed by this workgroup so far: selects the LDS buffer
   for (int it = 0; it < my_tiles; ++it) {
     const bool has_next = it + 1 < my_tiles;
     Tile next_t = cur_t;
-    if (has_next) next_t = tile_at(it + 1);
+    if (has_next) {
+      next_t = tile_at(it + 1);
+      tile_offsets(next_t, noff);
+    }
 
     f32x16 acc[2][2][C::MT][C::NT];  // [py][px]
 #pragma unroll
@@ -750,10 +808,16 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
     for (int ci = 0; ci < NC; ++ci, ++g) {
       const float* cur = lds + (g & 1) * C::BUF_FLOATS;
       float* nxt = lds + ((g + 1) & 1) * C::BUF_FLOATS;
-      if (ci + 1 < NC)
-        stage(cur_t, (ci + 1) * C::CK, nxt);
-      else if (has_next)
-        stage(next_t, 0, nxt);
+      // the next chunk's copies (of this tile, or the first chunk of the next one) are dealt out over the first SU units
+      constexpr int SU = C::V16 ? (NU >= 6 ? NU - 2 : (NU > 1 ? NU - 1 : 1)) : 1, PPU = (NPIECE + SU - 1) / SU;
+      const int smode = (dbg & 2) ? 0 : (ci + 1 < NC ? 1 : (has_next ? 2 : 0));
+      auto deal = [&](int u) {
+        if (smode == 1)
+          stage(cur_t, coff, (ci + 1) * C::CK, nxt, u * PPU, (u + 1) * PPU);
+        else if (smode == 2)
+          stage(next_t, noff, 0, nxt, u * PPU, (u + 1) * PPU);
+      };
+      if (!C::V16) deal(0);
       const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
       const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + j;
       float af[2][9][C::NT], bf[2][2][2][C::MT];  // bf[buf][ay][ox][mt]
@@ -775,6 +839,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         if (u + 1 < NU) load_frag(u + 1, af[(u + 1) & 1], bf[(u + 1) & 1]);
+        if (C::V16 && u < SU) deal(u);
         __builtin_amdgcn_sched_barrier(0);
         const auto& a = af[u & 1];
         const auto& bq = bf[u & 1];
@@ -801,7 +866,102 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
 
     // ---- epilogue of cur_t ----
     const int gzi = cur_t.z0 + wz;
-    if (gzi < D) {
+    if (C::V16 && vec_epi && !(dbg & 1)) {
+      // ---- vector epilogue: per (channel tile, 32-position tile, y parity) the two x-parity accumulator tiles are
+      // interleaved in LDS ([PCH channels][64 output columns], 8-byte writes), read back as 4 consecutive x of one
+      // channel and stored / residual-loaded as 16-byte words through buffer resources (lanes outside the volume get an
+      // out-of-range offset: branch-free).  Residual loads run one pass ahead of the stores.
+      // (g has been advanced past the last chunk: buffer (g & 1) is being filled for the next tile, ((g - 1) & 1) is
+      // the one just consumed; every wave's reads of it completed before the barrier that ended the chunk loop)
+      float* scr = C::SCR_PRIVATE ? lds + ((g - 1) & 1) * C::BUF_FLOATS + wave * C::PRIV_FLOATS
+                                  : lds + C::LDS_FLOATS + C::AFF_FLOATS + wave * (C::PCH * C::SCR_PITCH);
+      const unsigned gz = 2 * gzi + PZ;
+      float* yb = y + (size_t)cur_t.b * C::COUT * DHWo;
+      const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, (unsigned)C::COUT * DHWo * 4u);
+      const __amdgpu_buffer_rsrc_t rrs = make_rsrc(res ? res + (size_t)cur_t.b * C::COUT * DHWo : yb, (unsigned)C::COUT * DHWo * 4u);
+      const int rl = lane >> 4, x4 = (lane & 15) * 4;
+      const float lo = relu == 1 ? 0.f : -__builtin_inff();    // ReLU after the residual add
+      const float lo2 = relu == 2 ? 0.f : -__builtin_inff();   // ReLU before it (GC-Net)
+      constexpr int QP = 32 / C::PCH, KP = C::PCH / 4;        // passes per 32-channel tile, 16-byte words per lane and pass
+      constexpr int NPASS = C::NT * C::MT * 2 * QP;
+      auto pass_off = [&](int t, unsigned (&off)[KP], int (&ch)[KP]) {
+        const int q = t % QP, py = (t / QP) % 2, mt = (t / (2 * QP)) % C::MT, nt = t / (2 * QP * C::MT);
+        const int ly = (mt * 32) / C::P, lx0 = (mt * 32) % C::P;
+        const int gyi = cur_t.y0 + ly, gxi = cur_t.x0 + lx0 + x4 / 2;
+        const bool ok = gzi < D && gyi < H && lx0 + x4 / 2 < C::TX && gxi < W && !(dbg & 4);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          ch[k] = (wn * C::NT + nt) * 32 + q * C::PCH + 4 * k + rl;
+          off[k] = ok ? ((unsigned)ch[k] * DHWo + gz * HWo + (unsigned)(2 * gyi + py) * Wo + 2u * (unsigned)(cur_t.x0 + lx0) + (unsigned)x4) * 4u
+                      : DMA_OOB;
+        }
+      };
+      auto run = [&](auto has_res) {
+        constexpr bool HAS_RES = decltype(has_res)::value;
+        // A wave has no other work to hide a load behind (the accumulators take half of its registers), so the residual
+        // loads run in a ring RD passes deep (16 words of 16 bytes in flight per lane): one exposed latency per item
+        // instead of one per pass.
+        constexpr int RD = HAS_RES ? (16 / KP < NPASS ? 16 / KP : NPASS) : 1;
+        u32x4 rv[RD][KP];   // (offsets are recomputed at use: only the loaded words stay live across passes)
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int t = 0; t < RD; ++t) {
+            unsigned o0[KP];
+            int c0[KP];
+            pass_off(t, o0, c0);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) rv[t][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)o0[k], 0, DMB_EPI_LD);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NPASS; ++t) {
+          const int q = t % QP, py = (t / QP) % 2, mt = (t / (2 * QP)) % C::MT, nt = t / (2 * QP * C::MT);
+          const int sl = t % RD;
+          unsigned off[KP];
+          int ch[KP];
+          pass_off(t, off, ch);
+#pragma unroll
+          for (int rr = 0; rr < C::PCH / 2; ++rr) {
+            const int r = q * (C::PCH / 2) + rr;
+            const int row = (r & 3) + 4 * h + (C::PCH == 16 ? 8 * ((r >> 2) & 1) : 0);
+            *reinterpret_cast<float2*>(scr + row * C::SCR_PITCH + 2 * j) =
+                make_float2(acc[py][0][mt][nt][r], acc[py][1][mt][nt][r]);
+          }
+#pragma unroll
+          for (int k = 0; k < KP; ++k) {
+            float4 v = *reinterpret_cast<const float4*>(scr + (4 * k + rl) * C::SCR_PITCH + x4);
+            const float sc = aff[ch[k]], sh = aff[C::COUT + ch[k]];
+            v.x = fmaxf(fmaf(v.x, sc, sh), lo2);
+            v.y = fmaxf(fmaf(v.y, sc, sh), lo2);
+            v.z = fmaxf(fmaf(v.z, sc, sh), lo2);
+            v.w = fmaxf(fmaf(v.w, sc, sh), lo2);
+            if constexpr (HAS_RES) {
+              v.x += __uint_as_float(rv[sl][k].x);
+              v.y += __uint_as_float(rv[sl][k].y);
+              v.z += __uint_as_float(rv[sl][k].z);
+              v.w += __uint_as_float(rv[sl][k].w);
+            }
+            u32x4 o;
+            o.x = __float_as_uint(fmaxf(v.x, lo));
+            o.y = __float_as_uint(fmaxf(v.y, lo));
+            o.z = __float_as_uint(fmaxf(v.z, lo));
+            o.w = __float_as_uint(fmaxf(v.w, lo));
+            __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)off[k], 0, DMB_EPI_ST);
+          }
+          if constexpr (HAS_RES) {
+            if (t + RD < NPASS) {   // refill the slot just consumed
+              pass_off(t + RD, off, ch);
+#pragma unroll
+              for (int k = 0; k < KP; ++k) rv[sl][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[k], 0, DMB_EPI_LD);
+            }
+          }
+        }
+      };
+      if (res)
+        run(std::true_type{});
+      else
+        run(std::false_type{});
+    } else if (gzi < D && !(dbg & 1)) {
       const unsigned gz = 2 * gzi + PZ;
       const int cout = cvalid < C::COUT ? cvalid : C::COUT;   // channels the output tensor really has
       float* yb = y + (size_t)cur_t.b * cout * DHWo;
@@ -831,6 +991,8 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
       }
     }
     cur_t = next_t;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) coff[q] = noff[q];
   }
 }
 
@@ -1034,7 +1196,7 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
   const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long ntiles = (long long)B * ntx * nty * ntz;
   if (ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
-  const size_t lds = (size_t)(C::LDS_FLOATS + C::AFF_FLOATS) * sizeof(float);
+  const size_t lds = (size_t)(C::LDS_FLOATS + C::AFF_FLOATS + C::SCR_FLOATS) * sizeof(float);
   static bool attr_set = false;
   static int ncu = 256;
   if (!attr_set) {
@@ -1112,6 +1274,7 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     return fail(DMB_EUNSUPPORTED, "conv3d: 8 channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   const bool out_small = (long long)Co * D * H * W * 4 < 0x7fffffffLL;   // the vector epilogue addresses the whole output item
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 2) relu |= g_dev_opts[6] << 8;
 #define DMB_S1(CO, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
   if (stride == 1) {
     const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path
@@ -1168,7 +1331,12 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
   if ((long long)8 * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "deconv3d: 8 input channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
+  relu |= g_dev_opts[6] << 8;
   const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned rows
+  // 16-byte epilogue: aligned output / residual rows, every channel real, one batch item of the output below 2 GiB
+  if (v16 && Co % 32 == 0 && ((((uintptr_t)y | (uintptr_t)residual) & 15) == 0) && (long long)Co * 8 * D * H * W * 4 < 0x7fffffffLL &&
+      !g_dev_opts[7])
+    relu |= 1 << 4;
   // 2 rows x 28 columns per item instead of 1 x 60 where that computes fewer positions (input W = 64: 3 x 32 against
   // 2 x 64 per row; the tile width stays a multiple of 4 for the 16-byte staging)
   const bool narrow = v16 && cdiv(W, 28) * 32 < cdiv(W, 60) * 64;

@@ -11,6 +11,8 @@ class PSMAggregator(nn.Module):
     """raw_cost [B, in_planes, D/4, H/4, W/4] -> [cost3, cost2, cost1], each [B, max_disp, H, W] (best first).
     25 fused MFMA conv launches + 3 head convs + 3 trilinear up-samplings; all biases absent (PSMNet.py:31-54)."""
 
+    accepts_lazy_cat = True   # dres0[0] is a FusedConv3d: it takes a LazyCatVolume (cost_processors/utils/cat_fms.py)
+
     def __init__(self, max_disp, in_planes=64, batch_norm=True):
         super().__init__()
         self.max_disp, self.in_planes, self.batch_norm = max_disp, in_planes, batch_norm

@@ -87,6 +87,13 @@ class FusedConv3d(nn.Sequential):
         """``residual`` is added BEFORE the activation (hourglass.py:67-81), ``skip`` AFTER it (GC-Net,
         aggregators/GCNet.py:108-116: ``layer34(cost33 + cost29)`` -- the add runs in layer33's epilogue)."""
         act = self.has_relu if relu is None else relu
+        if hasattr(x, "materialize"):   # LazyCatVolume: the concatenation volume as a description (eval mode only)
+            if (residual is None and skip is None and not self.transposed and self.stride == 1 and not self.training
+                    and 2 * x.reference_fm.shape[1] == self.in_planes
+                    and ops.catconv_applicable(x.reference_fm, x.target_fm, x.disp_idx, self.out_planes)):
+                _, scale, shift = self._prepacked()
+                return ops.catconv_first(x.reference_fm, x.target_fm, len(x.disp_idx), self._prepacked_cat(), scale, shift, act)
+            x = x.materialize()
         if skip is not None:
             if residual is not None:
                 raise ValueError("FusedConv3d: residual and skip are mutually exclusive")
@@ -101,6 +108,12 @@ class FusedConv3d(nn.Sequential):
         if ops.conv3d_mode() == "bf16x6" and ops.conv3d_x6_applicable(x, self.out_planes, self.stride):
             return ops.conv3d_k3_x6(x, self._prepacked_x6(), self.out_planes, scale, shift, residual, act)   # opt-in only
         return ops.conv3d_k3(x, wp, self.out_planes, scale, shift, residual, self.stride, act)
+
+    def _prepacked_cat(self):
+        key = _versions(self[0].weight)
+        if getattr(self, "_cat_key", None) != key:
+            self._cat_key, self._cat = key, ops.catconv_pack(self[0].weight.detach())
+        return self._cat
 
     def _prepacked_x6(self):
         key = _versions(self[0].weight)

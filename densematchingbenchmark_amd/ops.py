@@ -169,6 +169,95 @@ def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, rel
     return y
 
 
+# ---------------------------------------------------------------------------------------------- first layer on a cat volume
+# The aggregators' first convolution (2C -> Co, k3 s1 p1) applied to a concatenation volume with unit disparity step
+# collapses into 2-D maps (csrc/catconv.hip): the volume is never written, 2/3 of the layer's multiplications vanish.
+# The module layer (FusedConv3d.forward_cat) decides when this applies; "off" forces the materialised volume everywhere.
+_cat_fusion = True
+
+
+def set_cat_fusion(flag):
+    global _cat_fusion
+    _cat_fusion = bool(flag)
+
+
+def cat_fusion():
+    return _cat_fusion
+
+
+def copy_window(src, Wd, xs):
+    """dst[..., j] = src[..., j + xs] (zero outside [0, W)), j in [0, Wd): zero-filled column window of a [.., W] tensor."""
+    lib = _lib.load()
+    src = _f32c(src, "src")
+    W = src.shape[-1]
+    dst = torch.empty(tuple(src.shape[:-1]) + (Wd,), dtype=torch.float32, device=src.device)
+    rows = src.numel() // W
+    check(lib.dmb_copy_window_f32(dev_ptr(src), dev_ptr(dst), rows, W, Wd, xs, stream_ptr(src.device)), "dmb_copy_window_f32")
+    return dst
+
+
+CATCONV_CH = 128   # channel count of the per-dz map tensors: 3 * Co used (Co <= 32), the rest are zero-weight rows
+
+
+def catconv_applicable(L, R, disp_idx, Co):
+    """Shapes the 2-D form covers: unit disparity step from 0 (d_k = k), at least 2 planes, Co <= 32, 16-byte rows,
+    the image wider than the near-diagonal band."""
+    if not _cat_fusion or L.dim() != 4 or L.shape != R.shape:
+        return False
+    D, W = len(disp_idx), L.shape[3]
+    return (list(disp_idx) == list(range(D)) and D >= 4 and D % 4 == 0 and W % 4 == 0 and W >= D + 8 and Co <= 32
+            and L.dtype == torch.float32 and L.is_cuda)
+
+
+def catconv_pack(w):
+    """nn.Conv3d weight [Co, 2C, 3, 3, 3] -> the five conv2d weight packs of the 2-D form (csrc/catconv.hip):
+    per-dz slices of the left half (all dx taps; dx >= 1; dx >= 2) and of the right half (all taps; without dx = 2),
+    stacked along the output-channel axis as dz * Co + co and zero-padded to CATCONV_CH rows."""
+    Co, C2 = w.shape[0], w.shape[1]
+    C = C2 // 2
+    w = w.detach().float()
+
+    def stack(half, dx_from, dx_to):
+        k = torch.zeros((CATCONV_CH, C, 3, 3), dtype=torch.float32, device=w.device)
+        for dz in range(3):
+            k[dz * Co:(dz + 1) * Co, :, :, dx_from:dx_to] = half[:, :, dz, :, dx_from:dx_to]
+        return pack_conv2d_weights(k)
+
+    wl, wr = w[:, :C], w[:, C:]
+    return {"A": stack(wl, 0, 3), "B1": stack(wl, 1, 3), "B2": stack(wl, 2, 3), "HC": stack(wr, 0, 3), "HD": stack(wr, 0, 2),
+            "Co": Co, "Cin": C}
+
+
+def catconv_first(L, R, D, packs, scale=None, shift=None, relu=False):
+    """relu?(scale * conv3d(cat_fms(L, R, d_k = k), w) + shift) without the volume: [B, C, H, W] x 2 -> [B, Co, D, H, W]."""
+    lib = _lib.load()
+    L, R = _f32c(L, "reference_fm"), _f32c(R, "target_fm")
+    B, C, H, W = L.shape
+    Co, CA = packs["Co"], CATCONV_CH
+    Wc = D + 4
+    dev = L.device
+    FA = conv2d(L, packs["A"], CA, 3)                                              # F_{dz, 0}          [B, CA, H, W]
+    Lc = copy_window(L, Wc, 0)                                                     # columns [0, D + 4)
+    FB = torch.empty((B, 2 * CA, H, Wc), dtype=torch.float32, device=dev)
+    conv2d(Lc, packs["B1"], CA, 3, out=FB, out_ch_offset=0)                        # F_{dz, 1}
+    conv2d(Lc, packs["B2"], CA, 3, out=FB, out_ch_offset=CA)                       # F_{dz, 2}
+    HC = conv2d(copy_window(R, W + 4, -4), packs["HC"], CA, 3)                     # H_dz at n = j - 4  [B, CA, H, W + 4]
+    HD = conv2d(copy_window(R, Wc, W - Wc), packs["HD"], CA, 3)                    # border variant     [B, CA, H, Wc]
+    FM = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
+    BAND = torch.empty((B, Co, H, D, 4), dtype=torch.float32, device=dev)
+    GM = torch.empty((B, Co, H, W + 4), dtype=torch.float32, device=dev)
+    GB = torch.empty((B, Co, H, D), dtype=torch.float32, device=dev)
+    # (FB holds m = 1 in channels [0, CA) and m = 2 in [CA, 2 CA), each as dz * Co + co like FA)
+    check(lib.dmb_catconv_finalize_f32(dev_ptr(FA), dev_ptr(FB), dev_ptr(HC), dev_ptr(HD), dev_ptr(FM), dev_ptr(BAND),
+                                       dev_ptr(GM), dev_ptr(GB), B, Co, CA, 2 * CA, D, H, W, Wc, stream_ptr(dev)),
+          "dmb_catconv_finalize_f32")
+    out = torch.empty((B, Co, D, H, W), dtype=torch.float32, device=dev)
+    check(lib.dmb_catconv_combine_f32(dev_ptr(FA), dev_ptr(HC), dev_ptr(FM), dev_ptr(BAND), dev_ptr(GM), dev_ptr(GB),
+                                      dev_ptr(scale, allow_none=True), dev_ptr(shift, allow_none=True), dev_ptr(out), B, Co, CA,
+                                      D, H, W, _relu_mode(relu), stream_ptr(dev)), "dmb_catconv_combine_f32")
+    return out
+
+
 # Opt-in arithmetic of the 32-channel stride-1 layers: "exact" (default) = FP32 MFMA, bitwise an fmaf chain;
 # "bf16x6" = FP32 operands split exactly into 3 bf16 pieces, 6 cross products on the bf16 matrix cores, FP32 accumulate
 # (EXPERIMENTAL: at least as accurate against FP64, not bit-identical; see csrc/conv3d_x6.hip).  Never changed implicitly.

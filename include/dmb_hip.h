@@ -62,6 +62,28 @@ int dmb_dif_fms_f32(const float* L, const float* R, float* out, int B, int C, in
 int dmb_gwc_fms_f32(const float* L, const float* R, float* out, int B, int C, int G, int H, int W, int D,
                     const int* disp_idx_host, int out_channels, int out_ch_offset, void* stream);
 
+/* First convolution of the aggregators (aggregators/PSMNet.py:31-33, AcfNet.py:28-31: dres0[0] = Conv3d(2C, Co, 3,
+ * padding 1) + BatchNorm3d + ReLU) applied to the concatenation volume of cat_fms (cat_fms.py:7-48) with d_k = k, WITHOUT
+ * the volume: the left half of that volume does not depend on z and the right half depends on (z, x) through x - z, so the
+ * layer is a sum of 2-D maps (3x3 convolutions of the two feature maps with the dz slices of the weight: dmb_conv2d_f32)
+ * looked up at x and at x - (z + dz - 1); see csrc/catconv.hip.  Same FP32 products, summed per dz.
+ *
+ * dmb_copy_window_f32: dst[r, j] = src[r, j + xs] (0 outside [0, W)), j in [0, Wd): the zero-extended / cropped feature
+ *   rows the 2-D convolutions run on.
+ * dmb_catconv_finalize_f32: per-dz maps -> sums over dz.  FA [B, CA, H, W] (channel dz*Co + co: left half, all taps),
+ *   FB [B, CB, H, Wc] (channel (m-1)*CB/2 + dz*Co + co: left half, taps dx >= m, m = 1, 2, columns [0, Wc)),
+ *   HC [B, CA, H, W+4] (right half at n = j - 4), HD [B, CA, H, Wc] (right half without the dx = 2 tap at n = j + W - Wc)
+ *   -> FM [B, Co, H, W] and GM [B, Co, H, W+4] (interior planes), BAND [B, Co, H, D, 4] (left half at x = z - 2 .. z + 1 of
+ *   plane z), GB [B, Co, H, D] (right half at x = W - 1 of plane z).  W % 4 == 0, D >= 3, D + 2 <= Wc <= W.
+ * dmb_catconv_combine_f32: out[b, co, z, y, x] = act(scale[co] * (f + g) + shift[co]) -> [B, Co, D, H, W], one pass
+ *   (planes 0 and D-1 are summed from FA / HC on the fly).  D % 4 == 0, W >= D + 8, Wc = D + 4. */
+int dmb_copy_window_f32(const float* src, float* dst, long long rows, int W, int Wd, int xs, void* stream);
+int dmb_catconv_finalize_f32(const float* FA, const float* FB, const float* HC, const float* HD, float* FM, float* BAND,
+                             float* GM, float* GB, int B, int Co, int CA, int CB, int D, int H, int W, int Wc, void* stream);
+int dmb_catconv_combine_f32(const float* FA, const float* HC, const float* FM, const float* BAND, const float* GM,
+                            const float* GB, const float* scale, const float* shift, float* out, int B, int Co, int CA, int D,
+                            int H, int W, int relu, void* stream);
+
 /* Same as dmb_cat_fms_f32 but writing into channels [out_ch_offset, out_ch_offset+2C) of a volume with
  * `out_channels` channels (GwcNet's gwc+concat volume). */
 int dmb_cat_fms_into_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,

@@ -1,0 +1,38 @@
+"""Development aid: run ONE layer of the cost path a few times (for rocprofv3 counter passes).
+    python scripts/kcase.py deconv6|deconv5|s2_1|s2_3|s1q|c1|tri [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from densematchingbenchmark_amd import ops
+
+dev = torch.device("cuda:0")
+B, D, H, W = 4, 48, 136, 240
+name = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+g = lambda *s: torch.randn(*s, device=dev)
+if name in ("deconv6", "deconv5"):
+    Ci, Co, d, h, w = (64, 32, D // 2, H // 2, W // 2) if name == "deconv6" else (64, 64, D // 4, H // 4, W // 4)
+    x, wp = g(B, Ci, d, h, w), ops.pack_deconv3d_weights(g(Ci, Co, 3, 3, 3) * 0.03)
+    sc, sh, r = torch.ones(Co, device=dev), torch.zeros(Co, device=dev), g(B, Co, 2 * d, 2 * h, 2 * w)
+    fn = lambda: ops.deconv3d_k3s2(x, wp, Co, sc, sh, r, True)
+elif name in ("s2_1", "s2_3", "s1q"):
+    Ci, Co, st, d, h, w = {"s2_1": (32, 64, 2, D, H, W), "s2_3": (64, 64, 2, D // 2, H // 2, W // 2),
+                           "s1q": (64, 64, 1, D // 4, H // 4, W // 4)}[name]
+    x, wp = g(B, Ci, d, h, w), ops.pack_conv3d_weights(g(Co, Ci, 3, 3, 3) * 0.03)
+    sc, sh = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
+    fn = lambda: ops.conv3d_k3(x, wp, Co, sc, sh, None, st, True)
+elif name == "c1":
+    x, w1, r = g(B, 32, D, H, W), g(1, 32, 3, 3, 3), g(B, 1, D, H, W)
+    fn = lambda: ops.conv3d_k3_c1(x, w1, 0.0, r)
+elif name == "tri":
+    c = g(B, D, H, W)
+    vals = ops.disp_sample_values(192, 0, 1)
+    fn = lambda: ops.trilinear_ac_soft_argmin(c, (192, 544, 960), vals, 1.0)
+else:
+    raise SystemExit("unknown case " + name)
+for _ in range(reps):
+    fn()
+torch.cuda.synchronize()

@@ -588,3 +588,40 @@ def test_conv3d_vector_and_scalar_staging_agree(dev, kind, shape):
         finally:
             lib.dmb_dev_set_option(3, 0)
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------- first conv on a cat volume, 2-D form
+@pytest.mark.parametrize("B,C,Co,D,H,W", [(2, 32, 32, 16, 12, 64), (1, 32, 32, 48, 9, 240), (1, 8, 32, 4, 5, 12),
+                                          (2, 6, 20, 8, 7, 16), (1, 32, 32, 2 * 4, 6, 20)])
+def test_catconv_first_layer(dev, B, C, Co, D, H, W):
+    """dres0[0] on the concatenation volume WITHOUT the volume (csrc/catconv.hip) against (a) an FP64 evaluation of the
+    reference arithmetic -- F.conv3d on the oracle's cat_fms volume -- and (b) this library's own 3-D kernel on the
+    materialised volume.  Same FP32 products, per-dz grouping of the sums: both stay within 2e-5 of the FP64 value on
+    O(1) outputs, every border included (z = 0 / D - 1, the four columns next to x == z, x == W - 1)."""
+    ops = _ops()
+    L, R = _rand((B, C, H, W), 301), _rand((B, C, H, W), 302)
+    w = _rand((Co, 2 * C, 3, 3, 3), 303, 1.0 / math.sqrt(2 * C * 27 / 8))
+    sc, sh = _affine(Co, 304)
+    idx = ops.disp_index_list(D, 0, 1)
+    assert ops.catconv_applicable(L.to(dev), R.to(dev), idx, Co)
+    vol = O.cat_fms(L, R, D, 0, 1)
+    ref = F.conv3d(vol.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)
+    for relu in (False, True):
+        want = F.relu(ref) if relu else ref
+        got = ops.catconv_first(L.to(dev), R.to(dev), D, ops.catconv_pack(w.to(dev)), sc.to(dev), sh.to(dev), relu).cpu()
+        assert got.shape == want.shape
+        assert (got.double() - want).abs().max().item() <= 2e-5
+    if Co == 32:
+        mat = ops.conv3d_k3(ops.cat_fms(L.to(dev), R.to(dev), idx), ops.pack_conv3d_weights(w.to(dev)), Co, sc.to(dev), sh.to(dev),
+                            None, 1, True).cpu()
+        assert (got - mat).abs().max().item() <= 4e-5      # two FP32 evaluations, each within 2e-5 of the FP64 value
+
+
+def test_catconv_not_applicable_shapes(dev):
+    ops = _ops()
+    L = _rand((1, 4, 5, 16), 1).to(dev)
+    assert not ops.catconv_applicable(L, L, ops.disp_index_list(12, 0, 1), 32)      # image narrower than the band + 8
+    assert not ops.catconv_applicable(L, L, ops.disp_index_list(8, -2, 1), 32)      # start_disp != 0
+    assert not ops.catconv_applicable(L, L, ops.disp_index_list(8, 0, 2), 32)       # dilation 2
+    assert not ops.catconv_applicable(L, L, ops.disp_index_list(4, 0, 1), 64)       # more than 32 output channels
+    assert not ops.catconv_applicable(L[..., :14].contiguous(), L[..., :14].contiguous(), ops.disp_index_list(4, 0, 1), 32)
