@@ -17,6 +17,8 @@ algorithmic FLOP per launch / mean launch duration measured live with HIP events
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,6 +47,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="stereo pairs per GPU per step (cfg2: 4)")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "PSMNet", "scene_flow.py"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (backbone, bf16x6, training step)")
     ap.add_argument("--conv3d-mode", default="exact", choices=["exact", "bf16x6"],
                     help="opt-in EXPERIMENT: 32-channel stride-1 layers on 3-way bf16 splits (FP32-equivalent accuracy, not "
                          "bit-identical); the headline is always measured with 'exact'")
@@ -73,23 +76,42 @@ def _pick_threads():
     return best
 
 
-def cpu_baseline(model, cfg, feat_hw, channels):
-    """Oracle (port of the reference's CPU path) on ONE full-size pair: ~10-30 s of host time."""
+def cpu_baseline(model, cfg, first_pair, ptype, agg):
+    """Oracle (port of the reference's CPU path) on ONE full-size pair of this configuration: ~10-40 s of host time.
+    Returns the baseline record and the oracle's outputs for that pair (the parity check of this run)."""
     from oracle import dmb_oracle as O   # checker / reported baseline only -- never on the product path
     cores = _pick_threads()
     torch.set_num_threads(cores)
     p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    lf, rf = synthetic.feature_pair(0, channels, feat_hw[0], feat_hw[1])
     md = cfg.model.max_disp
+    left, right = first_pair
+    if ptype == "Correlation":
+        run = lambda l, r: O.gwcnet_path(l, r, p, md, num_groups=cfg.model.cost_processor.cost_computation.get("num_groups", 40))  # noqa: E731
+        what = "gwc + cat volume + PSMAggregator + 3x FasterSoftArgmin"
+    elif agg == "AcfNet":
+        run = lambda l, r: O.acfnet_path(l, r, p, md, cmn_alpha=cfg.model.cmn.alpha, cmn_beta=cfg.model.cmn.beta)  # noqa: E731
+        what = "cat_fms + AcfAggregator + 3x FasterSoftArgmin + Cmn"
+    elif agg == "StereoNet":
+        run = lambda l, r: O.stereonet_path(l, r, p, md)  # noqa: E731
+        what = "dif_fms + StereoNetAggregator + FasterSoftArgmin at 1/8 resolution"
+    elif agg == "PSMNet":
+        run = lambda l, r: O.psmnet_path(l, r, p, md)  # noqa: E731
+        what = "cat_fms + PSMAggregator + 3x FasterSoftArgmin"
+    else:
+        return None, None
+    crop = lambda t: t[:, :, :32, :64].contiguous()  # noqa: E731
     with torch.no_grad():
-        sl, sr = lf[:, :, :32, :64].contiguous(), rf[:, :, :32, :64].contiguous()
-        O.psmnet_path(sl, sr, p, 32)                      # warm-up (thread pool, allocator) on a small crop
+        if isinstance(left, tuple):
+            run(tuple(crop(t) for t in left), tuple(crop(t) for t in right)) if md <= 32 else None
+        elif agg == "PSMNet":
+            O.psmnet_path(crop(left), crop(right), p, 32)     # warm-up (thread pool, allocator) on a small crop
         t0 = time.perf_counter()
-        disps, _ = O.psmnet_path(lf, rf, p, md)
+        outs = run(left, right)
         dt = time.perf_counter() - t0
+    shape = left[0].shape if isinstance(left, tuple) else left.shape
     return dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port",
-                sample="1 pair 544x960 max_disp=192 (cat_fms + PSMAggregator + 3x FasterSoftArgmin), torch CPU FP32, "
-                       "%d threads (fastest of a sweep on a %d-thread host), %.1f s" % (cores, os.cpu_count() or 1, dt)), disps
+                sample="1 pair, features %dx%d, max_disp=%d (%s), torch CPU FP32, %d threads (fastest of a sweep on a "
+                       "%d-thread host), %.1f s" % (shape[2], shape[3], md, what, cores, os.cpu_count() or 1, dt)), outs
 
 
 def end_to_end(model, dev, B, Hp, Wp, steps):
@@ -178,8 +200,26 @@ def training_leg(cfg, dev, steps):
     return out
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` started as ONE process: re-run this script as N ranks, one per GPU, under
+    torch.distributed.run (the shape of the reference's tools/dist_test.sh:9-10 -> tools/test.py:101-208).  The driver's
+    own ``python -m torch.distributed.run ... bench.py --gpus N`` arrives with WORLD_SIZE set and skips this."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -190,6 +230,8 @@ def main():
     backend = os.environ.get("DMB_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU over RCCL)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -222,17 +264,21 @@ def main():
     else:
         left, right = synthetic.feature_batch(rank, world, B, C, fh, fw, dev)
     pred_scale = md // cfg.model.disp_predictor.max_disp   # StereoNet regresses at 1/8 resolution
-    gt = synthetic.gt_disparity(rank, B, Hp // pred_scale, Wp // pred_scale, pad_top=(Hp - H0) // pred_scale, device=dev)
+    gt = synthetic.gt_batch(rank, world, B, Hp // pred_scale, Wp // pred_scale, pad_top=(Hp - H0) // pred_scale, device=dev)
     if pred_scale > 1:
         gt = gt / pred_scale
     acc = EpeAccumulator(dev, n_ids, cfg.model.eval.lower_bound, cfg.model.eval.upper_bound)
     batch = dict(leftFeature=left, rightFeature=right)
     fused = args.fused_regression
 
+    last_results = {}
+
     def step():
         if not fused:
             results, _ = model(batch)
             disps = results["disps"]
+            last_results.clear()
+            last_results.update({k: v for k, v in results.items() if k == "confs"})
         else:
             agg = model.cost_processor.aggregator
             raw = model.cost_processor.vol_func(left, right, **model.cost_processor.default_args)
@@ -286,7 +332,7 @@ def main():
                 traffic = None
         out = {
             "metric": "stereo pairs/s (540x960, max_disp=192)", "value": round(value, 3), "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "pairs": pairs,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.conv3d_mode == "exact" else "f32 as 3 bf16 pieces (6 products, f32 accumulate)",
             "data": "synthetic",
@@ -295,8 +341,8 @@ def main():
                                                                         ", fused up-sample+regression" if fused else ""),
                        "pairs_per_step_per_gpu": B, "sharding": "pair i -> rank i mod world; 1 all-reduce of the EPE accumulator",
                        "costs_materialised": not fused, "conv3d_mode": args.conv3d_mode},
-            "path_tflops": round(value * PATH_GFLOP_PER_PAIR / 1e3, 2),
-            "path_frac_fp32_peak": round(value * PATH_GFLOP_PER_PAIR / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+            "first_layer": "2-D maps, volume not materialised (csrc/catconv.hip)" if (ops.cat_fusion() and ptype == "Concatenation"
+                                                                                       and not fused) else "3-D convolution",
             "roofline": {"kernel": "conv3d_s1_kernel<32,32> (k3 s1 32->32, [%d,32,%d,%d,%d])" % (B, d4, h4, w4),
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -304,22 +350,32 @@ def main():
                          "flop_per_launch": flop},
             "epe_accumulator": metrics[0],
         }
+        if ptype == "Concatenation" and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and (Hp, Wp, md) == (544, 960, 192):
+            # arithmetic of the REFERENCE's formulation per second (1015.84 GFLOP per pair); the path itself
+            # executes less (dres0[0] in its 2-D form: 2/3 of that layer's multiplications do not exist)
+            out["path_tflops_reference_formulation"] = round(value * PATH_GFLOP_PER_PAIR / 1e3, 2)
+            out["path_frac_fp32_peak_reference_formulation"] = round(value * PATH_GFLOP_PER_PAIR / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4)
         if args.conv3d_mode != "exact":   # the split kernel issues 6 bf16 MFMAs per FP32 product (+ 28/27 tap padding)
             issued = achieved * 6.0 * 28.0 / 27.0
             out["roofline"].update({"kernel": "conv3d_s1_x6_kernel (k3 s1 32->32, bf16x6 split)", "achieved": round(issued, 1),
                                     "peak": 2500.0, "frac": round(issued / 2500.0, 4),
                                     "fp32_equivalent_tflops": round(achieved, 2), "traffic": None})
-        if world == 1 and not args.no_cpu_baseline and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and ptype == "Concatenation":
-            base, ref_disps = cpu_baseline(model, cfg, (fh, fw), C)
-            out["cpu_baseline"] = base
-            out["speedup_vs_cpu"] = round(value / base["value"], 1)
-            # parity of the first pair of the last step against the oracle's disparity maps
-            d_gpu = [d[0:1].cpu() for d in disps]
-            if not fused or True:
-                diffs = [(a - b).abs().max().item() for a, b in zip(d_gpu, ref_disps)]
-                out["parity_vs_cpu"] = {"max_abs_disp": [round(x, 7) for x in diffs],
-                                        "epe_delta": [round((a - b).abs().mean().item(), 8) for a, b in zip(d_gpu, ref_disps)]}
-        if world == 1 and ptype == "Concatenation" and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and not fused:
+        agg_type = cfg.model.cost_processor.cost_aggregator.type
+        if world == 1 and not args.no_cpu_baseline:
+            first = tuple(t[0:1].cpu() for t in left) if isinstance(left, tuple) else left[0:1].cpu()
+            first_r = tuple(t[0:1].cpu() for t in right) if isinstance(right, tuple) else right[0:1].cpu()
+            base, ref = cpu_baseline(model, cfg, (first, first_r), ptype, agg_type)
+            if base is not None:
+                out["cpu_baseline"] = base
+                out["speedup_vs_cpu"] = round(value / base["value"], 1)
+                # parity of the first pair of the last step against the oracle's outputs for that pair
+                d_gpu = [d[0:1].cpu() for d in disps]
+                out["parity_vs_cpu"] = {"max_abs_disp": [round((a - b).abs().max().item(), 7) for a, b in zip(d_gpu, ref[0])],
+                                        "epe_delta": [round((a - b).abs().mean().item(), 8) for a, b in zip(d_gpu, ref[0])]}
+                if len(ref) > 2 and "confs" in last_results:
+                    out["parity_vs_cpu"]["max_abs_conf"] = [round((a[0:1].cpu() - b).abs().max().item(), 7)
+                                                            for a, b in zip(last_results["confs"], ref[2])]
+        if world == 1 and ptype == "Concatenation" and agg_type == "PSMNet" and not fused and not args.no_extras:
             out["end_to_end_with_backbone"] = end_to_end(model, dev, B, Hp, Wp, min(args.steps, 5))
             if args.conv3d_mode == "exact":
                 out["opt_in_bf16x6"] = split_mode_leg(step, disps, B, min(args.steps, 5))

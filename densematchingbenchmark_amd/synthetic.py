@@ -80,3 +80,9 @@ def gt_disparity(global_pair_index, batch, height, width, pad_top=0, device="cpu
     if pad_top > 0:
         d[:, :pad_top, :] = 0.0
     return d.unsqueeze(1).contiguous().to(device)
+
+
+def gt_batch(first_pair_index, stride, batch, height, width, pad_top=0, device="cpu"):
+    """Ground truth of pairs ``first, first+stride, ...`` -- a function of the GLOBAL pair index only, so that a job's
+    accumulated errors do not depend on how its pairs are sharded over ranks."""
+    return torch.cat([gt_disparity(first_pair_index + j * stride, 1, height, width, pad_top) for j in range(batch)]).to(device)

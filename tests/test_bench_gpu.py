@@ -1,0 +1,39 @@
+"""bench.py as the driver starts it: ``python bench.py --gpus N`` launches N ranks by itself (the reference's
+tools/dist_test.sh:9-10 -> tools/test.py:101-208 shape).  On a one-GPU box the ranks share the GPU through the
+DMB_BENCH_BACKEND=gloo hook (RCCL refuses duplicate devices); everything else -- the sharding pair i -> rank i mod
+world, the barrier-fenced timing, the MAX-over-ranks clock, the single SUM all-reduce of the EPE accumulator -- is the
+code path of the N-GPU job."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extras"] + list(flags),
+                         capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]   # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_launches_the_ranks(dev):
+    one = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2")
+    two = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", env={"DMB_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["pairs"] == 4 and two["pairs"] == 4          # B * steps * world
+    assert two["config"]["pairs_per_step_per_gpu"] == 1 and two["scaling"] == "weak"
+    # same four (pair, step) evaluations -- pairs 0 and 1, twice -- however they are sharded: the dataset metrics agree
+    for k in ("epe", "1px", "3px"):
+        assert abs(one["epe_accumulator"][k] - two["epe_accumulator"][k]) <= 1e-9 * max(1.0, abs(one["epe_accumulator"][k]))
+    assert two["value"] > 0 and two["ms_per_step"] > 0

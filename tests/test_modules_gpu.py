@@ -252,10 +252,10 @@ def test_full_size_psmnet_pair_vs_oracle(dev):
     for a, b, t in zip(gpu, ref32, truth):
         err_gpu = (a.double() - t).abs().max().item()
         err_ref = (b.double() - t).abs().max().item()
-        assert err_gpu <= max(DISP_TOL, 1.25 * err_ref), (err_gpu, err_ref)
-        assert (a - b).abs().mean().item() <= 5e-5            # EPE delta vs the reference arithmetic (target 1e-4)
-        assert (a.double() - t).abs().mean().item() <= 2e-5   # EPE delta vs the truth
-        assert maxdiff(a, b) <= 5e-4
+        assert err_gpu <= max(DISP_TOL, err_ref), (err_gpu, err_ref)   # never farther from the exact value than the reference
+        assert (a - b).abs().mean().item() <= 3e-5            # EPE delta vs the reference arithmetic (measured 2e-5; target 1e-4)
+        assert (a.double() - t).abs().mean().item() <= 2e-5   # EPE delta vs the truth (measured 1e-5)
+        assert maxdiff(a, b) <= 2e-4                          # worst pixel vs the reference arithmetic (measured 1.1e-4 .. 1.5e-4)
 
 
 def _built(cfg_rel, seed, tweak=None):
