@@ -28,6 +28,7 @@ SIGNATURES = {
     "dmb_dif_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
     "dmb_gwc_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
     "dmb_cat_fms_into_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
+    "dmb_correlation1d_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _P]),
     "dmb_copy_window_f32": (_c_int, [_P, _P, _c_ll, _c_int, _c_int, _c_int, _P]),
     "dmb_catconv_finalize_f32": (_c_int, [_P] * 8 + [_c_int] * 8 + [_P]),
     "dmb_catconv_combine_f32": (_c_int, [_P] * 9 + [_c_int] * 7 + [_P]),

@@ -165,9 +165,49 @@ static int launch_volume(const float* L, const float* R, float* out, int B, int 
   return launch_status("volume kernel launch failed");
 }
 
+// correlation1d_cost (cost_processors/utils/correlation1d_cost.py:7-27): full-channel correlation along the epipolar
+// line, the first max_disp of the sampler's 2*max_disp - 1 patch offsets, leaky ReLU:
+//   out[b, j, y, x] = lrelu( sum_c L[b, c, y, x] * R[b, c, y, x + j - (D - 1)] ),  0 <= j < D, R = 0 left of the image
+// (channel j <-> disparity D - 1 - j; no 1/C normalisation).  One thread = one pixel x 16 consecutive offsets; the
+// channel sum is an FP32 fma chain in ascending c.  The 16 right-feature values of a channel are consecutive addresses.
+__global__ __launch_bounds__(256) void correlation1d_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                            float* __restrict__ out, int C, int H, int W, int D, float slope) {
+  const int HW = H * W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int j0 = blockIdx.y * 16, b = blockIdx.z;
+  if (i >= HW) return;
+  const int x = i % W;
+  const float* Lp = L + (size_t)b * C * HW + i;
+  const float* Rp = R + (size_t)b * C * HW + i;
+  float acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float l = Lp[(size_t)c * HW];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int off = j0 + t - (D - 1);   // <= 0
+      const float r = (x + off >= 0 && j0 + t < D) ? Rp[(size_t)c * HW + off] : 0.f;
+      acc[t] = fmaf(l, r, acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (j0 + t < D) out[((size_t)b * D + j0 + t) * HW + i] = acc[t] > 0.f ? acc[t] : acc[t] * slope;
+}
+
 }  // namespace dmb
 
 using namespace dmb;
+
+extern "C" int dmb_correlation1d_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,
+                                     float negative_slope, void* stream) {
+  if (!L || !R || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0) return fail(DMB_EINVAL, "correlation1d: bad argument");
+  if ((long long)C * H * W >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "correlation1d: feature map too large");
+  hipLaunchKernelGGL(correlation1d_kernel, dim3(cdiv(H * W, 256), cdiv(D, 16), B), dim3(256), 0, (hipStream_t)stream, L, R, out,
+                     C, H, W, D, negative_slope);
+  return launch_status("correlation1d launch failed");
+}
 
 extern "C" int dmb_cat_fms_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,
                                const int* disp_idx_host, void* stream) {

@@ -28,7 +28,7 @@ class ConfHead(nn.Module):
         conv1 = self.conf_net[0][0]
         bn = self.conf_net[0][1] if self.batch_norm else None
         conv2 = self.conf_net[1]
-        parts = [conv1.weight, conv2.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn else [])
+        parts = [conv1.weight, conv2.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked] if bn else [])
         key = _versions(*parts)
         if key != self._key:
             w1 = conv1.weight.detach()

@@ -1,9 +1,22 @@
-"""Group-wise correlation volumes (GwcNet).  The reference has no implementation (README.md:16 names the model
-only); these fill the ``COR_FUNCS`` slot of cost_processors/utils/correlation1d_cost.py:29-31 with the same
-call signature as the other builders.  Spec: SURVEY.md section 8-a4."""
+"""``COR_FUNCS``: the reference's own entry (``default`` = correlation1d_cost, cost_processors/utils/
+correlation1d_cost.py:7-31) and the group-wise correlation volumes of GwcNet, which the reference does not implement
+(README.md:16 names the model only; spec: SURVEY.md section 8-a4) under their own keys ``gwc`` / ``gwc_cat``."""
 import torch
 
 from ..... import ops
+
+
+def correlation1d_cost(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None,
+                       kernel_size=1, stride=1, padding=0, dilation_patch=1):
+    """correlation1d_cost.py:7-27: full-channel correlation over the first ``max_disp`` of the sampler's
+    ``2*max_disp - 1`` patch offsets (channel j = disparity max_disp - 1 - j), no normalisation, then
+    ``leaky_relu(0.1)``; output [B, max_disp, H, W].  ``start_disp`` / ``dilation`` / ``disp_sample`` are accepted and
+    ignored exactly as there.  The sampler package is not part of the reference tree: parity UNPINNED (include/dmb_hip.h)."""
+    if (kernel_size, stride, padding, dilation_patch) != (1, 1, 0, 1):
+        raise NotImplementedError("correlation1d_cost on the HIP path: kernel_size=1, stride=1, padding=0, dilation_patch=1 only")
+    if torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad):
+        raise NotImplementedError("correlation1d_cost has no backward on the HIP path")
+    return ops.correlation1d(reference_fm.float(), target_fm.float(), max_disp, 0.1)
 
 
 def gwc_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None, num_groups=40):
@@ -28,7 +41,7 @@ def gwc_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1,
 
 
 COR_FUNCS = dict(
-    default=gwc_fms,
+    default=correlation1d_cost,
     gwc=gwc_fms,
     gwc_cat=gwc_cat_fms,
 )

@@ -36,6 +36,9 @@ def fold_batch_norm(bn, conv_bias, out_planes, device):
 
 
 def _versions(*tensors):
+    """Cache key of folded / packed parameters.  BatchNorm's ``num_batches_tracked`` is part of every key that covers running
+    statistics: the training-mode kernel rewrites ``running_mean`` / ``running_var`` through raw device pointers (their
+    ``_version`` does not move), but every such forward bumps ``num_batches_tracked`` in place."""
     return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
 
 
@@ -74,7 +77,7 @@ class FusedConv3d(nn.Sequential):
         bn = self[1] if self.has_bn else None
         parts = [conv.weight, conv.bias]
         if bn is not None:
-            parts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            parts += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
         key = _versions(*parts)
         if key != self._cache_key:
             w = conv.weight.detach()

@@ -39,7 +39,7 @@ class FusedConv2d(nn.Sequential):
     def _prepacked(self):
         conv = self[0]
         bn = self[1] if self.has_bn else None
-        parts = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        parts = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked] if bn is not None else [])
         key = _versions(*parts)
         if key != self._cache_key:
             w = conv.weight.detach()

@@ -263,7 +263,10 @@ def _bn_forward(bn, training, raw, gamma, beta, C, device):
     del training   # the enclosing unit's flag is not what decides
     batch_stats = bn is not None and bn.training
     if batch_stats:
-        momentum = 0.1 if bn.momentum is None else bn.momentum
+        if bn.momentum is None:   # nn.BatchNorm: cumulative moving average, factor 1 / (batches seen including this one)
+            momentum = 1.0 / float(int(bn.num_batches_tracked) + 1) if bn.track_running_stats else 0.0
+        else:
+            momentum = bn.momentum
         mean, invstd, scale, shift = ops.bn_train_stats(raw, gamma.detach() if gamma is not None else None,
                                                         beta.detach() if beta is not None else None,
                                                         bn.running_mean if bn.track_running_stats else None,
@@ -508,10 +511,18 @@ class SoftArgminFn(torch.autograd.Function):
 
 
 def wants_grad(module, *tensors):
-    """True when a forward call must take the unit-by-unit path of this file instead of the fused inference kernels: the
-    module is in training mode (batch statistics and running-buffer updates are training-mode semantics with or without
-    autograd, e.g. a validation pass under torch.no_grad() inside train()), or gradients are enabled and one of its inputs
-    already carries one.  An eval-mode module fed plain tensors stays on the fused kernels even outside torch.no_grad()."""
+    """True when a forward call must take the unit-by-unit path of this file instead of the fused inference kernels:
+    (a) the module is in training mode (batch statistics and running-buffer updates are training-mode semantics with or
+    without autograd, e.g. a validation pass under torch.no_grad() inside train()); or (b) gradients are enabled and
+    something on this call can receive one -- an input that already carries a gradient, or one of the module's OWN
+    parameters (``model.train(); model.backbone.eval()`` freezes the backbone's BatchNorm statistics, not its weights: with
+    the reference's plain nn modules those weights still get gradients, and so they do here; each BatchNorm follows its own
+    ``training`` flag).  Under torch.no_grad() -- how the reference's tools run evaluation, and what
+    GeneralizedStereoModel's eval branch enters itself -- an eval-mode module always stays on the fused kernels."""
     if module.training:
         return True
-    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and getattr(t, "requires_grad", False) for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())

@@ -110,6 +110,17 @@ def gwc_fms(left, right, disp_idx, num_groups, out=None, out_ch_offset=0):
     return out
 
 
+def correlation1d(left, right, max_disp, negative_slope=0.1):
+    """correlation1d_cost.py:7-27: [B, C, H, W] x 2 -> [B, max_disp, H, W], channel j = disparity max_disp - 1 - j."""
+    lib = _lib.load()
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    B, C, H, W = left.shape
+    out = torch.empty((B, max_disp, H, W), dtype=torch.float32, device=left.device)
+    check(lib.dmb_correlation1d_f32(dev_ptr(left), dev_ptr(right), dev_ptr(out), B, C, H, W, max_disp, negative_slope,
+                                    stream_ptr(left.device)), "dmb_correlation1d_f32")
+    return out
+
+
 def cat_fms_into(left, right, disp_idx, out, out_ch_offset):
     lib = _lib.load()
     left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")

@@ -23,19 +23,30 @@ def to_cpu(obj):
     return obj
 
 
-def save_result(results, original_data, save_root, original_size=None):
-    """Write ``<save_root>/result.pkl`` in the reference's layout; returns the path."""
+def save_result(results, original_data, save_root, original_size=None, scale_factor=1.0):
+    """Write ``<save_root>/result.pkl`` in the reference's layout (inference.py:197-223); returns the path.
+    Every tensor of every list (``disps``, ``costs`` and, for AcfNet, ``confs``) is brought back to the input scale
+    (``scale_factor``: the test-time resampling of inference.py:183-189, undone at :205-206) and cropped to
+    ``original_size`` (top / right padding removed); pickle protocol 2 = what ``mmcv.dump`` writes for a .pkl path."""
     result = to_cpu(results)
     for k, v in result.items():
         if not isinstance(v, (list, tuple)):
             raise TypeError("results['%s'] must be a list of tensors (general_stereo_model.py:82-90)" % k)
-        if original_size is not None:
-            result[k] = [remove_padding(t, original_size).contiguous() if torch.is_tensor(t) else t for t in v]
+        out = []
+        for t in v:
+            if torch.is_tensor(t):
+                if scale_factor != 1.0:    # host-side post-processing of a saved result, as in the reference
+                    t = torch.nn.functional.interpolate(t * 1.0 / scale_factor, scale_factor=1.0 / scale_factor, mode="bilinear",
+                                                        align_corners=False)
+                if original_size is not None:
+                    t = remove_padding(t, original_size).contiguous()
+            out.append(t)
+        result[k] = out
     log_data = {"Result": result, "OriginalData": to_cpu(original_data)}
     os.makedirs(save_root, exist_ok=True)
     path = os.path.join(save_root, "result.pkl")
     with open(path, "wb") as fp:
-        pickle.dump(log_data, fp)
+        pickle.dump(log_data, fp, protocol=2)
     return path
 
 

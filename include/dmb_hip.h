@@ -84,6 +84,16 @@ int dmb_catconv_combine_f32(const float* FA, const float* HC, const float* FM, c
                             const float* GB, const float* scale, const float* shift, float* out, int B, int Co, int CA, int D,
                             int H, int W, int relu, void* stream);
 
+/* correlation1d_cost (cost_processors/utils/correlation1d_cost.py:7-27), the reference's COR_FUNCS['default']:
+ *   out[b, j, y, x] = leaky_relu( sum_c L[b,c,y,x] * R[b,c,y, x + j - (D-1)], negative_slope ),  0 <= j < D
+ * i.e. the first D of the 2D-1 patch offsets of SpatialCorrelationSampler(kernel_size 1, patch_size (1, 2D-1), stride 1,
+ * padding 0, dilation_patch 1) -- channel j is disparity D-1-j, R is 0 outside the image, no 1/C normalisation.
+ * L, R: [B, C, H, W]; out: [B, D, H, W] (4-D: this volume feeds 2-D aggregators).  The sampler is a third-party
+ * package absent from the reference tree (ClementPinard/Pytorch-Correlation-extension, branch fix_1.7 per
+ * INSTALL.md:60-66, unpinned in requirements.txt): restated from its published semantics, parity UNPINNED. */
+int dmb_correlation1d_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,
+                          float negative_slope, void* stream);
+
 /* Same as dmb_cat_fms_f32 but writing into channels [out_ch_offset, out_ch_offset+2C) of a volume with
  * `out_channels` channels (GwcNet's gwc+concat volume). */
 int dmb_cat_fms_into_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,

@@ -89,6 +89,22 @@ def dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, dis
     return out
 
 
+def correlation1d_cost(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
+    """cost_processors/utils/correlation1d_cost.py:7-27.  The arithmetic lives in SpatialCorrelationSampler
+    (ClementPinard/Pytorch-Correlation-extension, branch fix_1.7 per INSTALL.md:60-66; no version pin in requirements.txt),
+    which is NOT in the reference tree: restated from its published semantics -- PARITY UNPINNED.
+    sampler(kernel_size=1, patch_size=(1, 2D-1), stride=1, padding=0, dilation_patch=1):
+        out[b, 0, pw, y, x] = sum_c in1[b,c,y,x] * in2[b,c,y, x + pw - (D-1)]   (0 outside in2)
+    then ``[:, :max_disp]`` keeps pw in [0, D-1] (offsets -(D-1) .. 0) and leaky_relu(0.1) is applied (:21-25)."""
+    B, C, H, W = reference_fm.shape
+    out = reference_fm.new_zeros((B, max_disp, H, W))
+    for j in range(max_disp):
+        d = max_disp - 1 - j
+        if d < W:
+            out[:, j, :, d:] = (reference_fm[:, :, :, d:] * target_fm[:, :, :, :W - d]).sum(dim=1)
+    return F.leaky_relu(out, negative_slope=0.1)
+
+
 def gwc_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, num_groups=40, disp_sample=None):
     """Group-wise correlation (GwcNet, "gwc" volume).  NOT IN THE REFERENCE -- parity unpinned; spec SURVEY 8-a4:
     mean over the C/G channels of a group of L[c, y, x] * R[c, y, x - d], zero outside the valid columns, using the

@@ -92,7 +92,8 @@ def test_fullsize_acfnet_pair_vs_reference(dev):
     lf, rf = synthetic.feature_pair(0, 32, 136, 240)
     results, _ = model(dict(leftFeature=lf.to(dev), rightFeature=rf.to(dev)))
     assert set(results) == {"disps", "costs", "confs"}
-    variance, _ = model.cmn(results["costs"])
+    with torch.no_grad():
+        variance, _ = model.cmn(results["costs"])
     for lvl in range(3):
         k = 3 - lvl
         assert maxdiff(results["disps"][lvl][SUB], g["disp%d" % k]) <= DISP_MAX_FULL

@@ -87,7 +87,9 @@ def test_registries_and_builders():
     assert set(PROCESSORS) == {'Difference', 'Concatenation', 'Correlation'}
     assert {'PSMNet', 'AcfNet', 'StereoNet'} <= set(AGGREGATORS)
     assert set(CAT_FUNCS) == {'default', 'fast_mode'} and set(DIF_FUNCS) == {'default', 'fast_mode'}
-    assert 'default' in COR_FUNCS and set(PREDICTORS) == {'DEFAULT', 'FASTER', 'LOCAL'}
+    assert set(COR_FUNCS) == {'default', 'gwc', 'gwc_cat'} and set(PREDICTORS) == {'DEFAULT', 'FASTER', 'LOCAL'}
+    # the reference's own entry keeps the reference's semantics (correlation1d_cost.py:29-31); the group-wise volumes have their own keys
+    assert COR_FUNCS['default'].__name__ == 'correlation1d_cost' and COR_FUNCS['gwc'].__name__ == 'gwc_fms'
     cp = build_cost_processor(_cfg())
     assert cp.default_args == dict(max_disp=48, start_disp=0, dilation=1)
     assert type(cp.aggregator).__name__ == 'PSMAggregator' and cp.aggregator.max_disp == 192
@@ -161,6 +163,41 @@ def test_result_pkl_layout_matches_reference_reader(tmp_path):
     vol = r['Result']['costs'][0][0].cpu().numpy()
     assert est.shape == (6, 10) and vol.shape == (6, 6, 10) and r['OriginalData']['leftDisp'].shape == (6, 10)
     assert np.array_equal(est, res['disps'][0][0, 0, 2:, :10].numpy())   # top/right padding removed (eval.py:24-29)
+
+
+def test_result_pkl_equals_the_reference_writers_file(tmp_path):
+    """save_result on an AcfNet-style result (disps, costs AND confs) against the file the reference's writer produces for
+    the same inputs (tests/golden/result_reference.pkl: dmb/apis/inference.py:197-223 run by oracle/gen_golden_result.py),
+    then read back with the literal access pattern of tools/view_cost.py:71-101,132-150."""
+    import pickle
+    from densematchingbenchmark_amd.result_io import load_result, save_result
+    from oracle.gen_golden_result import inputs
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "result_reference.pkl"), "rb") as fp:
+        ref = pickle.load(fp)
+    result, ori, ori_size = inputs()
+    mine = load_result(save_result(result, ori, str(tmp_path / "0006"), original_size=ori_size, scale_factor=1.0))
+    assert set(mine) == set(ref) == {"Result", "OriginalData"}
+    assert set(mine["Result"]) == set(ref["Result"]) == {"disps", "costs", "confs"}
+    for k in ref["Result"]:
+        assert isinstance(mine["Result"][k], list) and len(mine["Result"][k]) == len(ref["Result"][k]) == 3
+        for a, b in zip(mine["Result"][k], ref["Result"][k]):
+            assert a.device.type == "cpu" and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b)
+    assert set(mine["OriginalData"]) == set(ref["OriginalData"])
+    for k, b in ref["OriginalData"].items():
+        a = mine["OriginalData"][k]
+        assert (a is None and b is None) or (type(a) is type(b) and np.array_equal(a, b))
+    # tools/view_cost.py:71-84
+    ori_data, net_result = mine['OriginalData'], mine['Result']
+    leftImage, gtDisp = ori_data['leftImage'], ori_data['leftDisp']
+    estDisp = net_result['disps'][0][0, 0, ].cpu().numpy()
+    costVolume = net_result['costs'][0][0].cpu().numpy()
+    err_map = np.abs(gtDisp - estDisp)
+    assert err_map.shape == (6, 10) == leftImage.shape[:2] and costVolume.shape == (6, 6, 10)
+    # tools/view_cost.py:132-150: the distribution at a pixel
+    prob = torch.softmax(torch.from_numpy(costVolume), dim=0)
+    h, w = 3, 4
+    assert abs(float(prob[:, h, w].sum()) - 1.0) < 1e-6 and np.isfinite(abs(gtDisp[h, w] - estDisp[h, w]))
+    assert net_result['confs'][2].shape == (1, 1, 6, 10)
 
 
 def test_registry_instantiate():

@@ -625,3 +625,21 @@ def test_catconv_not_applicable_shapes(dev):
     assert not ops.catconv_applicable(L, L, ops.disp_index_list(8, 0, 2), 32)       # dilation 2
     assert not ops.catconv_applicable(L, L, ops.disp_index_list(4, 0, 1), 64)       # more than 32 output channels
     assert not ops.catconv_applicable(L[..., :14].contiguous(), L[..., :14].contiguous(), ops.disp_index_list(4, 0, 1), 32)
+
+
+@pytest.mark.parametrize("B,C,H,W,D", [(2, 32, 7, 40, 9), (1, 5, 3, 21, 33), (1, 16, 4, 64, 16)])
+def test_correlation1d_cost_reference_semantics(dev, B, C, H, W, D):
+    """COR_FUNCS['default'] = the reference's correlation1d_cost (correlation1d_cost.py:7-27): sum over ALL channels, the
+    first D of the sampler's 2D-1 offsets (channel j = disparity D-1-j), leaky_relu(0.1), 4-D output.  Oracle = the
+    sampler's published semantics (parity UNPINNED: the sampler package is not in the reference tree)."""
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.gwc_fms import COR_FUNCS
+    L, R = _rand((B, C, H, W), 71), _rand((B, C, H, W), 72)
+    got = COR_FUNCS["default"](L.to(dev), R.to(dev), max_disp=D, start_disp=0, dilation=1, disp_sample=None).cpu()
+    want = O.correlation1d_cost(L, R, D)
+    assert got.shape == (B, D, H, W)
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, math.sqrt(C))
+    # channel D-1 is disparity 0: the plain per-pixel dot product
+    dot = F.leaky_relu((L * R).sum(1), 0.1)
+    assert (got[:, D - 1] - dot).abs().max().item() <= 1e-5 * max(1.0, math.sqrt(C))
+    with pytest.raises(NotImplementedError):
+        COR_FUNCS["default"](L.to(dev), R.to(dev), max_disp=D, kernel_size=3)

@@ -455,3 +455,21 @@ def test_oracle_at_baseline_size_matches_reference_psmnet_and_stereonet():
         for lvl in range(3):
             assert maxdiff(disps[lvl][sub], g["pair0_disp%d" % (3 - lvl)]) <= 5e-5
             assert maxdiff(costs[lvl][crows], g["pair0_cost%d_rows" % (3 - lvl)]) <= 2e-5
+
+
+def test_oracle_correlation1d_cost_is_the_samplers_published_semantics():
+    """UNPINNED (the sampler package is absent from the reference tree): the oracle against a brute-force statement of
+    SpatialCorrelationSampler(kernel_size=1, patch_size=(1, 2D-1), stride=1, padding=0, dilation_patch=1) followed by the
+    slicing and activation of correlation1d_cost.py:19-25, and the call-site facts that do not need the package."""
+    B, C, H, W, D = 1, 3, 2, 7, 4
+    L, R = rand((B, C, H, W), 5), rand((B, C, H, W), 6)
+    full = torch.zeros(B, 1, 2 * D - 1, H, W)
+    for pw in range(2 * D - 1):
+        for x in range(W):
+            x2 = x + pw - (D - 1)
+            if 0 <= x2 < W:
+                full[:, 0, pw, :, x] = (L[:, :, :, x] * R[:, :, :, x2]).sum(1)
+    want = torch.nn.functional.leaky_relu(full.squeeze(1)[:, :D], negative_slope=0.1)
+    got = O.correlation1d_cost(L, R, D)
+    assert got.shape == (B, D, H, W) and torch.allclose(got, want, atol=1e-6)
+    assert (got[:, :, :, 0] == torch.nn.functional.leaky_relu(torch.cat([torch.zeros(B, D - 1, H), (L[..., 0] * R[..., 0]).sum(1, keepdim=True)], 1), 0.1)).all()
