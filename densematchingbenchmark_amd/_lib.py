@@ -146,6 +146,11 @@ def dev_ptr(t, name="tensor", allow_none=False):
 
 
 def stream_ptr(device=None):
+    """The caller's current HIP stream on ``device``.  Kernels launch on the calling thread's CURRENT device: a tensor that
+    lives on another one is refused here instead of failing inside the launch (or worse, on a foreign stream)."""
+    if device is not None and getattr(device, "index", None) is not None and device.index != torch.cuda.current_device():
+        raise DmbLibraryError("operand on cuda:%d but the current device is cuda:%d: wrap the call in torch.cuda.device(%d) "
+                              "(one process per GPU sets it once)" % (device.index, torch.cuda.current_device(), device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

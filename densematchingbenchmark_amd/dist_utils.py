@@ -37,7 +37,11 @@ class FlatGradients(object):
         model._dmb_flat_grads = self
 
     def zero_(self):
-        """Replaces optimizer.zero_grad(): keeps the views, clears the buffer with one fill."""
+        """Replaces optimizer.zero_grad(): keeps the views, clears the buffer with one fill.
+        NOTE: every parameter keeps a (zero) ``.grad`` -- a parameter that takes no part in a step still gets an optimizer
+        update with a zero gradient (weight decay, Adam moments), where the reference leaves its ``.grad`` None and the
+        optimizer skips it.  The cost path has no such parameter; freeze one with ``requires_grad_(False)`` BEFORE building
+        FlatGradients (frozen parameters are left out of the buffer) if that difference matters."""
         self.flat.zero_()
         for p, o in zip(self.params, self.offsets):   # re-attach views an optimizer.zero_grad(set_to_none=True) dropped
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + o * self.flat.element_size():
@@ -55,11 +59,11 @@ class FlatGradients(object):
             return None
         if dist.get_backend(group) == "nccl":   # RCCL
             return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-        if async_op:
+        if async_op:   # checked BEFORE anything is launched: no half-done, un-averaged collective is left in flight
             raise ValueError("FlatGradients.all_reduce: async_op needs a backend with an averaging reduction (RCCL)")
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.div_(world)
-        return work
+        return None
 
 
 def all_reduce_grads(model, coalesce=True, bucket_size_mb=-1):

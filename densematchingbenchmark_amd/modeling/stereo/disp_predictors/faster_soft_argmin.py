@@ -34,7 +34,9 @@ class FasterSoftArgmin(_SoftArgminBase):
         hint = ops.RegressionHint.lookup(cost_volume, vals, self.alpha, self.normalize)
         if hint is not None:     # the producing kernel already regressed this very tensor with these parameters
             return hint
-        if self.normalize and torch.is_grad_enabled() and cost_volume.requires_grad:
+        if torch.is_grad_enabled() and cost_volume.requires_grad:
+            if not self.normalize:   # never return a silently detached result to a caller that asked for gradients
+                raise NotImplementedError("FasterSoftArgmin(normalize=False) has no backward on the HIP path")
             return train_fn.SoftArgminFn.apply(cost_volume, tuple(vals), self.alpha)
         return ops.soft_argmin(cost_volume, vals, self.alpha, self.normalize)
 

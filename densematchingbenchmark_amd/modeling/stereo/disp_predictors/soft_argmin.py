@@ -45,10 +45,14 @@ class SoftArgmin(_SoftArgminBase):
             hint = ops.RegressionHint.lookup(cost_volume, vals, self.alpha, self.normalize)
             if hint is not None:     # the producing kernel already regressed this very tensor with these parameters
                 return hint
-            if self.normalize and torch.is_grad_enabled() and cost_volume.requires_grad:
+            if torch.is_grad_enabled() and cost_volume.requires_grad:
+                if not self.normalize:   # never return a silently detached result to a caller that asked for gradients
+                    raise NotImplementedError("SoftArgmin(normalize=False) has no backward on the HIP path")
                 return train_fn.SoftArgminFn.apply(cost_volume, tuple(vals), self.alpha)
             return ops.soft_argmin(cost_volume, vals, self.alpha, self.normalize)
         assert D == disp_sample.shape[1], 'The number of disparity samples should be consistent!'
+        if torch.is_grad_enabled() and (cost_volume.requires_grad or disp_sample.requires_grad):
+            raise NotImplementedError("SoftArgmin with a per-pixel disp_sample has no backward on the HIP path")
         return ops.soft_argmin_sampled(cost_volume, disp_sample.float().expand_as(cost_volume).contiguous(),
                                        self.alpha, self.normalize)
 

@@ -47,7 +47,10 @@ class StereoFocalLoss(object):
             raise ValueError("cost volume has %d disparity samples, the loss expects %d" % (C, len(values)))
         var = variance
         if torch.is_tensor(var) and var.numel() == 1:
-            var = float(var)
+            if var.requires_grad and torch.is_grad_enabled():
+                raise NotImplementedError("StereoFocalLoss: a learnable scalar variance has no backward on the HIP path "
+                                          "(pass a [B, 1, H, W] map, as the confidence network does, or a float)")
+            var = float(var)   # (one host read; a Python float costs none)
         elif torch.is_tensor(var):
             var = var.expand(B, 1, H, W)
         return _FocalLevel.apply(estCost, var, gt.detach().contiguous(), values, lower, upper, self.start_disp,
