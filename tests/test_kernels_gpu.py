@@ -166,6 +166,30 @@ def test_conv3d_c1(dev, Ci):
     assert (got - ref).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 6, 9, 72), (1, 17, 10, 240), (1, 3, 19, 64), (1, 9, 8, 124)])
+def test_conv3d_c1_vector_rows(dev, shape):
+    """Rows that are 16-byte aligned (W % 4 == 0) take the register-staged kernel (16-byte fetches, one LDS word per input
+    row and thread, halo columns by lane shifts): same accumulation order as the dword kernel -> BIT-identical to it, and
+    within 1e-5 of the CPU convolution; tile edges in every direction (8 z x 8 y x 60 x tiles)."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, D, H, W = shape
+    x = _rand((B, 32, D, H, W), 16)
+    w = _rand((1, 32, 3, 3, 3), 17, 1.0 / math.sqrt(32 * 27))
+    res = _rand((B, 1, D, H, W), 18)
+    ref = F.conv3d(x, w, torch.tensor([-0.5]), padding=1) + res
+    got = ops.conv3d_k3_c1(x.to(dev), w.to(dev), -0.5, res.to(dev))
+    assert (got.cpu() - ref).abs().max().item() <= 1e-5
+    lib = _lib.load()
+    lib.dmb_dev_set_option(3, 1)     # force the dword kernel
+    try:
+        old = ops.conv3d_k3_c1(x.to(dev), w.to(dev), -0.5, res.to(dev))
+    finally:
+        lib.dmb_dev_set_option(3, 0)
+    assert torch.equal(got, old)
+    assert (ops.conv3d_k3_c1(x.to(dev), w.to(dev), 0.0, None).cpu() - (ref - res + 0.5)).abs().max().item() <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------- upsampling
 @pytest.mark.parametrize("ins,outs", [((4, 6, 10), (16, 24, 40)), ((3, 5, 7), (11, 17, 30))])
 def test_trilinear(dev, ins, outs):
