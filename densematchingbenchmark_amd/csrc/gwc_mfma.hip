@@ -16,6 +16,7 @@ constexpr int GW_RPAD = 64;           // zero columns staged left of the right-f
 constexpr int GW_LROW = 256;          // staged left-feature row length (x tiles of 32, up to 8 per pass)
 constexpr int GW_RROW = GW_RPAD + GW_LROW;
 constexpr int GW_CP = 98;             // scratch pitch
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int CG>
 __global__ __launch_bounds__(256, 2) void gwc_mfma_kernel(const float* __restrict__ L, const float* __restrict__ R,
@@ -37,6 +38,19 @@ __global__ __launch_bounds__(256, 2) void gwc_mfma_kernel(const float* __restric
   const __amdgpu_buffer_rsrc_t rrs = make_rsrc(Rb, (unsigned)CG * HW * 4u);
 
   // ---- stage the group's rows: CG left rows (256 floats) + CG right rows (64 zero columns + 256 floats)
+  if ((W & 3) == 0 && ((((uintptr_t)L | (uintptr_t)R) & 15) == 0)) {
+    // 16-byte words: a left row is one copy instruction (64 lanes x 16 bytes), a right row two (64 + 16 words)
+    for (int u = wave; u < CG * 3; u += 4) {
+      const int c = u / 3, seg = u - c * 3;   // 0: left row, 1: right row words 0..63, 2: right row words 64..79
+      const int word = (seg == 2 ? 64 : 0) + lane;
+      const int gx = (seg == 0 ? xbase : xbase - GW_RPAD) + word * 4;
+      const bool on = seg != 2 || lane < 16;
+      const unsigned voff = (on && gx >= 0 && gx < W) ? (unsigned)gx * 4u : DMA_OOB;
+      const unsigned soff = ((unsigned)c * HW + (unsigned)y * W) * 4u;
+      float* dst = seg == 0 ? lrow + c * GW_LROW : rrow + c * GW_RROW + (seg == 2 ? 256 : 0);
+      if (on) dma16(seg == 0 ? lrs : rrs, voff, soff, dst);
+    }
+  } else
   for (int u = wave; u < CG * 9; u += 4) {
     const int c = u / 9, seg = u - c * 9;  // segments 0..3: left row, 4..8: right row
     const bool left = seg < 4;
@@ -73,12 +87,38 @@ __global__ __launch_bounds__(256, 2) void gwc_mfma_kernel(const float* __restric
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) myscr[cd_row(r, h) * GW_CP + t * 32 + j] = acc[t][r];
-    // diagonals: half-wave h takes disparity samples k = 2 q + h
-    const int gx = xbase + x0 + j;
-    for (int k = h; k < D; k += 2) {
-      const int d = idx.d[k];
-      const float v = myscr[j * GW_CP + j + GW_RPAD - d];
-      if (gx < W) o[(size_t)k * HW + gx] = v / (float)CG;
+    if ((W & 3) == 0) {
+      // diagonals, 16-byte form: lane = (plane p of a group of 8, x quad q): four diagonal reads (rows 4q .. 4q + 3 of the
+      // scratch, bank stride 12 q - p: the 32 lanes of an LDS group cover the 32 banks once) -> one float4 -> one store
+      // instruction writes 8 planes x 128 bytes.  All reads of a block of planes are issued before the first store.
+      const int pq = lane >> 3, q4 = (lane & 7) * 4;
+      const int gx = xbase + x0 + q4;
+      constexpr int KB = 2;   // groups of 8 planes in flight
+      for (int k0 = 0; k0 < D; k0 += 8 * KB) {
+        float v[KB][4];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int k = k0 + kb * 8 + pq;
+          const int d = idx.d[k < D ? k : D - 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[kb][e] = myscr[(q4 + e) * GW_CP + (q4 + e) + GW_RPAD - d];
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int k = k0 + kb * 8 + pq;
+          if (k < D && gx < W)
+            __builtin_nontemporal_store(f32x4_t{v[kb][0] / (float)CG, v[kb][1] / (float)CG, v[kb][2] / (float)CG, v[kb][3] / (float)CG},
+                                        reinterpret_cast<f32x4_t*>(o + (size_t)k * HW + gx));
+        }
+      }
+    } else {
+      // diagonals: half-wave h takes disparity samples k = 2 q + h
+      const int gx = xbase + x0 + j;
+      for (int k = h; k < D; k += 2) {
+        const int d = idx.d[k];
+        const float v = myscr[j * GW_CP + j + GW_RPAD - d];
+        if (gx < W) o[(size_t)k * HW + gx] = v / (float)CG;
+      }
     }
   }
 }

@@ -83,6 +83,12 @@ bw_case("conv c1 32->1 full", lambda: ops.conv3d_k3_c1(x, w1, 0.0, None), x.nume
 L = torch.randn(B, 32, H, W, device=dev); R = torch.randn(B, 32, H, W, device=dev)
 idx = ops.disp_index_list(48, 0, 1)
 bw_case("cat_fms", lambda: ops.cat_fms(L, R, idx), B * 64 * D * H * W * 4 + 2 * L.numel() * 4)
+# GwcNet volume (BASELINE configs[2]): 40-group correlation of 320-channel features (MFMA inner products) + 2 x 12 concat
+lg, rg = torch.randn(B, 320, H, W, device=dev), torch.randn(B, 320, H, W, device=dev)
+gout = torch.empty(B, 64, D, H, W, device=dev)
+bw_case("gwc 320ch/40 groups (cfg3)", lambda: ops.gwc_fms(lg, rg, idx, 40, out=gout, out_ch_offset=0),
+        2 * lg.numel() * 4 + B * 40 * D * H * W * 4)
+del lg, rg, gout
 c = torch.randn(B, D, H, W, device=dev)
 bw_case("trilinear x4", lambda: ops.trilinear_ac(c, (192, 544, 960)), B * 192 * 544 * 960 * 4 + c.numel() * 4)
 big = torch.randn(B, 192, 544, 960, device=dev)

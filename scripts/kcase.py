@@ -1,5 +1,5 @@
 """Development aid: run ONE layer of the cost path a few times (for rocprofv3 counter passes).
-    python scripts/kcase.py deconv6|deconv5|s2_1|s2_3|s1q|c1|tri [reps]"""
+    python scripts/kcase.py deconv6|deconv5|s2_1|s2_3|s1q|c1|gwc|tri [reps]"""
 import os
 import sys
 
@@ -27,6 +27,13 @@ elif name in ("s2_1", "s2_3", "s1q"):
 elif name == "c1":
     x, w1, r = g(B, 32, D, H, W), g(1, 32, 3, 3, 3), g(B, 1, D, H, W)
     fn = lambda: ops.conv3d_k3_c1(x, w1, 0.0, r)
+elif name == "gwc":      # GwcNet volume (BASELINE configs[2]): 40-group correlation of 320-channel features + 2 x 12 concat channels
+    lg, rg, lc, rc = g(B, 320, H, W), g(B, 320, H, W), g(B, 12, H, W), g(B, 12, H, W)
+    idx = ops.disp_index_list(D, 0, 1)
+    out = torch.empty(B, 64, D, H, W, device=dev)
+    def fn():
+        ops.gwc_fms(lg, rg, idx, 40, out=out, out_ch_offset=0)
+        ops.cat_fms_into(lc, rc, idx, out, 40)
 elif name == "tri":
     c = g(B, D, H, W)
     vals = ops.disp_sample_values(192, 0, 1)
