@@ -8,6 +8,8 @@ class StereoNetAggregator(nn.Module):
     """``num`` x (Conv3d 32->32 + BN + ReLU, bias=True) + Conv3d 32->1 (bias=True); returns ``[cost]`` at the
     volume's own resolution, [B, D, H, W] (no up-sampling, StereoNet.py:42-55)."""
 
+    accepts_lazy_cat = True   # classify[0] is a FusedConv3d: it takes a LazyCatVolume (here: of the difference volume)
+
     def __init__(self, max_disp, in_planes=32, batch_norm=True, num=4):
         super().__init__()
         self.max_disp, self.in_planes, self.batch_norm, self.num = max_disp, in_planes, batch_norm, num

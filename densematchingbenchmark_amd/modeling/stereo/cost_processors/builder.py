@@ -1,11 +1,12 @@
 """cost_processors/builder.py:21-107: cost processors = volume builder + aggregator, selected by config strings."""
+import torch
 import torch.nn as nn
 
 from .... import ops
 from ..layers import train_fn
 from .aggregators import build_cost_aggregator
 from .utils.cat_fms import CAT_FUNCS, LazyCatVolume, cat_fms
-from .utils.dif_fms import DIF_FUNCS
+from .utils.dif_fms import DIF_FUNCS, dif_fms
 from .utils.gwc_fms import COR_FUNCS
 
 
@@ -23,11 +24,11 @@ class _VolumeThenAggregate(nn.Module):
         self.aggregator = build_cost_aggregator(cfg)
 
     def forward(self, ref_fms, tgt_fms, disp_sample=None):
-        if (self.vol_func is cat_fms and getattr(self.aggregator, "accepts_lazy_cat", False) and ops.cat_fusion()
-                and not train_fn.wants_grad(self, ref_fms, tgt_fms)):
+        if ((self.vol_func is cat_fms or self.vol_func is dif_fms) and getattr(self.aggregator, "accepts_lazy_cat", False)
+                and ops.cat_fusion() and torch.is_tensor(ref_fms) and not train_fn.wants_grad(self, ref_fms, tgt_fms)):
             # eval mode: the aggregator's first convolution consumes the volume's description (csrc/catconv.hip); the raw
             # volume is not part of the result contract (general_stereo_model.py:82-85) and is never written
-            raw_cost = LazyCatVolume(ref_fms, tgt_fms, **self.default_args)
+            raw_cost = LazyCatVolume(ref_fms, tgt_fms, kind="cat" if self.vol_func is cat_fms else "dif", **self.default_args)
         else:
             raw_cost = self.vol_func(ref_fms, tgt_fms, disp_sample=disp_sample, **self.default_args)
         return self.aggregator(raw_cost)

@@ -15,23 +15,24 @@ def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, dis
 
 
 class LazyCatVolume:
-    """The concatenation volume of cat_fms(reference_fm, target_fm, ...) as a DESCRIPTION: an aggregator whose first
-    convolution knows the volume's structure (FusedConv3d on csrc/catconv.hip) consumes it without the 1.6 GB tensor ever
-    being written; anything else calls ``materialize()`` and gets exactly cat_fms's tensor.  Built by the cost processor
-    in eval mode only (cost_processors/builder.py)."""
+    """The volume of cat_fms(reference_fm, target_fm, ...) -- or, ``kind="dif"``, of dif_fms -- as a DESCRIPTION: an
+    aggregator whose first convolution knows the volume's structure (FusedConv3d on csrc/catconv.hip) consumes it without
+    the tensor (1.6 GB at the BASELINE size) ever being written; anything else calls ``materialize()`` and gets exactly the
+    builder's tensor.  Built by the cost processor in eval mode only (cost_processors/builder.py)."""
 
-    def __init__(self, reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1):
-        self.reference_fm, self.target_fm = reference_fm.float(), target_fm.float()
+    def __init__(self, reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, kind="cat", **unused):
+        self.reference_fm, self.target_fm, self.kind = reference_fm.float(), target_fm.float(), kind
         self.disp_idx = ops.disp_index_list(max_disp, start_disp, dilation)
         B, C, H, W = reference_fm.shape
-        self.shape = torch.Size((B, 2 * C, len(self.disp_idx), H, W))
+        self.shape = torch.Size((B, 2 * C if kind == "cat" else C, len(self.disp_idx), H, W))
         self.device, self.dtype, self.requires_grad = reference_fm.device, torch.float32, False
 
     def dim(self):
         return 5
 
     def materialize(self):
-        return ops.cat_fms(self.reference_fm, self.target_fm, self.disp_idx)
+        build = ops.cat_fms if self.kind == "cat" else ops.dif_fms
+        return build(self.reference_fm, self.target_fm, self.disp_idx)
 
 
 def fast_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):

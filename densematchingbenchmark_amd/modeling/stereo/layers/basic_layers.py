@@ -92,10 +92,10 @@ class FusedConv3d(nn.Sequential):
         act = self.has_relu if relu is None else relu
         if hasattr(x, "materialize"):   # LazyCatVolume: the concatenation volume as a description (eval mode only)
             if (residual is None and skip is None and not self.transposed and self.stride == 1 and not self.training
-                    and 2 * x.reference_fm.shape[1] == self.in_planes
+                    and x.shape[1] == self.in_planes
                     and ops.catconv_applicable(x.reference_fm, x.target_fm, x.disp_idx, self.out_planes)):
                 _, scale, shift = self._prepacked()
-                return ops.catconv_first(x.reference_fm, x.target_fm, len(x.disp_idx), self._prepacked_cat(), scale, shift, act)
+                return ops.catconv_first(x.reference_fm, x.target_fm, len(x.disp_idx), self._prepacked_cat(x.kind), scale, shift, act)
             x = x.materialize()
         if skip is not None:
             if residual is not None:
@@ -112,10 +112,10 @@ class FusedConv3d(nn.Sequential):
             return ops.conv3d_k3_x6(x, self._prepacked_x6(), self.out_planes, scale, shift, residual, act)   # opt-in only
         return ops.conv3d_k3(x, wp, self.out_planes, scale, shift, residual, self.stride, act)
 
-    def _prepacked_cat(self):
-        key = _versions(self[0].weight)
+    def _prepacked_cat(self, kind):
+        key = _versions(self[0].weight) + (kind,)
         if getattr(self, "_cat_key", None) != key:
-            self._cat_key, self._cat = key, ops.catconv_pack(self[0].weight.detach())
+            self._cat_key, self._cat = key, ops.catconv_pack(self[0].weight.detach(), kind)
         return self._cat
 
     def _prepacked_x6(self):
@@ -134,6 +134,8 @@ class HeadConv3d(nn.Conv3d):
         self._bias_key, self._bias_val = None, 0.0
 
     def forward(self, x, residual=None):
+        if hasattr(x, "materialize"):   # a lazy volume reaching a head directly (an aggregator without trunk layers)
+            x = x.materialize()
         if train_fn.wants_grad(self, x, residual):
             return train_fn.HeadConvFn.apply(x, self.weight, self.bias, residual)
         b = 0.0

@@ -220,13 +220,20 @@ def catconv_applicable(L, R, disp_idx, Co):
             and L.dtype == torch.float32 and L.is_cuda)
 
 
-def catconv_pack(w):
-    """nn.Conv3d weight [Co, 2C, 3, 3, 3] -> the five conv2d weight packs of the 2-D form (csrc/catconv.hip):
-    per-dz slices of the left half (all dx taps; dx >= 1; dx >= 2) and of the right half (all taps; without dx = 2),
-    stacked along the output-channel axis as dz * Co + co and zero-padded to CATCONV_CH rows."""
-    Co, C2 = w.shape[0], w.shape[1]
-    C = C2 // 2
+def catconv_pack(w, kind="cat"):
+    """nn.Conv3d weight -> the five conv2d weight packs of the 2-D form (csrc/catconv.hip): per-dz slices of the left half
+    (all dx taps; dx >= 1; dx >= 2) and of the right half (all taps; without dx = 2), stacked along the output-channel axis
+    as dz * Co + co and zero-padded to CATCONV_CH rows.  ``kind="cat"``: w is [Co, 2C, 3, 3, 3], left half = channels
+    [0, C), right half = [C, 2C).  ``kind="dif"`` (difference volume, L - R shifted: dif_fms.py:7-46): w is [Co, C, 3, 3, 3]
+    and convolution is linear, so the left half takes w and the right half -w (a sign flip is exact)."""
+    Co = w.shape[0]
     w = w.detach().float()
+    if kind == "dif":
+        wl, wr = w, -w
+    else:
+        C = w.shape[1] // 2
+        wl, wr = w[:, :C], w[:, C:]
+    C = wl.shape[1]
 
     def stack(half, dx_from, dx_to):
         k = torch.zeros((CATCONV_CH, C, 3, 3), dtype=torch.float32, device=w.device)
@@ -234,13 +241,13 @@ def catconv_pack(w):
             k[dz * Co:(dz + 1) * Co, :, :, dx_from:dx_to] = half[:, :, dz, :, dx_from:dx_to]
         return pack_conv2d_weights(k)
 
-    wl, wr = w[:, :C], w[:, C:]
     return {"A": stack(wl, 0, 3), "B1": stack(wl, 1, 3), "B2": stack(wl, 2, 3), "HC": stack(wr, 0, 3), "HD": stack(wr, 0, 2),
             "Co": Co, "Cin": C}
 
 
 def catconv_first(L, R, D, packs, scale=None, shift=None, relu=False):
-    """relu?(scale * conv3d(cat_fms(L, R, d_k = k), w) + shift) without the volume: [B, C, H, W] x 2 -> [B, Co, D, H, W]."""
+    """relu?(scale * conv3d(V, w) + shift) without the volume V = cat_fms(L, R, d_k = k) (or dif_fms: the packs decide):
+    [B, C, H, W] x 2 -> [B, Co, D, H, W]."""
     lib = _lib.load()
     L, R = _f32c(L, "reference_fm"), _f32c(R, "target_fm")
     B, C, H, W = L.shape

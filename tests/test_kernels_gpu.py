@@ -667,3 +667,16 @@ def test_correlation1d_cost_reference_semantics(dev, B, C, H, W, D):
     assert (got[:, D - 1] - dot).abs().max().item() <= 1e-5 * max(1.0, math.sqrt(C))
     with pytest.raises(NotImplementedError):
         COR_FUNCS["default"](L.to(dev), R.to(dev), max_disp=D, kernel_size=3)
+
+
+@pytest.mark.parametrize("B,C,Co,D,H,W", [(2, 32, 32, 24, 10, 36), (1, 32, 32, 8, 6, 156), (1, 6, 32, 4, 5, 12)])
+def test_catconv_first_layer_on_a_difference_volume(dev, B, C, Co, D, H, W):
+    """The same 2-D form for dif_fms (StereoNet, BASELINE configs[4]): conv(L - R shifted) = conv_L(w) + conv_R(-w)."""
+    ops = _ops()
+    L, R = _rand((B, C, H, W), 311), _rand((B, C, H, W), 312)
+    w = _rand((Co, C, 3, 3, 3), 313, 1.0 / math.sqrt(C * 27 / 8))
+    sc, sh = _affine(Co, 314)
+    vol = O.dif_fms(L, R, D, 0, 1)
+    ref = F.relu(F.conv3d(vol.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
+    got = ops.catconv_first(L.to(dev), R.to(dev), D, ops.catconv_pack(w.to(dev), "dif"), sc.to(dev), sh.to(dev), True).cpu()
+    assert got.shape == ref.shape and (got.double() - ref).abs().max().item() <= 2e-5
