@@ -26,7 +26,7 @@ def short(name):
 
 rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(DST, tag + "_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 5 --warmup 2  (MI355X, batch 4)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2  (MI355X, batch 4; scripts/profile.sh)\n")
     f.write("kernel,calls,total_ms,avg_us,percent,min_us,max_us\n")
     for r in rows:
         if float(r["Percentage"]) < 0.05:
@@ -56,25 +56,34 @@ if os.path.exists(tr):
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    path = os.path.join(SRC, d, "pmc_counter_collection.csv")
-    if not os.path.exists(path):
+import glob
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_gwc", "pmc_write_gwc", "pmc_sq_gwc"):
+    paths = glob.glob(os.path.join(SRC, d, "**", "*counter_collection.csv"), recursive=True)
+    if not paths:
         continue
-    for r in csv.DictReader(open(path)):
-        k = short(r["Kernel_Name"])
-        pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if d == "pmc_sq" and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
-            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))   # dispatch -> counter -> sum over its rows
+    meta = {}
+    for r in csv.DictReader(open(paths[0])):
+        per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        meta[r["Dispatch_Id"]] = (short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for did, cs in per.items():
+        k, us = meta[did]
+        if d.endswith("_gwc") and not k.startswith("gwc"):
+            continue
+        for c, v in cs.items():
+            pmc[k][c].append(v)
+            if d.startswith("pmc_sq") and c == "GRBM_GUI_ACTIVE":
+                dur[k].append(us)
 counters = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_BUSY_CYCLES",
             "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]
 with open(os.path.join(DST, tag + "_pmc.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --pmc <one group per pass> -- python bench.py --no-cpu-baseline --steps 1 --warmup 1; "
+    f.write("# rocprofv3 --kernel-trace --pmc <one group per pass> -- python bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 (gwc_mfma_kernel: scripts/kcase.py gwc); "
             "means per launch.  hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction, see "
             "scripts/summarize_profiles.py); mfma_util = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); "
             "mfma_gflop = MOPS_F32 * 512 / 1e9\n")
     f.write("kernel,launches," + ",".join(counters) + ",hbm_bytes,mfma_util,mfma_gflop,pmc_pass_us\n")
     for k, v in sorted(pmc.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
-        if not k.startswith(("conv3d", "deconv3d", "trilinear", "soft_argmin", "volume", "epe", "conf_head", "gwc", "conv2d")):
+        if not k.startswith(("conv3d", "deconv3d", "trilinear", "soft_argmin", "volume", "epe", "conf_head", "gwc", "conv2d", "catconv", "copy_window")):
             continue
         m = {c: (sum(v[c]) / len(v[c]) if v.get(c) else float("nan")) for c in counters}
         hbm = 2 * m["FETCH_SIZE"] * 1024 + m["WRITE_SIZE"] * 1024
