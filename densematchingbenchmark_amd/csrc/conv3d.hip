@@ -607,10 +607,13 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
 // V16: rows are 16-byte aligned (W % 4 == 0, aligned base): the tile is staged with 16-byte LDS-DMA words (row pitch
 // rounded up to 64 floats).  A CU retires LDS-DMA at about one LANE per clock whatever the word size, and with dword
 // copies this kernel spent more TA cycles on staging than matrix-core cycles on arithmetic.
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false>
+// VEPI (with V16): the 16-byte epilogue through the LDS scratch; a separate instantiation, not a run-time switch -- with both
+// epilogues in one kernel the register allocation of the one not taken spilled into the other (the scalar form ran 1.6x
+// slower once the vector form was added next to it).
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false, bool VEPI_ = false>
 struct DCfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_;
-  static constexpr bool V16 = V16_;
+  static constexpr bool V16 = V16_, VEPI = V16_ && VEPI_;
   static constexpr int WZ = 4 / WN;
   static constexpr int TZ = WZ;
   static constexpr int P = V16 ? (TX + 1 + 3) / 4 * 4 : TX + 1;
@@ -636,7 +639,7 @@ struct DCfg {
   static constexpr int PRIV_FLOATS = (CK / 4) * CH_STRIDE;
   static constexpr int PCH = PRIV_FLOATS >= 16 * SCR_PITCH ? 16 : 8;
   static constexpr bool SCR_PRIVATE = PRIV_FLOATS >= PCH * SCR_PITCH;
-  static constexpr int SCR_FLOATS = (V16 && !SCR_PRIVATE) ? 4 * PCH * SCR_PITCH : 0;
+  static constexpr int SCR_FLOATS = (VEPI && !SCR_PRIVATE) ? 4 * PCH * SCR_PITCH : 0;
   static constexpr int WPE = ((LDS_FLOATS + AFF_FLOATS + SCR_FLOATS) * 4 * 2 <= 160 * 1024 && MT * NT <= 2) ? 2 : 1;  // workgroups per CU
   static_assert(P <= 64, "one wave stages one tile row per instruction");
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0 && (!V16 || (CH_STRIDE % 4 == 0 && TX % 4 == 0)), "shape");
@@ -664,7 +667,6 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + stride - 1) / stride;
   const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
-  const bool vec_epi = (relu >> 4) & 1;   // 16-byte stores through the LDS scratch (set by the host when the shapes allow)
   relu &= 0xf;
 
   struct Tile {
@@ -866,7 +868,8 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
 
     // ---- epilogue of cur_t ----
     const int gzi = cur_t.z0 + wz;
-    if (C::V16 && vec_epi && !(dbg & 1)) {
+    if constexpr (C::VEPI) {
+      if (!(dbg & 1)) {
       // ---- vector epilogue: per (channel tile, 32-position tile, y parity) the two x-parity accumulator tiles are
       // interleaved in LDS ([PCH channels][64 output columns], 8-byte writes), read back as 4 consecutive x of one
       // channel and stored / residual-loaded as 16-byte words through buffer resources (lanes outside the volume get an
@@ -961,6 +964,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
         run(std::true_type{});
       else
         run(std::false_type{});
+      }
     } else if (gzi < D && !(dbg & 1)) {
       const unsigned gz = 2 * gzi + PZ;
       const int cout = cvalid < C::COUT ? cvalid : C::COUT;   // channels the output tensor really has
@@ -1494,20 +1498,18 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
   relu |= g_dev_opts[6] << 8;
   const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned rows
   // 16-byte epilogue: aligned output / residual rows, every channel real, one batch item of the output below 2 GiB
-  if (v16 && Co % 32 == 0 && ((((uintptr_t)y | (uintptr_t)residual) & 15) == 0) && (long long)Co * 8 * D * H * W * 4 < 0x7fffffffLL &&
-      !g_dev_opts[7])
-    relu |= 1 << 4;
+  const bool vepi = v16 && Co % 32 == 0 && ((((uintptr_t)y | (uintptr_t)residual) & 15) == 0) &&
+                    (long long)Co * 8 * D * H * W * 4 < 0x7fffffffLL && !g_dev_opts[7];
   // 2 rows x 28 columns per item instead of 1 x 60 where that computes fewer positions (input W = 64: 3 x 32 against
   // 2 x 64 per row; the tile width stays a multiple of 4 for the 16-byte staging)
   const bool narrow = v16 && cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
-  if (Co == 64 && narrow) return launch_deconv<DCfg<0, 64, 2, 28, 4, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
-  if (Co <= 32 && narrow) return launch_deconv<DCfg<0, 32, 2, 28, 8, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
-  if (Co == 64)
-    return v16 ? launch_deconv<DCfg<0, 64, 1, 60, 4, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st)
-               : launch_deconv<DCfg<0, 64, 1, 60, 4, 2, false>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
-  if (Co <= 32)   // fewer than 32 channels (GC-Net's 1-channel head): zero-padded weight rows, masked epilogue
-    return v16 ? launch_deconv<DCfg<0, 32, 1, 60, 8, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st)
-               : launch_deconv<DCfg<0, 32, 1, 60, 8, 1, false>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
+#define DMB_DC(CO, TY, TX, CK, WN, V, E) launch_deconv<DCfg<0, CO, TY, TX, CK, WN, V, E>>(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st)
+  if (Co == 64 && narrow) return vepi ? DMB_DC(64, 2, 28, 4, 2, true, true) : DMB_DC(64, 2, 28, 4, 2, true, false);
+  if (Co <= 32 && narrow) return vepi ? DMB_DC(32, 2, 28, 8, 1, true, true) : DMB_DC(32, 2, 28, 8, 1, true, false);
+  if (Co == 64) return !v16 ? DMB_DC(64, 1, 60, 4, 2, false, false) : (vepi ? DMB_DC(64, 1, 60, 4, 2, true, true) : DMB_DC(64, 1, 60, 4, 2, true, false));
+  if (Co <= 32)   // fewer than 32 channels (GC-Net's 1-channel head): zero-padded weight rows, masked scalar epilogue
+    return !v16 ? DMB_DC(32, 1, 60, 8, 1, false, false) : (vepi ? DMB_DC(32, 1, 60, 8, 1, true, true) : DMB_DC(32, 1, 60, 8, 1, true, false));
+#undef DMB_DC
   return fail(DMB_EUNSUPPORTED, "deconv3d: output channels must be <= 32 or 64");
 }
 
