@@ -89,8 +89,15 @@ def cpu_baseline(model, cfg, first_pair, ptype, agg):
         run = lambda l, r: O.gwcnet_path(l, r, p, md, num_groups=cfg.model.cost_processor.cost_computation.get("num_groups", 40))  # noqa: E731
         what = "gwc + cat volume + PSMAggregator + 3x FasterSoftArgmin"
     elif agg == "AcfNet":
-        run = lambda l, r: O.acfnet_path(l, r, p, md, cmn_alpha=cfg.model.cmn.alpha, cmn_beta=cfg.model.cmn.beta)  # noqa: E731
-        what = "cat_fms + AcfAggregator + 3x FasterSoftArgmin + Cmn"
+        if "cmn" in cfg.model:
+            run = lambda l, r: O.acfnet_path(l, r, p, md, cmn_alpha=cfg.model.cmn.alpha, cmn_beta=cfg.model.cmn.beta)  # noqa: E731
+            what = "cat_fms + AcfAggregator + 3x FasterSoftArgmin + Cmn"
+        else:   # fixed-variance config: no confidence network
+            def run(l, r):
+                raw = O.cat_fms(l, r, md // 4, 0, 1)
+                costs = O.acf_aggregator(raw, p, md, "cost_processor.aggregator.")
+                return [O.faster_soft_argmin(c, md, 0, 1, 1.0, True) for c in costs], costs
+            what = "cat_fms + AcfAggregator + 3x FasterSoftArgmin"
     elif agg == "StereoNet":
         run = lambda l, r: O.stereonet_path(l, r, p, md)  # noqa: E731
         what = "dif_fms + StereoNetAggregator + FasterSoftArgmin at 1/8 resolution"
