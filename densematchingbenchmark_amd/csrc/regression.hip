@@ -271,6 +271,31 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
       o[j] = lerp2(a0, ly.w0, a1, ly.w1);
     }
   };
+  // The input plane after the newest cached one is fetched AHEAD as raw values (16 registers) and only blended when it is
+  // promoted, about four output planes later: loads and stores retire through one in-order counter on this chip, so a load
+  // issued and awaited between two stores drains every store before it (one full write round trip per input plane).
+  float raw[16];
+  int pz = -1;
+  auto prefetch = [&](int zi) {
+    const float* p0 = r0 + (size_t)zi * plane;
+    const float* p1 = r1 + (size_t)zi * plane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      raw[4 * j + 0] = p0[lx[j].i0];
+      raw[4 * j + 1] = p0[lx[j].i1];
+      raw[4 * j + 2] = p1[lx[j].i0];
+      raw[4 * j + 3] = p1[lx[j].i1];
+    }
+    pz = zi;
+  };
+  auto from_raw = [&](float (&o)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a0 = lerp2(raw[4 * j + 0], lx[j].w0, raw[4 * j + 1], lx[j].w1);
+      const float a1 = lerp2(raw[4 * j + 2], lx[j].w0, raw[4 * j + 3], lx[j].w1);
+      o[j] = lerp2(a0, ly.w0, a1, ly.w1);
+    }
+  };
   float h0[4], h1[4];
   int cz0 = -1, cz1 = -1;
   const size_t ostride = (size_t)Ho * Wo;
@@ -298,10 +323,13 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
       if (lz.i1 == cz0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) h1[j] = h0[j];
+      } else if (lz.i1 == pz) {
+        from_raw(h1);
       } else {
         hw(lz.i1, h1);
       }
       cz1 = lz.i1;
+      if (cz1 + 1 < Di) prefetch(cz1 + 1);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = lerp2(h0[j], lz.w0, h1[j], lz.w1);
