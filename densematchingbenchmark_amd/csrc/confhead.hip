@@ -169,6 +169,108 @@ __global__ __launch_bounds__(256, 2) void conf_head_kernel(const float* __restri
 
 using namespace dmb;
 
+namespace dmb {
+
+// ------------------------------------------------------------------------------------------------------------------
+// The confidence head on a cost volume that is the learned 4x up-sampling of a quarter-resolution volume
+// (aggregators/AcfNet.py:55-57,81-83: ConvTranspose3d(1, 1, 8, 4, 2) applied to c [B, Dq, Hq, Wq]).  The head's 3x3
+// convolution over the up-sampled volume (D = 4 Dq channels, cmn.py:21-27) composed with that up-sampling is, for each of the
+// 16 output phases (Y mod 4, X mod 4), a 3x3 convolution of c itself with Dq input channels -- 4x fewer multiplications,
+// on the 2-D convolution kernel (conv2d.hip) with BatchNorm + ReLU in its epilogue:
+//     hq[(phase, m), Y', X'] = relu(bn(sum_{z, ty, tx} K[(phase, m), z, ty, tx] * c[z, Y' + ty - 1, X' + tx - 1]))
+// The two kernels here finish the job: conf_gather = 1x1 convolution + sigmoid per full-resolution pixel; conf_ring =
+// the outermost pixel ring evaluated directly on the up-sampled volume (there the head's zero padding of that volume is not
+// what the composed form sees: it continues the up-sampling past the image border).
+// ------------------------------------------------------------------------------------------------------------------
+// hq: [B, 16 * M, Hq, Wq] (channel = (by * 4 + bx) * M + m) -> conf [B, 1, 4 Hq, 4 Wq]
+__global__ __launch_bounds__(256) void conf_gather_kernel(const float* __restrict__ hq, const float* __restrict__ w2,
+                                                          float* __restrict__ conf, int B, int M, int Hq, int Wq) {
+  const long long total = (long long)B * 16 * Hq * Wq;
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= total) return;
+  const int xq = (int)(i % Wq);
+  long long r = i / Wq;
+  const int yq = (int)(r % Hq); r /= Hq;
+  const int ph = (int)(r % 16), b = (int)(r / 16);
+  const size_t plane = (size_t)Hq * Wq;
+  const float* h = hq + ((size_t)b * 16 + ph) * M * plane + (size_t)yq * Wq + xq;
+  float acc = 0.f;
+  for (int m = 0; m < M; ++m) acc = fmaf(h[(size_t)m * plane], w2[m], acc);
+  const int Y = 4 * yq + (ph >> 2), X = 4 * xq + (ph & 3);
+  conf[((size_t)b * 4 * Hq + Y) * (4 * Wq) + X] = 1.f / (1.f + __expf(-acc));
+}
+
+// Ring pixels straight from the up-sampled volume.  Lane = ring pixel (64 per workgroup), the four waves split the D
+// planes; a lane keeps all M = 64 hidden sums in registers and the tap's 64 weights arrive as wave-uniform (scalar) loads
+// from w1t [D, 3, 3, 64] -- one vector load feeds 64 fmas.  Partial sums meet in LDS in a fixed order (reproducible).
+constexpr int RING_M = 64;
+__global__ __launch_bounds__(256) void conf_ring_kernel(const float* __restrict__ cost, const float* __restrict__ w1t,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ w2, float* __restrict__ conf, int B, int D,
+                                                        int H, int W) {
+  __shared__ float part[4][RING_M][64];
+  const int ring = 2 * W + 2 * (H - 2);
+  const int nblk = cdiv(ring, 64);
+  const int b = blockIdx.x / nblk;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int p = (blockIdx.x % nblk) * 64 + lane;
+  const bool live = p < ring;
+  if (!live) p = ring - 1;
+  int py, px;
+  if (p < W) { py = 0; px = p; }
+  else if (p < 2 * W) { py = H - 1; px = p - W; }
+  else if (p < 2 * W + (H - 2)) { py = p - 2 * W + 1; px = 0; }
+  else { py = p - 2 * W - (H - 2) + 1; px = W - 1; }
+  float acc[RING_M];
+#pragma unroll
+  for (int m = 0; m < RING_M; ++m) acc[m] = 0.f;
+  const size_t HW = (size_t)H * W;
+  const float* cb = cost + (size_t)b * D * HW;
+  const int d0 = wave * D / 4, d1 = (wave + 1) * D / 4;
+  for (int d = d0; d < d1; ++d)
+#pragma unroll 1   // (one tap's 64 weights fill the scalar registers; unrolled, 9 x 64 of them spilled)
+    for (int t = 0; t < 9; ++t) {
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? cb[(size_t)d * HW + (size_t)yy * W + xx] : 0.f;
+      const float* wv = w1t + ((size_t)d * 9 + t) * RING_M;   // wave-uniform: scalar loads
+#pragma unroll
+      for (int m = 0; m < RING_M; ++m) acc[m] = fmaf(v, wv[m], acc[m]);
+    }
+#pragma unroll
+  for (int m = 0; m < RING_M; ++m) part[wave][m][lane] = acc[m];
+  __syncthreads();
+  if (wave == 0) {
+    float logit = 0.f;
+    for (int m = 0; m < RING_M; ++m) {
+      const float s = ((part[0][m][lane] + part[1][m][lane]) + part[2][m][lane]) + part[3][m][lane];
+      logit = fmaf(fmaxf(fmaf(s, scale[m], shift[m]), 0.f), w2[m], logit);
+    }
+    if (live) conf[((size_t)b * H + py) * W + px] = 1.f / (1.f + __expf(-logit));
+  }
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+extern "C" int dmb_conf_gather_f32(const float* hq, const float* w2, float* conf, int B, int M, int Hq, int Wq, void* stream) {
+  if (!hq || !w2 || !conf || B <= 0 || M <= 0 || Hq <= 0 || Wq <= 0) return fail(DMB_EINVAL, "conf_gather: bad argument");
+  const long long total = (long long)B * 16 * Hq * Wq;
+  hipLaunchKernelGGL(conf_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hq, w2, conf, B,
+                     M, Hq, Wq);
+  return launch_status("conf_gather launch failed");
+}
+
+extern "C" int dmb_conf_ring_f32(const float* cost, const float* w1t, const float* scale, const float* shift, const float* w2,
+                                 float* conf, int B, int D, int M, int H, int W, void* stream) {
+  if (!cost || !w1t || !scale || !shift || !w2 || !conf || B <= 0 || D <= 0 || M != RING_M || H < 3 || W < 3)
+    return fail(DMB_EINVAL, "conf_ring: bad argument (64 hidden channels)");
+  const int ring = 2 * W + 2 * (H - 2);
+  hipLaunchKernelGGL(conf_ring_kernel, dim3((unsigned)(B * cdiv(ring, 64))), dim3(256), 0, (hipStream_t)stream, cost, w1t, scale,
+                     shift, w2, conf, B, D, H, W);
+  return launch_status("conf_ring launch failed");
+}
+
 extern "C" long long dmb_conf_head_packed_floats(int Cm, int D) {
   if (Cm <= 0 || D <= 0) return 0;
   const int NTT = cdiv(Cm, 32), Dpad = cdiv(D, CH_CK) * CH_CK;

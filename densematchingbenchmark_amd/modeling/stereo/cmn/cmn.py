@@ -43,6 +43,15 @@ class ConfHead(nn.Module):
 
     def forward(self, cost):
         wp, scale, shift, w2 = self._prepacked()
+        if ops.conf_head_composite_applicable(cost, self.sec_in_planes):
+            # ``cost`` is AcfNet's learned 4x up-sampling of a quarter-resolution volume (the aggregator left a note on the
+            # tensor): head o up-sampling = 16 phase-wise 3x3 convolutions of that volume, a quarter of the multiplications
+            src = ops.UpsampleSource.lookup(cost)
+            key = _versions(self.conf_net[0][0].weight, src.w8) + (self._key,)
+            if getattr(self, "_comp_key", None) != key:
+                self._comp_key = key
+                self._comp = ops.conf_head_k8s4_pack(self.conf_net[0][0].weight, src.w8, scale, shift)
+            return ops.conf_head_from_source(cost, self._comp, scale, shift, w2)
         return ops.conf_head(cost, wp, scale, shift, w2)
 
     def logits(self, cost):

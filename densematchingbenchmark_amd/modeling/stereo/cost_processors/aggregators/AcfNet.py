@@ -36,4 +36,9 @@ class AcfAggregator(PSMAggregator):
         pairs = ((cost3, self.deconv3), (cost2, self.deconv2), (cost1, self.deconv1))
         if train_fn.wants_grad(self, cost1):   # differentiable up-sampling
             return [train_fn.DeconvK8S4Fn.apply(c.squeeze(1), m.weight) for c, m in pairs]
-        return [ops.deconv3d_k8s4_c1(c.squeeze(1), m.weight.detach().view(8, 8, 8)) for c, m in pairs]
+        out = []
+        for c, m in pairs:
+            cq = c.squeeze(1)
+            cost = ops.deconv3d_k8s4_c1(cq, m.weight.detach().view(8, 8, 8))
+            out.append(ops.UpsampleSource.attach(cost, cq, m.weight))   # lets the confidence head work at quarter resolution
+        return out

@@ -785,6 +785,88 @@ def conf_head(cost, w1pack, scale, shift, w2):
     return conf
 
 
+class UpsampleSource:
+    """Side channel from AcfNet's learned up-sampling to the confidence head: the quarter-resolution volume and the
+    ConvTranspose3d(1, 1, 8, 4, 2) weight a full-resolution cost tensor was produced from.  Used only while every tensor is
+    unmodified (``_version``)."""
+
+    __slots__ = ("c", "w8", "versions")
+
+    def __init__(self, c, w8, cost):
+        self.c, self.w8 = c, w8
+        self.versions = (c._version, w8._version, w8.data_ptr(), cost._version)
+
+    @staticmethod
+    def attach(cost, c, w8):
+        cost._dmb_k8s4_source = UpsampleSource(c, w8, cost)
+        return cost
+
+    @staticmethod
+    def lookup(cost):
+        src = getattr(cost, "_dmb_k8s4_source", None)
+        if src is None or src.versions != (src.c._version, src.w8._version, src.w8.data_ptr(), cost._version):
+            return None
+        B, D, H, W = cost.shape
+        if tuple(src.c.shape) != (B, D // 4, H // 4, W // 4) or D % 4 or H % 4 or W % 4:
+            return None
+        return src
+
+
+_conf_composite = True
+
+
+def set_conf_head_composite(flag):
+    """False forces the confidence head's 3x3 convolution on the up-sampled volume itself everywhere."""
+    global _conf_composite
+    _conf_composite = bool(flag)
+
+
+def conf_head_k8s4_pack(w1, w8, scale, shift):
+    """Composed weights of (3x3 head convolution) o (k8 s4 p2 transposed convolution), see csrc/confhead.hip:
+    K[(by, bx, m), z, ty, tx] = sum_{dy, dx, kz} w1[m, 4z - 2 + kz, dy, dx] * w8[kz, by + dy + 5 - 4 ty, bx + dx + 5 - 4 tx]
+    (indices outside 0..7 / 0..D-1 contribute nothing), summed in FP64 and rounded once; packed for dmb_conv2d_f32 in launches
+    of 128 output channels (two phases x M = 64), with the folded BatchNorm affine tiled per launch."""
+    M, D = w1.shape[0], w1.shape[1]
+    Dq = D // 4
+    dev = w1.device
+    w1d = torch.nn.functional.pad(w1.detach().double(), (0, 0, 0, 0, 2, 2))        # D axis: index 4z + kz <-> D = 4z - 2 + kz
+    w1g = w1d.unfold(1, 8, 4)                                                        # [M, Dq, 3(dy), 3(dx), 8(kz)]
+    sel = torch.zeros((4, 3, 3, 8), dtype=torch.float64, device=dev)               # [phase, t, d, k]: k == phase + d + 5 - 4 t
+    for b in range(4):
+        for t in range(3):
+            for d in range(3):
+                k = b + d + 5 - 4 * t
+                if 0 <= k <= 7:
+                    sel[b, t, d, k] = 1.0
+    K = torch.einsum("mzdxk,kpq,btdp,euxq->bemztu", w1g, w8.detach().double().view(8, 8, 8), sel, sel)
+    K = K.reshape(16 * M, Dq, 3, 3).float().contiguous()
+    per = 128 // M                                                                   # phases per launch
+    packs = [pack_conv2d_weights(K[i * 128:(i + 1) * 128].contiguous()) for i in range(16 * M // 128)]
+    return {"packs": packs, "scale": scale.repeat(per).contiguous(), "shift": shift.repeat(per).contiguous(), "M": M,
+            "w1t": w1.detach().float().permute(1, 2, 3, 0).contiguous()}
+
+
+def conf_head_composite_applicable(cost, M):
+    return _conf_composite and M == 64 and UpsampleSource.lookup(cost) is not None and cost.shape[3] % 16 == 0
+
+
+def conf_head_from_source(cost, comp, scale, shift, w2):
+    """The confidence map of ``cost`` (which carries an UpsampleSource) through the composed quarter-resolution form."""
+    lib = _lib.load()
+    src = UpsampleSource.lookup(cost)
+    c = _f32c(src.c, "quarter-resolution cost")
+    B, Dq, Hq, Wq = c.shape
+    M = comp["M"]
+    hq = torch.empty((B, 16 * M, Hq, Wq), dtype=torch.float32, device=c.device)
+    for i, wp in enumerate(comp["packs"]):
+        conv2d(c, wp, 128, 3, scale=comp["scale"], shift=comp["shift"], relu=True, out=hq, out_ch_offset=128 * i)
+    conf = torch.empty((B, 1, 4 * Hq, 4 * Wq), dtype=torch.float32, device=c.device)
+    check(lib.dmb_conf_gather_f32(dev_ptr(hq), dev_ptr(w2), dev_ptr(conf), B, M, Hq, Wq, stream_ptr(c.device)), "dmb_conf_gather_f32")
+    check(lib.dmb_conf_ring_f32(dev_ptr(cost), dev_ptr(comp["w1t"]), dev_ptr(scale), dev_ptr(shift), dev_ptr(w2), dev_ptr(conf),
+                                B, 4 * Dq, M, 4 * Hq, 4 * Wq, stream_ptr(c.device)), "dmb_conf_ring_f32")
+    return conf
+
+
 def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
     """acc: float64[6] device tensor updated in place; est/gt: [B, 1, Hp, Wp]."""
     lib = _lib.load()

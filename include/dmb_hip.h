@@ -208,6 +208,18 @@ int dmb_conf_head_pack_weights_f32(const float* w1, float* w1pack, int Cm, int D
 int dmb_conf_head_f32(const float* cost, const float* w1pack, const float* scale, const float* shift,
                       const float* w2, float* conf, int B, int D, int Cm, int H, int W, void* stream);
 
+/* The same head when `cost` is AcfNet's learned 4x up-sampling (ConvTranspose3d(1, 1, 8, 4, 2), aggregators/AcfNet.py:
+ * 55-57,81-83) of a quarter-resolution volume c [B, Dq, Hq, Wq]: the head's 3x3 convolution composed with the up-sampling
+ * is, per output phase (Y mod 4, X mod 4), a 3x3 convolution of c (Dq channels) -- 4x fewer multiplications, run on
+ * dmb_conv2d_f32 with the composed weights (host side: ops.conf_head_k8s4_pack) into hq [B, 16*M, Hq, Wq], channel =
+ * (phase_y*4 + phase_x)*M + m, BatchNorm + ReLU applied.
+ * dmb_conf_gather_f32: conf[b, 0, 4y'+py, 4x'+px] = sigmoid(sum_m hq[b, (py*4+px)*M + m, y', x'] * w2[m]).
+ * dmb_conf_ring_f32: the outermost pixel ring of conf recomputed directly from the up-sampled volume cost [B, D, H, W]
+ *   (there the head zero-pads the volume, which the composed form cannot see); w1t = w1 transposed to [D, 3, 3, M], M = 64. */
+int dmb_conf_gather_f32(const float* hq, const float* w2, float* conf, int B, int M, int Hq, int Wq, void* stream);
+int dmb_conf_ring_f32(const float* cost, const float* w1t, const float* scale, const float* shift, const float* w2,
+                      float* conf, int B, int D, int M, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Evaluation accumulator (data/datasets/evaluation/stereo/pixel_error.py:6-73 + eval.py:12-31 crop +
  * tools/test.py:304-307 averaging).  For every image b: crop est/gt [Hp, Wp] to rows [Hp-H0, Hp) and

@@ -680,3 +680,32 @@ def test_catconv_first_layer_on_a_difference_volume(dev, B, C, Co, D, H, W):
     ref = F.relu(F.conv3d(vol.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
     got = ops.catconv_first(L.to(dev), R.to(dev), D, ops.catconv_pack(w.to(dev), "dif"), sc.to(dev), sh.to(dev), True).cpu()
     assert got.shape == ref.shape and (got.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("B,Hq,Wq", [(2, 5, 8), (1, 9, 12)])
+def test_conf_head_composed_with_learned_upsampling(dev, B, Hq, Wq):
+    """AcfNet's confidence head on a cost volume that is the learned 4x up-sampling of a quarter-resolution volume: the
+    composed quarter-resolution form (16 phase-wise 3x3 convolutions of that volume + 1x1 + sigmoid, outer pixel ring
+    directly) against the head evaluated on the up-sampled volume itself by the CPU oracle and by the direct kernel."""
+    ops = _ops()
+    Dq, M = 48, 64
+    c = _rand((B, Dq, Hq, Wq), 401)
+    w8 = _rand((1, 1, 8, 8, 8), 402, 0.2)
+    w1 = _rand((M, 4 * Dq, 3, 3), 403, 1.0 / math.sqrt(4 * Dq * 9 / 4))
+    w2 = _rand((M,), 404, 0.3)
+    sc, sh = _affine(M, 405)
+    cost_ref = F.conv_transpose3d(c.unsqueeze(1).double(), w8.double(), stride=4, padding=2).squeeze(1)
+    hid = F.relu(F.conv2d(cost_ref, w1.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    want = torch.sigmoid((hid * w2.double().view(1, -1, 1, 1)).sum(1, keepdim=True))
+    cq = c.to(dev)
+    w8d = w8.to(dev)
+    cost = ops.deconv3d_k8s4_c1(cq, w8d.view(8, 8, 8))
+    ops.UpsampleSource.attach(cost, cq, w8d)
+    assert ops.conf_head_composite_applicable(cost, M)
+    comp = ops.conf_head_k8s4_pack(w1.to(dev), w8d, sc.to(dev), sh.to(dev))
+    got = ops.conf_head_from_source(cost, comp, sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
+    direct = ops.conf_head(cost, ops.pack_conf_head_weights(w1.to(dev)), sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() <= 5e-6 and (direct.double() - want).abs().max().item() <= 5e-6
+    cost.add_(0.0)                                        # a modified tensor no longer matches its note
+    assert not ops.conf_head_composite_applicable(cost, M)
