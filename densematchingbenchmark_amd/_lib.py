@@ -41,6 +41,7 @@ SIGNATURES = {
     "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 7 + [_P]),
     "dmb_trilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),
     "dmb_deconv3d_k8s4_c1_f32": (_c_int, [_P, _P, _P] + [_c_int] * 4 + [_P]),
+    "dmb_deconv3d_k8s4_c1_soft_argmin_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 4 + [_c_float, _HF, _P]),
     "dmb_soft_argmin_f32": (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _HF, _P]),
     "dmb_soft_argmin_sampled_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _P]),
     "dmb_local_soft_argmin_f32": (_c_int, [_P, _P, _P] + [_c_int] * 8 + [_c_float, _P]),

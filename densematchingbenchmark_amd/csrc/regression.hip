@@ -662,6 +662,143 @@ extern "C" int dmb_deconv3d_k8s4_c1_f32(const float* x, const float* w, float* y
   return launch_status("deconv_k8s4 launch failed");
 }
 
+namespace dmb {
+
+// The same learned up-sampling as deconv_k8s4_kernel, as a z-column walk (the shape of trilinear_zcol_kernel): a thread owns
+// the four outputs 4q .. 4q + 3 of one output row and walks the Do = 4 D output planes.  The row's y phase -- hence the two
+// kh taps -- is uniform over the workgroup and the plane's two kd taps over the loop iteration, so the 32 weights of an output
+// plane are scalar loads; the six input values of a (plane, row) pair are kept for the two input planes in use, and the next
+// input plane's are fetched one step AHEAD (a load awaited between two stores would drain every store before it).  With
+// WITH_DISP the logits are folded into the soft-argmin exactly as soft_argmin_kernel folds them (same blocks, same order):
+// the regression costs no second pass over the 1.6 GB volume.  Per-output accumulation order = deconv_k8s4_kernel's.
+template <bool WITH_DISP>
+__global__ __launch_bounds__(256) void deconv_k8s4_zcol_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ y, float* __restrict__ disp, int D, int H,
+                                                               int W, float alpha, DispVal dv) {
+  const int Wo = 4 * W, Ho = 4 * H, Do = 4 * D;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= W) return;
+  const int yo = blockIdx.y, b = blockIdx.z;
+  const int py = (yo + 2) & 3, iy = (yo + 2) >> 2;   // kh = py uses input row iy, kh = py + 4 uses iy - 1
+  const float* xb = x + (size_t)b * D * H * W;
+  const bool rowok[2] = {iy < H, iy - 1 >= 0};
+  // v[c][3]: input values (q - 1, q, q + 1) of row iy - c of ONE input plane
+  auto fetch = [&](int zi, float (&v)[2][3]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bool ok = zi >= 0 && zi < D && rowok[c];
+      const float* row = xb + ((size_t)(ok ? zi : 0) * H + (ok ? iy - c : 0)) * W;
+      v[c][0] = (ok && q > 0) ? row[q - 1] : 0.f;
+      v[c][1] = ok ? row[q] : 0.f;
+      v[c][2] = (ok && q + 1 < W) ? row[q + 1] : 0.f;
+    }
+  };
+  float cur[2][3], prev[2][3], nxt[2][3];   // input planes iz, iz - 1 and the prefetched iz + 1
+  int iz_cur = 0;                           // plane zo = 0: iz = (0 + 2) >> 2 = 0
+  fetch(0, cur);
+  fetch(-1, prev);
+  fetch(1, nxt);
+  SoftState st[4];
+  float vb[4][SA_BLK];
+  if constexpr (WITH_DISP) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j].init();
+  }
+  float* yp = y + (((size_t)b * Do) * Ho + yo) * Wo + 4 * q;
+  const size_t ostride = (size_t)Ho * Wo;
+  auto out_plane = [&](int zo, float (&o)[4]) {
+    const int pz = (zo + 2) & 3, iz = (zo + 2) >> 2;
+    if (iz != iz_cur) {   // advances by one every four planes (uniform)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          prev[c][k] = cur[c][k];
+          cur[c][k] = nxt[c][k];
+        }
+      iz_cur = iz;
+      fetch(iz + 1, nxt);
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {   // ascending kd: kd = pz uses input iz, kd = pz + 4 uses iz - 1
+      const int kd = pz + 4 * a, zi = iz - a;
+      if (zi < 0 || zi >= D) continue;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (!rowok[c]) continue;
+        const float* wr = w + (kd * 8 + py + 4 * c) * 8;   // uniform: scalar loads
+        const float xm = a ? prev[c][0] : cur[c][0], x0 = a ? prev[c][1] : cur[c][1], xp = a ? prev[c][2] : cur[c][2];
+        acc[0] = fmaf(x0, wr[2], acc[0]);
+        acc[0] = fmaf(xm, wr[6], acc[0]);
+        acc[1] = fmaf(x0, wr[3], acc[1]);
+        acc[1] = fmaf(xm, wr[7], acc[1]);
+        acc[2] = fmaf(xp, wr[0], acc[2]);
+        acc[2] = fmaf(x0, wr[4], acc[2]);
+        acc[3] = fmaf(xp, wr[1], acc[3]);
+        acc[3] = fmaf(x0, wr[5], acc[3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = acc[j];
+    __builtin_nontemporal_store(f32x4_t{acc[0], acc[1], acc[2], acc[3]}, reinterpret_cast<f32x4_t*>(yp));   // streaming (1.6 GB)
+    yp += ostride;
+  };
+  if constexpr (WITH_DISP) {
+    const int full = Do - Do % SA_BLK;
+    for (int zb = 0; zb < full; zb += SA_BLK) {
+      float d[SA_BLK];
+#pragma unroll
+      for (int i = 0; i < SA_BLK; ++i) {
+        float o[4];
+        out_plane(zb + i, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vb[j][i] = o[j] * alpha;
+        d[i] = dv.v[zb + i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st[j].template fold<SA_BLK>(vb[j], d);
+    }
+    for (int zo = full; zo < Do; ++zo) {
+      float o[4];
+      out_plane(zo, o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v1[1] = {o[j] * alpha};
+        float d1[1] = {dv.v[zo]};
+        st[j].template fold<1>(v1, d1);
+      }
+    }
+    float* dp = disp + ((size_t)b * Ho + yo) * Wo + 4 * q;
+    *reinterpret_cast<float4*>(dp) = make_float4(st[0].result(), st[1].result(), st[2].result(), st[3].result());
+  } else {
+    for (int zo = 0; zo < Do; ++zo) {
+      float o[4];
+      out_plane(zo, o);
+    }
+  }
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+extern "C" int dmb_deconv3d_k8s4_c1_soft_argmin_f32(const float* x, const float* w, float* y, float* disp, int B, int D, int H,
+                                                    int W, float alpha, const float* disp_sample_host, void* stream) {
+  if (!x || !w || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv_k8s4_soft_argmin: bad argument");
+  if (4 * H > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "deconv_k8s4_soft_argmin: grid too large");
+  dim3 grid(cdiv(W, 256), 4 * H, B);
+  if (disp) {
+    DispVal dv;
+    if (int e = fill_samples(disp_sample_host, 4 * D, dv)) return e;
+    hipLaunchKernelGGL(deconv_k8s4_zcol_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, w, y, disp, D, H, W, alpha, dv);
+  } else {
+    DispVal dv = {};
+    hipLaunchKernelGGL(deconv_k8s4_zcol_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, w, y, disp, D, H, W, alpha, dv);
+  }
+  return launch_status("deconv_k8s4_soft_argmin launch failed");
+}
+
 extern "C" int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* workspace, int B, int Hp,
                                  int Wp, int H0, int W0, float lb, float ub, void* stream) {
   if (!est || !gt || !acc || !workspace || B <= 0 || B > 65535 || Hp <= 0 || Wp <= 0 || H0 <= 0 || W0 <= 0)

@@ -36,9 +36,16 @@ class AcfAggregator(PSMAggregator):
         pairs = ((cost3, self.deconv3), (cost2, self.deconv2), (cost1, self.deconv1))
         if train_fn.wants_grad(self, cost1):   # differentiable up-sampling
             return [train_fn.DeconvK8S4Fn.apply(c.squeeze(1), m.weight) for c, m in pairs]
+        # as in PSMAggregator: the up-sampling kernel also regresses the standard soft-argmin of the volume it writes and
+        # leaves it as a hint on the tensor (bit-identical to the predictor's own pass, which then is not needed)
+        vals = ops.disp_sample_values(self.max_disp, 0, 1)
         out = []
         for c, m in pairs:
             cq = c.squeeze(1)
-            cost = ops.deconv3d_k8s4_c1(cq, m.weight.detach().view(8, 8, 8))
+            if W % 4 == 0:
+                cost, disp = ops.deconv3d_k8s4_c1_soft_argmin(cq, m.weight.detach().view(8, 8, 8), vals, 1.0)
+                ops.RegressionHint.attach(cost, vals, 1.0, disp)
+            else:
+                cost = ops.deconv3d_k8s4_c1(cq, m.weight.detach().view(8, 8, 8))
             out.append(ops.UpsampleSource.attach(cost, cq, m.weight))   # lets the confidence head work at quarter resolution
         return out

@@ -738,6 +738,20 @@ def trilinear_ac_soft_argmin(x, out_size, disp_values, alpha=1.0):
     return y, disp
 
 
+def deconv3d_k8s4_c1_soft_argmin(x, w, disp_values=None, alpha=1.0):
+    """AcfNet's learned 4x up-sampling (ConvTranspose3d(1, 1, 8, 4, 2)) of x [B, D, H, W] AND, when ``disp_values`` is given,
+    the soft-argmin (normalize=True) of the volume it writes, in one pass: returns (cost [B, 4D, 4H, 4W], disp or None)."""
+    lib = _lib.load()
+    x, w = _f32c(x, "x"), _f32c(w, "weight")
+    B, D, H, W = x.shape
+    y = torch.empty((B, 4 * D, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
+    disp = torch.empty((B, 1, 4 * H, 4 * W), dtype=torch.float32, device=x.device) if disp_values is not None else None
+    check(lib.dmb_deconv3d_k8s4_c1_soft_argmin_f32(dev_ptr(x), dev_ptr(w), dev_ptr(y), dev_ptr(disp, allow_none=True), B, D, H, W,
+                                                   float(alpha), host_floats(disp_values) if disp_values is not None else None,
+                                                   stream_ptr(x.device)), "dmb_deconv3d_k8s4_c1_soft_argmin_f32")
+    return y, disp
+
+
 class RegressionHint:
     """Side channel from a cost producer to the soft-argmin predictors: a disparity map that the producing kernel
     already regressed from exactly this cost tensor (same sample values, alpha, normalize=True).  The predictor uses it

@@ -160,6 +160,12 @@ int dmb_trilinear_ac_f32(const float* x, float* y, int B, int Di, int Hi, int Wi
 int dmb_deconv3d_k8s4_c1_f32(const float* x, const float* w, float* y, int B, int D, int H, int W,
                              void* stream);
 
+/* The same up-sampling with the standard soft-argmin of the volume it writes folded in (what dmb_trilinear_ac_soft_argmin_f32 is
+ * to the tri-linear up-sampling): y [B, 4D, 4H, 4W] and disp [B, 1, 4H, 4W] = soft_argmin(y, samples, alpha, normalize) bit
+ * for bit, one pass.  disp may be NULL (up-sampling only, z-column form).  Per-output arithmetic = dmb_deconv3d_k8s4_c1_f32. */
+int dmb_deconv3d_k8s4_c1_soft_argmin_f32(const float* x, const float* w, float* y, float* disp, int B, int D, int H, int W,
+                                         float alpha, const float* disp_sample_host, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Disparity regression
  * ---------------------------------------------------------------------------------------- */

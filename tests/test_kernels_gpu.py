@@ -709,3 +709,20 @@ def test_conf_head_composed_with_learned_upsampling(dev, B, Hq, Wq):
     assert (got.double() - want).abs().max().item() <= 5e-6 and (direct.double() - want).abs().max().item() <= 5e-6
     cost.add_(0.0)                                        # a modified tensor no longer matches its note
     assert not ops.conf_head_composite_applicable(cost, M)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 5, 12), (1, 48, 9, 16), (1, 3, 7, 260)])
+def test_deconv_k8s4_zcol_with_regression_is_bit_identical(dev, shape):
+    """The z-column form of AcfNet's learned up-sampling: its volume equals dmb_deconv3d_k8s4_c1_f32's bit for bit (same
+    per-output fma order), the folded disparity equals soft_argmin of that volume bit for bit."""
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, D, H, W), 501).to(dev)
+    w = _rand((8, 8, 8), 502, 0.2).to(dev)
+    vals = ops.disp_sample_values(4 * D, 0, 1)
+    ref = ops.deconv3d_k8s4_c1(x, w)
+    cost, disp = ops.deconv3d_k8s4_c1_soft_argmin(x, w, vals, 1.0)
+    assert torch.equal(cost, ref)
+    assert torch.equal(disp, ops.soft_argmin(ref, vals, 1.0, True))
+    only, none = ops.deconv3d_k8s4_c1_soft_argmin(x, w, None)
+    assert none is None and torch.equal(only, ref)
