@@ -348,8 +348,10 @@ def main():
                                                                         ", fused up-sample+regression" if fused else ""),
                        "pairs_per_step_per_gpu": B, "sharding": "pair i -> rank i mod world; 1 all-reduce of the EPE accumulator",
                        "costs_materialised": not fused, "conv3d_mode": args.conv3d_mode},
-            "first_layer": "2-D maps, volume not materialised (csrc/catconv.hip)" if (ops.cat_fusion() and ptype == "Concatenation"
-                                                                                       and not fused) else "3-D convolution",
+            "first_layer": ("3-D convolution on the materialised volume" if (fused or not ops.cat_fusion()) else
+                            {"Concatenation": "2-D maps, volume not materialised (csrc/catconv.hip)",
+                             "Difference": "2-D maps, volume not materialised (csrc/catconv.hip)",
+                             "Correlation": "correlation channels 3-D, concat channels as 2-D maps (csrc/catconv.hip)"}.get(ptype, "3-D convolution")),
             "roofline": {"kernel": "conv3d_s1_kernel<32,32> (k3 s1 32->32, [%d,32,%d,%d,%d])" % (B, d4, h4, w4),
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,

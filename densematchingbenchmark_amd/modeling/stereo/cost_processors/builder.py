@@ -7,7 +7,7 @@ from ..layers import train_fn
 from .aggregators import build_cost_aggregator
 from .utils.cat_fms import CAT_FUNCS, LazyCatVolume, cat_fms
 from .utils.dif_fms import DIF_FUNCS, dif_fms
-from .utils.gwc_fms import COR_FUNCS
+from .utils.gwc_fms import COR_FUNCS, LazyGwcCatVolume, gwc_cat_fms
 
 
 class _VolumeThenAggregate(nn.Module):
@@ -29,6 +29,9 @@ class _VolumeThenAggregate(nn.Module):
             # eval mode: the aggregator's first convolution consumes the volume's description (csrc/catconv.hip); the raw
             # volume is not part of the result contract (general_stereo_model.py:82-85) and is never written
             raw_cost = LazyCatVolume(ref_fms, tgt_fms, kind="cat" if self.vol_func is cat_fms else "dif", **self.default_args)
+        elif (self.vol_func is gwc_cat_fms and getattr(self.aggregator, "accepts_lazy_cat", False) and ops.cat_fusion()
+              and not train_fn.wants_grad(self, *ref_fms, *tgt_fms)):
+            raw_cost = LazyGwcCatVolume(ref_fms, tgt_fms, **self.default_args)   # concat channels as 2-D maps, correlation channels 3-D
         else:
             raw_cost = self.vol_func(ref_fms, tgt_fms, disp_sample=disp_sample, **self.default_args)
         return self.aggregator(raw_cost)

@@ -40,6 +40,33 @@ def gwc_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1,
     return out
 
 
+class LazyGwcCatVolume:
+    """The "gwc + concat" volume as a DESCRIPTION (eval mode, built by the cost processor): its concat channels have the
+    structure csrc/catconv.hip exploits (2-D maps instead of a 3-D convolution over them), its correlation channels do not
+    and are materialised on their own.  ``materialize()`` gives exactly gwc_cat_fms's tensor."""
+
+    kind = "gwc_cat"
+
+    def __init__(self, reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, num_groups=40, **unused):
+        (self.lg, self.lc), (self.rg, self.rc) = reference_fm, target_fm
+        self.args = dict(max_disp=max_disp, start_disp=start_disp, dilation=dilation, num_groups=num_groups)
+        self.num_groups = num_groups
+        self.reference_fm, self.target_fm = self.lc.float(), self.rc.float()       # the concat part
+        self.disp_idx = ops.disp_index_list(max_disp, start_disp, dilation)
+        B, _, H, W = self.lg.shape
+        self.shape = torch.Size((B, num_groups + 2 * self.lc.shape[1], len(self.disp_idx), H, W))
+        self.device, self.dtype, self.requires_grad = self.lg.device, torch.float32, False
+
+    def dim(self):
+        return 5
+
+    def correlation_part(self):
+        return ops.gwc_fms(self.lg.float(), self.rg.float(), self.disp_idx, self.num_groups)
+
+    def materialize(self):
+        return gwc_cat_fms((self.lg, self.lc), (self.rg, self.rc), **self.args)
+
+
 COR_FUNCS = dict(
     default=correlation1d_cost,
     gwc=gwc_fms,

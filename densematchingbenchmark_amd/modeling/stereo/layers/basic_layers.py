@@ -90,7 +90,24 @@ class FusedConv3d(nn.Sequential):
         """``residual`` is added BEFORE the activation (hourglass.py:67-81), ``skip`` AFTER it (GC-Net,
         aggregators/GCNet.py:108-116: ``layer34(cost33 + cost29)`` -- the add runs in layer33's epilogue)."""
         act = self.has_relu if relu is None else relu
-        if hasattr(x, "materialize"):   # LazyCatVolume: the concatenation volume as a description (eval mode only)
+        if getattr(x, "kind", None) == "gwc_cat":   # LazyGwcCatVolume: correlation channels 3-D, concat channels as 2-D maps
+            G = x.num_groups
+            if (residual is None and skip is None and not self.transposed and self.stride == 1 and not self.training
+                    and x.shape[1] == self.in_planes and G % 2 == 0 and self.out_planes == 32
+                    and ops.catconv_applicable(x.reference_fm, x.target_fm, x.disp_idx, self.out_planes)):
+                key = _versions(self[0].weight)
+                if getattr(self, "_gwc_key", None) != key:
+                    w = self[0].weight.detach()
+                    self._gwc_key = key
+                    self._gwc = (ops.pack_conv3d_weights(w[:, :G].contiguous()), ops.catconv_pack(w[:, G:].contiguous(), "cat"))
+                wp_g, packs = self._gwc
+                _, scale, shift = self._prepacked()
+                # convolution is linear in its input channels: relu(scale * (conv(gwc) + maps(cat)) + shift), the maps' part
+                # entering the 3-D kernel's epilogue as its residual operand, already scaled
+                part = ops.catconv_first(x.reference_fm, x.target_fm, len(x.disp_idx), packs, scale, None, False)
+                return ops.conv3d_k3(x.correlation_part(), wp_g, self.out_planes, scale, shift, part, 1, act)
+            x = x.materialize()
+        elif hasattr(x, "materialize"):   # LazyCatVolume: the concatenation volume as a description (eval mode only)
             if (residual is None and skip is None and not self.transposed and self.stride == 1 and not self.training
                     and x.shape[1] == self.in_planes
                     and ops.catconv_applicable(x.reference_fm, x.target_fm, x.disp_idx, self.out_planes)):
