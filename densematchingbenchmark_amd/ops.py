@@ -835,13 +835,13 @@ def set_conf_head_composite(flag):
     _conf_composite = bool(flag)
 
 
-def conf_head_k8s4_pack(w1, w8, scale, shift):
+def conf_head_k8s4_weights(w1, w8):
     """Composed weights of (3x3 head convolution) o (k8 s4 p2 transposed convolution), see csrc/confhead.hip:
     K[(by, bx, m), z, ty, tx] = sum_{dy, dx, kz} w1[m, 4z - 2 + kz, dy, dx] * w8[kz, by + dy + 5 - 4 ty, bx + dx + 5 - 4 tx]
-    (indices outside 0..7 / 0..D-1 contribute nothing), summed in FP64 and rounded once; packed for dmb_conv2d_f32 in launches
-    of 128 output channels (two phases x M = 64), with the folded BatchNorm affine tiled per launch."""
-    M, D = w1.shape[0], w1.shape[1]
-    Dq = D // 4
+    (indices outside 0..7 / 0..D-1 contribute nothing), summed in FP64 and rounded once -> [16 * M, D / 4, 3, 3] FP32,
+    output channel = (by * 4 + bx) * M + m.  Pure tensor algebra (runs on any device; pinned on CPU by
+    tests/test_host_logic.py against the plain loop nest)."""
+    M = w1.shape[0]
     dev = w1.device
     w1d = torch.nn.functional.pad(w1.detach().double(), (0, 0, 0, 0, 2, 2))        # D axis: index 4z + kz <-> D = 4z - 2 + kz
     w1g = w1d.unfold(1, 8, 4)                                                        # [M, Dq, 3(dy), 3(dx), 8(kz)]
@@ -853,7 +853,14 @@ def conf_head_k8s4_pack(w1, w8, scale, shift):
                 if 0 <= k <= 7:
                     sel[b, t, d, k] = 1.0
     K = torch.einsum("mzdxk,kpq,btdp,euxq->bemztu", w1g, w8.detach().double().view(8, 8, 8), sel, sel)
-    K = K.reshape(16 * M, Dq, 3, 3).float().contiguous()
+    return K.reshape(16 * M, w1.shape[1] // 4, 3, 3).float().contiguous()
+
+
+def conf_head_k8s4_pack(w1, w8, scale, shift):
+    """conf_head_k8s4_weights packed for dmb_conv2d_f32 in launches of 128 output channels (two phases x M = 64), with the
+    folded BatchNorm affine tiled per launch, plus w1 transposed for the pixel-ring kernel."""
+    M = w1.shape[0]
+    K = conf_head_k8s4_weights(w1, w8)
     per = 128 // M                                                                   # phases per launch
     packs = [pack_conv2d_weights(K[i * 128:(i + 1) * 128].contiguous()) for i in range(16 * M // 128)]
     return {"packs": packs, "scale": scale.repeat(per).contiguous(), "shift": shift.repeat(per).contiguous(), "M": M,

@@ -105,6 +105,46 @@ def correlation1d_cost(reference_fm, target_fm, max_disp=192, start_disp=0, dila
     return F.leaky_relu(out, negative_slope=0.1)
 
 
+def first_layer_from_maps(reference_fm, target_fm, weight, max_disp, kind="cat"):
+    """conv3d(V, weight, padding=1) for V = cat_fms(L, R) (or dif_fms: ``kind="dif"``) with unit disparity step, WITHOUT V:
+    the decomposition csrc/catconv.hip executes, restated with torch's 2-D convolutions (checker for that file; the
+    arithmetic it must reproduce is cat_fms.py:7-48 / dif_fms.py:7-46 followed by aggregators/PSMNet.py:31-33,58).
+        out[z] = sum_{dz: 0 <= z+dz-1 < D} ( F_{dz, m}[y, x] + H_dz[y, x - (z + dz - 1)] ),  m = max(0, dz - (x - z))
+    F_{dz, m} = 3x3 conv of L with weight[:, :C, dz] restricted to taps dx >= m; H_dz = 3x3 conv of R (zero-extended to
+    the left: that IS the mask x >= z' of the right half) with weight[:, C:, dz]; at x = W-1 without the dx = 2 tap."""
+    L, R, w = reference_fm, target_fm, weight
+    B, C, H, W = L.shape
+    D = max_disp
+    wl, wr = (w, -w) if kind == "dif" else (w[:, :C], w[:, C:])
+    ext = D + 2
+
+    def taps(k, lo, hi):      # keep dx in [lo, hi)
+        k = k.clone()
+        k[..., :lo] = 0
+        k[..., hi:] = 0
+        return k
+
+    Rz = F.pad(R, (ext, 0))                                                       # column j <-> n = j - ext
+    Fm = [[F.conv2d(L, taps(wl[:, :, dz], m, 3), padding=1) for dz in range(3)] for m in range(3)]
+    Hc = [F.conv2d(Rz, wr[:, :, dz], padding=1) for dz in range(3)]
+    Hd = [F.conv2d(Rz, taps(wr[:, :, dz], 0, 2), padding=1) for dz in range(3)]
+    x = torch.arange(W)
+    out = L.new_zeros((B, w.shape[0], D, H, W))
+    for z in range(D):
+        for dz in range(3):
+            zp = z + dz - 1
+            if zp < 0 or zp >= D:
+                continue
+            g = Hc[dz][..., x - zp + ext].clone()
+            g[..., W - 1] = Hd[dz][..., W - 1 - zp + ext]
+            m = (dz - (x - z)).clamp(min=0)
+            f = torch.zeros_like(g)
+            for mm in range(3):
+                f = torch.where(m == mm, Fm[mm][dz], f)
+            out[:, :, z] += f + g
+    return out
+
+
 def gwc_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, num_groups=40, disp_sample=None):
     """Group-wise correlation (GwcNet, "gwc" volume).  NOT IN THE REFERENCE -- parity unpinned; spec SURVEY 8-a4:
     mean over the C/G channels of a group of L[c, y, x] * R[c, y, x - d], zero outside the valid columns, using the

@@ -282,3 +282,25 @@ def test_flat_gradients_views():
     assert not flat.attached()
     flat.zero_()
     assert flat.attached() and flat.flat.abs().sum().item() == 0
+
+
+def test_confidence_head_composed_with_upsampling_weights():
+    """ops.conf_head_k8s4_weights (pure tensor algebra, CPU) against the definition: for interior pixels, the head's 3x3
+    convolution of ConvTranspose3d(1, 1, 8, 4, 2)(c) equals the phase-wise 3x3 convolution of c with the composed weights
+    (cmn/cmn.py:21-27 o aggregators/AcfNet.py:55-57,81-83)."""
+    import torch.nn.functional as F
+    from densematchingbenchmark_amd import ops
+    g = torch.Generator().manual_seed(3)
+    Dq, Hq, Wq, M = 3, 5, 6, 4
+    c = torch.randn((1, 1, Dq, Hq, Wq), generator=g, dtype=torch.float64)
+    w8 = torch.randn((1, 1, 8, 8, 8), generator=g, dtype=torch.float64)
+    w1 = torch.randn((M, 4 * Dq, 3, 3), generator=g, dtype=torch.float64)
+    hidden = F.conv2d(F.conv_transpose3d(c, w8, stride=4, padding=2).squeeze(1), w1, padding=1)      # [1, M, 4Hq, 4Wq]
+    K = ops.conf_head_k8s4_weights(w1.float(), w8.float())
+    assert K.shape == (16 * M, Dq, 3, 3) and K.dtype == torch.float32
+    hq = F.conv2d(c.squeeze(1), K.double(), padding=1).reshape(1, 4, 4, M, Hq, Wq)                   # [by, bx, m]
+    comp = hq.permute(0, 3, 4, 1, 5, 2).reshape(1, M, 4 * Hq, 4 * Wq)
+    inner = (slice(None), slice(None), slice(1, -1), slice(1, -1))
+    assert (comp[inner] - hidden[inner]).abs().max().item() <= 1e-5 * hidden.abs().max().item()
+    # the outermost pixel ring is where the two differ (the head zero-pads the up-sampled volume): conf_ring_kernel's job
+    assert (comp - hidden).abs().max().item() > 1e-3

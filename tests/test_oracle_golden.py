@@ -473,3 +473,20 @@ def test_oracle_correlation1d_cost_is_the_samplers_published_semantics():
     got = O.correlation1d_cost(L, R, D)
     assert got.shape == (B, D, H, W) and torch.allclose(got, want, atol=1e-6)
     assert (got[:, :, :, 0] == torch.nn.functional.leaky_relu(torch.cat([torch.zeros(B, D - 1, H), (L[..., 0] * R[..., 0]).sum(1, keepdim=True)], 1), 0.1)).all()
+
+
+@pytest.mark.parametrize("kind", ["cat", "dif"])
+def test_first_layer_from_maps_is_the_3d_convolution_of_the_volume(kind):
+    """The algebra csrc/catconv.hip rests on, on CPU in FP64: the aggregator's first convolution applied to cat_fms's (or
+    dif_fms's) volume equals the sum of 2-D maps of the two feature maps -- every border included (z = 0 / D-1, the columns
+    next to x == z, x == 0, x == W-1, the image's first and last rows)."""
+    B, C, H, W, D, Co = 2, 4, 7, 19, 6, 5
+    L, R = rand((B, C, H, W), 11).double(), rand((B, C, H, W), 12).double()
+    w = rand((Co, 2 * C if kind == "cat" else C, 3, 3, 3), 13).double()
+    vol = O.cat_fms(L.float(), R.float(), D, 0, 1).double()          # copies: exact
+    if kind == "dif":                                                 # L - R in FP64 (the oracle's dif_fms rounds it to FP32)
+        vol = vol[:, :C] - vol[:, C:]
+        assert (vol.float() - O.dif_fms(L.float(), R.float(), D, 0, 1)).abs().max().item() <= 1e-6
+    want = torch.nn.functional.conv3d(vol, w, padding=1)
+    got = O.first_layer_from_maps(L, R, w, D, kind)
+    assert got.shape == want.shape and (got - want).abs().max().item() <= 1e-12
