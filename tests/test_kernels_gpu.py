@@ -726,3 +726,28 @@ def test_deconv_k8s4_zcol_with_regression_is_bit_identical(dev, shape):
     assert torch.equal(disp, ops.soft_argmin(ref, vals, 1.0, True))
     only, none = ops.deconv3d_k8s4_c1_soft_argmin(x, w, None)
     assert none is None and torch.equal(only, ref)
+
+
+@pytest.mark.parametrize("Co,shape", [(32, (1, 5, 6, 120)), (64, (2, 3, 5, 60)), (32, (1, 4, 7, 64))])
+def test_deconv3d_vector_and_scalar_epilogues_agree(dev, Co, shape):
+    """The transposed convolution's 16-byte epilogue (two x parities interleaved through a per-wave LDS scratch, residual
+    ring) against its 8-byte scattered form: same fma / add / max sequence per output -> bit-identical, with and without the
+    skip operand, both ReLU placements."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, D, H, W = shape
+    x = _rand((B, 64, D, H, W), 601).to(dev)
+    w = _rand((64, Co, 3, 3, 3), 602, 0.05).to(dev)
+    wp = ops.pack_deconv3d_weights(w)
+    sc, sh = _affine(Co, 603)
+    res = _rand((B, Co, 2 * D, 2 * H, 2 * W), 604).to(dev)
+    lib = _lib.load()
+    for r, relu in ((None, True), (res, True), (res, False), (res, "pre")):
+        outs = []
+        for scalar in (0, 1):
+            lib.dmb_dev_set_option(7, scalar)
+            try:
+                outs.append(ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu))
+            finally:
+                lib.dmb_dev_set_option(7, 0)
+        assert torch.equal(outs[0], outs[1])
