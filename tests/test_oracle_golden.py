@@ -100,8 +100,10 @@ def test_psmnet_path_cfg1():
     p = O.with_prefix(O.random_params_psm(seed=2, classif_gain=10.0), "cost_processor.aggregator.")
     lf, rf = rand((1, 32, 64, 128), 401), rand((1, 32, 64, 128), 402)
     disps, costs = O.psmnet_path(lf, rf, p, 64)
+    # same arithmetic on the same library as the fixture's generator; the bound leaves room for torch's thread-count
+    # dependent summation order (2.3e-5 between 1 and 8 threads; 2.1e-5 seen on a 256-thread host)
     for i, (d, c) in enumerate(zip(disps, costs)):
-        assert maxdiff(d[:, :, ::2, ::2], g["disp%d" % (3 - i)]) <= 2e-5
+        assert maxdiff(d[:, :, ::2, ::2], g["disp%d" % (3 - i)]) <= 4e-5
         assert maxdiff(c[:, ::8, ::32, :], g["cost%d_rows" % (3 - i)]) <= 2e-5
 
 
