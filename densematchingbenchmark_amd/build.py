@@ -14,9 +14,11 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmb_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip", "path_bwd.hip", "catconv.hip"]
+SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip", "path_bwd.hip", "catconv.hip", "warp_volume.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# warp_volume.hip restates the reference's FP32 sampler arithmetic operation by operation: no fused multiply-adds there
+EXTRA_FLAGS = {"warp_volume.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():
@@ -46,7 +48,7 @@ def build_library(force=False, verbose=True):
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+            cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print("[dmb build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

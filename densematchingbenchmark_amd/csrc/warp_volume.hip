@@ -1,0 +1,145 @@
+// Sample-based cost-volume builders ("fast_mode"): the target features are WARPED by per-plane or per-pixel disparity
+// samples instead of shifted by integers.
+//
+// Reference semantics: dmb/modeling/stereo/cost_processors/utils/cat_fms.py:51-82 (fast_cat_fms), dif_fms.py:49-86
+// (fast_dif_fms), layers/inverse_warp_3d.py:4-52.  The reference reaches F.grid_sample on a 5-D grid normalised with
+// (size - 1) but sampled with align_corners=False (the default since torch 1.3), so every output voxel is a tri-linear
+// blend around  ix = (x - s) * W / (W - 1) - 0.5,  iy = y * H / (H - 1) - 0.5,  iz = k * D / (D - 1) - 0.5  with zero
+// padding -- a misaligned blend that is part of the behaviour a drop-in has to reproduce.  The arithmetic
+// below follows the reference's FP32 operations one by one (no contraction into FMAs), and the eight neighbours are
+// accumulated in the sampler's order, so the result is bit-identical to the reference on CPU.
+//
+// HBM-write-bound: one pass over the output [B, 2C | C, D, H, W]; the target features (a few MB) are gathered through
+// L2.  One thread per (b, k, y, x): grid coordinates and blend weights once, then a loop over the channels.
+#include "dmb_common.h"
+
+namespace dmb {
+
+enum { WARP_CAT = 0, WARP_DIF = 1, WARP_DIF_NORM = 2 };
+
+struct WarpTaps {
+  float w[8];      // tnw, tne, tsw, tse, bnw, bne, bsw, bse (top/bottom = plane, north/south = row, west/east = column)
+  int off[4];      // nw, ne, sw, se offsets into a feature plane (0 when the tap is out of range)
+  unsigned valid;  // bit t: tap t is inside the volume
+};
+
+// No contraction anywhere in this file: every product and sum below rounds as the reference's does (build.py also
+// compiles this file with -ffp-contract=off).
+#pragma clang fp contract(off)
+__device__ inline WarpTaps warp_taps(float disp, int k, int y, int x, int D, int H, int W) {
+  // inverse_warp_3d.py:33-43: mesh + disparity, then (g / (size - 1) * 2) - 1
+  const float gd = ((((float)k / (float)(D - 1)) * 2.f) - 1.f);
+  const float gh = ((((float)y / (float)(H - 1)) * 2.f) - 1.f);
+  const float gw = (((((float)x + disp) / (float)(W - 1)) * 2.f) - 1.f);
+  // grid_sample, align_corners=False: ((g + 1) * size - 1) / 2
+  const float ix = ((((gw + 1.f) * (float)W) - 1.f) / 2.f);
+  const float iy = ((((gh + 1.f) * (float)H) - 1.f) / 2.f);
+  const float iz = ((((gd + 1.f) * (float)D) - 1.f) / 2.f);
+  const float x0 = floorf(ix), y0 = floorf(iy), z0 = floorf(iz);
+  const float x1 = (x0 + 1.f), y1 = (y0 + 1.f), z1 = (z0 + 1.f);
+  const float wx0 = (x1 - ix), wx1 = (ix - x0);
+  const float wy0 = (y1 - iy), wy1 = (iy - y0);
+  const float wz0 = (z1 - iz), wz1 = (iz - z0);
+  WarpTaps t;
+  t.w[0] = ((wx0 * wy0) * wz0);
+  t.w[1] = ((wx1 * wy0) * wz0);
+  t.w[2] = ((wx0 * wy1) * wz0);
+  t.w[3] = ((wx1 * wy1) * wz0);
+  t.w[4] = ((wx0 * wy0) * wz1);
+  t.w[5] = ((wx1 * wy0) * wz1);
+  t.w[6] = ((wx0 * wy1) * wz1);
+  t.w[7] = ((wx1 * wy1) * wz1);
+  const bool vx0 = x0 >= 0.f && x0 < (float)W, vx1 = x1 >= 0.f && x1 < (float)W;   // false for NaN samples
+  const bool vy0 = y0 >= 0.f && y0 < (float)H, vy1 = y1 >= 0.f && y1 < (float)H;
+  const bool vz0 = z0 >= 0.f && z0 < (float)D, vz1 = z1 >= 0.f && z1 < (float)D;
+  const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
+  t.off[0] = yi0 * W + xi0;
+  t.off[1] = yi0 * W + xi1;
+  t.off[2] = yi1 * W + xi0;
+  t.off[3] = yi1 * W + xi1;
+  const unsigned q = (vx0 && vy0 ? 1u : 0u) | (vx1 && vy0 ? 2u : 0u) | (vx0 && vy1 ? 4u : 0u) | (vx1 && vy1 ? 8u : 0u);
+  t.valid = (vz0 ? q : 0u) | (vz1 ? q << 4 : 0u);
+  return t;
+}
+
+// the sampler's accumulation: out = 0; out += v * w for each tap inside the volume, in tap order
+#pragma clang fp contract(off)
+__device__ inline float warp_blend(const WarpTaps& t, const float* __restrict__ plane) {
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = ((t.valid | (t.valid >> 4)) >> q & 1u) ? plane[t.off[q]] : 0.f;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (t.valid >> i & 1u) acc = (acc + (v[i & 3] * t.w[i]));
+  return acc;
+}
+
+// disp: [B, D, H, W] when per_pixel, else [D] (one sample per plane); the warp uses -disp (cat_fms.py:74)
+template <int MODE>
+__global__ __launch_bounds__(256) void warp_volume_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                          const float* __restrict__ disp, float* __restrict__ out,
+                                                          int C, int D, int H, int W, int per_pixel, float p) {
+  const int HW = H * W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y, b = blockIdx.z;
+  if (i >= HW) return;
+  const int y = i / W, x = i - y * W;
+  const float s = per_pixel ? disp[((size_t)b * D + k) * HW + i] : disp[k];
+  const WarpTaps t = warp_taps(-s, k, y, x, D, H, W);
+  const float* Lp = L + (size_t)b * C * HW + i;
+  const float* Rp = R + (size_t)b * C * HW;
+  const size_t DHW = (size_t)D * HW;
+  if (MODE == WARP_DIF_NORM) {
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float tv = warp_blend(t, Rp + (size_t)c * HW);
+      const float v = fabsf(Lp[(size_t)c * HW] * (tv > 0.f ? 1.f : 0.f) - tv);
+      acc += p == 1.f ? v : (p == 2.f ? v * v : powf(v, p));
+    }
+    out[((size_t)b * D + k) * HW + i] = p == 1.f ? acc : (p == 2.f ? sqrtf(acc) : powf(acc, 1.f / p));
+    return;
+  }
+  const int OC = MODE == WARP_CAT ? 2 * C : C;
+  float* o = out + ((size_t)b * OC * D + k) * HW + i;
+#pragma unroll 4
+  for (int c = 0; c < C; ++c) {
+    const float tv = warp_blend(t, Rp + (size_t)c * HW);
+    const float lv = Lp[(size_t)c * HW] * (tv > 0.f ? 1.f : 0.f);   // reference features masked where the warped target <= 0 (:77)
+    if (MODE == WARP_CAT) {
+      __builtin_nontemporal_store(lv, o + (size_t)c * DHW);
+      __builtin_nontemporal_store(tv, o + (size_t)(C + c) * DHW);
+    } else {
+      __builtin_nontemporal_store((lv - tv), o + (size_t)c * DHW);
+    }
+  }
+}
+
+template <int MODE>
+static int launch_warp(const float* L, const float* R, const float* disp, float* out, int B, int C, int D, int H, int W,
+                       int per_pixel, float p, hipStream_t st) {
+  if (!L || !R || !disp || !out || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "fast_fms: bad argument");
+  if (D < 2 || H < 2 || W < 2) return fail(DMB_EINVAL, "fast_fms: the reference divides by (size - 1); D, H, W must be >= 2");
+  if ((long long)C * H * W >= 0x7fffffffLL || D > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "fast_fms: feature map too large");
+  hipLaunchKernelGGL((warp_volume_kernel<MODE>), dim3(cdiv(H * W, 256), D, B), dim3(256), 0, st, L, R, disp, out, C, D, H,
+                     W, per_pixel, p);
+  return launch_status("fast_fms launch failed");
+}
+
+}  // namespace dmb
+
+using namespace dmb;
+
+extern "C" int dmb_fast_cat_fms_f32(const float* L, const float* R, const float* disp_sample, float* out, int B, int C,
+                                    int D, int H, int W, int per_pixel, void* stream) {
+  return launch_warp<WARP_CAT>(L, R, disp_sample, out, B, C, D, H, W, per_pixel, 0.f, (hipStream_t)stream);
+}
+
+extern "C" int dmb_fast_dif_fms_f32(const float* L, const float* R, const float* disp_sample, float* out, int B, int C,
+                                    int D, int H, int W, int per_pixel, int normalize, float p, void* stream) {
+  if (normalize) {
+    if (!(p > 0.f)) return fail(DMB_EINVAL, "fast_dif_fms: norm order must be positive");
+    return launch_warp<WARP_DIF_NORM>(L, R, disp_sample, out, B, C, D, H, W, per_pixel, p, (hipStream_t)stream);
+  }
+  return launch_warp<WARP_DIF>(L, R, disp_sample, out, B, C, D, H, W, per_pixel, 0.f, (hipStream_t)stream);
+}

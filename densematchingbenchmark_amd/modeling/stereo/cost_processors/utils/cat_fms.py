@@ -36,9 +36,17 @@ class LazyCatVolume:
 
 
 def fast_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
-    """cat_fms.py:51-82 depends on F.grid_sample's torch-version-specific align_corners default and is not
-    equivalent to cat_fms; it is outside the HIP path."""
-    raise NotImplementedError("cost_computation type 'fast_mode' is not on the HIP path; use type='default'")
+    """cat_fms.py:51-82: the target features WARPED by ``disp_sample`` ([B, D, H, W], per pixel) -- or by the
+    linspace(start, end, D) samples the builder generates itself -- and the reference features masked where the warped
+    target is not positive.  Not equivalent to cat_fms: the reference samples a (size - 1)-normalised grid with
+    F.grid_sample's align_corners=False default; csrc/warp_volume.hip reproduces that blend bit for bit.
+    Forward only (the reference differentiates it through grid_sample; no backward kernel here)."""
+    if torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad or
+                                    (disp_sample is not None and disp_sample.requires_grad)):
+        raise NotImplementedError("fast_cat_fms has no backward on the HIP path; use type='default' for training")
+    if disp_sample is None:
+        disp_sample = ops.fast_disp_samples(max_disp, start_disp, dilation)
+    return ops.fast_cat_fms(reference_fm.float(), target_fm.float(), disp_sample)
 
 
 CAT_FUNCS = dict(

@@ -16,7 +16,15 @@ def dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, dis
 
 def fast_dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None,
                  normalize=False, p=1.0):
-    raise NotImplementedError("cost_computation type 'fast_mode' is not on the HIP path; use type='default'")
+    """dif_fms.py:49-86: reference features (masked where the warped target is not positive) minus the target features
+    warped by ``disp_sample`` ([B, D, H, W]) or by the builder's own linspace samples; ``normalize`` reduces the channels
+    with a p-norm ([B, D, H, W]).  Same sampling convention as fast_cat_fms (csrc/warp_volume.hip); forward only."""
+    if torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad or
+                                    (disp_sample is not None and disp_sample.requires_grad)):
+        raise NotImplementedError("fast_dif_fms has no backward on the HIP path; use type='default' for training")
+    if disp_sample is None:
+        disp_sample = ops.fast_disp_samples(max_disp, start_disp, dilation)
+    return ops.fast_dif_fms(reference_fm.float(), target_fm.float(), disp_sample, normalize, p)
 
 
 DIF_FUNCS = dict(

@@ -97,6 +97,48 @@ def dif_fms(left, right, disp_idx):
     return out
 
 
+def fast_disp_samples(max_disp, start_disp=0, dilation=1):
+    """cat_fms.py:55-63: the samples the sample-based builders generate themselves -- linspace(start, end, D), FP32, not
+    truncated to integers (max_disp 192 with dilation 2 steps by 191/95)."""
+    D = (max_disp + dilation - 1) // dilation
+    return torch.linspace(start_disp, start_disp + max_disp - 1, D).float()
+
+
+def _fast_samples(left, disp_sample):
+    B, C, H, W = left.shape
+    ds = _f32c(disp_sample.to(left.device), "disp_sample")
+    if ds.dim() == 1:
+        return ds, ds.numel(), 0
+    if ds.dim() != 4 or ds.shape[0] != B or tuple(ds.shape[2:]) != (H, W):
+        raise _lib.DmbLibraryError("disp_sample must be [D] or [B, D, H, W] matching the features, got %s" % (tuple(ds.shape),))
+    return ds, ds.shape[1], 1
+
+
+def fast_cat_fms(left, right, disp_sample):
+    """cat_fms.py:51-82 on csrc/warp_volume.hip: [B, C, H, W] x 2, samples [D] or [B, D, H, W] -> [B, 2C, D, H, W]."""
+    lib = _lib.load()
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    B, C, H, W = left.shape
+    ds, D, per_pixel = _fast_samples(left, disp_sample)
+    out = torch.empty((B, 2 * C, D, H, W), dtype=torch.float32, device=left.device)
+    check(lib.dmb_fast_cat_fms_f32(dev_ptr(left), dev_ptr(right), dev_ptr(ds), dev_ptr(out), B, C, D, H, W, per_pixel,
+                                   stream_ptr(left.device)), "dmb_fast_cat_fms_f32")
+    return out
+
+
+def fast_dif_fms(left, right, disp_sample, normalize=False, p=1.0):
+    """dif_fms.py:49-86: -> [B, C, D, H, W], or [B, D, H, W] (p-norm over the channels) with ``normalize``."""
+    lib = _lib.load()
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    B, C, H, W = left.shape
+    ds, D, per_pixel = _fast_samples(left, disp_sample)
+    shape = (B, D, H, W) if normalize else (B, C, D, H, W)
+    out = torch.empty(shape, dtype=torch.float32, device=left.device)
+    check(lib.dmb_fast_dif_fms_f32(dev_ptr(left), dev_ptr(right), dev_ptr(ds), dev_ptr(out), B, C, D, H, W, per_pixel,
+                                   1 if normalize else 0, float(p), stream_ptr(left.device)), "dmb_fast_dif_fms_f32")
+    return out
+
+
 def gwc_fms(left, right, disp_idx, num_groups, out=None, out_ch_offset=0):
     lib = _lib.load()
     left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")

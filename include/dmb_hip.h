@@ -53,6 +53,23 @@ int dmb_cat_fms_f32(const float* L, const float* R, float* out, int B, int C, in
 int dmb_dif_fms_f32(const float* L, const float* R, float* out, int B, int C, int H, int W, int D,
                     const int* disp_idx_host, void* stream);
 
+/* fast_cat_fms: dmb/modeling/stereo/cost_processors/utils/cat_fms.py:51-82 (CAT_FUNCS["fast_mode"]; the builder
+ * DeepPruner.py:192 calls with per-pixel samples) on layers/inverse_warp_3d.py:4-52.
+ *   T[b, c, k, y, x]     = tri-linear blend of R[b, c] around ix = (x - s) * W / (W - 1) - 0.5, iy = y * H / (H - 1) - 0.5,
+ *                          iz = k * D / (D - 1) - 0.5, zero padding (F.grid_sample on a (size - 1)-normalised grid with
+ *                          align_corners=False: what the reference computes on torch >= 1.3), s = disp_sample
+ *   out[b, c,     k, y, x] = L[b, c, y, x] * (T > 0)        (cat_fms.py:77)
+ *   out[b, C + c, k, y, x] = T
+ * disp_sample (DEVICE): [B, D, H, W] if per_pixel else [D] (cat_fms.py:55-63: linspace(start, end, D), not truncated).
+ * FP32 operation for operation as the reference on CPU: bit-exact.  D, H, W >= 2 (the reference divides by size - 1). */
+int dmb_fast_cat_fms_f32(const float* L, const float* R, const float* disp_sample, float* out, int B, int C, int D, int H,
+                         int W, int per_pixel, void* stream);
+
+/* fast_dif_fms: dif_fms.py:49-86 (DIF_FUNCS["fast_mode"]; AnyNet.py:73).  out[b, c, k, y, x] = L * (T > 0) - T with T as
+ * above; normalize != 0: out[b, k, y, x] = || . ||_p over the channels (dif_fms.py:80-82), out is [B, D, H, W]. */
+int dmb_fast_dif_fms_f32(const float* L, const float* R, const float* disp_sample, float* out, int B, int C, int D, int H,
+                         int W, int per_pixel, int normalize, float p, void* stream);
+
 /* Group-wise correlation volume (GwcNet).  ABSENT from the reference (README.md:16 only names it);
  * occupies the COR_FUNCS slot of cost_processors/utils/correlation1d_cost.py:29-31.  Spec:
  *   out[b, g, k, y, x] = (1/(C/G)) * sum_{c in group g} L[b,c,y,x] * R[b,c,y,x-d_k]  if in range else 0

@@ -89,6 +89,82 @@ def dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, dis
     return out
 
 
+def fast_disp_samples(max_disp, start_disp=0, dilation=1):
+    """cat_fms.py:55-63 / dif_fms.py:54-62: linspace(start, end, D) -- NOT truncated to integers, unlike the default
+    builders (max_disp 192, dilation 2 gives a step of 191/95)."""
+    D = (max_disp + dilation - 1) // dilation
+    return torch.linspace(start_disp, start_disp + max_disp - 1, D).float()
+
+
+def inverse_warp_3d(img, disp):
+    """layers/inverse_warp_3d.py:4-52 for a [B, C, H, W] image expanded over the D planes of disp [B, D, H, W], zero
+    padding: a restatement of F.grid_sample's 5-D "bilinear" (tri-linear) algorithm as the reference reaches it on
+    torch >= 1.3 -- the grid is normalised with (size - 1) (:41-43) but sampled with align_corners=False, i.e. the source
+    index is ((g + 1) * size - 1) / 2 -- in FP32, operation by operation, neighbours accumulated in the sampler's order
+    (top/bottom = z, north/south = y, west/east = x)."""
+    f = np.float32
+    img = img.detach().cpu().numpy().astype(f)
+    disp = disp.detach().cpu().numpy().astype(f)
+    B, D, H, W = disp.shape
+    C = img.shape[1]
+    if min(D, H, W) < 2:
+        raise ValueError("inverse_warp_3d divides by (size - 1)")
+    with np.errstate(all="ignore"):
+        gd = np.broadcast_to(np.arange(D, dtype=f).reshape(1, D, 1, 1), disp.shape)
+        gh = np.broadcast_to(np.arange(H, dtype=f).reshape(1, 1, H, 1), disp.shape)
+        gw = np.arange(W, dtype=f).reshape(1, 1, 1, W) + disp
+        gd = (gd / f(D - 1) * f(2)) - f(1)
+        gh = (gh / f(H - 1) * f(2)) - f(1)
+        gw = (gw / f(W - 1) * f(2)) - f(1)
+        ix = ((gw + f(1)) * f(W) - f(1)) / f(2)
+        iy = ((gh + f(1)) * f(H) - f(1)) / f(2)
+        iz = ((gd + f(1)) * f(D) - f(1)) / f(2)
+        x0, y0, z0 = np.floor(ix), np.floor(iy), np.floor(iz)
+        x1, y1, z1 = x0 + f(1), y0 + f(1), z0 + f(1)
+        # (weight, z index, y index, x index) in accumulation order tnw, tne, tsw, tse, bnw, bne, bsw, bse
+        terms = [((x1 - ix) * (y1 - iy) * (z1 - iz), z0, y0, x0), ((ix - x0) * (y1 - iy) * (z1 - iz), z0, y0, x1),
+                 ((x1 - ix) * (iy - y0) * (z1 - iz), z0, y1, x0), ((ix - x0) * (iy - y0) * (z1 - iz), z0, y1, x1),
+                 ((x1 - ix) * (y1 - iy) * (iz - z0), z1, y0, x0), ((ix - x0) * (y1 - iy) * (iz - z0), z1, y0, x1),
+                 ((x1 - ix) * (iy - y0) * (iz - z0), z1, y1, x0), ((ix - x0) * (iy - y0) * (iz - z0), z1, y1, x1)]
+        out = np.zeros((B, C, D, H, W), dtype=f)
+        bidx = np.arange(B).reshape(B, 1, 1, 1)
+        for wgt, zz, yy, xx in terms:
+            ok = (zz >= 0) & (zz < D) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W) & np.isfinite(xx)
+            yi = np.clip(np.nan_to_num(yy), 0, H - 1).astype(np.int64)
+            xi = np.clip(np.nan_to_num(xx), 0, W - 1).astype(np.int64)
+            for c in range(C):
+                v = img[:, c][bidx, yi, xi]                      # the expanded image is the same on every plane
+                out[:, c] = np.where(ok, out[:, c] + v * wgt, out[:, c])
+    return torch.from_numpy(out)
+
+
+def _fast_samples(reference_fm, max_disp, start_disp, dilation, disp_sample):
+    B, C, H, W = reference_fm.shape
+    if disp_sample is None:
+        ds = fast_disp_samples(max_disp, start_disp, dilation)
+        return ds.view(1, -1, 1, 1).expand(B, ds.numel(), H, W)
+    return disp_sample.float()
+
+
+def fast_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
+    """cat_fms.py:51-82: target features warped by -disp_sample, reference features masked where the warped target is
+    not positive (:77), concatenated."""
+    ds = _fast_samples(reference_fm, max_disp, start_disp, dilation, disp_sample)
+    tgt = inverse_warp_3d(target_fm, -ds)
+    ref = reference_fm.float().unsqueeze(2) * (tgt > 0).float()
+    return torch.cat((ref, tgt), dim=1)
+
+
+def fast_dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None, normalize=False, p=1.0):
+    """dif_fms.py:49-86."""
+    ds = _fast_samples(reference_fm, max_disp, start_disp, dilation, disp_sample)
+    tgt = inverse_warp_3d(target_fm, -ds)
+    dif = reference_fm.float().unsqueeze(2) * (tgt > 0).float() - tgt
+    if normalize:
+        dif = torch.norm(dif, p=p, dim=1, keepdim=False)
+    return dif
+
+
 def correlation1d_cost(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
     """cost_processors/utils/correlation1d_cost.py:7-27.  The arithmetic lives in SpatialCorrelationSampler
     (ClementPinard/Pytorch-Correlation-extension, branch fix_1.7 per INSTALL.md:60-66; no version pin in requirements.txt),

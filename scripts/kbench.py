@@ -83,6 +83,13 @@ bw_case("conv c1 32->1 full", lambda: ops.conv3d_k3_c1(x, w1, 0.0, None), x.nume
 L = torch.randn(B, 32, H, W, device=dev); R = torch.randn(B, 32, H, W, device=dev)
 idx = ops.disp_index_list(48, 0, 1)
 bw_case("cat_fms", lambda: ops.cat_fms(L, R, idx), B * 64 * D * H * W * 4 + 2 * L.numel() * 4)
+# the sample-based builders (cat_fms.py:51-82): per-plane and per-pixel samples
+fs = ops.fast_disp_samples(48, 0, 1).to(dev)
+bw_case("fast_cat_fms (plane samples)", lambda: ops.fast_cat_fms(L, R, fs), B * 64 * D * H * W * 4 + 2 * L.numel() * 4)
+fpp = fs.view(1, D, 1, 1) + 0.5 * torch.rand(B, D, H, W, device=dev)      # smooth per-pixel samples, as a sampler produces
+bw_case("fast_cat_fms (per-pixel samples)", lambda: ops.fast_cat_fms(L, R, fpp), B * 64 * D * H * W * 4 + 2 * L.numel() * 4 + fpp.numel() * 4)
+bw_case("fast_dif_fms (per-pixel samples)", lambda: ops.fast_dif_fms(L, R, fpp), B * 32 * D * H * W * 4 + 2 * L.numel() * 4 + fpp.numel() * 4)
+del fpp
 # GwcNet volume (BASELINE configs[2]): 40-group correlation of 320-channel features (MFMA inner products) + 2 x 12 concat
 lg, rg = torch.randn(B, 320, H, W, device=dev), torch.randn(B, 320, H, W, device=dev)
 gout = torch.empty(B, 64, D, H, W, device=dev)

@@ -6,9 +6,11 @@ import math
 
 import pytest
 import torch
+import numpy as np
 import torch.nn.functional as F
 
 from oracle import dmb_oracle as O
+from tests._util import golden, maxdiff, sha
 
 pytestmark = pytest.mark.gpu
 
@@ -51,6 +53,55 @@ def test_cat_known_answer(dev):
     assert out.shape == (1, 2, 3, 3, 4)
     assert out[0, 0, :, 0].tolist() == [[1, 2, 0, 0], [1, 2, 3, 4], [0, 0, 3, 4]]
     assert out[0, 1, :, 0].tolist() == [[15, 16, 0, 0], [13, 14, 15, 16], [0, 0, 13, 14]]
+
+
+def _fast_case(row):
+    shape, D, seed = tuple(int(v) for v in row[:4]), int(row[4]), int(row[5])
+    a, b = _rand(shape, seed), _rand(shape, seed + 1000)
+    g = torch.Generator().manual_seed(seed + 2000)
+    ds = torch.rand((shape[0], D, shape[2], shape[3]), generator=g) * shape[3] * 0.6 - 2.0
+    return a, b, ds
+
+
+def test_fast_mode_volumes_bit_exact(dev):
+    """csrc/warp_volume.hip against the REFERENCE's fast_cat_fms / fast_dif_fms outputs (tests/golden/fast_volumes.npz):
+    the known-answer case of its test, per-pixel non-integer samples, the builder's own linspace samples -- bit for bit."""
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import CAT_FUNCS
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.dif_fms import DIF_FUNCS
+    fast_cat, fast_dif = CAT_FUNCS["fast_mode"], DIF_FUNCS["fast_mode"]
+    g = golden("fast_volumes.npz")
+    L = torch.arange(1, 13, dtype=torch.float32).view(1, 1, 3, 4).to(dev)
+    R = torch.arange(13, 25, dtype=torch.float32).view(1, 1, 3, 4).to(dev)
+    assert np.array_equal(fast_cat(L, R, 5, -2, 2).cpu().numpy(), g["ka_cat"])
+    ka_samples = torch.linspace(-2, 2, 3).repeat(1, 3, 4, 1).permute(0, 3, 1, 2).contiguous().to(dev)
+    assert np.array_equal(fast_cat(L, R, 5, -2, 2, ka_samples).cpu().numpy(), g["ka_cat_samples"])
+    assert np.array_equal(fast_dif(L, R, 5, -2, 2).cpu().numpy(), g["ka_dif"])
+    for i, row in enumerate(g["cases"]):
+        a, b, ds = _fast_case(row)
+        c = fast_cat(a.to(dev), b.to(dev), disp_sample=ds.to(dev))
+        d = fast_dif(a.to(dev), b.to(dev), disp_sample=ds.to(dev))
+        assert sha(c) == str(g["cat_sha_%d" % i]) and sha(d) == str(g["dif_sha_%d" % i])
+        assert torch.equal(c.cpu(), O.fast_cat_fms(a, b, disp_sample=ds))
+        for p_, key in ((1.0, "dif_norm1_%d"), (2.0, "dif_norm2_%d")):
+            n = fast_dif(a.to(dev), b.to(dev), disp_sample=ds.to(dev), normalize=True, p=p_)
+            assert maxdiff(n, g[key % i]) <= 1e-5 * max(1.0, float(np.abs(g[key % i]).max()))
+        n3 = fast_dif(a.to(dev), b.to(dev), disp_sample=ds.to(dev), normalize=True, p=3.0)
+        assert maxdiff(n3, O.fast_dif_fms(a, b, disp_sample=ds, normalize=True, p=3.0)) <= 2e-5 * max(1.0, n3.abs().max().item())
+        c = fast_cat(a.to(dev), b.to(dev), 24, -3, 2)
+        assert sha(c) == str(g["cat_default_sha_%d" % i])
+
+
+def test_fast_mode_argument_errors(dev):
+    from densematchingbenchmark_amd import _lib
+    ops = _ops()
+    a = torch.randn(1, 2, 4, 6, device=dev)
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.fast_cat_fms(a, a, torch.zeros(1, 3, 4, 5, device=dev))     # samples do not match the features
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.fast_cat_fms(a, a, torch.zeros(1, device=dev))               # D = 1: the reference divides by D - 1
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import fast_cat_fms
+    with pytest.raises(NotImplementedError):
+        fast_cat_fms(a.requires_grad_(), a, 4)
 
 
 @pytest.mark.parametrize("C,G", [(16, 2), (32, 8), (12, 12), (320, 40)])

@@ -106,6 +106,31 @@ def test_psmnet_path_cfg1_through_builders(dev):
         assert maxdiff(c[:, ::8, ::32, :], g["cost%d_rows" % (3 - i)]) <= COST_TOL
 
 
+def test_fast_mode_cost_processor_through_builders(dev):
+    """cost_computation.type='fast_mode' (the AnyNet config's builder, configs/AnyNet/scene_flow.py:34-35) through
+    build_cost_processor: the warped volume feeds the same aggregator; with and without explicit per-pixel samples."""
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors import build_cost_processor
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "PSMNet", "scene_flow.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 4
+    cfg.model.cost_processor.cost_computation.type = "fast_mode"
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cp = build_cost_processor(cfg).eval()
+    p = O.random_params_psm(seed=4, classif_gain=10.0)
+    _load(cp, p, "aggregator.")
+    cp = cp.to(dev)
+    lf, rf = rand((1, 32, 16, 32), 411), rand((1, 32, 16, 32), 412)
+    with torch.no_grad():
+        for ds in (None, (torch.arange(8.0).view(1, 8, 1, 1) + rand((1, 8, 16, 32), 413, 0.3))):
+            costs = cp(lf.to(dev), rf.to(dev), disp_sample=None if ds is None else ds.to(dev))
+            raw = O.fast_cat_fms(lf, rf, md // 4, 0, 1, disp_sample=ds)
+            want = O.psm_aggregator(raw, p, md)
+            for a, b in zip(costs, want):
+                assert maxdiff(a, b) <= COST_TOL
+
+
 def test_predictor_modules_vs_golden(dev):
     from densematchingbenchmark_amd.modeling.stereo.disp_predictors import PREDICTORS
     g = golden("predictors.npz")

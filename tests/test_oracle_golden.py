@@ -34,6 +34,39 @@ def test_volumes_known_answer_and_seeded():
             assert np.array_equal(c.numpy(), g["cat_%d" % i]) and np.array_equal(d.numpy(), g["dif_%d" % i])
 
 
+def _fast_case(row):
+    shape, D, seed = tuple(int(v) for v in row[:4]), int(row[4]), int(row[5])
+    a, b = rand(shape, seed), rand(shape, seed + 1000)
+    g = torch.Generator().manual_seed(seed + 2000)
+    ds = torch.rand((shape[0], D, shape[2], shape[3]), generator=g) * shape[3] * 0.6 - 2.0
+    return a, b, ds
+
+
+def test_fast_mode_volumes_vs_reference():
+    """The sample-based builders (cat_fms.py:51-82, dif_fms.py:49-86): the oracle's own statement of the sampler against
+    the reference's outputs on this torch, bit for bit -- its test's case (test_cat_fms.py:52-80) and seeded per-pixel samples."""
+    g = golden("fast_volumes.npz")
+    L = torch.arange(1, 13, dtype=torch.float32).view(1, 1, 3, 4)
+    R = torch.arange(13, 25, dtype=torch.float32).view(1, 1, 3, 4)
+    assert np.array_equal(O.fast_cat_fms(L, R, 5, -2, 2).numpy(), g["ka_cat"])
+    ka_samples = torch.linspace(-2, 2, 3).repeat(1, 3, 4, 1).permute(0, 3, 1, 2).contiguous()
+    assert np.array_equal(O.fast_cat_fms(L, R, 5, -2, 2, ka_samples).numpy(), g["ka_cat_samples"])
+    assert np.array_equal(g["ka_cat"], g["ka_cat_samples"])
+    assert np.array_equal(O.fast_dif_fms(L, R, 5, -2, 2).numpy(), g["ka_dif"])
+    assert not np.array_equal(g["ka_cat"], golden("volumes.npz")["ka_cat"])      # SURVEY 0-5: not the default builder's volume
+    for i, row in enumerate(g["cases"]):
+        a, b, ds = _fast_case(row)
+        c, d = O.fast_cat_fms(a, b, disp_sample=ds), O.fast_dif_fms(a, b, disp_sample=ds)
+        assert sha(c) == str(g["cat_sha_%d" % i]) and sha(d) == str(g["dif_sha_%d" % i])
+        if "cat_%d" % i in g:
+            assert np.array_equal(c.numpy(), g["cat_%d" % i]) and np.array_equal(d.numpy(), g["dif_%d" % i])
+        assert maxdiff(O.fast_dif_fms(a, b, disp_sample=ds, normalize=True, p=1.0), g["dif_norm1_%d" % i]) <= 1e-5
+        assert maxdiff(O.fast_dif_fms(a, b, disp_sample=ds, normalize=True, p=2.0), g["dif_norm2_%d" % i]) <= 1e-5
+        c = O.fast_cat_fms(a, b, 24, -3, 2)
+        assert sha(c) == str(g["cat_default_sha_%d" % i])
+        assert np.array_equal(c[:, :, ::5, 1::3].numpy(), g["cat_default_rows_%d" % i])
+
+
 def test_predictors():
     g = golden("predictors.npz")
     ones = torch.ones(1, 5, 2, 2)
