@@ -147,6 +147,8 @@ def dev_ptr(t, name="tensor", allow_none=False):
         raise DmbLibraryError("%s has dtype %s; FP32 expected" % (name, t.dtype))
     if not t.is_contiguous():
         raise DmbLibraryError("%s must be contiguous" % name)
+    if t.device.index != torch.cuda.current_device():   # every operand, not only the one the stream is taken from
+        raise DmbLibraryError("%s lives on cuda:%d but the current device is cuda:%d" % (name, t.device.index, torch.cuda.current_device()))
     return ctypes.c_void_p(t.data_ptr())
 
 

@@ -74,10 +74,30 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+def _same_shape(a, b, what):
+    """Operands a kernel indexes with one set of sizes must HAVE those sizes: a mismatch would read out of bounds on the device."""
+    if tuple(a.shape) != tuple(b.shape):
+        raise _lib.DmbLibraryError("%s: shapes differ, %s vs %s" % (what, tuple(a.shape), tuple(b.shape)))
+
+
+def _feature_pair(left, right, what):
+    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    if left.dim() != 4:
+        raise _lib.DmbLibraryError("%s: features must be [B, C, H, W], got %s" % (what, tuple(left.shape)))
+    _same_shape(left, right, what)
+    return left, right
+
+
+def _affine_ok(scale, shift, Co, what):
+    for t, n in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != Co:
+            raise _lib.DmbLibraryError("%s: %s has %d elements for %d output channels" % (what, n, t.numel(), Co))
+
+
 # ---------------------------------------------------------------------------------------------- volumes
 def cat_fms(left, right, disp_idx):
     lib = _lib.load()
-    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    left, right = _feature_pair(left, right, "cat_fms")
     B, C, H, W = left.shape
     D = len(disp_idx)
     out = torch.empty((B, 2 * C, D, H, W), dtype=torch.float32, device=left.device)
@@ -88,7 +108,7 @@ def cat_fms(left, right, disp_idx):
 
 def dif_fms(left, right, disp_idx):
     lib = _lib.load()
-    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    left, right = _feature_pair(left, right, "dif_fms")
     B, C, H, W = left.shape
     D = len(disp_idx)
     out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=left.device)
@@ -117,7 +137,7 @@ def _fast_samples(left, disp_sample):
 def fast_cat_fms(left, right, disp_sample):
     """cat_fms.py:51-82 on csrc/warp_volume.hip: [B, C, H, W] x 2, samples [D] or [B, D, H, W] -> [B, 2C, D, H, W]."""
     lib = _lib.load()
-    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    left, right = _feature_pair(left, right, "fast_cat_fms")
     B, C, H, W = left.shape
     ds, D, per_pixel = _fast_samples(left, disp_sample)
     out = torch.empty((B, 2 * C, D, H, W), dtype=torch.float32, device=left.device)
@@ -129,7 +149,7 @@ def fast_cat_fms(left, right, disp_sample):
 def fast_dif_fms(left, right, disp_sample, normalize=False, p=1.0):
     """dif_fms.py:49-86: -> [B, C, D, H, W], or [B, D, H, W] (p-norm over the channels) with ``normalize``."""
     lib = _lib.load()
-    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    left, right = _feature_pair(left, right, "fast_dif_fms")
     B, C, H, W = left.shape
     ds, D, per_pixel = _fast_samples(left, disp_sample)
     shape = (B, D, H, W) if normalize else (B, C, D, H, W)
@@ -141,7 +161,7 @@ def fast_dif_fms(left, right, disp_sample, normalize=False, p=1.0):
 
 def gwc_fms(left, right, disp_idx, num_groups, out=None, out_ch_offset=0):
     lib = _lib.load()
-    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    left, right = _feature_pair(left, right, "gwc_fms")
     B, C, H, W = left.shape
     D = len(disp_idx)
     if out is None:
@@ -155,7 +175,7 @@ def gwc_fms(left, right, disp_idx, num_groups, out=None, out_ch_offset=0):
 def correlation1d(left, right, max_disp, negative_slope=0.1):
     """correlation1d_cost.py:7-27: [B, C, H, W] x 2 -> [B, max_disp, H, W], channel j = disparity max_disp - 1 - j."""
     lib = _lib.load()
-    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    left, right = _feature_pair(left, right, "correlation1d")
     B, C, H, W = left.shape
     out = torch.empty((B, max_disp, H, W), dtype=torch.float32, device=left.device)
     check(lib.dmb_correlation1d_f32(dev_ptr(left), dev_ptr(right), dev_ptr(out), B, C, H, W, max_disp, negative_slope,
@@ -165,7 +185,7 @@ def correlation1d(left, right, max_disp, negative_slope=0.1):
 
 def cat_fms_into(left, right, disp_idx, out, out_ch_offset):
     lib = _lib.load()
-    left, right = _f32c(left, "reference_fm"), _f32c(right, "target_fm")
+    left, right = _feature_pair(left, right, "cat_fms_into")
     B, C, H, W = left.shape
     check(lib.dmb_cat_fms_into_f32(dev_ptr(left), dev_ptr(right), dev_ptr(out), B, C, H, W, len(disp_idx),
                                    host_ints(disp_idx), out.shape[1], out_ch_offset, stream_ptr(left.device)),
@@ -211,6 +231,10 @@ def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, rel
     y = torch.empty((B, Co, Do, Ho, Wo), dtype=torch.float32, device=x.device)
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    _affine_ok(scale, shift, Co, "conv3d_k3")
+    if wpack.numel() != lib.dmb_conv3d_packed_floats(Co, Ci):
+        raise _lib.DmbLibraryError("conv3d_k3: packed weights hold %d floats, %d -> %d channels need %d"
+                                   % (wpack.numel(), Ci, Co, lib.dmb_conv3d_packed_floats(Co, Ci)))
     tag = "conv3d_k3_s%d_%dto%d" % (stride, Ci, Co)
     if _kernel_timer is not None:
         _kernel_timer.start(tag)
@@ -374,6 +398,10 @@ def conv3d_k3_c1(x, w, bias=0.0, residual=None):
     x, w = _f32c(x, "x"), _f32c(w, "weight")
     B, Ci, D, H, W = x.shape
     y = torch.empty((B, 1, D, H, W), dtype=torch.float32, device=x.device)
+    if w.numel() != Ci * 27:
+        raise _lib.DmbLibraryError("conv3d_k3_c1: weight %s for %d input channels" % (tuple(w.shape), Ci))
+    if residual is not None:
+        _same_shape(residual, y, "conv3d_k3_c1 residual")
     check(lib.dmb_conv3d_k3_c1_f32(dev_ptr(x), dev_ptr(w), float(bias), dev_ptr(residual, allow_none=True), dev_ptr(y),
                                    B, Ci, D, H, W, stream_ptr(x.device)), "dmb_conv3d_k3_c1_f32")
     return y
@@ -386,6 +414,10 @@ def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=Fals
     y = torch.empty((B, Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    _affine_ok(scale, shift, Co, "deconv3d_k3s2")
+    if wpack.numel() != lib.dmb_deconv3d_packed_floats(Ci, Co):
+        raise _lib.DmbLibraryError("deconv3d_k3s2: packed weights hold %d floats, %d -> %d channels need %d"
+                                   % (wpack.numel(), Ci, Co, lib.dmb_deconv3d_packed_floats(Ci, Co)))
     check(lib.dmb_deconv3d_k3s2_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                     dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
                                     B, Ci, Co, D, H, W, _relu_mode(relu), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
@@ -735,6 +767,7 @@ def soft_argmin_sampled(cost, disp_sample, alpha=1.0, normalize=True):
     lib = _lib.load()
     cost, disp_sample = _f32c(cost, "cost_volume"), _f32c(disp_sample, "disp_sample")
     B, D, H, W = cost.shape
+    _same_shape(disp_sample, cost, "soft_argmin: cost volume and per-pixel disparity samples")
     disp = torch.empty((B, 1, H, W), dtype=torch.float32, device=cost.device)
     check(lib.dmb_soft_argmin_sampled_f32(dev_ptr(cost), dev_ptr(disp_sample), dev_ptr(disp), B, D, H, W, float(alpha),
                                           int(bool(normalize)), stream_ptr(cost.device)), "dmb_soft_argmin_sampled_f32")
@@ -939,6 +972,10 @@ def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
     H0, W0 = original_size
     if acc.dtype != torch.float64 or acc.numel() != 6:
         raise _lib.DmbLibraryError("acc must be a float64[6] tensor")
+    _same_shape(est, gt, "epe_accumulate: estimate and ground truth")
+    if est.numel() != B * Hp * Wp or not (0 < int(H0) <= Hp and 0 < int(W0) <= Wp):
+        raise _lib.DmbLibraryError("epe_accumulate: maps must be [B, 1, Hp, Wp] with the original size inside, got %s / %s"
+                                   % (tuple(est.shape), (H0, W0)))
     ws = torch.empty((B, 6), dtype=torch.float64, device=est.device)
     check(lib.dmb_epe_accum_f64(dev_ptr(est), dev_ptr(gt), dev_ptr(acc), dev_ptr(ws), B, Hp, Wp, int(H0), int(W0),
                                 float(lower_bound), float(upper_bound), stream_ptr(est.device)), "dmb_epe_accum_f64")
@@ -1039,6 +1076,10 @@ def stereo_focal_loss_fwd(cost, gt, variance, disp_values, lower, upper, start_d
     cost, gt = _f32c(cost, "cost"), _f32c(gt, "gt")
     B, D, H, W = cost.shape
     vmap = _f32c(variance, "variance") if torch.is_tensor(variance) else None
+    if gt.numel() != B * H * W or len(disp_values) != D or (vmap is not None and vmap.numel() != B * H * W):
+        raise _lib.DmbLibraryError("stereo_focal_loss_fwd: cost %s needs gt / variance maps of %d elements and %d disparity values, got %s / %s / %d"
+                                   % (tuple(cost.shape), B * H * W, D, tuple(gt.shape),
+                                      tuple(vmap.shape) if vmap is not None else None, len(disp_values)))
     stats = torch.empty((B, H, W, 2), dtype=torch.float32, device=cost.device)
     out = torch.empty((2,), dtype=torch.float32, device=cost.device)
     check(lib.dmb_stereo_focal_loss_fwd_f32(dev_ptr(cost), dev_ptr(gt), dev_ptr(vmap, allow_none=True),
@@ -1056,6 +1097,10 @@ def stereo_focal_loss_bwd(cost, gt, variance, disp_values, stats, loss_out, grad
     cost, gt = _f32c(cost, "cost"), _f32c(gt, "gt")
     B, D, H, W = cost.shape
     vmap = _f32c(variance, "variance") if torch.is_tensor(variance) else None
+    if gt.numel() != B * H * W or len(disp_values) != D or (vmap is not None and vmap.numel() != B * H * W):
+        raise _lib.DmbLibraryError("stereo_focal_loss_bwd: cost %s needs gt / variance maps of %d elements and %d disparity values, got %s / %s / %d"
+                                   % (tuple(cost.shape), B * H * W, D, tuple(gt.shape),
+                                      tuple(vmap.shape) if vmap is not None else None, len(disp_values)))
     gcost = torch.empty_like(cost)
     gvar = torch.empty((B, 1, H, W), dtype=torch.float32, device=cost.device) if (want_grad_variance and vmap is not None) else None
     go = _f32c(grad_out.reshape(1), "grad_out")
@@ -1071,6 +1116,8 @@ def stereo_focal_loss_bwd(cost, gt, variance, disp_values, stats, loss_out, grad
 def map_loss_fwd(x, gt, lower, upper, mode):
     lib = _lib.load()
     x, gt = _f32c(x, "x"), _f32c(gt, "gt")
+    if gt.numel() != x.numel():
+        raise _lib.DmbLibraryError("map_loss_fwd: map %s and ground truth %s differ in size" % (tuple(x.shape), tuple(gt.shape)))
     out = torch.empty((2,), dtype=torch.float32, device=x.device)
     check(lib.dmb_map_loss_fwd_f32(dev_ptr(x), dev_ptr(gt), dev_ptr(_loss_workspace(x.numel(), x.device)), dev_ptr(out),
                                    x.numel(), float(lower), float(upper), int(mode), stream_ptr(x.device)),
@@ -1081,6 +1128,8 @@ def map_loss_fwd(x, gt, lower, upper, mode):
 def map_loss_bwd(x, gt, loss_out, grad_out, lower, upper, mode):
     lib = _lib.load()
     x, gt = _f32c(x, "x"), _f32c(gt, "gt")
+    if gt.numel() != x.numel():
+        raise _lib.DmbLibraryError("map_loss_bwd: map %s and ground truth %s differ in size" % (tuple(x.shape), tuple(gt.shape)))
     gx = torch.empty_like(x)
     go = _f32c(grad_out.reshape(1), "grad_out")
     check(lib.dmb_map_loss_bwd_f32(dev_ptr(x), dev_ptr(gt), dev_ptr(loss_out), dev_ptr(go), 1.0, dev_ptr(gx), x.numel(),

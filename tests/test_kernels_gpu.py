@@ -91,6 +91,36 @@ def test_fast_mode_volumes_bit_exact(dev):
         assert sha(c) == str(g["cat_default_sha_%d" % i])
 
 
+def test_wrappers_refuse_mismatched_operands(dev):
+    """Sizes a kernel indexes with come from ONE operand; the wrappers refuse the others when they disagree instead of
+    letting the device read out of bounds."""
+    from densematchingbenchmark_amd import _lib
+    ops = _ops()
+    a, b = torch.randn(1, 4, 6, 16, device=dev), torch.randn(1, 4, 6, 12, device=dev)
+    idx = ops.disp_index_list(4, 0, 1)
+    for call in (lambda: ops.cat_fms(a, b, idx), lambda: ops.dif_fms(a, b, idx), lambda: ops.gwc_fms(a, b, idx, 2),
+                 lambda: ops.correlation1d(a, b, 4), lambda: ops.fast_cat_fms(a, b, torch.zeros(4, device=dev)),
+                 lambda: ops.cat_fms(a[0], a[0], idx)):
+        with pytest.raises(_lib.DmbLibraryError):
+            call()
+    x = torch.randn(1, 8, 4, 6, 16, device=dev)
+    wp = ops.pack_conv3d_weights(torch.randn(32, 8, 3, 3, 3, device=dev))
+    ops.conv3d_k3(x, wp, 32)
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.conv3d_k3(x, wp, 64)                                            # weights packed for 32 output channels
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.conv3d_k3(x, wp, 32, scale=torch.ones(8, device=dev))
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.conv3d_k3_c1(x, torch.randn(1, 4, 3, 3, 3, device=dev))
+    cost = torch.randn(1, 4, 6, 16, device=dev)
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.soft_argmin_sampled(cost, torch.zeros(1, 4, 6, 12, device=dev))
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.stereo_focal_loss_fwd(cost, torch.zeros(2, 1, 6, 16, device=dev), 1.0, [0.0, 1.0, 2.0, 3.0], 0, 4, 0, 3, 0.0)
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.map_loss_fwd(torch.zeros(1, 1, 6, 16, device=dev), torch.zeros(1, 1, 6, 12, device=dev), 0, 4, 0)
+
+
 def test_fast_mode_argument_errors(dev):
     from densematchingbenchmark_amd import _lib
     ops = _ops()
