@@ -44,7 +44,7 @@ def deconv_case(Ci, Co, d, h, w, name):
 
 
 def bw_case(name, fn, nbytes):
-    ms = timeit(fn)
+    ms = timeit(fn, n=40, warm=10)
     print("%-28s %8.3f ms  %7.1f GB/s  (%.1f%% of 8000)" % (name, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 8000 * 100), flush=True)
 
 
