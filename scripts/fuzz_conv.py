@@ -16,7 +16,7 @@ def rnd(shape, scale=1.0):
 
 
 for it in range(N):
-    kind = rng.choice(["s1", "s1", "s2", "deconv", "c2d", "c2d", "x6"])
+    kind = rng.choice(["s1", "s1", "s2", "deconv", "c2d", "c2d", "x6", "c1", "gwc", "gwc", "catfirst"])
     B = rng.choice([1, 1, 2])
     try:
         if kind in ("s1", "s2", "deconv", "x6"):
@@ -53,6 +53,49 @@ for it in range(N):
             else:
                 got = ops.conv3d_k3(x.to(dev), ops.pack_conv3d_weights(w.to(dev)), Co, *args, 2 if kind == "s2" else 1, relu)
             desc = (kind, B, Ci, Co, D, H, W, relu, use_res)
+        elif kind == "c1":       # 32 -> 1 head: the 16-byte form (W % 4 == 0) and the dword form
+            D, H = rng.randint(1, 19), rng.randint(1, 19)
+            W = rng.choice([rng.randint(1, 130), 60, 64, 120, 124, 240])
+            Ci = rng.choice([1, 2, 5, 32])
+            x, w = rnd((B, Ci, D, H, W)), rnd((1, Ci, 3, 3, 3), 1.0 / math.sqrt(Ci * 27))
+            res = rnd((B, 1, D, H, W)) if rng.random() < 0.5 else None
+            y = F.conv3d(x, w, None, padding=1) + 0.25
+            if res is not None:
+                y = y + res
+            got = ops.conv3d_k3_c1(x.to(dev), w.to(dev), 0.25, res.to(dev) if res is not None else None)
+            desc = (kind, B, Ci, D, H, W, res is not None)
+        elif kind == "gwc":      # group-wise correlation: matrix-core form (0 <= d <= 64) and the fallback
+            G = rng.choice([1, 2, 5, 8])
+            CG = rng.choice([2, 4, 8, 16])
+            H, W = rng.randint(1, 7), rng.choice([rng.randint(2, 300), 64, 240, 256, 260, 512])
+            start, dil = rng.choice([0, 0, 0, -3, 2]), rng.choice([1, 1, 2])
+            md = rng.randint(1, 70)
+            idx = ops.disp_index_list(md, start, dil)
+            L, R = rnd((B, G * CG, H, W)), rnd((B, G * CG, H, W))
+            y = torch.zeros(B, G, len(idx), H, W)
+            for k, d in enumerate(idx):
+                if abs(d) < W:
+                    xs = slice(max(d, 0), W + min(d, 0))
+                    xt = slice(max(-d, 0), W - max(d, 0))
+                    y[:, :, k, :, xs] = (L[..., xs] * R[..., xt]).view(B, G, CG, H, -1).mean(2)
+            got = ops.gwc_fms(L.to(dev), R.to(dev), idx, G)
+            desc = (kind, B, G, CG, H, W, md, start, dil)
+        elif kind == "catfirst":  # first layer on the concatenation / difference volume without the volume
+            C, Co = rng.choice([4, 16, 32]), 32
+            D = rng.choice([4, 8, 12, 24])
+            H, W = rng.randint(1, 9), rng.choice([D + 8, D + 12, 64, 72, 100, 120])
+            kd = rng.choice(["cat", "dif"])
+            L, R = rnd((B, C, H, W)), rnd((B, C, H, W))
+            idx = list(range(D))
+            Cin = 2 * C if kd == "cat" else C
+            w = rnd((Co, Cin, 3, 3, 3), 1.0 / math.sqrt(Cin * 27))
+            sc, sh = 0.5 + torch.rand(Co), torch.rand(Co) - 0.5
+            vol = (ops.cat_fms if kd == "cat" else ops.dif_fms)(L.to(dev), R.to(dev), idx).cpu()
+            y = F.relu(F.conv3d(vol, w, None, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+            if not ops.catconv_applicable(L.to(dev), R.to(dev), idx, Co):
+                continue
+            got = ops.catconv_first(L.to(dev), R.to(dev), D, ops.catconv_pack(w.to(dev), kd), sc.to(dev), sh.to(dev), True)
+            desc = (kind, kd, B, C, D, H, W)
         else:
             H = rng.randint(1, 40)
             W = rng.choice([rng.randint(1, 100), 16, 48, 52, 96, 100])
