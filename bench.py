@@ -169,6 +169,28 @@ def split_mode_leg(step, exact_disps, B, steps):
             "note": "6 bf16 MFMA products per FP32 product, FP32 accumulate; see DESIGN.md section 8-1"}
 
 
+def overlap_leg(step, exact_disps, B, steps):
+    """Secondary figure, NOT the headline: the same step with the classifier branches on a second HIP stream next to the
+    following hourglass (ops.set_branch_overlap): identical results, but concurrent kernels, so not the configuration the
+    per-kernel roofline accounting is taken on."""
+    ops.set_branch_overlap(True)
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                disps = step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                disps = step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        ops.set_branch_overlap(False)
+    same = all(torch.equal(a, b) for a, b in zip(disps, exact_disps))
+    return {"pairs_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "identical_to_sequential": bool(same)}
+
+
 def training_leg(cfg, dev, steps):
     """Secondary figure, NOT the headline: one training iteration of the same cost path -- features -> volume ->
     aggregator with batch-statistics BatchNorm -> fused regression -> weighted smooth-L1, backward through the HIP kernels,
@@ -387,6 +409,7 @@ def main():
         if world == 1 and ptype == "Concatenation" and agg_type == "PSMNet" and not fused and not args.no_extras:
             out["end_to_end_with_backbone"] = end_to_end(model, dev, B, Hp, Wp, min(args.steps, 5))
             if args.conv3d_mode == "exact":
+                out["opt_in_branch_overlap"] = overlap_leg(step, disps, B, min(args.steps, 10))
                 out["opt_in_bf16x6"] = split_mode_leg(step, disps, B, min(args.steps, 5))
                 if "losses" in cfg.model:
                     out["training_step"] = training_leg(cfg, dev, min(args.steps, 5))

@@ -40,8 +40,50 @@ class PSMAggregator(nn.Module):
         cost3 = self.classif3[1](self.classif3[0](out3), residual=cost2)
         return cost1, cost2, cost3
 
+    def _forward_overlapped(self, raw_cost):
+        """Eval only: the same launches as trunk() + the up-sampling loop, with classifier branch k (and its up-sampling /
+        regression) on a second stream next to hourglass k + 1.  Same kernels on the same operands: identical results."""
+        import torch
+        B, C, D, H, W = raw_cost.shape
+        size = (self.max_disp, H * 4, W * 4)
+        vals = ops.disp_sample_values(self.max_disp, 0, 1)
+        main = torch.cuda.current_stream(raw_cost.device)
+        side = ops.side_stream(raw_cost.device)
+
+        def upsample(c):
+            cost, disp = ops.trilinear_ac_soft_argmin(c.squeeze(1), size, vals, 1.0)
+            cost.record_stream(main)            # returned to the caller, who works on its own stream
+            disp.record_stream(main)
+            return ops.RegressionHint.attach(cost, vals, 1.0, disp)
+
+        cost0 = self.dres0(raw_cost)
+        cost0 = self.dres1[1](self.dres1[0](cost0), residual=cost0)
+        out1, pre1, post1 = self.dres2(cost0, None, None, skip=cost0)
+        fork1 = main.record_event()
+        with torch.cuda.stream(side):
+            side.wait_event(fork1)
+            cost1 = self.classif1[1](self.classif1[0](out1))
+            up1 = upsample(cost1)
+        out2, pre2, post2 = self.dres3(out1, pre1, post1, skip=cost0)
+        fork2 = main.record_event()
+        with torch.cuda.stream(side):
+            side.wait_event(fork2)
+            cost2 = self.classif2[1](self.classif2[0](out2), residual=cost1)
+            cost2.record_stream(main)           # allocated on the side stream, read by classif3 on the caller's
+            join2 = side.record_event()
+            up2 = upsample(cost2)
+            done = side.record_event()
+        out3, pre3, post3 = self.dres4(out2, pre2, post2, skip=cost0)
+        main.wait_event(join2)
+        cost3 = self.classif3[1](self.classif3[0](out3), residual=cost2)
+        up3 = upsample(cost3)
+        main.wait_event(done)
+        return [up3, up2, up1]
+
     def forward(self, raw_cost):
         B, C, D, H, W = raw_cost.shape
+        if ops.branch_overlap() and raw_cost.device.type == "cuda" and not train_fn.wants_grad(self, raw_cost):
+            return self._forward_overlapped(raw_cost)
         cost1, cost2, cost3 = self.trunk(raw_cost)
         size = (self.max_disp, H * 4, W * 4)                             # PSMNet.py:75-88, align_corners=True
         # The up-sampling kernel also regresses the standard soft-argmin (alpha 1, samples 0..max_disp-1) of the volume

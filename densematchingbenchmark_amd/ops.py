@@ -262,6 +262,34 @@ def cat_fusion():
     return _cat_fusion
 
 
+# Branch overlap (eval): the classifier branch of hourglass k (two full-resolution convolutions, the up-sampling and the
+# regression) depends on that hourglass's output only, and so does hourglass k + 1 -- whose quarter-resolution layers cannot fill
+# the chip.  With the switch on, the aggregators issue the branch on a second HIP stream (fork / join with events):
+# same kernels, same operands, identical results; 27.28 -> 27.03 ms per BASELINE step (scripts/overlap_probe.py).  The
+# opposite arrangement -- the dependent chain on a high-priority stream, the branches on the caller's -- gains half as much.
+# Off by default: under concurrency the per-kernel durations that the roofline accounting rests on (HIP events in bench.py,
+# rocprofv3 --stats) no longer describe one kernel alone; bench.py reports the overlapped step as a secondary leg.
+_branch_overlap = False
+_side_streams = {}
+
+
+def set_branch_overlap(flag):
+    global _branch_overlap
+    _branch_overlap = bool(flag)
+
+
+def branch_overlap():
+    return _branch_overlap
+
+
+def side_stream(device):
+    """One extra HIP stream per device for the overlapped branches."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
+
+
 def copy_window(src, Wd, xs):
     """dst[..., j] = src[..., j + xs] (zero outside [0, W)), j in [0, Wd): zero-filled column window of a [.., W] tensor."""
     lib = _lib.load()

@@ -106,6 +106,29 @@ def test_psmnet_path_cfg1_through_builders(dev):
         assert maxdiff(c[:, ::8, ::32, :], g["cost%d_rows" % (3 - i)]) <= COST_TOL
 
 
+def test_branch_overlap_is_identical(dev):
+    """ops.set_branch_overlap: the classifier branches on a second stream next to the following hourglass -- same kernels, same
+    operands, so every output is bit-identical to the sequential issue order (twice: the second call reuses the stream)."""
+    from densematchingbenchmark_amd import ops
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.aggregators import PSMAggregator
+    m = _load(PSMAggregator(max_disp=32, in_planes=64), O.random_params_psm(seed=6, classif_gain=10.0)).to(dev).eval()
+    raw = rand((2, 64, 8, 16, 32), 305).to(dev)
+    with torch.no_grad():
+        want = m(raw)
+        ops.set_branch_overlap(True)
+        try:
+            for _ in range(2):
+                got = m(raw)
+                torch.cuda.synchronize()
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b)
+                    vals = ops.disp_sample_values(32, 0, 1)
+                    ha, hb = ops.RegressionHint.lookup(a, vals, 1.0, True), ops.RegressionHint.lookup(b, vals, 1.0, True)
+                    assert ha is not None and torch.equal(ha, hb)
+        finally:
+            ops.set_branch_overlap(False)
+
+
 def test_fast_mode_cost_processor_through_builders(dev):
     """cost_computation.type='fast_mode' (the AnyNet config's builder, configs/AnyNet/scene_flow.py:34-35) through
     build_cost_processor: the warped volume feeds the same aggregator; with and without explicit per-pixel samples."""
