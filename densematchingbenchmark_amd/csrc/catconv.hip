@@ -127,7 +127,7 @@ __device__ __forceinline__ void catconv_combine_body(const float* __restrict__ F
                                                      const float* __restrict__ GM, const float* __restrict__ GB,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      float* __restrict__ out, int Co, int CA, int D, int H, int W, int relu,
-                                                     long long rowid, int x) {
+                                                     long long rowid, int x, int zlo, int zhi) {
   const int Wg = W + 4;
   long long r = rowid;
   const int y = (int)(r % H); r /= H;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void catconv_combine_body(const float* __restrict__ F
     // streaming store: the 0.8 GB output is far larger than the caches it would otherwise evict the maps from
     __builtin_nontemporal_store(f32x4_t{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_t*>(op + (size_t)z * HW));
   };
-  {   // plane 0: taps dz = 1, 2 (input planes 0 and 1)
+  if (zlo == 0) {   // plane 0: taps dz = 1, 2 (input planes 0 and 1)
     const float4 a1 = fa4(1), a2 = fa4(2);
     float g[4];
 #pragma unroll
@@ -187,14 +187,15 @@ __device__ __forceinline__ void catconv_combine_body(const float* __restrict__ F
       if (!NEAR) gq[k] = gb[z];
     }
   };
-  load_block(1, win, bnd, gbw);
-  for (int z0 = 1; z0 < D - 1; z0 += ZB) {
+  const int zb = zlo > 1 ? zlo : 1, ze = zhi < D - 1 ? zhi : D - 1;   // interior planes of this thread's range
+  load_block(zb, win, bnd, gbw);
+  for (int z0 = zb; z0 < ze; z0 += ZB) {
     float nwin[ZB + 3], ngbw[ZB];
     float4 nbnd[ZB];
-    if (z0 + ZB < D - 1) load_block(z0 + ZB, nwin, nbnd, ngbw);
+    if (z0 + ZB < ze) load_block(z0 + ZB, nwin, nbnd, ngbw);
 #pragma unroll
     for (int k = 0; k < ZB; ++k) {
-      if (z0 + k < D - 1) {
+      if (z0 + k < ze) {
         const float g[4] = {win[3 + k], win[2 + k], win[1 + k], win[k]};
         plane(z0 + k, fm, g, bnd[k], gbw[k]);
       }
@@ -207,7 +208,7 @@ __device__ __forceinline__ void catconv_combine_body(const float* __restrict__ F
       gbw[k] = ngbw[k];
     }
   }
-  {   // plane D - 1: taps dz = 0, 1 (input planes D - 2 and D - 1)
+  if (zhi == D) {   // plane D - 1: taps dz = 0, 1 (input planes D - 2 and D - 1)
     const float4 a0 = fa4(0), a1 = fa4(1);
     const int u0 = x - (D - 1);
     float g[4];
@@ -227,12 +228,18 @@ __global__ __launch_bounds__(256) void catconv_combine_kernel(const float* __res
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               float* __restrict__ out, long long rows, int Co, int CA, int D,
                                                               int H, int W, int XS, int relu) {
+  // NEAR: the few columns next to the band give one wave of work per 4 rows when a thread walks all D planes -- a chain of
+  // dependent map loads at half occupancy; the planes are independent, so each (row, column quad) is split over ZSPLIT threads.
+  constexpr int ZSPLIT = NEAR ? 4 : 1;
   const int W4 = NEAR ? XS >> 2 : (W - XS) >> 2;
-  const long long idx = blockIdx.x * 256LL + threadIdx.x;
-  if (idx >= rows * W4) return;
+  long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= rows * W4 * ZSPLIT) return;
+  const int zc = (int)(idx / (rows * W4));
+  idx -= zc * (rows * W4);
   const long long rowid = idx / W4;
+  const int dz = D / ZSPLIT;   // D is a multiple of 4
   catconv_combine_body<NEAR>(FA, HC, FM, BAND, GM, GB, scale, shift, out, Co, CA, D, H, W, relu, rowid,
-                             (int)(idx - rowid * W4) * 4 + (NEAR ? 0 : XS));
+                             (int)(idx - rowid * W4) * 4 + (NEAR ? 0 : XS), zc * dz, (zc + 1) * dz);
 }
 
 }  // namespace dmb
@@ -268,7 +275,7 @@ extern "C" int dmb_catconv_combine_f32(const float* FA, const float* HC, const f
     return fail(DMB_EINVAL, "catconv_combine: bad argument (D, W multiples of 4, W >= D + 8, tensors 16-byte aligned)");
   int XS = (D + 4 + 15) / 16 * 16;   // first column no mask band reaches, rounded up to 64 bytes
   if (XS > W - 4) XS = W - 4;
-  const long long rows = (long long)B * Co * H, tn = rows * (XS / 4), tf = rows * ((W - XS) / 4);
+  const long long rows = (long long)B * Co * H, tn = rows * (XS / 4) * 4, tf = rows * ((W - XS) / 4);   // near: 4 plane ranges per quad
   if ((tf + 255) / 256 > 0x7fffffffLL || (tn + 255) / 256 > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "catconv_combine: grid too large");
   hipLaunchKernelGGL(catconv_combine_kernel<false>, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, (hipStream_t)stream, FA,
                      HC, FM, BAND, GM, GB, scale, shift, out, rows, Co, CA, D, H, W, XS, relu);
