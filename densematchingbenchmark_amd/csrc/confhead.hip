@@ -204,11 +204,14 @@ __global__ __launch_bounds__(256) void conf_gather_kernel(const float* __restric
 // planes; a lane keeps all M = 64 hidden sums in registers and the tap's 64 weights arrive as wave-uniform (scalar) loads
 // from w1t [D, 3, 3, 64] -- one vector load feeds 64 fmas.  Partial sums meet in LDS in a fixed order (reproducible).
 constexpr int RING_M = 64;
-__global__ __launch_bounds__(256) void conf_ring_kernel(const float* __restrict__ cost, const float* __restrict__ w1t,
-                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        const float* __restrict__ w2, float* __restrict__ conf, int B, int D,
-                                                        int H, int W) {
-  __shared__ float part[4][RING_M][64];
+constexpr int RING_NW = 16;  // waves per workgroup = slices of the D planes: the ring is only ~3000 pixels per image, i.e. one
+                             // wave per SIMD at best; a lane's chain of D * 9 * 64 fmas is what the kernel's time is made of
+__global__ __launch_bounds__(64 * RING_NW) void conf_ring_kernel(const float* __restrict__ cost, const float* __restrict__ w1t,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ w2, float* __restrict__ conf, int B,
+                                                                 int D, int H, int W) {
+  extern __shared__ float ring_lds[];   // part[RING_NW][RING_M / 2][64]
+  float (*part)[RING_M / 2][64] = reinterpret_cast<float (*)[RING_M / 2][64]>(ring_lds);
   const int ring = 2 * W + 2 * (H - 2);
   const int nblk = cdiv(ring, 64);
   const int b = blockIdx.x / nblk;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void conf_ring_kernel(const float* __restrict_
   for (int m = 0; m < RING_M; ++m) acc[m] = 0.f;
   const size_t HW = (size_t)H * W;
   const float* cb = cost + (size_t)b * D * HW;
-  const int d0 = wave * D / 4, d1 = (wave + 1) * D / 4;
+  const int d0 = wave * D / RING_NW, d1 = (wave + 1) * D / RING_NW;
   for (int d = d0; d < d1; ++d)
 #pragma unroll 1   // (one tap's 64 weights fill the scalar registers; unrolled, 9 x 64 of them spilled)
     for (int t = 0; t < 9; ++t) {
@@ -236,17 +239,25 @@ __global__ __launch_bounds__(256) void conf_ring_kernel(const float* __restrict_
 #pragma unroll
       for (int m = 0; m < RING_M; ++m) acc[m] = fmaf(v, wv[m], acc[m]);
     }
+  // the partial sums meet in LDS, half of the hidden channels at a time (16 waves x 64 channels x 64 lanes would not fit)
+  float logit = 0.f;
 #pragma unroll
-  for (int m = 0; m < RING_M; ++m) part[wave][m][lane] = acc[m];
-  __syncthreads();
-  if (wave == 0) {
-    float logit = 0.f;
-    for (int m = 0; m < RING_M; ++m) {
-      const float s = ((part[0][m][lane] + part[1][m][lane]) + part[2][m][lane]) + part[3][m][lane];
-      logit = fmaf(fmaxf(fmaf(s, scale[m], shift[m]), 0.f), w2[m], logit);
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+#pragma unroll
+    for (int m = 0; m < RING_M / 2; ++m) part[wave][m][lane] = acc[half * (RING_M / 2) + m];
+    __syncthreads();
+    if (wave == 0) {
+      for (int m = 0; m < RING_M / 2; ++m) {
+        float s = part[0][m][lane];
+#pragma unroll
+        for (int w = 1; w < RING_NW; ++w) s += part[w][m][lane];   // fixed order: reproducible
+        const int mm = half * (RING_M / 2) + m;
+        logit = fmaf(fmaxf(fmaf(s, scale[mm], shift[mm]), 0.f), w2[mm], logit);
+      }
     }
-    if (live) conf[((size_t)b * H + py) * W + px] = 1.f / (1.f + __expf(-logit));
   }
+  if (wave == 0 && live) conf[((size_t)b * H + py) * W + px] = 1.f / (1.f + __expf(-logit));
 }
 
 }  // namespace dmb
@@ -266,8 +277,14 @@ extern "C" int dmb_conf_ring_f32(const float* cost, const float* w1t, const floa
   if (!cost || !w1t || !scale || !shift || !w2 || !conf || B <= 0 || D <= 0 || M != RING_M || H < 3 || W < 3)
     return fail(DMB_EINVAL, "conf_ring: bad argument (64 hidden channels)");
   const int ring = 2 * W + 2 * (H - 2);
-  hipLaunchKernelGGL(conf_ring_kernel, dim3((unsigned)(B * cdiv(ring, 64))), dim3(256), 0, (hipStream_t)stream, cost, w1t, scale,
-                     shift, w2, conf, B, D, H, W);
+  const size_t lds = (size_t)RING_NW * (RING_M / 2) * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conf_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conf_ring_kernel, dim3((unsigned)(B * cdiv(ring, 64))), dim3(64 * RING_NW), lds, (hipStream_t)stream, cost,
+                     w1t, scale, shift, w2, conf, B, D, H, W);
   return launch_status("conf_ring launch failed");
 }
 
