@@ -53,6 +53,7 @@ SIGNATURES = {
     "dmb_conf_head_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conf_head_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 5 + [_P]),
     "dmb_conf_gather_f32": (_c_int, [_P, _P, _P] + [_c_int] * 4 + [_P]),
+    "dmb_conf_phase_conv2d_f32": (_c_int, [_P] * 6 + [_c_int] * 5 + [_P]),
     "dmb_conf_ring_f32": (_c_int, [_P] * 6 + [_c_int] * 5 + [_P]),
     "dmb_conv2d_packed_floats": (_c_ll, [_c_int, _c_int, _c_int]),
     "dmb_conv2d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),

@@ -41,10 +41,16 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ w, float* __restric
 // Both cut the vector-memory INSTRUCTION count 4x: measured on MI355X these layers are bound by the rate at which a CU
 // issues 64-lane memory instructions (a 3x3 layer has 3x less arithmetic per staged byte than the 3x3x3 ones), not by
 // bytes: 32->32 at 384x1248 ran 1.65 ms with dword copies / stores against 0.97 ms with neither.
-template <int NTT_, int KS_, int DIL_, int S_ = 1, bool V16_ = true>
+template <int NTT_, int KS_, int DIL_, int S_ = 1, bool V16_ = true, bool DOT_ = false>
 struct C2Cfg {
   static constexpr int NTT = NTT_, KS = KS_, DIL = DIL_, S = S_;
   static constexpr bool V16 = V16_;
+  // DOT (128 output channels = two groups of 64): instead of storing the activations, every pixel's ReLU(BN(.)) vector of a
+  // 64-channel group is reduced against a weight vector and the sigmoid of that sum is scattered into a 4x finer map --
+  // AcfNet's confidence head composed with its learned up-sampling (ops.conf_head_from_source): the [B, 1024, H/4, W/4]
+  // hidden tensor (0.5 GB at the BASELINE size) is never written.  `res` = the 64 weights, `y` = the confidence map
+  // [B, 1, 4 H, 4 W], `out_ctot` = the first of the launch's two phases (phase = 4 * (y mod 4) + (x mod 4)).
+  static constexpr bool DOT = DOT_;
   static constexpr int WN = NTT;               // one 32-channel row tile per wave column (1, 2 or 4)
   static constexpr int WY = 4 / WN;            // waves stacked along y
   static constexpr int RY = (S == 1) ? 4 : 2;  // output rows per wave (row pairs); strided tiles read 2x2 the input
@@ -176,11 +182,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
   // Per-channel affine of this lane's output channels, loaded ONCE: a load inside the tile loop that some path leaves
   // unconsumed stays "pending" in the compiler's wait-count model across the back edge, and the first instruction that
   // reuses its register then drains vmcnt(0) -- including the chunk copy that was just put in flight.
-  constexpr int NAFF = C::V16 ? 4 : 16;
+  constexpr int NAFF = (C::V16 && !C::DOT) ? 4 : 16;
   float sc[NAFF], sh[NAFF];
 #pragma unroll
   for (int k = 0; k < NAFF; ++k) {
-    const int co = wn * 32 + (C::V16 ? k * 8 + (lane >> 3) : cd_row(k, h));
+    const int co = wn * 32 + ((C::V16 && !C::DOT) ? k * 8 + (lane >> 3) : cd_row(k, h));
     sc[k] = (scale && co < Co) ? scale[co] : 1.f;
     sh[k] = (shift && co < Co) ? shift[co] : 0.f;
   }
@@ -278,6 +284,32 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
     }
   };
 
+  // DOT epilogue: lane (j, h) of wave wn holds, for pixel j of each row-pair tile, channels wn * 32 + cd_row(r, h)
+  auto dot_epilogue = [&](const Tile& tl, float* scratch) {
+    float w2r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w2r[r] = res[(wn & 1) * 32 + cd_row(r, h)];
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) {
+      float p = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p = fmaf(fmaxf(fmaf(acc[mt][r], sc[r], sh[r]), 0.f), w2r[r], p);
+      scratch[((wave * 2 + h) * C::MT + mt) * 32 + j] = p;
+    }
+    __syncthreads();
+    constexpr int NOUT = 2 * C::MT * 32;   // (phase of the launch, tile, pixel)
+    float* cb = y + (size_t)tl.b * 16 * HWo;
+    for (int o = threadIdx.x; o < NOUT; o += 256) {
+      const int phl = o / (C::MT * 32), rem = o - phl * (C::MT * 32), mt = rem >> 5, jj = rem & 31;
+      const float* q0 = scratch + ((2 * phl) * 2 * C::MT + mt) * 32 + jj;           // wave 2 phl: halves h = 0, 1
+      const float* q1 = scratch + ((2 * phl + 1) * 2 * C::MT + mt) * 32 + jj;       // wave 2 phl + 1
+      const float s = ((q0[0] + q0[C::MT * 32]) + q1[0]) + q1[C::MT * 32];         // fixed order: reproducible
+      const int gy = tl.y0 + 2 * (mt / C::XS) + (jj >> 4), gx = tl.x0 + (mt % C::XS) * 16 + (jj & 15);
+      const int ph = out_ctot + phl;
+      if (gy < Ho && gx < Wo) cb[(size_t)(4 * gy + (ph >> 2)) * (4 * Wo) + 4 * gx + (ph & 3)] = 1.f / (1.f + __expf(-s));
+    }
+  };
+
   const int NC = Cipad / C::CK;
   Tile cur_t = tile_at(0);
   stage(cur_t, 0, lds);
@@ -329,11 +361,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
     }
     // the chunk buffer just consumed is free until the next copy lands in it: it doubles as transposition scratch
     float* scratch = C::TR_OWN ? lds + 2 * C::BUF_FLOATS : lds + ((g + 1) & 1) * C::BUF_FLOATS;
-    if (res)
-      epilogue(std::true_type{}, cur_t, scratch);
-    else
-      epilogue(std::false_type{}, cur_t, scratch);
-    if constexpr (C::V16 && !C::TR_OWN) __syncthreads();
+    if constexpr (C::DOT) {
+      dot_epilogue(cur_t, scratch);
+    } else {
+      if (res)
+        epilogue(std::true_type{}, cur_t, scratch);
+      else
+        epilogue(std::false_type{}, cur_t, scratch);
+    }
+    if constexpr ((C::V16 && !C::TR_OWN) || C::DOT) __syncthreads();
     cur_t = next_t;
   }
 }
@@ -514,6 +550,21 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
 #undef DMB_C2
   return fail(DMB_EUNSUPPORTED, "conv2d: stride 1 with kernel 1 | 3, dilation 1 | 2 (4 | 8 up to 32 output channels), output channels <= 128; "
                                 "stride 2 with kernel 1 | 3 (<= 64 output channels) or 5 (<= 32), dilation 1");
+}
+
+extern "C" int dmb_conf_phase_conv2d_f32(const float* c, const float* wpack, const float* scale, const float* shift,
+                                         const float* w2, float* conf, int B, int Ci, int Hq, int Wq, int phase_base,
+                                         void* stream) {
+  if (!c || !wpack || !scale || !shift || !w2 || !conf || B <= 0 || Ci <= 0 || Hq <= 0 || Wq <= 0 || phase_base < 0 ||
+      phase_base > 14 || (phase_base & 1))
+    return fail(DMB_EINVAL, "conf_phase_conv2d: bad argument");
+  if ((long long)Ci * Hq * Wq * 4 >= 0x7fffffffLL || (long long)16 * Hq * Wq * 4 >= 0x7fffffffLL)
+    return fail(DMB_EUNSUPPORTED, "conf_phase_conv2d: one batch item must stay below 2 GiB");
+  hipStream_t st = (hipStream_t)stream;
+  const bool v16 = Wq % 4 == 0 && !g_dev_opts[3] && (((uintptr_t)c) & 15) == 0;
+  // (`res` carries the 64 dot weights, `y` the confidence map, `out_ctot` the first phase: see C2Cfg::DOT)
+  return v16 ? launch_conv2d<C2Cfg<4, 3, 1, 1, true, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, phase_base, 0, st)
+             : launch_conv2d<C2Cfg<4, 3, 1, 1, false, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, phase_base, 0, st);
 }
 
 extern "C" int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int k, int in_channels_total,

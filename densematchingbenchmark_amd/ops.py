@@ -974,6 +974,14 @@ def conf_head_composite_applicable(cost, M):
     return _conf_composite and M == 64 and UpsampleSource.lookup(cost) is not None and cost.shape[3] % 16 == 0
 
 
+_conf_dot_epilogue = True   # development switch: False = hidden tensor + dmb_conf_gather_f32
+
+
+def set_conf_dot_epilogue(flag):
+    global _conf_dot_epilogue
+    _conf_dot_epilogue = bool(flag)
+
+
 def conf_head_from_source(cost, comp, scale, shift, w2):
     """The confidence map of ``cost`` (which carries an UpsampleSource) through the composed quarter-resolution form."""
     lib = _lib.load()
@@ -981,11 +989,19 @@ def conf_head_from_source(cost, comp, scale, shift, w2):
     c = _f32c(src.c, "quarter-resolution cost")
     B, Dq, Hq, Wq = c.shape
     M = comp["M"]
-    hq = torch.empty((B, 16 * M, Hq, Wq), dtype=torch.float32, device=c.device)
-    for i, wp in enumerate(comp["packs"]):
-        conv2d(c, wp, 128, 3, scale=comp["scale"], shift=comp["shift"], relu=True, out=hq, out_ch_offset=128 * i)
     conf = torch.empty((B, 1, 4 * Hq, 4 * Wq), dtype=torch.float32, device=c.device)
-    check(lib.dmb_conf_gather_f32(dev_ptr(hq), dev_ptr(w2), dev_ptr(conf), B, M, Hq, Wq, stream_ptr(c.device)), "dmb_conf_gather_f32")
+    if M == 64 and len(comp["packs"]) == 8 and _conf_dot_epilogue:
+        # two phases per launch; the 64-vector of every pixel is reduced against w2 in the convolution's epilogue, so the
+        # [B, 1024, Hq, Wq] hidden tensor (0.5 GB at the BASELINE size) is never written
+        w2c = _f32c(w2.reshape(-1), "w2")
+        for i, wp in enumerate(comp["packs"]):
+            check(lib.dmb_conf_phase_conv2d_f32(dev_ptr(c), dev_ptr(wp), dev_ptr(comp["scale"]), dev_ptr(comp["shift"]), dev_ptr(w2c),
+                                                dev_ptr(conf), B, Dq, Hq, Wq, 2 * i, stream_ptr(c.device)), "dmb_conf_phase_conv2d_f32")
+    else:
+        hq = torch.empty((B, 16 * M, Hq, Wq), dtype=torch.float32, device=c.device)
+        for i, wp in enumerate(comp["packs"]):
+            conv2d(c, wp, 128, 3, scale=comp["scale"], shift=comp["shift"], relu=True, out=hq, out_ch_offset=128 * i)
+        check(lib.dmb_conf_gather_f32(dev_ptr(hq), dev_ptr(w2), dev_ptr(conf), B, M, Hq, Wq, stream_ptr(c.device)), "dmb_conf_gather_f32")
     check(lib.dmb_conf_ring_f32(dev_ptr(cost), dev_ptr(comp["w1t"]), dev_ptr(scale), dev_ptr(shift), dev_ptr(w2), dev_ptr(conf),
                                 B, 4 * Dq, M, 4 * Hq, 4 * Wq, stream_ptr(c.device)), "dmb_conf_ring_f32")
     return conf

@@ -763,7 +763,7 @@ def test_catconv_first_layer_on_a_difference_volume(dev, B, C, Co, D, H, W):
     assert got.shape == ref.shape and (got.double() - ref).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("B,Hq,Wq", [(2, 5, 8), (1, 9, 12)])
+@pytest.mark.parametrize("B,Hq,Wq", [(2, 5, 8), (1, 9, 12), (1, 7, 52), (2, 9, 100)])
 def test_conf_head_composed_with_learned_upsampling(dev, B, Hq, Wq):
     """AcfNet's confidence head on a cost volume that is the learned 4x up-sampling of a quarter-resolution volume: the
     composed quarter-resolution form (16 phase-wise 3x3 convolutions of that volume + 1x1 + sigmoid, outer pixel ring
@@ -788,6 +788,13 @@ def test_conf_head_composed_with_learned_upsampling(dev, B, Hq, Wq):
     direct = ops.conf_head(cost, ops.pack_conf_head_weights(w1.to(dev)), sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
     assert got.shape == want.shape
     assert (got.double() - want).abs().max().item() <= 5e-6 and (direct.double() - want).abs().max().item() <= 5e-6
+    # the same path with the hidden tensor materialised and reduced by dmb_conf_gather_f32 (a different summation order)
+    ops.set_conf_dot_epilogue(False)
+    try:
+        via_hidden = ops.conf_head_from_source(cost, comp, sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
+    finally:
+        ops.set_conf_dot_epilogue(True)
+    assert (via_hidden.double() - want).abs().max().item() <= 5e-6 and (via_hidden - got).abs().max().item() <= 2e-6
     cost.add_(0.0)                                        # a modified tensor no longer matches its note
     assert not ops.conf_head_composite_applicable(cost, M)
 
