@@ -49,7 +49,8 @@ struct C2Cfg {
   // 64-channel group is reduced against a weight vector and the sigmoid of that sum is scattered into a 4x finer map --
   // AcfNet's confidence head composed with its learned up-sampling (ops.conf_head_from_source): the [B, 1024, H/4, W/4]
   // hidden tensor (0.5 GB at the BASELINE size) is never written.  `res` = the 64 weights, `y` = the confidence map
-  // [B, 1, 4 H, 4 W], `out_ctot` = the first of the launch's two phases (phase = 4 * (y mod 4) + (x mod 4)).
+  // [B, 1, 4 H, 4 W], `res_ctot` = the number of weight sets laid out one after the other in `wp`: ONE launch walks
+  // (spatial tile, weight set) work items, set p = phases 2 p and 2 p + 1 (phase = 4 * (y mod 4) + (x mod 4)).
   static constexpr bool DOT = DOT_;
   static constexpr int WN = NTT;               // one 32-channel row tile per wave column (1, 2 or 4)
   static constexpr int WY = 4 / WN;            // waves stacked along y
@@ -116,10 +117,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
 
   struct Tile {
     int b, x0, y0;   // batch item, output coordinates of the tile origin
+    int p;           // DOT: which of the launch's weight sets (pairs of phases); 0 otherwise
   };
   auto tile_at = [&](int it) {
     int t = xcd_remap((int)blockIdx.x + it * G, ntiles);
     Tile tl;
+    tl.p = 0;
+    if constexpr (C::DOT) {   // res_ctot = number of weight sets; the set is the fastest index: 8 consecutive work items
+      tl.p = t % res_ctot;    // share one input tile
+      t /= res_ctot;
+    }
     tl.x0 = (t % ntx) * C::TX;
     t /= ntx;
     tl.y0 = (t % nty) * C::TY;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
 
   constexpr int WPW = C::W_FLOATS / 16;      // 16-byte weight words per wave
   constexpr int WI = (WPW + 63) / 64;
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)((Cipad / 2) * C::KK * C::NTT * 64) * 4u);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)((C::DOT ? res_ctot : 1) * (Cipad / 2) * C::KK * C::NTT * 64) * 4u);
   auto stage = [&](const Tile& tl, int c0, float* buf) {
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * in_ctot * HW, (unsigned)Ci * HW * 4u);
     if constexpr (C::V16) {
@@ -167,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
     for (int i = 0; i < WI; ++i) {
       const int q4 = wave * WPW + i * 64 + lane;
       if (i * 64 + lane < WPW)
-        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (C::KK * C::NTT * 64 * 4), buf + C::IN_FLOATS + (wave * WPW + i * 64) * 4);
+        dma16(wrs, (unsigned)q4 * 16u, ((unsigned)(c0 / 2) + (unsigned)tl.p * (unsigned)(Cipad / 2)) * (C::KK * C::NTT * 64 * 4),
+              buf + C::IN_FLOATS + (wave * WPW + i * 64) * 4);
     }
   };
 
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
       const float* q1 = scratch + ((2 * phl + 1) * 2 * C::MT + mt) * 32 + jj;       // wave 2 phl + 1
       const float s = ((q0[0] + q0[C::MT * 32]) + q1[0]) + q1[C::MT * 32];         // fixed order: reproducible
       const int gy = tl.y0 + 2 * (mt / C::XS) + (jj >> 4), gx = tl.x0 + (mt % C::XS) * 16 + (jj & 15);
-      const int ph = out_ctot + phl;
+      const int ph = 2 * tl.p + phl;
       if (gy < Ho && gx < Wo) cb[(size_t)(4 * gy + (ph >> 2)) * (4 * Wo) + 4 * gx + (ph & 3)] = 1.f / (1.f + __expf(-s));
     }
   };
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
           st_t.b = same ? cur_t.b : next_t.b;
           st_t.x0 = same ? cur_t.x0 : next_t.x0;
           st_t.y0 = same ? cur_t.y0 : next_t.y0;
+          st_t.p = same ? cur_t.p : next_t.p;
           if (same || has_next) stage(st_t, same ? (ci + 1) * C::CK : 0, nxt);
         }
         const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
@@ -459,7 +468,7 @@ static int launch_conv2d(const float* x, const float* wp, const float* scale, co
                          int res_ctot, hipStream_t st) {
   const int Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
   const int ntx = cdiv(Wo, C::TX), nty = cdiv(Ho, C::TY);
-  const long long ntiles = (long long)B * ntx * nty;
+  const long long ntiles = (long long)B * ntx * nty * (C::DOT ? res_ctot : 1);
   if (ntiles > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
@@ -553,18 +562,16 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
 }
 
 extern "C" int dmb_conf_phase_conv2d_f32(const float* c, const float* wpack, const float* scale, const float* shift,
-                                         const float* w2, float* conf, int B, int Ci, int Hq, int Wq, int phase_base,
-                                         void* stream) {
-  if (!c || !wpack || !scale || !shift || !w2 || !conf || B <= 0 || Ci <= 0 || Hq <= 0 || Wq <= 0 || phase_base < 0 ||
-      phase_base > 14 || (phase_base & 1))
+                                         const float* w2, float* conf, int B, int Ci, int Hq, int Wq, int nsets, void* stream) {
+  if (!c || !wpack || !scale || !shift || !w2 || !conf || B <= 0 || Ci <= 0 || Hq <= 0 || Wq <= 0 || nsets <= 0 || nsets > 8)
     return fail(DMB_EINVAL, "conf_phase_conv2d: bad argument");
   if ((long long)Ci * Hq * Wq * 4 >= 0x7fffffffLL || (long long)16 * Hq * Wq * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "conf_phase_conv2d: one batch item must stay below 2 GiB");
   hipStream_t st = (hipStream_t)stream;
   const bool v16 = Wq % 4 == 0 && !g_dev_opts[3] && (((uintptr_t)c) & 15) == 0;
-  // (`res` carries the 64 dot weights, `y` the confidence map, `out_ctot` the first phase: see C2Cfg::DOT)
-  return v16 ? launch_conv2d<C2Cfg<4, 3, 1, 1, true, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, phase_base, 0, st)
-             : launch_conv2d<C2Cfg<4, 3, 1, 1, false, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, phase_base, 0, st);
+  // (`res` carries the 64 dot weights, `y` the confidence map, `res_ctot` the number of weight sets: see C2Cfg::DOT)
+  return v16 ? launch_conv2d<C2Cfg<4, 3, 1, 1, true, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, 0, nsets, st)
+             : launch_conv2d<C2Cfg<4, 3, 1, 1, false, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, 0, nsets, st);
 }
 
 extern "C" int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int k, int in_channels_total,

@@ -991,12 +991,13 @@ def conf_head_from_source(cost, comp, scale, shift, w2):
     M = comp["M"]
     conf = torch.empty((B, 1, 4 * Hq, 4 * Wq), dtype=torch.float32, device=c.device)
     if M == 64 and len(comp["packs"]) == 8 and _conf_dot_epilogue:
-        # two phases per launch; the 64-vector of every pixel is reduced against w2 in the convolution's epilogue, so the
+        # one launch over (spatial tile, weight set) work items, two phases per set; the 64-vector of every pixel is reduced against w2 in the convolution's epilogue, so the
         # [B, 1024, Hq, Wq] hidden tensor (0.5 GB at the BASELINE size) is never written
         w2c = _f32c(w2.reshape(-1), "w2")
-        for i, wp in enumerate(comp["packs"]):
-            check(lib.dmb_conf_phase_conv2d_f32(dev_ptr(c), dev_ptr(wp), dev_ptr(comp["scale"]), dev_ptr(comp["shift"]), dev_ptr(w2c),
-                                                dev_ptr(conf), B, Dq, Hq, Wq, 2 * i, stream_ptr(c.device)), "dmb_conf_phase_conv2d_f32")
+        if "pack_all" not in comp:
+            comp["pack_all"] = torch.cat([wp.reshape(-1) for wp in comp["packs"]]).contiguous()   # the 8 weight sets back to back
+        check(lib.dmb_conf_phase_conv2d_f32(dev_ptr(c), dev_ptr(comp["pack_all"]), dev_ptr(comp["scale"]), dev_ptr(comp["shift"]),
+                                            dev_ptr(w2c), dev_ptr(conf), B, Dq, Hq, Wq, 8, stream_ptr(c.device)), "dmb_conf_phase_conv2d_f32")
     else:
         hq = torch.empty((B, 16 * M, Hq, Wq), dtype=torch.float32, device=c.device)
         for i, wp in enumerate(comp["packs"]):

@@ -241,13 +241,14 @@ int dmb_conf_head_f32(const float* cost, const float* w1pack, const float* scale
  *   (there the head zero-pads the volume, which the composed form cannot see); w1t = w1 transposed to [D, 3, 3, M], M = 64. */
 int dmb_conf_gather_f32(const float* hq, const float* w2, float* conf, int B, int M, int Hq, int Wq, void* stream);
 
-/* The same composed head, one launch per pair of sub-pixel phases, WITHOUT the hidden tensor: the 3x3 convolution 48 -> 128
- * (two phases x 64 hidden channels, weights of ops.conf_head_k8s4_pack) of the quarter-resolution volume c [B, Ci, Hq, Wq]
- * with BN scale/shift and ReLU, each pixel's 64-vector reduced against w2 [64] in the kernel's epilogue, sigmoid, scattered
- * to conf[b, 0, 4 y + by, 4 x + bx] for the phases phase_base and phase_base + 1 (phase = 4 by + bx, phase_base even).
- * Replaces conv2d + dmb_conf_gather_f32 on the composed path (cmn/cmn.py:27-43 on aggregators/AcfNet.py:55-57,81-83). */
+/* The same composed head WITHOUT the hidden tensor, in one launch: for each of the nsets weight sets laid out one after the
+ * other in wpack (set p = the sub-pixel phases 2 p and 2 p + 1 x 64 hidden channels, weights of ops.conf_head_k8s4_pack), the
+ * 3x3 convolution Ci -> 128 of the quarter-resolution volume c [B, Ci, Hq, Wq] with BN scale/shift and ReLU, each pixel's
+ * 64-vector reduced against w2 [64] in the kernel's epilogue, sigmoid, scattered to conf[b, 0, 4 y + by, 4 x + bx]
+ * (phase = 4 by + bx).  Replaces conv2d + dmb_conf_gather_f32 on the composed path (cmn/cmn.py:27-43 on
+ * aggregators/AcfNet.py:55-57,81-83); nsets = 8 covers all 16 phases. */
 int dmb_conf_phase_conv2d_f32(const float* c, const float* wpack, const float* scale, const float* shift, const float* w2,
-                              float* conf, int B, int Ci, int Hq, int Wq, int phase_base, void* stream);
+                              float* conf, int B, int Ci, int Hq, int Wq, int nsets, void* stream);
 int dmb_conf_ring_f32(const float* cost, const float* w1t, const float* scale, const float* shift, const float* w2,
                       float* conf, int B, int D, int M, int H, int W, void* stream);
 
