@@ -1,4 +1,5 @@
 """PSMNet stacked-hourglass cost aggregation: drop-in for cost_processors/aggregators/PSMNet.py:9-95."""
+import torch
 import torch.nn as nn
 
 from ..... import ops
@@ -43,7 +44,6 @@ class PSMAggregator(nn.Module):
     def _forward_overlapped(self, raw_cost):
         """Eval only: the same launches as trunk() + the up-sampling loop, with classifier branch k (and its up-sampling /
         regression) on a second stream next to hourglass k + 1.  Same kernels on the same operands: identical results."""
-        import torch
         B, C, D, H, W = raw_cost.shape
         size = (self.max_disp, H * 4, W * 4)
         vals = ops.disp_sample_values(self.max_disp, 0, 1)

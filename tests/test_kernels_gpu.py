@@ -795,6 +795,14 @@ def test_conf_head_composed_with_learned_upsampling(dev, B, Hq, Wq):
     finally:
         ops.set_conf_dot_epilogue(True)
     assert (via_hidden.double() - want).abs().max().item() <= 5e-6 and (via_hidden - got).abs().max().item() <= 2e-6
+    # ... and with the dword staging path of the convolution kernel (development option 3), which the fused epilogue shares
+    from densematchingbenchmark_amd import _lib
+    _lib.load().dmb_dev_set_option(3, 1)
+    try:
+        scalar_path = ops.conf_head_from_source(cost, comp, sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
+    finally:
+        _lib.load().dmb_dev_set_option(3, 0)
+    assert torch.equal(scalar_path, got)
     cost.add_(0.0)                                        # a modified tensor no longer matches its note
     assert not ops.conf_head_composite_applicable(cost, M)
 
