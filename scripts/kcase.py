@@ -1,5 +1,5 @@
 """Development aid: run ONE layer of the cost path a few times (for rocprofv3 counter passes).
-    python scripts/kcase.py deconv6|deconv5|s2_1|s2_3|s1q|c1|gwc|tri [reps]"""
+    python scripts/kcase.py deconv6|deconv5|s2_1|s2_3|s1q|s1f|s1h|c1|gwc|tri [reps]"""
 import os
 import sys
 
@@ -18,9 +18,10 @@ if name in ("deconv6", "deconv5"):
     x, wp = g(B, Ci, d, h, w), ops.pack_deconv3d_weights(g(Ci, Co, 3, 3, 3) * 0.03)
     sc, sh, r = torch.ones(Co, device=dev), torch.zeros(Co, device=dev), g(B, Co, 2 * d, 2 * h, 2 * w)
     fn = lambda: ops.deconv3d_k3s2(x, wp, Co, sc, sh, r, True)
-elif name in ("s2_1", "s2_3", "s1q"):
+elif name in ("s2_1", "s2_3", "s1q", "s1f", "s1h"):
     Ci, Co, st, d, h, w = {"s2_1": (32, 64, 2, D, H, W), "s2_3": (64, 64, 2, D // 2, H // 2, W // 2),
-                           "s1q": (64, 64, 1, D // 4, H // 4, W // 4)}[name]
+                           "s1q": (64, 64, 1, D // 4, H // 4, W // 4), "s1f": (32, 32, 1, D, H, W),
+                           "s1h": (64, 64, 1, D // 2, H // 2, W // 2)}[name]
     x, wp = g(B, Ci, d, h, w), ops.pack_conv3d_weights(g(Co, Ci, 3, 3, 3) * 0.03)
     sc, sh = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
     fn = lambda: ops.conv3d_k3(x, wp, Co, sc, sh, None, st, True)
