@@ -181,6 +181,8 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
                                                            const float* __restrict__ res, float* __restrict__ y, int Ci,
                                                            int D, int H, int W, int ntx, int nty, int ntz, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
+  relu &= 0xf;
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
   t /= ntx;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
   __syncthreads();
   for (int ci = 0; ci < NC; ++ci) {
     const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
-    if (ci + 1 < NC) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);  // lands while we compute
+    if (ci + 1 < NC && !(dbg & 2)) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);  // lands while we compute
     // ---- NK k-steps on the current buffer; A and B fragments register double-buffered one k-step ahead ----
     const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
     const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + C::lane_off(j) + C::XOFF;
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
   }
 
   // ---- epilogue ----
+  if (dbg & 1) return;
   const int gz = z0 + wz;
   float* yb = y + (size_t)b * C::COUT * DHW;
   const float* rb = res ? res + (size_t)b * C::COUT * DHW : nullptr;
@@ -1438,7 +1441,7 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     return fail(DMB_EUNSUPPORTED, "conv3d: 8 channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   const bool out_small = (long long)Co * D * H * W * 4 < 0x7fffffffLL;   // the vector epilogue addresses the whole output item
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 2) relu |= g_dev_opts[6] << 8;
+  relu |= g_dev_opts[6] << 8;   // development diagnostics (see the kernels)
 #define DMB_S1(CO, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
   if (stride == 1) {
     const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path

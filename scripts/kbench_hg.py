@@ -43,7 +43,7 @@ def conv_case(Ci, Co, stride, d, h, w, name, res=False):
     do, ho, wo = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
     r = torch.randn(B, Co, do, ho, wo, device=dev) if res else None
     fl = 2.0 * 27 * Ci * Co * B * do * ho * wo
-    for opt in ((0, 1, 2, 3) if diag and stride == 2 else (0,)):
+    for opt in ((0, 1, 2, 3) if diag else (0,)):
         lib.dmb_dev_set_option(6, opt)
         report(name + (" +res" if res else "") + (" [diag %d]" % opt if opt else ""),
                timeit(lambda: ops.conv3d_k3(x, wp, Co, sc, sh, r, stride, True)), fl)
