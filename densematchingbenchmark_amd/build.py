@@ -44,7 +44,7 @@ def build_library(force=False, verbose=True):
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
-            continue
+            raise FileNotFoundError("libdmb_hip.so source listed in build.SOURCES is missing: %s" % sp)
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
