@@ -12,7 +12,8 @@ all-reduce of the FP64 EPE accumulator over RCCL at the end of the job (inside t
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (conv3d k3 s1 32->32, FP32 MFMA bound):
 algorithmic FLOP per launch / mean launch duration measured live with HIP events on the launch stream.
-``cpu_baseline`` times the CPU oracle (a port of the reference's PyTorch-CPU path) on one pair on the host.
+``cpu_baseline`` times the CPU oracle (a port of the reference's PyTorch-CPU path) on the host: 1 warm-up + 3 timed full-size
+pairs.
 """
 import argparse
 import json
@@ -35,7 +36,11 @@ from densematchingbenchmark_amd.modeling import build_model  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
-PATH_GFLOP_PER_PAIR = 1015.84   # SURVEY.md 8-d, PSMNet 544x960 D=192
+PATH_GFLOP_PER_PAIR = 1015.84   # SURVEY.md 8-d, PSMNet 544x960 D=192: the REFERENCE's formulation of the path
+# what the path here EXECUTES per pair: dres0[0] runs as 2-D maps (csrc/catconv.hip): its 173.27 GFLOP become 6.5
+PATH_GFLOP_PER_PAIR_EXECUTED = 1015.84 - 173.27 + 6.5
+PATH_GB_PER_PAIR = 9.716        # module-boundary traffic per pair (each tensor read once + written once)
+DISTINCT_BATCHES = 4            # a rank cycles through this many distinct batches (16 distinct pairs at batch 4)
 DOMINANT = "conv3d_k3_s1_32to32"
 
 
@@ -76,9 +81,10 @@ def _pick_threads():
     return best
 
 
-def cpu_baseline(model, cfg, first_pair, ptype, agg):
-    """Oracle (port of the reference's CPU path) on ONE full-size pair of this configuration: ~10-40 s of host time.
-    Returns the baseline record and the oracle's outputs for that pair (the parity check of this run)."""
+def cpu_baseline(model, cfg, first_pair, ptype, agg, timed=3):
+    """Oracle (port of the reference's CPU path) at the configuration's full size: 1 warm-up + ``timed`` timed evaluations of one
+    pair (15-40 s of host time).  Returns the baseline record and the oracle's outputs for that pair
+    (the parity check of this run)."""
     from oracle import dmb_oracle as O   # checker / reported baseline only -- never on the product path
     cores = _pick_threads()
     torch.set_num_threads(cores)
@@ -106,19 +112,48 @@ def cpu_baseline(model, cfg, first_pair, ptype, agg):
         what = "cat_fms + PSMAggregator + 3x FasterSoftArgmin"
     else:
         return None, None
-    crop = lambda t: t[:, :, :32, :64].contiguous()  # noqa: E731
+    # 1 warm-up + 3 timed pairs at the configuration's full size (the SAME pair each time: the
+    # arithmetic does not depend on the data), mean s/pair; plus one full-size 32 -> 32 layer on ONE thread for scaling context
+    times = []
     with torch.no_grad():
-        if isinstance(left, tuple):
-            run(tuple(crop(t) for t in left), tuple(crop(t) for t in right)) if md <= 32 else None
-        elif agg == "PSMNet":
-            O.psmnet_path(crop(left), crop(right), p, 32)     # warm-up (thread pool, allocator) on a small crop
         t0 = time.perf_counter()
-        outs = run(left, right)
-        dt = time.perf_counter() - t0
+        outs = run(left, right)                       # warm-up at full size (thread pool, allocator, mkldnn primitives)
+        cold = time.perf_counter() - t0
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            outs = run(left, right)
+            times.append(time.perf_counter() - t0)
     shape = left[0].shape if isinstance(left, tuple) else left.shape
+    tail = "features %dx%d, max_disp=%d (%s), torch CPU FP32, %d threads (fastest of a sweep on a %d-thread host)" % (
+        shape[2], shape[3], md, what, cores, os.cpu_count() or 1)
+    if not times:   # abbreviated (N > 1 jobs): the one cold pair
+        return dict(value=1.0 / cold, unit="pairs/s", cores=cores, kind="port",
+                    sample="1 pair without warm-up (%.2f s; abbreviated in multi-rank jobs, the N = 1 line carries BASELINE.md's "
+                           "protocol), %s" % (cold, tail)), outs
+    dt = sum(times) / len(times)
     return dict(value=1.0 / dt, unit="pairs/s", cores=cores, kind="port",
-                sample="1 pair, features %dx%d, max_disp=%d (%s), torch CPU FP32, %d threads (fastest of a sweep on a "
-                       "%d-thread host), %.1f s" % (shape[2], shape[3], md, what, cores, os.cpu_count() or 1, dt)), outs
+                sample="1 warm-up + %d timed pairs (mean %.2f s; each %s), %s" % (len(times), dt, [round(t, 2) for t in times], tail),
+                single_thread_context=_single_thread_layer(cores)), outs
+
+
+CPU_TIMED_PAIRS = 3
+
+
+def _single_thread_layer(cores):
+    """Scaling context: ONE full-size 32 -> 32 3x3x3 layer (86.6 GFLOP, 1/12 of a pair's arithmetic) on
+    one thread and on the chosen thread count."""
+    import torch.nn.functional as F
+    x = torch.randn(1, 32, 48, 136, 240)
+    w = torch.randn(32, 32, 3, 3, 3) * 0.03
+    out = {}
+    for n in (1, cores):
+        torch.set_num_threads(n)
+        F.conv3d(x[:, :, :8], w, padding=1)
+        t0 = time.perf_counter()
+        F.conv3d(x, w, padding=1)
+        out["conv3d_32to32_fullsize_s_%dthr" % n] = round(time.perf_counter() - t0, 3)
+    torch.set_num_threads(cores)
+    return out
 
 
 def end_to_end(model, dev, B, Hp, Wp, steps):
@@ -263,9 +298,18 @@ def main():
         raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU over RCCL)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # DMB_BENCH_FORCE_PG=1: a ONE-rank job also goes through the process group, so that RCCL initialisation, the FP64
+    # accumulator all-reduce, the barrier fence and the MAX clock reduce -- the exchange of tools/test.py:172-208 -- execute on
+    # whatever hardware is there (tests/test_bench_gpu.py runs it on the single leased MI355X)
+    use_pg = world > 1 or os.environ.get("DMB_BENCH_FORCE_PG", "0") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         kw = dict(device_id=dev) if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)  # nccl == RCCL on ROCm
 
@@ -284,25 +328,38 @@ def main():
     model = model.to(dev)
     n_ids = len(cfg.get("eval_disparity_id", [0]))
 
-    # inputs resident in HBM before the timed region: this rank's pairs are rank, rank + world, ...
+    # inputs resident in HBM before the timed region.  The job's pairs are numbered globally and pair i goes to rank i mod world
+    # (tools/test.py:108); a rank holds DISTINCT_BATCHES distinct local batches (16 distinct pairs at batch 4) and step k
+    # evaluates batch k mod DISTINCT_BATCHES, so the "dataset" metrics and the sharding rule run over many pairs, not over four
     ptype = cfg.model.cost_processor.type
-    if ptype == "Correlation":   # GwcNet-style: (320-ch correlation features, 12-ch concat features) per view
-        lg, rg = synthetic.feature_batch(rank, world, B, 320, fh, fw, dev)
-        lc, rc = synthetic.feature_batch(rank + 100000, world, B, 12, fh, fw, dev)
-        left, right = (lg, lc), (rg, rc)
-    else:
-        left, right = synthetic.feature_batch(rank, world, B, C, fh, fw, dev)
     pred_scale = md // cfg.model.disp_predictor.max_disp   # StereoNet regresses at 1/8 resolution
-    gt = synthetic.gt_batch(rank, world, B, Hp // pred_scale, Wp // pred_scale, pad_top=(Hp - H0) // pred_scale, device=dev)
-    if pred_scale > 1:
-        gt = gt / pred_scale
+    nb = max(1, min(DISTINCT_BATCHES, args.steps))
+    batches = []
+    for k in range(nb):
+        first = rank + world * B * k     # this rank's pairs of batch k: first, first + world, ...
+        if ptype == "Correlation":   # GwcNet-style: (320-ch correlation features, 12-ch concat features) per view
+            lg, rg = synthetic.feature_batch(first, world, B, 320, fh, fw, dev)
+            lc, rc = synthetic.feature_batch(first + 100000, world, B, 12, fh, fw, dev)
+            lft, rgt = (lg, lc), (rg, rc)
+        else:
+            lft, rgt = synthetic.feature_batch(first, world, B, C, fh, fw, dev)
+        g_k = synthetic.gt_batch(first, world, B, Hp // pred_scale, Wp // pred_scale, pad_top=(Hp - H0) // pred_scale, device=dev)
+        if pred_scale > 1:
+            g_k = g_k / pred_scale
+        batches.append((dict(leftFeature=lft, rightFeature=rgt), g_k))
+    left, right = batches[0][0]["leftFeature"], batches[0][0]["rightFeature"]
     acc = EpeAccumulator(dev, n_ids, cfg.model.eval.lower_bound, cfg.model.eval.upper_bound)
-    batch = dict(leftFeature=left, rightFeature=right)
     fused = args.fused_regression
+    counter = [0]
 
     last_results = {}
 
-    def step():
+    def step(k=None):
+        if k is None:
+            k = counter[0]
+            counter[0] += 1
+        batch, gt = batches[k % nb]
+        left, right = batch["leftFeature"], batch["rightFeature"]
         if not fused:
             results, _ = model(batch)
             disps = results["disps"]
@@ -320,7 +377,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -328,6 +385,7 @@ def main():
         for _ in range(args.warmup):
             disps = step()
         acc.acc.zero_()
+        counter[0] = 0
         timer = ops.KernelTimer([DOMINANT])
         ops.set_kernel_timer(timer)
         fence()
@@ -340,7 +398,7 @@ def main():
         ops.set_kernel_timer(None)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = tmax.item()
     pairs = B * args.steps * world
@@ -386,20 +444,32 @@ def main():
             # executes less (dres0[0] in its 2-D form: 2/3 of that layer's multiplications do not exist)
             out["path_tflops_reference_formulation"] = round(value * PATH_GFLOP_PER_PAIR / 1e3, 2)
             out["path_frac_fp32_peak_reference_formulation"] = round(value * PATH_GFLOP_PER_PAIR / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4)
+            # ... and the arithmetic the path really EXECUTES (849.07 GFLOP per pair): the achieved fraction of the matrix peak
+            out["path_tflops_executed"] = round(value * PATH_GFLOP_PER_PAIR_EXECUTED / 1e3, 2)
+            out["path_frac_fp32_peak_executed"] = round(value * PATH_GFLOP_PER_PAIR_EXECUTED / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4)
+            # north_star: throughput as a fraction of the HBM roofline (9.716 GB of module-boundary traffic per pair
+            # / 8 TB/s = 823 pairs/s per GPU; the path is compute-bound, the FP32 matrix peak caps this fraction at 0.188)
+            out["path_hbm_gbs_algorithmic"] = round(value * PATH_GB_PER_PAIR, 1)
+            out["path_frac_hbm_roofline"] = round(value * PATH_GB_PER_PAIR / world / PEAK_HBM_GBS, 4)
         if args.conv3d_mode != "exact":   # the split kernel issues 6 bf16 MFMAs per FP32 product (+ 28/27 tap padding)
             issued = achieved * 6.0 * 28.0 / 27.0
             out["roofline"].update({"kernel": "conv3d_s1_x6_kernel (k3 s1 32->32, bf16x6 split)", "achieved": round(issued, 1),
                                     "peak": 2500.0, "frac": round(issued / 2500.0, 4),
                                     "fp32_equivalent_tflops": round(achieved, 2), "traffic": None})
         agg_type = cfg.model.cost_processor.cost_aggregator.type
-        if world == 1 and not args.no_cpu_baseline:
+        out["distinct_pairs_per_gpu"] = nb * B
+        with torch.no_grad():
+            disps = step(0)      # batch 0 again: the parity check and the secondary legs below all look at global pair 0
+        if not args.no_cpu_baseline:
             first = tuple(t[0:1].cpu() for t in left) if isinstance(left, tuple) else left[0:1].cpu()
             first_r = tuple(t[0:1].cpu() for t in right) if isinstance(right, tuple) else right[0:1].cpu()
-            base, ref = cpu_baseline(model, cfg, (first, first_r), ptype, agg_type)
+            # N = 1: BASELINE.md's protocol (1 warm-up + 3 timed pairs).  N > 1: ONE pair, enough for the parity record and an
+            # abbreviated baseline, while the other ranks wait at the final barrier
+            base, ref = cpu_baseline(model, cfg, (first, first_r), ptype, agg_type, timed=CPU_TIMED_PAIRS if world == 1 else 0)
             if base is not None:
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu"] = round(value / base["value"], 1)
-                # parity of the first pair of the last step against the oracle's outputs for that pair
+                # parity of global pair 0 against the oracle's outputs for that pair
                 d_gpu = [d[0:1].cpu() for d in disps]
                 out["parity_vs_cpu"] = {"max_abs_disp": [round((a - b).abs().max().item(), 7) for a, b in zip(d_gpu, ref[0])],
                                         "epe_delta": [round((a - b).abs().mean().item(), 8) for a, b in zip(d_gpu, ref[0])]}
@@ -409,12 +479,12 @@ def main():
         if world == 1 and ptype == "Concatenation" and agg_type == "PSMNet" and not fused and not args.no_extras:
             out["end_to_end_with_backbone"] = end_to_end(model, dev, B, Hp, Wp, min(args.steps, 5))
             if args.conv3d_mode == "exact":
-                out["opt_in_branch_overlap"] = overlap_leg(step, disps, B, min(args.steps, 10))
-                out["opt_in_bf16x6"] = split_mode_leg(step, disps, B, min(args.steps, 5))
+                out["opt_in_branch_overlap"] = overlap_leg(lambda: step(0), disps, B, min(args.steps, 10))
+                out["opt_in_bf16x6"] = split_mode_leg(lambda: step(0), disps, B, min(args.steps, 5))
                 if "losses" in cfg.model:
                     out["training_step"] = training_leg(cfg, dev, min(args.steps, 5))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,7 +43,7 @@ class EpeAccumulator:
 
     def all_reduce(self):
         """One 48*num_ids-byte SUM all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():   # (a one-rank group reduces too: the collective still executes)
             dist.all_reduce(self.acc, op=dist.ReduceOp.SUM)
         return self
 

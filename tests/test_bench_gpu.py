@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*flags, env=None):
+def _bench(*flags, env=None, want_text=False):
     e = dict(os.environ)
     e.update(env or {})
     e.pop("WORLD_SIZE", None)
@@ -24,6 +24,8 @@ def _bench(*flags, env=None):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]   # ONE JSON line, from rank 0
+    if want_text:
+        return json.loads(lines[0]), out.stdout + out.stderr
     return json.loads(lines[0])
 
 
@@ -37,3 +39,19 @@ def test_bench_gpus_flag_launches_the_ranks(dev):
     for k in ("epe", "1px", "3px"):
         assert abs(one["epe_accumulator"][k] - two["epe_accumulator"][k]) <= 1e-9 * max(1.0, abs(one["epe_accumulator"][k]))
     assert two["value"] > 0 and two["ms_per_step"] > 0
+
+
+def test_bench_one_rank_through_rccl(dev):
+    """The exchange of tools/test.py:172-208 on the hardware that is there: a ONE-rank job forced through an ``nccl`` (= RCCL)
+    process group with ``device_id`` -- RCCL initialisation, the FP64 accumulator all-reduce, the barrier fences and the MAX
+    clock reduce all execute on the MI355X.  The RCCL banner (NCCL_DEBUG=VERSION) is captured as evidence."""
+    plain = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2")
+    rccl, text = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", want_text=True,
+                        env={"DMB_BENCH_FORCE_PG": "1", "NCCL_DEBUG": "VERSION", "MASTER_ADDR": "127.0.0.1"})
+    banner = [ln for ln in text.splitlines() if "NCCL version" in ln or "RCCL version" in ln]
+    print("\n".join(banner[:3]))
+    assert banner, "no RCCL version banner in the job's output:\n" + text[-2000:]
+    assert rccl["n_gpus"] == 1 and rccl["pairs"] == plain["pairs"] == 4
+    for k in ("epe", "1px", "3px"):   # the all-reduced accumulator of a one-rank group is the rank's own
+        assert rccl["epe_accumulator"][k] == plain["epe_accumulator"][k]
+    assert rccl["value"] > 0
