@@ -278,11 +278,7 @@ extern "C" int dmb_conf_ring_f32(const float* cost, const float* w1t, const floa
     return fail(DMB_EINVAL, "conf_ring: bad argument (64 hidden channels)");
   const int ring = 2 * W + 2 * (H - 2);
   const size_t lds = (size_t)RING_NW * (RING_M / 2) * 64 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conf_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conf_ring_kernel), (size_t)(lds));
   hipLaunchKernelGGL(conf_ring_kernel, dim3((unsigned)(B * cdiv(ring, 64))), dim3(64 * RING_NW), lds, (hipStream_t)stream, cost,
                      w1t, scale, shift, w2, conf, B, D, H, W);
   return launch_status("conf_ring launch failed");
@@ -310,12 +306,7 @@ static int launch_conf(const float* cost, const float* wp, const float* scale, c
   const long long nblk = (long long)B * ntx * nty;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conf_head: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conf_head_kernel<NTT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conf_head_kernel<NTT>), (size_t)(lds));
   hipLaunchKernelGGL((conf_head_kernel<NTT>), dim3((unsigned)nblk), dim3(256), lds, st, cost, wp, scale, shift, w2, conf,
                      D, Cm, H, W, ntx, nty);
   return launch_status("conf_head launch failed");

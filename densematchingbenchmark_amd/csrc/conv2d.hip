@@ -471,12 +471,7 @@ static int launch_conv2d(const float* x, const float* wp, const float* scale, co
   const long long ntiles = (long long)B * ntx * nty * (C::DOT ? res_ctot : 1);
   if (ntiles > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv2d_kernel<C>), (size_t)(lds));
   const long long slots = 2LL * num_cus();   // two workgroups per CU, a multiple of the 8 XCDs
   const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
   hipLaunchKernelGGL((conv2d_kernel<C>), dim3(grid), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, Co, H, W, relu,

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
                                                            int D, int H, int W, int ntx, int nty, int ntz, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
-  relu &= 0xf;
+  relu &= 0xff;
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
   t /= ntx;
@@ -670,7 +670,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + stride - 1) / stride;
   const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
-  relu &= 0xf;
+  relu &= 0xff;
 
   struct Tile {
     int b, x0, y0, z0;
@@ -1327,12 +1327,7 @@ static int launch_s1(const float* x, const float* wp, const float* scale, const 
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_kernel<C>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv3d_s1_kernel<C>), (size_t)(lds));
   hipLaunchKernelGGL((conv3d_s1_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
                      H, W, ntx, nty, ntz, relu);
   return launch_status("conv3d stride-1 launch failed");
@@ -1346,12 +1341,7 @@ static int launch_s2(const float* x, const float* wp, const float* scale, const 
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s2_kernel<C>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv3d_s2_kernel<C>), (size_t)(lds));
   hipLaunchKernelGGL((conv3d_s2_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
                      H, W, Do, Ho, Wo, ntx, nty, ntz, relu);
   return launch_status("conv3d stride-2 launch failed");
@@ -1364,16 +1354,15 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
   const long long ntiles = (long long)B * ntx * nty * ntz;
   if (ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
   const size_t lds = (size_t)(C::LDS_FLOATS + C::AFF_FLOATS + C::SCR_FLOATS) * sizeof(float);
-  static bool attr_set = false;
-  static int ncu = 256;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3d_kernel<C>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  DMB_ENSURE_LDS((&deconv3d_kernel<C>), (size_t)(lds));
+  static int ncu = 0;
+  if (!ncu) {
+    
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       ncu = prop.multiProcessorCount;
-    attr_set = true;
+    if (ncu <= 0) ncu = 256;
   }
   // persistent grid: C::WPE workgroups per CU; a third of them walk the even-z items, two thirds the odd-z items
   // (twice the work each).  With fewer items than slots every workgroup gets exactly one item.
@@ -1523,12 +1512,7 @@ extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, 
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: grid too large");
   const size_t lds = (size_t)2 * C1_BUF * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_c1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv3d_c1_kernel), (size_t)(lds));
   if ((long long)2 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: tensor too large for 32-bit offsets");
   if (W % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) && !g_dev_opts[3]) {   // 16-byte rows
     const int vx = cdiv(W, C1V_TX), vy = cdiv(H, C1V_TY), vz = cdiv(D, C1V_TZ);

@@ -312,12 +312,7 @@ static int launch_x6(const float* x, const void* wpack, const float* scale, cons
   const int ntx = W / C::TX, nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_x6: grid too large");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_x6_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              C::LDS_BYTES);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv3d_s1_x6_kernel<C>), (size_t)(C::LDS_BYTES));
   hipLaunchKernelGGL((conv3d_s1_x6_kernel<C>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, x,
                      (const unsigned short*)wpack, scale, shift, residual, y, Ci, D, H, W, ntx, nty, ntz, relu);
   return launch_status("conv3d_x6 launch failed");

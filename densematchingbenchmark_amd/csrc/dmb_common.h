@@ -25,6 +25,26 @@ inline int launch_status(const char* what) {
   return DMB_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: `*seen` (one static per kernel
+// instantiation) remembers the device ordinals it has been raised on, so a process that moves to a second GPU
+// (torch.cuda.device(1)) sets it there too.  Returns DMB_OK or the failure (never ignored: the launch would fail opaquely).
+inline int ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned long long* seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*seen & bit) return DMB_OK;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  *seen |= bit;
+  return DMB_OK;
+}
+#define DMB_ENSURE_LDS(kernel, bytes)                                                                       \
+  do {                                                                                                      \
+    static unsigned long long dmb_seen_ = 0;                                                                \
+    const int dmb_rc_ = dmb::ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (bytes), &dmb_seen_); \
+    if (dmb_rc_ != DMB_OK) return dmb_rc_;                                                                  \
+  } while (0)
+
 // Disparity sample indices travel as a by-value kernel argument (<= 1 KiB of kernarg).
 struct DispIdx {
   int d[DMB_MAX_DISP_SAMPLES];

@@ -158,12 +158,7 @@ template <int CG>
 static int launch_gwc_mfma(const float* L, const float* R, float* out, int B, int C, int G, int H, int W, int D,
                            const DispIdx& idx, int out_channels, int och_off, hipStream_t st) {
   const size_t lds = (size_t)(CG * (GW_LROW + GW_RROW) + 4 * GW_SCR + DMB_MAX_DISP_SAMPLES) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gwc_mfma_kernel<CG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&gwc_mfma_kernel<CG>), (size_t)(lds));
   const int rpw = g_dev_opts[5] > 0 ? g_dev_opts[5] : 2;   // rows per workgroup (g_dev_opts[5]: development knob)
   int dmax = 0;
   for (int k = 0; k < D; ++k) dmax = idx.d[k] > dmax ? idx.d[k] : dmax;

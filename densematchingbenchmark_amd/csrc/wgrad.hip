@@ -557,13 +557,9 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
   if (g_dev_opts[5] > 0) zseg = cdiv(D, g_dev_opts[5]);   // development knob: number of z segments
   const int nzs = cdiv(D, zseg);
   const bool v16 = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)dc) & 15) == 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<true, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<24>::LDS_FLOATS * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<32>::LDS_FLOATS * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s1_kernel<false, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<24>::LDS_FLOATS * 4);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv3d_wgrad_s1_kernel<true, 24>), (size_t)(WgCfg<24>::LDS_FLOATS * 4));
+  DMB_ENSURE_LDS((&conv3d_wgrad_s1_kernel<true, 32>), (size_t)(WgCfg<32>::LDS_FLOATS * 4));
+  DMB_ENSURE_LDS((&conv3d_wgrad_s1_kernel<false, 24>), (size_t)(WgCfg<24>::LDS_FLOATS * 4));
   const long long items3 = (long long)B * ntx * nty * nzs;
   const int nused = (int)(items3 < nslots ? items3 : nslots);   // small layers: no idle slots to write and add zeros for
   const dim3 grid((unsigned)nused, (unsigned)nblk);
@@ -605,12 +601,8 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
     }
   }
   const int nzs = cdiv(Ds, zseg);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2Cfg::LDS_FLOATS * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_s2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg2Cfg::LDS_FLOATS * 4);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv3d_wgrad_s2_kernel<true>), (size_t)(Wg2Cfg::LDS_FLOATS * 4));
+  DMB_ENSURE_LDS((&conv3d_wgrad_s2_kernel<false>), (size_t)(Wg2Cfg::LDS_FLOATS * 4));
   const long long items2 = (long long)B * ntx * nty * nzs;
   const int nused = (int)(items2 < nslots ? items2 : nslots);
   if (v16)
@@ -841,11 +833,7 @@ static int launch_wgrad2d(const float* x, const float* dc, float* dw, float* wor
     }
   }
   const int nys = cdiv(HC, yseg);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<KS, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
-    attr_set = true;
-  }
+  DMB_ENSURE_LDS((&conv2d_wgrad_kernel<KS, DIL>), (size_t)(C::LDS_FLOATS * 4));
   const long long items = (long long)B * ntx * DIL * nys;
   const int nused = (int)(items < nslots ? items : nslots);   // small layers: no idle slots to write and add zeros for
   hipLaunchKernelGGL((conv2d_wgrad_kernel<KS, DIL>), dim3((unsigned)nused, (unsigned)nblk), dim3(256), C::LDS_FLOATS * 4, st, x, dc, workspace, B,

@@ -42,10 +42,8 @@ class AcfAggregator(PSMAggregator):
         out = []
         for c, m in pairs:
             cq = c.squeeze(1)
-            if W % 4 == 0:
-                cost, disp = ops.deconv3d_k8s4_c1_soft_argmin(cq, m.weight.detach().view(8, 8, 8), vals, 1.0)
-                ops.RegressionHint.attach(cost, vals, 1.0, disp)
-            else:
-                cost = ops.deconv3d_k8s4_c1(cq, m.weight.detach().view(8, 8, 8))
+            # (any W: the kernel's 16-byte stores go to column 4 q of rows of 4 W floats -- always aligned)
+            cost, disp = ops.deconv3d_k8s4_c1_soft_argmin(cq, m.weight.detach().view(8, 8, 8), vals, 1.0)
+            ops.RegressionHint.attach(cost, vals, 1.0, disp)
             out.append(ops.UpsampleSource.attach(cost, cq, m.weight))   # lets the confidence head work at quarter resolution
         return out

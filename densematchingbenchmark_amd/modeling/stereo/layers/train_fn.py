@@ -525,4 +525,22 @@ def wants_grad(module, *tensors):
         return False
     if any(t is not None and getattr(t, "requires_grad", False) for t in tensors):
         return True
-    return any(p.requires_grad for p in module.parameters())
+    if any(p.requires_grad for p in module.parameters()):
+        _warn_eval_on_training_path(module)
+        return True
+    return False
+
+
+_warned_eval_path = [False]
+
+
+def _warn_eval_on_training_path(module):
+    """An eval-mode module called with gradients enabled and trainable parameters takes the unit-by-unit autograd path (full-size
+    activations saved, no fused volume / regression kernels): several times the memory and latency of the inference path.
+    That is what the reference's nn modules would do too, but it is easy to hit by accident -- say so once."""
+    if not _warned_eval_path[0]:
+        _warned_eval_path[0] = True
+        import warnings
+        warnings.warn("%s is in eval mode but gradients are enabled and its parameters require grad: taking the autograd "
+                      "(training) path.  Wrap inference in torch.no_grad() -- as GeneralizedStereoModel's eval branch does -- to "
+                      "stay on the fused inference kernels." % type(module).__name__, stacklevel=3)

@@ -343,8 +343,10 @@ def catconv_first(L, R, D, packs, scale=None, shift=None, relu=False):
     """relu?(scale * conv3d(V, w) + shift) without the volume V = cat_fms(L, R, d_k = k) (or dif_fms: the packs decide):
     [B, C, H, W] x 2 -> [B, Co, D, H, W]."""
     lib = _lib.load()
-    L, R = _f32c(L, "reference_fm"), _f32c(R, "target_fm")
+    L, R = _feature_pair(L, R, "catconv_first")
     B, C, H, W = L.shape
+    if packs.get("Cin") is not None and packs["Cin"] != C:
+        raise _lib.DmbLibraryError("catconv_first: weights were packed for %d feature channels, the maps have %d" % (packs["Cin"], C))
     Co, CA = packs["Co"], CATCONV_CH
     Wc = D + 4
     dev = L.device
@@ -846,7 +848,13 @@ def deconv3d_k8s4_c1_soft_argmin(x, w, disp_values=None, alpha=1.0):
     the soft-argmin (normalize=True) of the volume it writes, in one pass: returns (cost [B, 4D, 4H, 4W], disp or None)."""
     lib = _lib.load()
     x, w = _f32c(x, "x"), _f32c(w, "weight")
+    if x.dim() != 4:
+        raise _lib.DmbLibraryError("deconv3d_k8s4_c1_soft_argmin: x must be [B, D, H, W], got %s" % (tuple(x.shape),))
     B, D, H, W = x.shape
+    if w.numel() != 512:   # the kernel reads 8 x 8 x 8 weights
+        raise _lib.DmbLibraryError("deconv3d_k8s4_c1_soft_argmin: weight must hold 8x8x8 values, got %s" % (tuple(w.shape),))
+    if disp_values is not None and len(disp_values) != 4 * D:   # ... and 4 D host floats
+        raise _lib.DmbLibraryError("deconv3d_k8s4_c1_soft_argmin: %d disparity samples for %d output planes" % (len(disp_values), 4 * D))
     y = torch.empty((B, 4 * D, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
     disp = torch.empty((B, 1, 4 * H, 4 * W), dtype=torch.float32, device=x.device) if disp_values is not None else None
     check(lib.dmb_deconv3d_k8s4_c1_soft_argmin_f32(dev_ptr(x), dev_ptr(w), dev_ptr(y), dev_ptr(disp, allow_none=True), B, D, H, W,

@@ -86,3 +86,21 @@ def gt_batch(first_pair_index, stride, batch, height, width, pad_top=0, device="
     """Ground truth of pairs ``first, first+stride, ...`` -- a function of the GLOBAL pair index only, so that a job's
     accumulated errors do not depend on how its pairs are sharded over ranks."""
     return torch.cat([gt_disparity(first_pair_index + j * stride, 1, height, width, pad_top) for j in range(batch)]).to(device)
+
+
+def peaked_cost_volume(seed, planes, height, width):
+    """A quarter-resolution cost volume [1, planes, height, width] with ground-truth-like peaks: the peak plane
+    follows a smooth field that sits near plane 1.25 (full-resolution disparity 5) on the left quarter of the image, near plane
+    46.25 (disparity 185) on the right quarter and ramps in between; costs fall from +12 at the peak to -12 four planes away,
+    plus 0.3 sigma of noise -- the ends of the disparity range and strongly peaked volumes, which the random-weight networks
+    never produce."""
+    g = torch.Generator().manual_seed(9000 + int(seed))
+    ys = torch.linspace(0, 1, height).view(1, height, 1)
+    xs = torch.linspace(0, 1, width).view(1, 1, width)
+    t = ((xs - 0.25) / 0.5).clamp(0, 1)
+    ramp = t * t * (3 - 2 * t)
+    peak = 1.25 + 45.0 * ramp + 0.6 * torch.sin(9.0 * ys) * torch.sin(5.0 * xs)      # in planes
+    peak = peak.clamp(0.25, planes - 1.25) * (planes - 1) / 47.0 if planes != 48 else peak.clamp(0.25, planes - 1.25)
+    z = torch.arange(planes, dtype=torch.float32).view(planes, 1, 1)
+    cost = (12.0 - 6.0 * (z - peak).abs()).clamp(min=-12.0) + 0.3 * torch.randn((planes, height, width), generator=g)
+    return cost.unsqueeze(0).contiguous()

@@ -13,7 +13,11 @@ Pinning: ``oracle/gen_golden.py`` imports the real reference (in the build conta
 inputs/outputs under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function here against
 those vectors, including the reference's own known-answer cases (tests/.../test_cat_fms.py:30-40 and
 test_disp_predictors.py:42-102).  The group-wise correlation volume has NO reference implementation
-(README.md:16 only names GwcNet): for that one function parity is UNPINNED and the spec is SURVEY 8-a4.
+(README.md:16 only names GwcNet): for that one function parity is UNPINNED and the spec is SURVEY 8-a4.  It has two
+witnesses that share no code with it (tests/test_oracle_golden.py::test_oracle_gwc_has_two_witnesses, and the same on the
+GPU): with one channel per group it must equal the product of the two halves of cat_fms's volume (cat_fms IS pinned bit
+for bit), and with one group, rescaled by C, correlation1d_cost's pre-activation channels in disparity order
+(correlation1d_cost.py:12-25; itself unpinned: the sampler package is not in the reference tree).
 
 Training side: the ``*_train_step`` / ``*_backward`` functions differentiate the same restatements with
 torch.autograd in training mode (``bn_training()``); they are pinned too -- gen_golden.py section 4h runs one training
@@ -229,7 +233,7 @@ def gwc_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, num
     assert C % num_groups == 0
     cg = C // num_groups
     idx = disp_index_list(max_disp, start_disp, dilation)
-    out = torch.zeros(N, num_groups, len(idx), H, W, dtype=torch.float32)
+    out = torch.zeros(N, num_groups, len(idx), H, W, dtype=reference_fm.dtype if reference_fm.dtype == torch.float64 else torch.float32)
     for k, d in enumerate(idx):
         if abs(d) >= W:
             continue

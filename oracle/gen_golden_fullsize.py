@@ -6,6 +6,12 @@ seeded parameters and inputs the GPU tests regenerate.  Stored: sub-sampled disp
 files at the sizes the CPU suite can afford).
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py          (about five minutes on 8 cores)
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py round3   (only the families added in round 3)
+
+Round 3 added (parity): PSMNet pair 0 at classifier gain 30 (fullsize_psmnet_gain30.npz); one FULL AcfNet
+disparity / confidence map instead of every 64th pixel (fullsize_acfnet_map.npz); and the regression tail -- trilinear x4
+up-sampling (PSMNet.py:74-93) + FasterSoftArgmin / SoftArgmin -- on a volume with ground-truth-like peaks near disparity 5
+and 185 and costs spanning +-12 (fullsize_regression_ends.npz), which the random-weight networks never produce.
 """
 import os
 import sys
@@ -29,9 +35,71 @@ class _M(torch.nn.Module):
     pass
 
 
+def round3():
+    """The fixture families added in round 3 (see the module docstring)."""
+    import torch.nn.functional as F
+    from dmb.modeling.stereo.cost_processors import build_cost_processor
+    from dmb.modeling.stereo.disp_predictors import build_disp_predictor
+    from dmb.modeling.stereo.disp_predictors.soft_argmin import SoftArgmin
+    from dmb.modeling.stereo.disp_predictors.faster_soft_argmin import FasterSoftArgmin
+    from dmb.modeling.stereo.cmn.cmn import Cmn, ConfHead
+    from densematchingbenchmark_amd import synthetic
+
+    with torch.no_grad():
+        # ---- PSMNet pair 0 at classifier gain 30: costs three times as peaked as the gain-10 family ---------------------
+        cfg = G.load_cfg("configs/PSMNet/scene_flow.py")
+        m = _M()
+        m.cost_processor = build_cost_processor(cfg)
+        m.disp_predictor = build_disp_predictor(cfg)
+        m.eval()
+        synthetic.init_params_(m, seed=0, classif_gain=30.0)
+        lf, rf = synthetic.feature_pair(0, 32, 136, 240)
+        costs = m.cost_processor(lf, rf)
+        disps = [m.disp_predictor(c) for c in costs]
+        out = {}
+        for lvl, (d, c) in enumerate(zip(disps, costs)):
+            out["pair0_disp%d" % (3 - lvl)] = G.npy(d[SUB])
+            out["pair0_cost%d_rows" % (3 - lvl)] = G.npy(c[CROWS])
+        print("psmnet gain 30: disp3 range %.2f..%.2f, cost3 range %.2f..%.2f" % (disps[0].min().item(), disps[0].max().item(),
+                                                                                 costs[0].min().item(), costs[0].max().item()), flush=True)
+        np.savez_compressed(os.path.join(OUT, "fullsize_psmnet_gain30.npz"), **out)
+        del costs, disps
+
+        # ---- AcfNet (as in main(): seed 5, pair 0): the FULL best-level disparity and confidence maps ----------------------
+        cfg = G.load_cfg("configs/AcfNet/scene_flow_adaptive.py")
+        m = _M()
+        m.cost_processor = build_cost_processor(cfg)
+        m.disp_predictor = build_disp_predictor(cfg)
+        m.cmn = Cmn.__new__(Cmn)
+        torch.nn.Module.__init__(m.cmn)
+        m.cmn.conf_heads = torch.nn.ModuleList([ConfHead(cfg.model.cmn.in_planes, True) for _ in range(3)])
+        m.cmn.alpha, m.cmn.beta = cfg.model.cmn.alpha, cfg.model.cmn.beta
+        m.eval()
+        synthetic.init_params_(m, seed=5, classif_gain=10.0)
+        costs = m.cost_processor(lf, rf)
+        d3 = m.disp_predictor(costs[0])
+        confs, _, _ = Cmn.get_confidence(m.cmn, costs)
+        np.savez_compressed(os.path.join(OUT, "fullsize_acfnet_map.npz"), disp3=G.npy(d3), conf3=G.npy(confs[0]).astype(np.float16))
+        print("acfnet full maps: disp3 range %.2f..%.2f" % (d3.min().item(), d3.max().item()), flush=True)
+        del costs, confs
+
+        # ---- regression tail at the ends of the range: trilinear x4 (PSMNet.py:74-93) + the two soft-argmin modules --------
+        q = synthetic.peaked_cost_volume(0, 48, 136, 240)
+        full = F.interpolate(q.unsqueeze(1), [192, 544, 960], mode="trilinear", align_corners=True).squeeze(1)
+        fast = FasterSoftArgmin(max_disp=192, start_disp=0, dilation=1, alpha=1.0, normalize=True)(full)
+        slow = SoftArgmin(max_disp=192, start_disp=0, dilation=1, alpha=1.0, normalize=True)(full)
+        print("regression ends: disparity range %.3f..%.3f, cost range %.2f..%.2f, faster-vs-plain %.2e" % (
+            fast.min().item(), fast.max().item(), full.min().item(), full.max().item(), (fast - slow).abs().max().item()), flush=True)
+        np.savez_compressed(os.path.join(OUT, "fullsize_regression_ends.npz"), faster=G.npy(fast[SUB]), plain=G.npy(slow[SUB]),
+                            cost_rows=G.npy(full[CROWS]))
+
+
 def main():
     G.import_reference()
     torch.set_num_threads(int(os.environ.get("DMB_THREADS", "8")))
+    if "round3" in sys.argv[1:]:
+        round3()
+        return
     from dmb.modeling.stereo.cost_processors import build_cost_processor
     from dmb.modeling.stereo.disp_predictors import build_disp_predictor
     from dmb.modeling.stereo.cmn.cmn import Cmn, ConfHead
@@ -96,6 +164,7 @@ def main():
         d = m.disp_predictor(costs[0])
         np.savez_compressed(os.path.join(OUT, "fullsize_stereonet.npz"), disp=G.npy(d), cost=G.npy(costs[0][:, :, 1::2, :]))
         print("stereonet disp range %.2f..%.2f" % (d.min().item(), d.max().item()), flush=True)
+    round3()
     for f in sorted(os.listdir(OUT)):
         if f.startswith("fullsize"):
             print("%-28s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))

@@ -155,6 +155,25 @@ def test_gwc(dev, C, G, W, md, sd):
     assert torch.equal(valu, got)
 
 
+@pytest.mark.parametrize("C,W,D", [(8, 40, 9), (32, 300, 48), (6, 23, 9)])
+def test_gwc_second_witness(dev, C, W, D):
+    """The group-wise correlation kernels against two statements that share no code with the gwc oracle (which has no
+    reference implementation to be pinned to): (i) G = C is the element-wise product of the two halves of cat_fms's volume --
+    the HIP cat_fms is bit-exact against the reference's; (ii) G = 1 rescaled by C is correlation1d_cost's channels in
+    disparity order (correlation1d_cost.py:12-25), leaky-ReLU applied to both."""
+    ops = _ops()
+    L, R = _rand((2, C, 5, W), 13), _rand((2, C, 5, W), 14)
+    Ld, Rd = L.to(dev), R.to(dev)
+    idx = ops.disp_index_list(D, 0, 1)
+    cat = ops.cat_fms(Ld, Rd, idx)
+    per_channel = ops.gwc_fms(Ld, Rd, idx, C)
+    assert torch.equal(per_channel, cat[:, :C] * cat[:, C:])                 # one product per element: exact
+    assert torch.equal(per_channel.cpu(), O.gwc_fms(L, R, D, 0, 1, C))
+    dot = ops.gwc_fms(Ld, Rd, idx, 1)[:, 0] * C
+    cor = ops.correlation1d(Ld, Rd, D, 0.1)
+    assert (F.leaky_relu(dot, 0.1) - cor.flip(1)).abs().max().item() <= 1e-5 * max(1.0, math.sqrt(C))
+
+
 # ------------------------------------------------------------------------------------------- conv family
 def _affine(C, seed):
     g = torch.Generator().manual_seed(seed)
