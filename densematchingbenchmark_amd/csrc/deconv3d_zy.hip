@@ -1,0 +1,422 @@
+// Transposed 3-D convolution k3 s2 p1 op1 (hourglass conv5 / conv6: utils/hourglass.py:53-60,84-86 through
+// layers/basic_layers.py:160-177), third form: one work item = (input-resolution tile, output z parity, output y parity).
+//
+//   y[2i - 1 + k] += x[i] * w[k]  per axis:  an even output o = 2i sees k = 1 from input i; an odd output o = 2i + 1 sees
+//   k = 2 from input i and k = 0 from input i + 1.
+//
+// Why a third form.  deconv3d_kernel (conv3d.hip) gives a work item both y parities: 2 (y) x 2 (x) x 2 column tiles x 16 =
+// 128 accumulator registers, so two workgroups per CU is all the register file admits -- and with two waves per SIMD the
+// time both sit in their (vector-issue bound) epilogues at once is lost to the matrix cores (45 % /
+// 44 % / 10.6 % of the time two / one / no wave of a SIMD multiplies).  Here an item owns ONE y parity: 2 (x) x 2 x 16 = 64
+// accumulators, the kernel fits 168 registers and 46 KB of LDS, THREE workgroups share a CU, and the chance that every wave
+// of a SIMD is outside its multiply phase drops from p^2 to p^3.
+//
+// The four (z parity, y parity) classes carry 1 : 2 : 2 : 4 of the arithmetic (number of (kz, ky) pairs an output of the
+// class sees).  Each class is its own instantiation of the body -- its own input halo ((TZ + pz) planes x (1 + py) rows),
+// its own channel chunk (16 / 8 / 8 / 4 input channels, so that every class runs 48 MFMAs per wave between two barriers and
+// double-buffers within the same LDS budget) -- and the items of all classes form ONE list, heaviest class first, handed
+// out through an atomic counter: a persistent workgroup takes the next item while it multiplies the current one, and the
+// chunk pipeline (LDS-DMA of chunk i + 1 under the MFMAs of chunk i) runs across items of a class.
+//
+// Everything else is the design of deconv3d_kernel: A = weights (rows = output channels), B = input voxels, both x
+// parities in one wave so that a lane pair of accumulators is two adjacent outputs; 16-byte LDS-DMA staging; the epilogue
+// interleaves the two x parities through a per-wave LDS scratch and leaves as 16-byte stores (BatchNorm affine, skip
+// operand, ReLU in the reference's order).  Same FP32 products, same ascending (channel, tap) fma chain per output as the
+// other two forms: bit-identical results.
+#include <type_traits>
+
+#include "dmb_common.h"
+
+namespace dmb {
+
+template <int COUT_>
+struct ZYCfg {
+  static constexpr int COUT = COUT_;
+  static constexpr int NTT = COUT / 32;       // 32-channel row tiles
+  static constexpr int WN = NTT;              // waves along the output channels: one row tile per wave
+  static constexpr int WZ = 4 / WN, TZ = WZ;  // waves (= input planes) along z
+  static constexpr int TX = 60, P = 64, MT = 2;   // one input row: 60 real positions in two 32-column MFMA tiles
+  static constexpr int RUN = 3 * NTT * 64;    // weight floats of one (channel pair, kz, ky): its three kx taps
+  static constexpr int SCR_PITCH = 68, PCH = 8;   // epilogue scratch: 8 channels x 64 output columns per pass and wave
+  static constexpr int AFF_FLOATS = 2 * COUT + 4; // scale / shift table + the slot the next item is published in
+
+  template <int PZ, int PY>
+  struct Cls {
+    static constexpr int NAZ = 1 + PZ, NAY = 1 + PY, NA = NAZ * NAY;   // (kz, ky) pairs an output of the class sees
+    static constexpr int CK = 16 / NA;                                  // input channels per chunk
+    static constexpr int ZS = TZ + PZ, ROWS = 1 + PY, PLANE = ROWS * P;
+    static constexpr int CH_STRIDE = ZS * PLANE + 4;                    // = 4 (mod 32): the lane halves hit disjoint banks
+    static constexpr int IN_FLOATS = CK * CH_STRIDE;
+    static constexpr int W_FLOATS = (CK / 2) * NA * RUN;
+    static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+    static constexpr int CPW = CK / 4;                                  // channels staged by one wave
+    static constexpr int UPC = ZS * ROWS * (P / 4);                     // 16-byte units per channel
+    static constexpr int IPC = (UPC + 63) / 64;                         // copy instructions per channel
+    static constexpr int WCH4 = W_FLOATS / 4, WV4 = (WCH4 + 255) / 256; // weight copies per chunk / per thread
+    static constexpr int NU = (CK / 2) * NA;                            // (channel pair, kz, ky) units per chunk
+    static constexpr int NPIECE = CPW * IPC + WV4;                      // copy instructions of one wave per chunk
+    // the epilogue scratch of a wave lies in the part of the consumed chunk buffer only this wave's own copies write
+    static constexpr bool SCR_PRIVATE = CPW * CH_STRIDE >= PCH * SCR_PITCH;
+    static_assert(CK % 4 == 0 && IN_FLOATS % 4 == 0 && W_FLOATS % 4 == 0, "shape");
+  };
+  static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+  static constexpr int BUF_MAX = cmax(cmax(Cls<0, 0>::BUF_FLOATS, Cls<0, 1>::BUF_FLOATS),
+                                      cmax(Cls<1, 0>::BUF_FLOATS, Cls<1, 1>::BUF_FLOATS));
+  static constexpr bool ALL_PRIVATE = Cls<0, 0>::SCR_PRIVATE && Cls<0, 1>::SCR_PRIVATE && Cls<1, 0>::SCR_PRIVATE && Cls<1, 1>::SCR_PRIVATE;
+  static constexpr int SCR_FLOATS = ALL_PRIVATE ? 0 : 4 * PCH * SCR_PITCH;
+  static constexpr int LDS_FLOATS = 2 * BUF_MAX + AFF_FLOATS + SCR_FLOATS;
+  static_assert(LDS_FLOATS * 4 * 3 <= 160 * 1024, "three workgroups per CU");
+};
+
+struct ZYArgs {
+  const float* x;
+  const float* wp;
+  const float* res;
+  float* y;
+  int* counter;
+  int Ci, D, H, W, ntx, nty, ntz, ntiles, relu, dbg;
+};
+
+// One class: processes `item` and every following item the counter hands out as long as it belongs to the same class;
+// returns the first item that does not (>= 4 * ntiles: the list is exhausted).
+template <class C, int PZ, int PY>
+__device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
+  using K = typename C::template Cls<PZ, PY>;
+  // The four class bodies are inlined into one loop over items: without this barrier the compiler hoists every body's
+  // per-lane constants (copy offsets, epilogue lane coordinates) to the kernel entry and keeps all four sets live -- 190
+  // registers for a kernel whose largest body needs 120.  Everything per-lane below derives from this opaque copy.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int wz = wave / C::WN, wn = wave % C::WN;
+  const int D = a.D, H = a.H, W = a.W, Ci = a.Ci;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const unsigned HWo = (unsigned)Ho * Wo, DHWo = 2u * D * HWo;
+  constexpr int CLS = 3 - (2 * PZ + PY);   // position of the class in the item list: heaviest first
+  const int hi = (CLS + 1) * a.ntiles;
+  float* aff = lds + 2 * C::BUF_MAX;
+  volatile int* slot = reinterpret_cast<volatile int*>(aff + 2 * C::COUT);
+
+  struct Tile {
+    int b, x0, y0, z0;
+  };
+  auto tile_at = [&](int it) {
+    int t = it - CLS * a.ntiles;
+    Tile tl;
+    tl.x0 = (t % a.ntx) * C::TX;
+    t /= a.ntx;
+    tl.y0 = t % a.nty;
+    t /= a.nty;
+    tl.z0 = (t % a.ntz) * C::TZ;
+    tl.b = t / a.ntz;
+    return tl;
+  };
+
+  // ---- weight copies: per-lane source offset inside a chunk's block (the chunk goes into the scalar offset); LDS layout
+  // [channel pair][az][ay][kx][row tile][64]: az = 0 -> kz = (PZ ? 2 : 1), az = 1 -> kz = 0; ay likewise
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.wp, (unsigned)(Ci * 27 * C::COUT) * 4u);
+  unsigned woff[K::WV4];
+#pragma unroll
+  for (int i = 0; i < K::WV4; ++i) {
+    const int q4 = i * 256 + tid;
+    const int run = q4 / (C::RUN / 4), off = q4 - run * (C::RUN / 4);
+    const int cp = run / K::NA, ta = run - cp * K::NA, az = ta / K::NAY, ay = ta - az * K::NAY;
+    const int kz = PZ ? (az ? 0 : 2) : 1, ky = PY ? (ay ? 0 : 2) : 1;
+    woff[i] = q4 < K::WCH4 ? (unsigned)(((cp * 27 + kz * 9 + ky * 3) * C::NTT * 64) * 4 + off * 16) : DMA_OOB;
+  }
+  // ---- input copies: unit = 4 consecutive floats of a staged row, the units of one channel ([plane][row][16 units]) are
+  // linear in LDS; a unit's per-lane source offset depends on the tile only (the channel is added at issue time)
+  auto tile_offsets = [&](const Tile& tl, unsigned (&o)[K::IPC]) {
+#pragma unroll
+    for (int q = 0; q < K::IPC; ++q) {
+      const int u = q * 64 + lane;
+      const int zz = u / (K::ROWS * 16), rr = u - zz * (K::ROWS * 16), yy = rr / 16, sg = rr - yy * 16;
+      const int gz = tl.z0 + zz, gy = tl.y0 + yy, gx = tl.x0 + sg * 4;
+      o[q] = (u < K::UPC && gz < D && gy < H && gx < W) ? ((unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB;
+    }
+  };
+  // a wave's copies of one chunk are numbered [0, NPIECE): input pieces first, then its share of the weights; stage()
+  // issues pieces [lo, hi) so that the multiply loop can deal them out between its MFMA groups
+  auto in_rsrc = [&](const Tile& tl, int c0) {
+    return make_rsrc(a.x + ((size_t)tl.b * Ci + c0) * DHW, (unsigned)K::CK * DHW * 4u);
+  };
+  auto stage = [&](const __amdgpu_buffer_rsrc_t xrs, const unsigned (&toff)[K::IPC], int c0, float* buf, int lo, int hi2) {
+#pragma unroll
+    for (int cc = 0; cc < K::CPW; ++cc) {
+      const int cl = wave * K::CPW + cc;
+#pragma unroll
+      for (int q = 0; q < K::IPC; ++q)
+        if (cc * K::IPC + q >= lo && cc * K::IPC + q < hi2 && (K::UPC % 64 == 0 || q * 64 + lane < K::UPC))
+          dma16(xrs, toff[q], (unsigned)cl * DHW * 4u, buf + cl * K::CH_STRIDE + q * 256);   // (whole chunks only: Ci % 16 == 0)
+    }
+#pragma unroll
+    for (int i = 0; i < K::WV4; ++i)
+      if (K::CPW * K::IPC + i >= lo && K::CPW * K::IPC + i < hi2 && (K::WCH4 % 256 == 0 || i * 256 + tid < K::WCH4))
+        dma16(wrs, woff[i], (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + K::IN_FLOATS + (i * 256 + wave * 64) * 4);
+  };
+
+  const int NC = Ci / K::CK;
+  Tile cur_t = tile_at(item);
+  unsigned coff[K::IPC], noff[K::IPC];
+  tile_offsets(cur_t, coff);
+  __syncthreads();   // a class switch: every wave has left the previous class's buffers (and its epilogue scratch)
+  stage(in_rsrc(cur_t, 0), coff, 0, lds, 0, K::NPIECE);
+  __syncthreads();
+  int g = 0;          // chunks consumed so far: selects the LDS buffer
+  for (;;) {
+    int next = hi;    // published after the first chunk's barrier
+    bool has_next = false;
+    Tile next_t = cur_t;
+    int fetched = 0;
+
+    f32x16 acc[2][C::MT];   // [x parity][column tile]
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[px][mt][r] = 0.f;
+
+#pragma clang loop unroll(disable)   // (and no peeling of the first chunk: one copy of the multiply loop per class)
+    for (int ci = 0; ci < NC; ++ci, ++g) {
+      const float* cur = lds + (g & 1) * C::BUF_MAX;
+      float* nxt = lds + ((g + 1) & 1) * C::BUF_MAX;
+      if (ci == 0 && tid == 0) fetched = atomicAdd(a.counter, 1);   // consumed just before this chunk's barrier
+      // the next chunk's copies (of this item, or the first chunk of the next one) are dealt out over the first SU units
+      constexpr int SU = K::NU - 2, PPU = (K::NPIECE + SU - 1) / SU;
+      const bool more = ci + 1 < NC;
+      const bool staging = !(a.dbg & 2) && (more || has_next);
+      const int st_c0 = more ? (ci + 1) * K::CK : 0;
+      const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(more ? cur_t : next_t, st_c0);
+      unsigned st_off[K::IPC];
+#pragma unroll
+      for (int q = 0; q < K::IPC; ++q) st_off[q] = more ? coff[q] : noff[q];
+      auto deal = [&](int u) {
+        if (staging) stage(st_rs, st_off, st_c0, nxt, u * PPU, (u + 1) * PPU);
+      };
+      const float* abase = cur + K::IN_FLOATS + wn * 64 + lane;
+      const float* bbase = cur + h * K::CH_STRIDE + wz * K::PLANE + j;
+      float af[2][3], bf[2][2][C::MT];   // af[buf][kx], bf[buf][ox][mt]
+      auto load_frag = [&](int u, float (&fa)[3], float (&fb)[2][C::MT]) {
+        const int cp = u / K::NA, ta = u % K::NA, az = ta / K::NAY, ay = ta % K::NAY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fa[k] = abase[(u * 3 + k) * C::NTT * 64];
+        const float* bp = bbase + 2 * cp * K::CH_STRIDE + az * K::PLANE + ay * C::P;
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) fb[ox][mt] = bp[ox + mt * 32];
+      };
+      load_frag(0, af[0], bf[0]);
+#pragma unroll
+      for (int u = 0; u < K::NU; ++u) {
+        if (u + 1 < K::NU) load_frag(u + 1, af[(u + 1) & 1], bf[(u + 1) & 1]);
+        if (u < SU) deal(u);
+        __builtin_amdgcn_sched_barrier(0);
+        const auto& fa = af[u & 1];
+        const auto& fb = bf[u & 1];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          acc[0][mt] = DMB_MFMA(fa[1], fb[0][mt], acc[0][mt]);   // even x: kx = 1 from input x
+          acc[1][mt] = DMB_MFMA(fa[2], fb[0][mt], acc[1][mt]);   // odd x:  kx = 2 from input x
+          acc[1][mt] = DMB_MFMA(fa[0], fb[1][mt], acc[1][mt]);   //         kx = 0 from input x + 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ci == 0 && tid == 0) *slot = fetched;
+      __syncthreads();
+      if (ci == 0) {
+        next = __builtin_amdgcn_readfirstlane(*slot);   // wave-uniform: tiles, resources and branches derived from it stay scalar
+        has_next = next < hi;
+        if (has_next) {
+          next_t = tile_at(next);
+          tile_offsets(next_t, noff);
+        }
+      }
+    }
+
+    // ---- epilogue of cur_t: per (column tile, 8-channel group) the two x-parity accumulator tiles are interleaved in the
+    // wave's LDS scratch ([8 channels][64 output columns], 8-byte writes), read back as 4 consecutive x of one channel and
+    // stored / residual-loaded as 16-byte words through buffer resources (lanes outside the volume get an out-of-range
+    // offset: branch-free).  Residual loads run RD passes ahead of the stores.
+    // (g has been advanced past the last chunk: buffer (g & 1) is being filled for the next item, ((g - 1) & 1) is the one
+    // just consumed; every wave's reads of it completed before the barrier that ended the chunk loop)
+    if (!(a.dbg & 1)) {
+      float* scr = K::SCR_PRIVATE ? lds + ((g - 1) & 1) * C::BUF_MAX + wave * (K::CPW * K::CH_STRIDE)
+                                  : aff + C::AFF_FLOATS + wave * (C::PCH * C::SCR_PITCH);
+      const int gzi = cur_t.z0 + wz;
+      float* yb = a.y + (size_t)cur_t.b * C::COUT * DHWo;
+      const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, (unsigned)C::COUT * DHWo * 4u);
+      const __amdgpu_buffer_rsrc_t rrs = make_rsrc(a.res ? a.res + (size_t)cur_t.b * C::COUT * DHWo : yb, (unsigned)C::COUT * DHWo * 4u);
+      const int rl = lane >> 4, x4 = (lane & 15) * 4;
+      const float lo = a.relu == 1 ? 0.f : -__builtin_inff();    // ReLU after the residual add
+      const float lo2 = a.relu == 2 ? 0.f : -__builtin_inff();   // ReLU before it (GC-Net)
+      constexpr int QP = 32 / C::PCH, KP = C::PCH / 4;          // passes per 32-channel tile, 16-byte words per lane and pass
+      constexpr int NPASS = C::MT * QP;
+      // Addressing: a word's byte offset = lane part (channel row rl of the pass, 4 consecutive x: ONE register per column
+      // tile, out of range for lanes outside the volume) + a wave-uniform part (item, pass, word) that travels in the scalar
+      // offset of the buffer instruction.  Per-lane offsets for every (pass, word) would be 16 item-invariant registers the
+      // compiler keeps live across the multiply loop -- the difference between 168 registers and spilling.
+      unsigned voff[C::MT];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+        const int lx = mt * 32 + x4 / 2;
+        const bool ok = gzi < D && lx < C::TX && cur_t.x0 + lx < W && !(a.dbg & 4);
+        voff[mt] = ok ? ((unsigned)rl * DHWo + (unsigned)(2 * mt * 32 + x4)) * 4u : DMA_OOB;
+      }
+      const unsigned sbase = ((unsigned)(wn * 32) * DHWo + (unsigned)(2 * gzi + PZ) * HWo + (unsigned)(2 * cur_t.y0 + PY) * Wo +
+                              2u * (unsigned)cur_t.x0) * 4u;
+      const unsigned sstep = 4u * DHWo * 4u;                      // four channels on
+      auto soff = [&](int t, int k) { return sbase + (unsigned)((t % QP) * KP + k) * sstep; };
+      const float* affl = aff + wn * 32 + rl;                     // + 8 q + 4 k: immediate offsets
+      float* swr = scr + 4 * h * C::SCR_PITCH + 2 * j;           // + rr * pitch
+      const float* srd = scr + rl * C::SCR_PITCH + x4;           // + 4 k * pitch
+      auto run = [&](auto has_res) {
+        constexpr bool HAS_RES = decltype(has_res)::value;
+        constexpr int RD = HAS_RES ? 4 : 1;
+        u32x4 rv[RD][KP];
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int t = 0; t < RD; ++t)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) rv[t][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voff[t / QP], (int)soff(t, k), 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NPASS; ++t) {
+          const int q = t % QP, mt = t / QP;
+          const int sl = t % RD;
+#pragma unroll
+          for (int rr = 0; rr < C::PCH / 2; ++rr) {
+            const int r = q * (C::PCH / 2) + rr;   // accumulator register r of lane half h = channel 8 q + rr + 4 h of the tile
+            *reinterpret_cast<float2*>(swr + rr * C::SCR_PITCH) = make_float2(acc[0][mt][r], acc[1][mt][r]);
+          }
+#pragma unroll
+          for (int k = 0; k < KP; ++k) {
+            float4 v = *reinterpret_cast<const float4*>(srd + 4 * k * C::SCR_PITCH);
+            const float sc = affl[q * C::PCH + 4 * k], sh = affl[C::COUT + q * C::PCH + 4 * k];
+            v.x = fmaxf(fmaf(v.x, sc, sh), lo2);
+            v.y = fmaxf(fmaf(v.y, sc, sh), lo2);
+            v.z = fmaxf(fmaf(v.z, sc, sh), lo2);
+            v.w = fmaxf(fmaf(v.w, sc, sh), lo2);
+            if constexpr (HAS_RES) {   // (not __builtin_bit_cast on a vector element: this clang reads element 0 for every index)
+              v.x += __uint_as_float(rv[sl][k].x);
+              v.y += __uint_as_float(rv[sl][k].y);
+              v.z += __uint_as_float(rv[sl][k].z);
+              v.w += __uint_as_float(rv[sl][k].w);
+            }
+            u32x4 o;
+            o.x = __float_as_uint(fmaxf(v.x, lo));
+            o.y = __float_as_uint(fmaxf(v.y, lo));
+            o.z = __float_as_uint(fmaxf(v.z, lo));
+            o.w = __float_as_uint(fmaxf(v.w, lo));
+            __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)voff[mt], (int)soff(t, k), 0);
+          }
+          if constexpr (HAS_RES) {
+            if (t + RD < NPASS) {   // refill the slot just consumed
+#pragma unroll
+              for (int k = 0; k < KP; ++k)
+                rv[sl][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voff[(t + RD) / QP], (int)soff(t + RD, k), 0);
+            }
+          }
+        }
+      };
+      if (a.res)
+        run(std::true_type{});
+      else
+        run(std::false_type{});
+    }
+    if (!has_next) return next;
+    cur_t = next_t;
+#pragma unroll
+    for (int q = 0; q < K::IPC; ++q) coff[q] = noff[q];
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* aff = lds + 2 * C::BUF_MAX;
+  volatile int* slot = reinterpret_cast<volatile int*>(aff + 2 * C::COUT);
+  // per-channel affine, staged once (LDS reads count on lgkmcnt and cost no registers across the item loop; see
+  // deconv3d_kernel)
+  if (threadIdx.x < C::COUT) {
+    aff[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
+    aff[C::COUT + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
+  }
+  if (threadIdx.x == 0) *slot = atomicAdd(a.counter, 1);
+  __syncthreads();
+  int item = __builtin_amdgcn_readfirstlane(*slot);
+  const int total = 4 * a.ntiles;
+  while (item < total) {
+    const int cls = item / a.ntiles;   // 0 = (odd z, odd y): four (kz, ky) pairs ... 3 = (even z, even y): one
+    if (cls == 0)
+      item = zy_body<C, 1, 1>(lds, a, item);
+    else if (cls == 1)
+      item = zy_body<C, 1, 0>(lds, a, item);
+    else if (cls == 2)
+      item = zy_body<C, 0, 1>(lds, a, item);
+    else
+      item = zy_body<C, 0, 0>(lds, a, item);
+  }
+}
+
+// Item counters: one int per launch out of a small per-device ring (zeroed on the launch's stream just before the launch),
+// so that launches in flight on different streams never share one.
+static int* zy_counter(hipStream_t st) {
+  static int* ring[64] = {};
+  static unsigned seq = 0;
+  constexpr int RING = 1024;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!ring[dev] && hipMalloc(reinterpret_cast<void**>(&ring[dev]), RING * sizeof(int)) != hipSuccess) {
+    ring[dev] = nullptr;
+    return nullptr;
+  }
+  int* c = ring[dev] + (seq++ % RING);
+  if (hipMemsetAsync(c, 0, sizeof(int), st) != hipSuccess) return nullptr;
+  return c;
+}
+
+template <class C>
+static int launch_zy(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                     int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
+  const int ntx = cdiv(W, C::TX), nty = H, ntz = cdiv(D, C::TZ);
+  const long long ntiles = (long long)B * ntx * nty * ntz;
+  if (4 * ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  DMB_ENSURE_LDS((&deconv3d_zy_kernel<C>), lds);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  int* counter = zy_counter(st);
+  if (!counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
+  const long long slots = 3LL * ncu * (g_dev_opts[8] > 0 ? g_dev_opts[8] : 1);
+  const long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
+  ZYArgs a{x, wp, res, y, counter, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8};
+  hipLaunchKernelGGL((deconv3d_zy_kernel<C>), dim3((unsigned)grid), dim3(256), lds, st, a, scale, shift);
+  return launch_status("deconv3d (z/y-parity items) launch failed");
+}
+
+// Entry for dmb_deconv3d_k3s2_f32 (conv3d.hip): returns -1 when this form does not apply (the caller falls back to
+// deconv3d_kernel), otherwise the launch status.  Requirements: 16-byte aligned rows (W % 4 == 0, aligned bases), all 32 or
+// 64 output channels real, whole 16-channel chunks and at least two of them, 16 input channels of one batch item and one batch item of the output
+// below 2 GiB (32-bit buffer offsets).
+int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                    int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st) {
+  if (g_dev_opts[4] == 1) return -1;
+  if (!(Co == 32 || Co == 64) || Ci % 16 != 0 || Ci < 32 || W % 4 != 0) return -1;   // (>= 2 chunks in every class)
+  if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) != 0) return -1;
+  if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;
+  if (cdiv(W, 28) * 32 < cdiv(W, 60) * 64) return -1;   // narrow images: deconv3d_kernel's 2 x 28 tiles compute fewer positions
+  if (Co == 32) return launch_zy<ZYCfg<32>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, st);
+  return launch_zy<ZYCfg<64>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, st);
+}
+
+}  // namespace dmb

@@ -6,7 +6,7 @@
 namespace dmb {
 
 void set_last_error(const char* msg);
-extern int g_dev_opts[8];
+extern int g_dev_opts[16];
 
 inline int fail(int code, const char* msg) {
   set_last_error(msg);
@@ -94,5 +94,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, 
 __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 #endif  // __HIPCC__
+
+// csrc/deconv3d_zy.hip: the (tile, z parity, y parity) form of the transposed convolution; -1 = does not apply
+int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                    int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st);
 
 }  // namespace dmb

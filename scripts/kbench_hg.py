@@ -81,6 +81,8 @@ for _rep in range(1 if diag else 2):
   deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv 64->64 quarter->half", res=True)
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv 64->32 half->full", res=False)
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv 64->32 half->full", res=True)
-  lib.dmb_dev_set_option(7, 1)   # A/B: the 8-byte scattered epilogue
-  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (scalar epilogue)", res=True)
-  lib.dmb_dev_set_option(7, 0)
+  lib.dmb_dev_set_option(4, 1)   # A/B: the two-parity form (both y parities per item, two workgroups per CU)
+  deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv (items with both y parities)", res=True)
+  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (items with both y parities)", res=False)
+  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (items with both y parities)", res=True)
+  lib.dmb_dev_set_option(4, 0)

@@ -137,9 +137,14 @@ def test_fullsize_gwcnet_pair_vs_oracle(dev):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# The FP32-floor contract on every D = 192 configuration: against an FP64 evaluation of the same network (the exact value
-# both FP32 evaluations approximate) the HIP path is never farther than max(1e-4, the reference arithmetic's own error).
+# The FP32-floor contract on every D = 192 configuration, against an FP64 evaluation of the same network (the exact value
+# both FP32 evaluations approximate).  Both worst-pixel errors are maxima of FP32 noise over 522 240 pixels and come out at
+# 1.4e-4 .. 2.2e-4; which of the two is larger on a given map is chance (measured hip / reference = 0.86 .. 1.07 over pairs and
+# levels), so the worst-pixel bound carries a 25 % margin: |hip - fp64| <= max(1e-4, 1.25 |reference arithmetic - fp64|).
+# The MEAN error has no such noise and is asserted strictly: never above the reference arithmetic's (measured about half:
+# the kernel's soft-argmin accumulates in FP64, the reference's in FP32).
 # ----------------------------------------------------------------------------------------------------------------------
+YARD_MARGIN = 1.25
 def _f64(p):
     return {k: (v.double() if v.is_floating_point() else v) for k, v in p.items()}
 
@@ -151,8 +156,10 @@ def _assert_yardstick(tag, gpu_disps, ref32_disps, costs64):
         err_ref = (b.double() - truth).abs().max().item()
         print("%s level %d: |hip - fp64| = %.3g   |reference arithmetic - fp64| = %.3g   |hip - reference| = %.3g" %
               (tag, 3 - lvl, err_gpu, err_ref, maxdiff(a, b)))
-        assert err_gpu <= max(DISP_TOL, err_ref), (tag, lvl, err_gpu, err_ref)
-        assert (a.cpu().double() - truth).abs().mean().item() <= 2e-5      # EPE delta vs the exact value (measured 1e-5)
+        mean_gpu, mean_ref = (a.cpu().double() - truth).abs().mean().item(), (b.double() - truth).abs().mean().item()
+        print("%s level %d: mean |hip - fp64| = %.3g   mean |reference arithmetic - fp64| = %.3g" % (tag, 3 - lvl, mean_gpu, mean_ref))
+        assert err_gpu <= max(DISP_TOL, YARD_MARGIN * err_ref), (tag, lvl, err_gpu, err_ref)
+        assert mean_gpu <= 2e-5 and mean_gpu <= mean_ref, (tag, lvl, mean_gpu, mean_ref)   # EPE delta vs the exact value
         assert maxdiff(a, b) <= DISP_MAX_FULL and _meandiff(a, b) <= DISP_MEAN_FULL
 
 
@@ -243,7 +250,7 @@ def test_fullsize_psmnet_gain30_vs_reference(dev):
         print("gain 30 level %d: |hip - reference| = %.3g (sampled)  |hip - fp64| = %.3g  |reference arithmetic - fp64| = %.3g" %
               (3 - lvl, maxdiff(gpu[lvl][SUB], ref), err_gpu, err_ref))
         assert maxdiff(ref32[lvl][SUB], ref) <= 2e-5          # the oracle IS the reference here too
-        assert err_gpu <= max(DISP_TOL, err_ref)
+        assert err_gpu <= max(DISP_TOL, YARD_MARGIN * err_ref)
         assert maxdiff(gpu[lvl][SUB], ref) <= 6e-4 and _meandiff(gpu[lvl][SUB], ref) <= 1e-4
         assert maxdiff(results["costs"][lvl][CROWS], g["pair0_cost%d_rows" % (3 - lvl)]) <= 3 * COST_TOL
 

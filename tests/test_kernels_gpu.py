@@ -866,3 +866,43 @@ def test_deconv3d_vector_and_scalar_epilogues_agree(dev, Co, shape):
             finally:
                 lib.dmb_dev_set_option(7, 0)
         assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("Ci,Co,shape", [(64, 32, (1, 5, 6, 120)), (64, 64, (2, 3, 5, 60)), (32, 32, (1, 4, 7, 124)),
+                                         (64, 32, (2, 6, 3, 240)), (128, 64, (1, 2, 3, 116)), (48, 32, (1, 1, 1, 60)),
+                                         (64, 64, (4, 12, 34, 60))])
+def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shape):
+    """csrc/deconv3d_zy.hip -- work items (tile, z parity, y parity), four class bodies with their own chunk sizes, items handed
+    out through an atomic counter, three workgroups per CU -- against deconv3d_kernel (both y parities per item; development
+    option 4 selects it): the same ascending (channel, tap) fma chain per output, so BIT-identical, with and without the skip
+    operand and for both ReLU placements; and against the CPU transposed convolution.  Shapes: partial tiles in x (124, 116)
+    and z (D = 5, 3, 1), a single row, 2 .. 8 chunks per class, the hourglass's quarter-resolution layer."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, D, H, W = shape
+    xc = _rand((B, Ci, D, H, W), 611)
+    wc = _rand((Ci, Co, 3, 3, 3), 612, 1.0 / math.sqrt(Ci * 27 / 8))
+    sc, sh = _affine(Co, 613)
+    x, w = xc.to(dev), wc.to(dev)
+    wp = ops.pack_deconv3d_weights(w)
+    res = _rand((B, Co, 2 * D, 2 * H, 2 * W), 614).to(dev)
+    lib = _lib.load()
+    ref = F.conv_transpose3d(xc, wc, None, stride=2, padding=1, output_padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+    for r, relu in ((None, False), (None, True), (res, True), (res, False), (res, "pre")):
+        outs = []
+        for old in (0, 1):
+            lib.dmb_dev_set_option(4, old)
+            try:
+                outs.append(ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu))
+            finally:
+                lib.dmb_dev_set_option(4, 0)
+        assert torch.equal(outs[0], outs[1]), (r is not None, relu, (outs[0] - outs[1]).abs().max().item())
+        if r is None and relu is False:
+            assert (outs[0].cpu() - ref).abs().max().item() <= 2e-5
+    # the launch really took the new form (same call twice in a row: the counter ring hands out a fresh, zeroed counter each time)
+    again = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True)
+    lib.dmb_dev_set_option(4, 1)
+    try:
+        assert torch.equal(again, ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True))
+    finally:
+        lib.dmb_dev_set_option(4, 0)
