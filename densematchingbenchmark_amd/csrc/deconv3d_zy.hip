@@ -38,7 +38,7 @@ struct ZYCfg {
   static constexpr int TX = 60, P = 64, MT = 2;   // one input row: 60 real positions in two 32-column MFMA tiles
   static constexpr int RUN = 3 * NTT * 64;    // weight floats of one (channel pair, kz, ky): its three kx taps
   static constexpr int SCR_PITCH = 68, PCH = 8;   // epilogue scratch: 8 channels x 64 output columns per pass and wave
-  static constexpr int AFF_FLOATS = 2 * COUT + 4; // scale / shift table + the slot the next item is published in
+  static constexpr int AFF_FLOATS = 2 * COUT;     // scale / shift table
 
   template <int PZ, int PY>
   struct Cls {
@@ -80,7 +80,7 @@ struct ZYArgs {
 // One class: processes `item` and every following item the counter hands out as long as it belongs to the same class;
 // returns the first item that does not (>= 4 * ntiles: the list is exhausted).
 template <class C, int PZ, int PY>
-__device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
+__device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, int item) {
   using K = typename C::template Cls<PZ, PY>;
   // The four class bodies are inlined into one loop over items: without this barrier the compiler hoists every body's
   // per-lane constants (copy offsets, epilogue lane coordinates) to the kernel entry and keeps all four sets live -- 190
@@ -97,7 +97,6 @@ __device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
   constexpr int CLS = 3 - (2 * PZ + PY);   // position of the class in the item list: heaviest first
   const int hi = (CLS + 1) * a.ntiles;
   float* aff = lds + 2 * C::BUF_MAX;
-  volatile int* slot = reinterpret_cast<volatile int*>(aff + 2 * C::COUT);
 
   struct Tile {
     int b, x0, y0, z0;
@@ -157,7 +156,7 @@ __device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
         dma16(wrs, woff[i], (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + K::IN_FLOATS + (i * 256 + wave * 64) * 4);
   };
 
-  const int NC = Ci / K::CK;
+  const int NC = (a.dbg & 64) ? 2 : Ci / K::CK;   // (development: two chunks per item -- the memory side of an item almost alone)
   Tile cur_t = tile_at(item);
   unsigned coff[K::IPC], noff[K::IPC];
   tile_offsets(cur_t, coff);
@@ -194,7 +193,8 @@ __device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
 #pragma unroll
       for (int q = 0; q < K::IPC; ++q) st_off[q] = more ? coff[q] : noff[q];
       auto deal = [&](int u) {
-        if (staging) stage(st_rs, st_off, st_c0, nxt, u * PPU, (u + 1) * PPU);
+        if (staging && !(a.dbg & 32)) stage(st_rs, st_off, st_c0, nxt, u * PPU, (u + 1) * PPU);
+        if (staging && (a.dbg & 32) && u == 0) stage(st_rs, st_off, st_c0, nxt, 0, K::NPIECE);
       };
       const float* abase = cur + K::IN_FLOATS + wn * 64 + lane;
       const float* bbase = cur + h * K::CH_STRIDE + wz * K::PLANE + j;
@@ -225,11 +225,11 @@ __device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (ci == 0 && tid == 0) *slot = fetched;
+      if (ci == 0 && tid == 0) __atomic_store_n(slot, fetched, __ATOMIC_RELAXED);
       __syncthreads();
       if (ci == 0) {
-        next = __builtin_amdgcn_readfirstlane(*slot);   // wave-uniform: tiles, resources and branches derived from it stay scalar
-        has_next = next < hi;
+        next = __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED));   // wave-uniform: tiles, resources and branches derived from it stay scalar
+        has_next = next < hi && !(a.dbg & 16);
         if (has_next) {
           next_t = tile_at(next);
           tile_offsets(next_t, noff);
@@ -264,12 +264,15 @@ __device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
       for (int mt = 0; mt < C::MT; ++mt) {
         const int lx = mt * 32 + x4 / 2;
         const bool ok = gzi < D && lx < C::TX && cur_t.x0 + lx < W && !(a.dbg & 4);
-        voff[mt] = ok ? ((unsigned)rl * DHWo + (unsigned)(2 * mt * 32 + x4)) * 4u : DMA_OOB;
+        voff[mt] = ok ? ((a.dbg & 8) ? (unsigned)lane * 16u : ((unsigned)rl * DHWo + (unsigned)(2 * mt * 32 + x4)) * 4u) : DMA_OOB;
       }
       const unsigned sbase = ((unsigned)(wn * 32) * DHWo + (unsigned)(2 * gzi + PZ) * HWo + (unsigned)(2 * cur_t.y0 + PY) * Wo +
                               2u * (unsigned)cur_t.x0) * 4u;
       const unsigned sstep = 4u * DHWo * 4u;                      // four channels on
-      auto soff = [&](int t, int k) { return sbase + (unsigned)((t % QP) * KP + k) * sstep; };
+      auto soff = [&](int t, int k) {
+        const unsigned o = sbase + (unsigned)((t % QP) * KP + k) * sstep;
+        return (a.dbg & 8) ? (o & 0x1fff80u) : o;   // development: epilogue traffic confined to a 2 MiB window
+      };
       const float* affl = aff + wn * 32 + rl;                     // + 8 q + 4 k: immediate offsets
       float* swr = scr + 4 * h * C::SCR_PITCH + 2 * j;           // + rr * pitch
       const float* srd = scr + rl * C::SCR_PITCH + x4;           // + 4 k * pitch
@@ -311,7 +314,13 @@ __device__ __forceinline__ int zy_body(float* lds, const ZYArgs& a, int item) {
             o.y = __float_as_uint(fmaxf(v.y, lo));
             o.z = __float_as_uint(fmaxf(v.z, lo));
             o.w = __float_as_uint(fmaxf(v.w, lo));
-            __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)voff[mt], (int)soff(t, k), 0);
+            // The uniform part goes into the VECTOR offset for stores (one v_add each), not into the scalar-offset operand:
+            // with an SGPR soffset the compiler's hazard model lets the next VALU instruction overwrite the store's data
+            // registers at once, and on this chip a 16-byte store still reads the data of its last lanes then -- under load
+            // (three workgroups per CU) lanes 12..15 of each 16 stored the NEXT pass's accumulator values (found with
+            // scripts/zy_debug.py: one wrong float in 10^3, only with more than one workgroup per CU).  With a literal
+            // soffset the compiler inserts the wait states itself.
+            __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(voff[mt] + soff(t, k)), 0, 0);
           }
           if constexpr (HAS_RES) {
             if (t + RD < NPASS) {   // refill the slot just consumed
@@ -339,27 +348,27 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
                                                              const float* __restrict__ shift) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * C::BUF_MAX;
-  volatile int* slot = reinterpret_cast<volatile int*>(aff + 2 * C::COUT);
+  __shared__ int slot[1];   // the next item, published by thread 0
   // per-channel affine, staged once (LDS reads count on lgkmcnt and cost no registers across the item loop; see
   // deconv3d_kernel)
   if (threadIdx.x < C::COUT) {
     aff[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
     aff[C::COUT + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
   }
-  if (threadIdx.x == 0) *slot = atomicAdd(a.counter, 1);
+  if (threadIdx.x == 0) __atomic_store_n(slot, atomicAdd(a.counter, 1), __ATOMIC_RELAXED);
   __syncthreads();
-  int item = __builtin_amdgcn_readfirstlane(*slot);
+  int item = __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED));
   const int total = 4 * a.ntiles;
   while (item < total) {
     const int cls = item / a.ntiles;   // 0 = (odd z, odd y): four (kz, ky) pairs ... 3 = (even z, even y): one
     if (cls == 0)
-      item = zy_body<C, 1, 1>(lds, a, item);
+      item = zy_body<C, 1, 1>(lds, slot, a, item);
     else if (cls == 1)
-      item = zy_body<C, 1, 0>(lds, a, item);
+      item = zy_body<C, 1, 0>(lds, slot, a, item);
     else if (cls == 2)
-      item = zy_body<C, 0, 1>(lds, a, item);
+      item = zy_body<C, 0, 1>(lds, slot, a, item);
     else
-      item = zy_body<C, 0, 0>(lds, a, item);
+      item = zy_body<C, 0, 0>(lds, slot, a, item);
   }
 }
 
@@ -398,7 +407,8 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
   int* counter = zy_counter(st);
   if (!counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
   const long long slots = 3LL * ncu * (g_dev_opts[8] > 0 ? g_dev_opts[8] : 1);
-  const long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
+  long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
+  if (g_dev_opts[9] > 0 && g_dev_opts[9] < grid) grid = g_dev_opts[9];   // development: few workgroups walk many items
   ZYArgs a{x, wp, res, y, counter, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8};
   hipLaunchKernelGGL((deconv3d_zy_kernel<C>), dim3((unsigned)grid), dim3(256), lds, st, a, scale, shift);
   return launch_status("deconv3d (z/y-parity items) launch failed");

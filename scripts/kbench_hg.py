@@ -58,7 +58,7 @@ def deconv_case(Ci, Co, d, h, w, name, res=False):
     sh = torch.zeros(Co, device=dev)
     r = torch.randn(B, Co, 2 * d, 2 * h, 2 * w, device=dev) if res else None
     fl = 2.0 * 27 * Ci * Co * B * d * h * w
-    for opt in ((0, 1, 2, 3, 4) if diag else (0,)):
+    for opt in ((0, 1, 2, 3, 4, 8, 64, 65, 72) if diag else (0,)):
         lib.dmb_dev_set_option(6, opt)
         report(name + (" +res" if res else "") + (" [diag %d]" % opt if opt else ""),
                timeit(lambda: ops.deconv3d_k3s2(x, wp, Co, sc, sh, r, True)), fl)
