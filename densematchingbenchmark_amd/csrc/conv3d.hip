@@ -408,10 +408,14 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
 // V16 (W % 4 == 0, aligned base): rows are staged with 16-byte LDS-DMA words from the aligned column 2*x0 - 4 (XOFF = 3
 // unused floats in front of the halo column), row pitch 64 floats = output-position pitch 32: with dword copies a
 // stride-2 tile (4x the input per output) cost more TA cycles than its MFMAs cost matrix-core cycles.
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false>
+// WM: wave groups along the output positions.  WM = 2 makes a workgroup of EIGHT waves on the same LDS tile, each with half of
+// the tile's 32-position column tiles (32 instead of 64 accumulator registers): two workgroups per CU (the LDS bound) then
+// put four waves on every SIMD instead of two, so that one wave's staging waits and epilogue hide behind three others.
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false, int WM_ = 1>
 struct S2Cfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_;
   static constexpr bool V16 = V16_;
+  static constexpr int WM = WM_, NWAVES = 4 * WM_, NTHREADS = 64 * NWAVES;
   static constexpr int WZ = 4 / WN;
   static constexpr int TZ = WZ;
   static constexpr int XOFF = V16 ? 3 : 0;
@@ -423,6 +427,7 @@ struct S2Cfg {
   static constexpr int INROWS = 2 * TY + 1;
   static constexpr int INCOLS = 2 * TX + 1;
   static constexpr int MT = (TY * PO + 31) / 32;
+  static constexpr int MTW = MT / WM;          // column tiles per wave
   static constexpr int NTT = COUT / 32;
   static constexpr int NT = NTT / WN;
   static constexpr int CH_STRIDE = ZS * ZPL + 72;
@@ -435,10 +440,13 @@ struct S2Cfg {
   static constexpr int WPE = (LDS_FLOATS * 4 * 2 <= 160 * 1024) ? 2 : 1;  // workgroups per CU the LDS admits
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+  static_assert(MT % WM == 0, "the column tiles are dealt evenly to the wave groups");
 };
 
 template <class C>
-__global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+// (HIP: the second launch-bounds figure is the minimum number of WAVES PER SIMD, which for four-wave workgroups equals the
+// workgroups per CU)
+__global__ __launch_bounds__(C::NTHREADS, C::WPE * C::WM) void conv3d_s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ res, float* __restrict__ y, int Ci,
@@ -458,13 +466,14 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
-  const int wz = wave / C::WN, wn = wave % C::WN;
+  const int wm = wave / 4, w4 = wave % 4;      // wave group along the positions; (z, channel tile) inside the group
+  const int wz = w4 / C::WN, wn = w4 % C::WN;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   const float* xb = x + (size_t)b * Ci * DHW;
 
-  f32x16 acc[C::MT][C::NT];
+  f32x16 acc[C::MTW][C::NT];
 #pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
+  for (int mt = 0; mt < C::MTW; ++mt)
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
@@ -474,15 +483,15 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
   // waves in contiguous runs (see conv3d_s1_kernel).  Rows go to the y-parity plane they belong to.
   constexpr int NPASS = (C::INCOLS + 63) / 64;
   constexpr int NUNIT = C::CK * C::ZS * NPASS;
-  constexpr int UPW = (NUNIT + 3) / 4;
+  constexpr int UPW = (NUNIT + C::NWAVES - 1) / C::NWAVES;
   constexpr int WCH = C::NK * C::NTT * 64;
-  constexpr int WV4 = (WCH / 4 + 255) / 256;
+  constexpr int WV4 = (WCH / 4 + C::NTHREADS - 1) / C::NTHREADS;
   static_assert(WCH % 4 == 0, "weights are staged with 16-byte copies");
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)(cdiv(Ci, C::CK) * C::CK * 27 * C::COUT) * 4u);
   // Vector path: the per-lane source offsets of a chunk's copies depend on the tile only, not on the chunk (the chunk's
   // channels are selected by the resource base), so they are computed ONCE here.  Recomputing the unit -> (z, parity, row,
   // column) decode and the bounds tests for every copy of every chunk cost about two vector instructions per MFMA.
-  constexpr int S_NI = C::CK * C::IPC, S_IPW = (S_NI + 3) / 4;
+  constexpr int S_NI = C::CK * C::IPC, S_IPW = (S_NI + C::NWAVES - 1) / C::NWAVES;
   unsigned xoff[C::V16 ? S_IPW : 1];
   if constexpr (C::V16) {
 #pragma unroll
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
 #pragma unroll
       for (int q = 0; q < S_IPW; ++q) {
         const int id = wave * S_IPW + q;
-        if (S_NI % 4 == 0 || id < S_NI) {
+        if (S_NI % C::NWAVES == 0 || id < S_NI) {
           const int cl = id / C::IPC, qi = id - cl * C::IPC;
           if (qi * 64 + lane < C::UPC) dma16(xrs, xoff[q], 0u, buf + cl * C::CH_STRIDE + qi * 256);
         }
@@ -535,9 +544,9 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
     }
 #pragma unroll
     for (int i = 0; i < WV4; ++i) {
-      const int q4 = i * 256 + threadIdx.x;
+      const int q4 = i * C::NTHREADS + threadIdx.x;
       if (q4 < WCH / 4)
-        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + C::IN_FLOATS + (i * 256 + wave * 64) * 4);
+        dma16(wrs, (unsigned)q4 * 16u, (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + C::IN_FLOATS + (i * C::NTHREADS + wave * 64) * 4);
     }
   };
 
@@ -548,16 +557,16 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
     const float* cur = lds + (ci & 1) * C::BUF_FLOATS;
     if (ci + 1 < NC && !(dbg & 2)) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);
     const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + (2 * wz) * C::ZPL + 2 * j + C::XOFF;
-    float af[2][C::NT], bf[2][C::MT];
-    auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MT]) {
+    const float* bbase = cur + h * C::CH_STRIDE + (2 * wz) * C::ZPL + 2 * j + C::XOFF + wm * C::MTW * 64;
+    float af[2][C::NT], bf[2][C::MTW];
+    auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MTW]) {
       const int cp = ks / 27, tap = ks % 27;
       const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) a[nt] = abase[(ks * C::NTT + nt) * 64];
       const float* bp = bbase + 2 * cp * C::CH_STRIDE + dz * C::ZPL + (dy & 1) * C::PYPL + (dy >> 1) * C::R + dx;
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[mt * 64];
+      for (int mt = 0; mt < C::MTW; ++mt) bq[mt] = bp[mt * 64];
     };
     load_frag(0, af[0], bf[0]);
 #pragma unroll
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
       if (ks + 1 < C::NK) load_frag(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
+      for (int mt = 0; mt < C::MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(af[ks & 1][nt], bf[ks & 1][mt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
@@ -589,8 +598,8 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s2_kernel(const float* __r
       sh[r] = shift ? shift[co] : 0.f;
     }
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt) {
-      const int m = mt * 32 + j;
+    for (int mt = 0; mt < C::MTW; ++mt) {
+      const int m = (wm * C::MTW + mt) * 32 + j;
       const int ly = m / C::PO, lx = m - ly * C::PO;
       const int gy = y0 + ly, gxo = x0 + lx;
       if (m < C::TY * C::PO && lx < C::TX && gy < Ho && gxo < Wo) {
@@ -1342,7 +1351,7 @@ static int launch_s2(const float* x, const float* wp, const float* scale, const 
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   DMB_ENSURE_LDS((&conv3d_s2_kernel<C>), (size_t)(lds));
-  hipLaunchKernelGGL((conv3d_s2_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
+  hipLaunchKernelGGL((conv3d_s2_kernel<C>), dim3((unsigned)nblk), dim3(C::NTHREADS), lds, st, x, wp, scale, shift, res, y, Ci, D,
                      H, W, Do, Ho, Wo, ntx, nty, ntz, relu);
   return launch_status("conv3d stride-2 launch failed");
 }
@@ -1470,7 +1479,9 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       const int Wo = (W - 1) / 2 + 1;
       if (cdiv(Wo, 22) * 96 < cdiv(Wo, 30) * 128)
         return launch_s2<S2Cfg<0, 64, 4, 22, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
-      return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      if (g_dev_opts[10] == 1)   // A/B: four-wave workgroups
+        return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     }
     if (Co == 64) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     if (Co == 32) return launch_s2<S2Cfg<0, 32, 4, 30, 2, 1>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);

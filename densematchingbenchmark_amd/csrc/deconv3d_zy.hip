@@ -74,6 +74,7 @@ struct ZYArgs {
   const float* res;
   float* y;
   int* counter;
+  unsigned base;   // value of the counter when this launch starts (see zy_ticket)
   int Ci, D, H, W, ntx, nty, ntz, ntiles, relu, dbg;
 };
 
@@ -182,7 +183,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
     for (int ci = 0; ci < NC; ++ci, ++g) {
       const float* cur = lds + (g & 1) * C::BUF_MAX;
       float* nxt = lds + ((g + 1) & 1) * C::BUF_MAX;
-      if (ci == 0 && tid == 0) fetched = atomicAdd(a.counter, 1);   // consumed just before this chunk's barrier
+      if (ci == 0 && tid == 0) fetched = (int)((unsigned)atomicAdd(a.counter, 1) - a.base);   // consumed just before this chunk's barrier
       // the next chunk's copies (of this item, or the first chunk of the next one) are dealt out over the first SU units
       constexpr int SU = K::NU - 2, PPU = (K::NPIECE + SU - 1) / SU;
       const bool more = ci + 1 < NC;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
     aff[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
     aff[C::COUT + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
   }
-  if (threadIdx.x == 0) __atomic_store_n(slot, atomicAdd(a.counter, 1), __ATOMIC_RELAXED);
+  if (threadIdx.x == 0) __atomic_store_n(slot, (int)((unsigned)atomicAdd(a.counter, 1) - a.base), __ATOMIC_RELAXED);
   __syncthreads();
   int item = __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED));
   const int total = 4 * a.ntiles;
@@ -372,21 +373,36 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
   }
 }
 
-// Item counters: one int per launch out of a small per-device ring (zeroed on the launch's stream just before the launch),
-// so that launches in flight on different streams never share one.
-static int* zy_counter(hipStream_t st) {
+// Item counters: one counter per launch out of a small per-device ring, so that launches in flight on different streams
+// never share one.  A counter is never reset: every workgroup takes items until it draws one past the end, so a launch of
+// `total` items on `grid` workgroups advances its counter by exactly total + grid, and the next launch on that slot is
+// told where the counter stands (`base`; unsigned arithmetic, wrap-around included).  No memset launch per convolution.
+struct ZYTicket {
+  int* counter;
+  unsigned base;
+};
+static unsigned* zy_slot_base(int dev) {
+  static unsigned base[64][1024] = {};
+  return base[dev];
+}
+static ZYTicket zy_ticket(unsigned advance) {
   static int* ring[64] = {};
   static unsigned seq = 0;
   constexpr int RING = 1024;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!ring[dev] && hipMalloc(reinterpret_cast<void**>(&ring[dev]), RING * sizeof(int)) != hipSuccess) {
-    ring[dev] = nullptr;
-    return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u};
+  if (!ring[dev]) {
+    if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), RING * sizeof(int)) != hipSuccess ||
+        hipMemset(ring[dev], 0, RING * sizeof(int)) != hipSuccess) {
+      ring[dev] = nullptr;
+      return {nullptr, 0u};
+    }
   }
-  int* c = ring[dev] + (seq++ % RING);
-  if (hipMemsetAsync(c, 0, sizeof(int), st) != hipSuccess) return nullptr;
-  return c;
+  const unsigned slot = seq++ % RING;
+  unsigned* base = zy_slot_base(dev);
+  ZYTicket t{ring[dev] + slot, base[slot]};
+  base[slot] += advance;
+  return t;
 }
 
 template <class C>
@@ -404,12 +420,12 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     if (ncu <= 0) ncu = 256;
   }
-  int* counter = zy_counter(st);
-  if (!counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
   const long long slots = 3LL * ncu * (g_dev_opts[8] > 0 ? g_dev_opts[8] : 1);
   long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
   if (g_dev_opts[9] > 0 && g_dev_opts[9] < grid) grid = g_dev_opts[9];   // development: few workgroups walk many items
-  ZYArgs a{x, wp, res, y, counter, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8};
+  const ZYTicket tk = zy_ticket((unsigned)(4 * ntiles + grid));
+  if (!tk.counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
+  ZYArgs a{x, wp, res, y, tk.counter, tk.base, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8};
   hipLaunchKernelGGL((deconv3d_zy_kernel<C>), dim3((unsigned)grid), dim3(256), lds, st, a, scale, shift);
   return launch_status("deconv3d (z/y-parity items) launch failed");
 }
