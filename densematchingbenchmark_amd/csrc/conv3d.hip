@@ -1500,7 +1500,9 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
   hipStream_t st = (hipStream_t)stream;
   relu |= g_dev_opts[6] << 8;
   if (!g_dev_opts[3] && !g_dev_opts[7]) {   // three workgroups per CU where the shape admits it (csrc/deconv3d_zy.hip)
-    const int rc = deconv3d_zy_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
+    int rc = deconv3d_w16_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);   // many tiles per CU
+    if (rc != -1) return rc;
+    rc = deconv3d_zy_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
     if (rc != -1) return rc;
   }
   const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned rows

@@ -76,6 +76,7 @@ struct ZYArgs {
   int* counter;
   unsigned base;   // value of the counter when this launch starts (see zy_ticket)
   int Ci, D, H, W, ntx, nty, ntz, ntiles, relu, dbg;
+  int stagger;   // start-up delay unit (see the kernel)
 };
 
 // One class: processes `item` and every following item the counter hands out as long as it belongs to the same class;
@@ -350,6 +351,14 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * C::BUF_MAX;
   __shared__ int slot[1];   // the next item, published by thread 0
+  // De-phase the workgroups ACROSS THE CHIP.  All workgroups start together on equal items, so they all reach their
+  // epilogues together: the layer's output and skip traffic arrives as chip-wide bursts during which every workgroup waits
+  // on memory and no CU multiplies, and the memory system idles in between -- the memory phase ADDS to the multiply time
+  // instead of hiding under it.  A start-up delay of (workgroup index mod 16) x stagger x 3.4 us spreads the phases.
+  if (a.stagger > 0) {
+    const int n = (int)((blockIdx.x * 7u) & 15u) * a.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // per-channel affine, staged once (LDS reads count on lgkmcnt and cost no registers across the item loop; see
   // deconv3d_kernel)
   if (threadIdx.x < C::COUT) {
@@ -425,7 +434,7 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
   if (g_dev_opts[9] > 0 && g_dev_opts[9] < grid) grid = g_dev_opts[9];   // development: few workgroups walk many items
   const ZYTicket tk = zy_ticket((unsigned)(4 * ntiles + grid));
   if (!tk.counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
-  ZYArgs a{x, wp, res, y, tk.counter, tk.base, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8};
+  ZYArgs a{x, wp, res, y, tk.counter, tk.base, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8, g_dev_opts[12]};
   hipLaunchKernelGGL((deconv3d_zy_kernel<C>), dim3((unsigned)grid), dim3(256), lds, st, a, scale, shift);
   return launch_status("deconv3d (z/y-parity items) launch failed");
 }
@@ -436,7 +445,7 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
 // below 2 GiB (32-bit buffer offsets).
 int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                     int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st) {
-  if (g_dev_opts[4] == 1) return -1;
+  if (g_dev_opts[4] == 1) return -1;   // (development option 4: 1 = deconv3d_kernel, 2 = this form even where the sixteen-wave one applies)
   if (!(Co == 32 || Co == 64) || Ci % 16 != 0 || Ci < 32 || W % 4 != 0) return -1;   // (>= 2 chunks in every class)
   if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) != 0) return -1;
   if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;

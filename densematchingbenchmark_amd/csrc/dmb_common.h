@@ -99,4 +99,8 @@ __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >>
 int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                     int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st);
 
+// csrc/deconv3d_w16.hip: one sixteen-wave workgroup per CU computes all eight parity classes of a tile; -1 = does not apply
+int deconv3d_w16_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                     int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st);
+
 }  // namespace dmb

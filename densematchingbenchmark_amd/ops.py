@@ -282,12 +282,21 @@ def branch_overlap():
     return _branch_overlap
 
 
-def side_stream(device):
-    """One extra HIP stream per device for the overlapped branches."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def side_stream(device, which=0):
+    """Extra HIP streams per device (``which`` = 0, 1, ...) for independent launches that run next to the caller's stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device)
     return _side_streams[key]
+
+
+_first_layer_streams = True
+
+
+def set_first_layer_streams(flag):
+    """The five 2-D convolutions of the volume-free first layer (catconv_first) on three streams (default) or on one."""
+    global _first_layer_streams
+    _first_layer_streams = bool(flag)
 
 
 def copy_window(src, Wd, xs):
@@ -350,13 +359,46 @@ def catconv_first(L, R, D, packs, scale=None, shift=None, relu=False):
     Co, CA = packs["Co"], CATCONV_CH
     Wc = D + 4
     dev = L.device
-    FA = conv2d(L, packs["A"], CA, 3)                                              # F_{dz, 0}          [B, CA, H, W]
-    Lc = copy_window(L, Wc, 0)                                                     # columns [0, D + 4)
-    FB = torch.empty((B, 2 * CA, H, Wc), dtype=torch.float32, device=dev)
-    conv2d(Lc, packs["B1"], CA, 3, out=FB, out_ch_offset=0)                        # F_{dz, 1}
-    conv2d(Lc, packs["B2"], CA, 3, out=FB, out_ch_offset=CA)                       # F_{dz, 2}
-    HC = conv2d(copy_window(R, W + 4, -4), packs["HC"], CA, 3)                     # H_dz at n = j - 4  [B, CA, H, W + 4]
-    HD = conv2d(copy_window(R, Wc, W - Wc), packs["HD"], CA, 3)                    # border variant     [B, CA, H, Wc]
+    # The five 2-D convolutions are independent and three of them are small (the 52-column border maps: 272 tiles each
+    # for 512 workgroup slots): one after the other they take six rounds of the chip where their arithmetic fills less than
+    # four.  The border maps run on two side streams next to the two big ones (fork / join by events; same kernels on the
+    # same operands: identical results); ``set_first_layer_streams(False)`` issues them on one stream.
+    def big():
+        fa = conv2d(L, packs["A"], CA, 3)                                          # F_{dz, 0}          [B, CA, H, W]
+        hc = conv2d(copy_window(R, W + 4, -4), packs["HC"], CA, 3)                 # H_dz at n = j - 4  [B, CA, H, W + 4]
+        return fa, hc
+
+    def left_border():
+        lc = copy_window(L, Wc, 0)                                                 # columns [0, D + 4)
+        fb = torch.empty((B, 2 * CA, H, Wc), dtype=torch.float32, device=dev)
+        conv2d(lc, packs["B1"], CA, 3, out=fb, out_ch_offset=0)                    # F_{dz, 1}
+        conv2d(lc, packs["B2"], CA, 3, out=fb, out_ch_offset=CA)                   # F_{dz, 2}
+        return fb
+
+    def right_border():
+        return conv2d(copy_window(R, Wc, W - Wc), packs["HD"], CA, 3)              # border variant     [B, CA, H, Wc]
+
+    if _first_layer_streams:
+        main = torch.cuda.current_stream(dev)
+        s1, s2 = side_stream(dev), side_stream(dev, 1)
+        fork = main.record_event()
+        with torch.cuda.stream(s1):
+            s1.wait_event(fork)
+            FB = left_border()
+            FB.record_stream(main)      # allocated on the side stream, read (and released) on the caller's
+            j1 = s1.record_event()
+        with torch.cuda.stream(s2):
+            s2.wait_event(fork)
+            HD = right_border()
+            HD.record_stream(main)
+            j2 = s2.record_event()
+        FA, HC = big()
+        main.wait_event(j1)
+        main.wait_event(j2)
+    else:
+        FA, HC = big()
+        FB = left_border()
+        HD = right_border()
     FM = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
     BAND = torch.empty((B, Co, H, D, 4), dtype=torch.float32, device=dev)
     GM = torch.empty((B, Co, H, W + 4), dtype=torch.float32, device=dev)

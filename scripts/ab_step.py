@@ -1,0 +1,61 @@
+"""Development aid: A/B the whole PSMNet step (bench.py's configuration) under development options, alternating the variants
+inside ONE process on ONE chip (numbers from different gpurun boxes differ by ~1 %).
+    python scripts/ab_step.py "4=1" "10=1" "4=1,10=1"      each argument: comma-separated option=value pairs of a variant"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from densematchingbenchmark_amd import _lib, ops, synthetic
+from densematchingbenchmark_amd.config import Config
+from densematchingbenchmark_amd.modeling import build_model
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "PSMNet", "scene_flow.py"))
+model = build_model(cfg).eval()
+synthetic.init_params_(model, seed=0, classif_gain=10.0)
+model = model.to(dev)
+left, right = synthetic.feature_batch(0, 1, 4, 32, 136, 240, dev)
+batch = dict(leftFeature=left, rightFeature=right)
+# an option is "<development option index>=<value>", or "fls=0" (first-layer convolutions on one stream), "ovl=1" (branch overlap)
+def _parse(kv):
+    k, v = kv.split("=")
+    return (k if k in ("fls", "ovl") else int(k), int(v))
+
+
+def _set(k, v):
+    if k == "fls":
+        ops.set_first_layer_streams(bool(v))
+    elif k == "ovl":
+        ops.set_branch_overlap(bool(v))
+    else:
+        lib.dmb_dev_set_option(k, v)
+
+
+_DEFAULT = {"fls": 1, "ovl": 0}
+variants = [("default", [])] + [(a, [_parse(kv) for kv in a.split(",")]) for a in sys.argv[1:]]
+
+
+def run(n):
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        model(batch)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+with torch.no_grad():
+    run(5)
+    acc = {name: [] for name, _ in variants}
+    for rep in range(4):
+        for name, opts in variants:
+            for k, v in opts:
+                _set(k, v)
+            run(2)
+            acc[name].append(run(8))
+            for k, _ in opts:
+                _set(k, _DEFAULT.get(k, 0))
+for name, ts in acc.items():
+    print("%-24s %s  -> min %.3f ms, median %.3f ms" % (name, " ".join("%.3f" % t for t in ts), min(ts), sorted(ts)[len(ts) // 2]))

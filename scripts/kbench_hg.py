@@ -85,6 +85,10 @@ for _rep in range(1 if diag else 2):
   conv_case(32, 64, 2, D, H, W, "conv1 s2 32->64 (4-wave workgroups)")
   conv_case(64, 64, 2, D // 2, H // 2, W // 2, "conv3 s2 64->64 (4-wave workgroups)")
   lib.dmb_dev_set_option(10, 0)
+  lib.dmb_dev_set_option(11, 1)   # A/B: one sixteen-wave workgroup per CU computes all eight parity classes of a tile (opt-in)
+  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (sixteen-wave workgroups)", res=False)
+  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (sixteen-wave workgroups)", res=True)
+  lib.dmb_dev_set_option(11, 0)
   lib.dmb_dev_set_option(4, 1)   # A/B: the two-parity form (both y parities per item, two workgroups per CU)
   deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv (items with both y parities)", res=True)
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (items with both y parities)", res=False)

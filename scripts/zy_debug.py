@@ -23,9 +23,13 @@ ref = ops.deconv3d_k3s2(x, wp, Co, None, None, None, False)
 lib.dmb_dev_set_option(4, 0)
 lib.dmb_dev_set_option(9, grid)
 lib.dmb_dev_set_option(6, dbg)
+lib.dmb_dev_set_option(11, int(os.environ.get("W16", "0")))    # W16=1: the sixteen-wave form wherever its shape constraints allow
+lib.dmb_dev_set_option(4, int(os.environ.get("FORM", "0")))    # FORM=2: the z/y-parity item form
 got = ops.deconv3d_k3s2(x, wp, Co, None, None, None, False)
 lib.dmb_dev_set_option(9, 0)
 lib.dmb_dev_set_option(6, 0)
+lib.dmb_dev_set_option(11, 0)
+lib.dmb_dev_set_option(4, 0)
 torch.cuda.synchronize()
 bad = (got != ref)
 print("shape", (Ci, Co, B, D, H, W), "grid", grid, "dbg", dbg, "mismatching elements:", int(bad.sum()), "of", bad.numel(), "max diff", float((got - ref).abs().max()))

@@ -155,7 +155,7 @@ def test_gwc(dev, C, G, W, md, sd):
     assert torch.equal(valu, got)
 
 
-@pytest.mark.parametrize("C,W,D", [(8, 40, 9), (32, 300, 48), (6, 23, 9)])
+@pytest.mark.parametrize("C,W,D", [(8, 40, 9), (32, 300, 48), (4, 23, 9)])
 def test_gwc_second_witness(dev, C, W, D):
     """The group-wise correlation kernels against two statements that share no code with the gwc oracle (which has no
     reference implementation to be pinned to): (i) G = C is the element-wise product of the two halves of cat_fms's volume --
@@ -739,6 +739,13 @@ def test_catconv_first_layer(dev, B, C, Co, D, H, W):
         mat = ops.conv3d_k3(ops.cat_fms(L.to(dev), R.to(dev), idx), ops.pack_conv3d_weights(w.to(dev)), Co, sc.to(dev), sh.to(dev),
                             None, 1, True).cpu()
         assert (got - mat).abs().max().item() <= 4e-5      # two FP32 evaluations, each within 2e-5 of the FP64 value
+    # the five 2-D convolutions on three streams (default) and on one: the same kernels on the same operands
+    ops.set_first_layer_streams(False)
+    try:
+        one = ops.catconv_first(L.to(dev), R.to(dev), D, ops.catconv_pack(w.to(dev)), sc.to(dev), sh.to(dev), True).cpu()
+    finally:
+        ops.set_first_layer_streams(True)
+    assert torch.equal(one, got)
 
 
 def test_catconv_not_applicable_shapes(dev):
@@ -870,7 +877,7 @@ def test_deconv3d_vector_and_scalar_epilogues_agree(dev, Co, shape):
 
 @pytest.mark.parametrize("Ci,Co,shape", [(64, 32, (1, 5, 6, 120)), (64, 64, (2, 3, 5, 60)), (32, 32, (1, 4, 7, 124)),
                                          (64, 32, (2, 6, 3, 240)), (128, 64, (1, 2, 3, 116)), (48, 32, (1, 1, 1, 60)),
-                                         (64, 64, (4, 12, 34, 60))])
+                                         (64, 64, (4, 12, 34, 60)), (64, 32, (2, 24, 68, 120))])
 def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shape):
     """csrc/deconv3d_zy.hip -- work items (tile, z parity, y parity), four class bodies with their own chunk sizes, items handed
     out through an atomic counter, three workgroups per CU -- against deconv3d_kernel (both y parities per item; development
@@ -890,8 +897,8 @@ def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shap
     ref = F.conv_transpose3d(xc, wc, None, stride=2, padding=1, output_padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
     for r, relu in ((None, False), (None, True), (res, True), (res, False), (res, "pre")):
         outs = []
-        for old in (0, 1):
-            lib.dmb_dev_set_option(4, old)
+        for form in (2, 1):   # development option 4: 2 = this form, 1 = deconv3d_kernel
+            lib.dmb_dev_set_option(4, form)
             try:
                 outs.append(ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu))
             finally:
@@ -899,7 +906,25 @@ def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shap
         assert torch.equal(outs[0], outs[1]), (r is not None, relu, (outs[0] - outs[1]).abs().max().item())
         if r is None and relu is False:
             assert (outs[0].cpu() - ref).abs().max().item() <= 2e-5
-    # the launch really took the new form (same call twice in a row: the counter ring hands out a fresh, zeroed counter each time)
+    # ... and, where it applies (64 -> 32 with many tiles per CU; development option 11 forces it on the small test shapes),
+    # the sixteen-wave form of csrc/deconv3d_w16.hip: all eight parity classes from one staged tile, bit-identical again
+    if Co == 32:
+        for grid in (0, 3):
+            lib.dmb_dev_set_option(11, 1)
+            lib.dmb_dev_set_option(9, grid)
+            try:
+                for r, relu in ((None, False), (res, True), (res, "pre")):
+                    w16 = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu)
+                    lib.dmb_dev_set_option(4, 1)
+                    old_form = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu)
+                    lib.dmb_dev_set_option(4, 0)
+                    assert torch.equal(w16, old_form), (grid, r is not None, relu, (w16 - old_form).abs().max().item())
+            finally:
+                lib.dmb_dev_set_option(11, 0)
+                lib.dmb_dev_set_option(9, 0)
+                lib.dmb_dev_set_option(4, 0)
+    # the launch really took the new form (same call twice in a row: the counter ring hands out a fresh counter each time)
+    lib.dmb_dev_set_option(4, 2)
     again = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True)
     lib.dmb_dev_set_option(4, 1)
     try:
