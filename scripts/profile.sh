@@ -3,7 +3,7 @@
 #   gpurun_out/prof_<tag>/trace      rocprofv3 --kernel-trace --stats of the headline bench command
 #   gpurun_out/prof_<tag>/pmc_*      counter passes (one group per run; never combined with sys/hip tracing)
 # then scripts/summarize_profiles.py <tag> turns them into profiles/<tag>_kernel_stats.csv, <tag>_pmc.csv, pmc_dominant.json
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
