@@ -304,3 +304,38 @@ def test_confidence_head_composed_with_upsampling_weights():
     assert (comp[inner] - hidden[inner]).abs().max().item() <= 1e-5 * hidden.abs().max().item()
     # the outermost pixel ring is where the two differ (the head zero-pads the up-sampled volume): conf_ring_kernel's job
     assert (comp - hidden).abs().max().item() > 1e-3
+
+
+def test_pfm_loader_matches_the_reference_loader(tmp_path):
+    """disp_io.load_pfm / load_scene_flow_disp (drop-in for dmb/data/datasets/utils/load_disp.py:5-68) on three files whose
+    bytes and expected contents -- as the REFERENCE's loader returns them -- are fixtures (oracle/gen_golden_pfm.py): gray
+    little-endian, gray big-endian with a scale, colour; same array (rows flipped to top-down), same byte-order dtype, same
+    scale; the reference's two error cases; and a write -> read round trip."""
+    import numpy as np
+    from densematchingbenchmark_amd import disp_io
+    g = golden("pfm_files.npz")
+    for name in ("gray_le", "gray_be", "color_le"):
+        p = str(tmp_path / (name + ".pfm"))
+        with open(p, "wb") as fp:
+            fp.write(g[name + "_bytes"].tobytes())
+        data, scale = disp_io.load_pfm(p)
+        assert np.array_equal(data, g[name + "_data"]) and scale == float(g[name + "_scale"])
+        assert data.dtype.str == str(g[name + "_dtype"])
+        if name.startswith("gray"):
+            assert np.array_equal(disp_io.load_scene_flow_disp(p), g[name + "_data"])
+    bad = str(tmp_path / "bad.pfm")
+    with open(bad, "wb") as fp:
+        fp.write(b"P6\n2 2\n-1.0\n" + b"\0" * 16)
+    with pytest.raises(Exception, match="Not a PFM file"):
+        disp_io.load_pfm(bad)
+    with open(bad, "wb") as fp:
+        fp.write(b"Pf\n2x2\n-1.0\n" + b"\0" * 16)
+    with pytest.raises(Exception, match="Malformed PFM header"):
+        disp_io.load_pfm(bad)
+    with pytest.raises(AssertionError):
+        disp_io.load_scene_flow_disp(str(tmp_path / "x.png"))
+    arr = np.arange(12, dtype=np.float32).reshape(3, 4) * 0.5
+    rt = str(tmp_path / "rt.pfm")
+    disp_io.write_pfm(rt, arr, 3.0, little_endian=False)
+    back, s = disp_io.load_pfm(rt)
+    assert np.array_equal(back, arr) and s == 3.0
