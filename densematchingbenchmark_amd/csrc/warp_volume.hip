@@ -20,6 +20,7 @@ enum { WARP_CAT = 0, WARP_DIF = 1, WARP_DIF_NORM = 2 };
 struct WarpTaps {
   float w[8];      // tnw, tne, tsw, tse, bnw, bne, bsw, bse (top/bottom = plane, north/south = row, west/east = column)
   int off[4];      // nw, ne, sw, se offsets into a feature plane (0 when the tap is out of range)
+  int xi[2], yi[2];   // west / east column, north / south row (0 when out of range)
   unsigned valid;  // bit t: tap t is inside the volume
 };
 
@@ -53,6 +54,10 @@ __device__ inline WarpTaps warp_taps(float disp, int k, int y, int x, int D, int
   const bool vy0 = y0 >= 0.f && y0 < (float)H, vy1 = y1 >= 0.f && y1 < (float)H;
   const bool vz0 = z0 >= 0.f && z0 < (float)D, vz1 = z1 >= 0.f && z1 < (float)D;
   const int xi0 = vx0 ? (int)x0 : 0, xi1 = vx1 ? (int)x1 : 0, yi0 = vy0 ? (int)y0 : 0, yi1 = vy1 ? (int)y1 : 0;
+  t.xi[0] = xi0;
+  t.xi[1] = xi1;
+  t.yi[0] = yi0;
+  t.yi[1] = yi1;
   t.off[0] = yi0 * W + xi0;
   t.off[1] = yi0 * W + xi1;
   t.off[2] = yi1 * W + xi0;
@@ -126,9 +131,115 @@ static int launch_warp(const float* L, const float* R, const float* disp, float*
   return launch_status("fast_fms launch failed");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the sample-based builders (the adjoint of the tri-linear sampler; the reference gets it from autograd through
+// F.grid_sample and the expand of inverse_warp_3d.py:19-20).  With T the warped target:
+//     cat:  out = [L * (T > 0), T]      dL = sum_k G_ref * (T > 0),     dT = G_tgt
+//     dif:  out = L * (T > 0) - T       dL = sum_k G * (T > 0),         dT = -G
+//     dR[b, c, yn, xn] = sum over (k, y, x) and the taps of (k, y, x) that land on (yn, xn) of  w_tap * dT[b, c, k, y, x]
+// (the target image is the same on every plane, so the two plane taps of a (row, column) add up).  The rows a sample touches
+// depend on y only and the columns on the sample: kernel A owns ONE output row y and a group of channels, walks all planes and
+// columns and scatters into two LDS rows (north / south source row) with LDS atomics -- the order of the adds is the
+// hardware's, as in the reference's own GPU backward (atomicAdd) -- and leaves them as partial rows; kernel B adds, per
+// source row, the two or three partial rows that point at it in ascending y.  dL needs no scatter: one register per column.
+// The gradient with respect to the disparity samples themselves is not provided (the builders raise for it).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WB_CG = 8;   // channels per workgroup (two per wave)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void warp_volume_bwd_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                              const float* __restrict__ disp, const float* __restrict__ G,
+                                                              float* __restrict__ dL, float* __restrict__ part, int C, int D,
+                                                              int H, int W, int per_pixel) {
+  extern __shared__ float rows[];   // [2][WB_CG][W]
+  const int y = blockIdx.x, c0 = blockIdx.y * WB_CG, b = blockIdx.z;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int HW = H * W;
+  const size_t DHW = (size_t)D * HW;
+  for (int i = threadIdx.x; i < 2 * WB_CG * W; i += 256) rows[i] = 0.f;
+  __syncthreads();
+  const int OC = MODE == WARP_CAT ? 2 * C : C;
+  const float* Rb = R + (size_t)b * C * HW;
+  for (int x = lane; x < W; x += 64) {
+    float dl[2] = {0.f, 0.f};
+    for (int k = 0; k < D; ++k) {
+      const float s = per_pixel ? disp[((size_t)b * D + k) * HW + y * W + x] : disp[k];
+      const WarpTaps t = warp_taps(-s, k, y, x, D, H, W);
+      // weight of (north | south, west | east): the two plane taps of one image point add up
+      float wq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wq[q] = ((t.valid >> q & 1u) ? t.w[q] : 0.f) + ((t.valid >> (q + 4) & 1u) ? t.w[q + 4] : 0.f);
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int cl = wave + 4 * cc, c = c0 + cl;
+        if (c >= C) continue;
+        const float tv = warp_blend(t, Rb + (size_t)c * HW);
+        const size_t o = ((size_t)b * OC * D + k) * HW + (size_t)y * W + x;
+        const float g_ref = G[o + (size_t)c * DHW];
+        const float g_tgt = MODE == WARP_CAT ? G[o + (size_t)(C + c) * DHW] : -g_ref;
+        if (tv > 0.f) dl[cc] += g_ref;
+        float* r0 = rows + (size_t)cl * W;                 // north source row
+        float* r1 = rows + (size_t)(WB_CG + cl) * W;       // south source row
+        if (wq[0] != 0.f) atomicAdd(r0 + t.xi[0], wq[0] * g_tgt);
+        if (wq[1] != 0.f) atomicAdd(r0 + t.xi[1], wq[1] * g_tgt);
+        if (wq[2] != 0.f) atomicAdd(r1 + t.xi[0], wq[2] * g_tgt);
+        if (wq[3] != 0.f) atomicAdd(r1 + t.xi[1], wq[3] * g_tgt);
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = c0 + wave + 4 * cc;
+      if (c < C) dL[((size_t)b * C + c) * HW + (size_t)y * W + x] = dl[cc];
+    }
+  }
+  __syncthreads();
+  // partial rows: part[b][c][y][ns][W]
+  for (int i = threadIdx.x; i < 2 * WB_CG * W; i += 256) {
+    const int ns = i / (WB_CG * W), r = i - ns * (WB_CG * W), cl = r / W, x = r - cl * W;
+    if (c0 + cl < C) part[((((size_t)b * C + c0 + cl) * H + y) * 2 + ns) * W + x] = rows[i];
+  }
+}
+
+// dR[b, c, yn, x] = sum, in ascending y, of the partial rows of the output rows y whose north (south) source row is yn
+__global__ __launch_bounds__(256) void warp_volume_bwd_rows_kernel(const float* __restrict__ part, float* __restrict__ dR,
+                                                                   int C, int H, int W) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int bc = blockIdx.y;
+  if (i >= H * W) return;
+  const int yn = i / W, x = i - yn * W;
+  float acc = 0.f;
+  for (int y = max(0, yn - 2); y <= min(H - 1, yn + 2); ++y) {
+    const float gh = ((((float)y / (float)(H - 1)) * 2.f) - 1.f);
+    const float iy = ((((gh + 1.f) * (float)H) - 1.f) / 2.f);
+    const float y0 = floorf(iy), y1 = y0 + 1.f;
+    const float* p = part + (((size_t)bc * H + y) * 2) * W + x;
+    if (y0 >= 0.f && y0 < (float)H && (int)y0 == yn) acc += p[0];
+    if (y1 >= 0.f && y1 < (float)H && (int)y1 == yn) acc += p[W];
+  }
+  dR[(size_t)bc * H * W + i] = acc;
+}
+
 }  // namespace dmb
 
 using namespace dmb;
+
+extern "C" int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol, float* dL,
+                                    float* dR, float* partial, int B, int C, int D, int H, int W, int per_pixel, int dif,
+                                    void* stream) {
+  if (!L || !R || !disp_sample || !dvol || !dL || !dR || !partial || B <= 0 || C <= 0 || D < 2 || H < 2 || W < 2)
+    return fail(DMB_EINVAL, "fast_fms_bwd: bad argument");
+  if ((long long)C * H * W >= 0x7fffffffLL || H > 65535 || B > 65535 || (size_t)2 * WB_CG * W * 4 > 64 * 1024)
+    return fail(DMB_EUNSUPPORTED, "fast_fms_bwd: feature map too large");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * WB_CG * W * sizeof(float);
+  const dim3 grid(H, cdiv(C, WB_CG), B);
+  if (dif)
+    hipLaunchKernelGGL((warp_volume_bwd_kernel<WARP_DIF>), grid, dim3(256), lds, st, L, R, disp_sample, dvol, dL, partial, C, D, H, W, per_pixel);
+  else
+    hipLaunchKernelGGL((warp_volume_bwd_kernel<WARP_CAT>), grid, dim3(256), lds, st, L, R, disp_sample, dvol, dL, partial, C, D, H, W, per_pixel);
+  hipLaunchKernelGGL(warp_volume_bwd_rows_kernel, dim3(cdiv(H * W, 256), B * C), dim3(256), 0, st, partial, dR, C, H, W);
+  return launch_status("fast_fms_bwd launch failed");
+}
 
 extern "C" int dmb_fast_cat_fms_f32(const float* L, const float* R, const float* disp_sample, float* out, int B, int C,
                                     int D, int H, int W, int per_pixel, void* stream) {

@@ -181,6 +181,23 @@ class DifFmsFn(torch.autograd.Function):
         return dL, dR, None
 
 
+class FastFmsFn(torch.autograd.Function):
+    """fast_cat_fms / fast_dif_fms (normalize=False) under autograd: gradients for the two feature maps (the sampler's adjoint,
+    csrc/warp_volume.hip); the disparity samples are treated as constants."""
+
+    @staticmethod
+    def forward(ctx, left, right, disp_sample, dif):
+        ctx.save_for_backward(left, right, disp_sample)
+        ctx.dif = bool(dif)
+        return ops.fast_dif_fms(left, right, disp_sample) if dif else ops.fast_cat_fms(left, right, disp_sample)
+
+    @staticmethod
+    def backward(ctx, dvol):
+        left, right, disp_sample = ctx.saved_tensors
+        dL, dR = ops.fast_fms_bwd(left, right, disp_sample, dvol.contiguous(), ctx.dif)
+        return dL, dR, None, None
+
+
 class UpsampleRegressFn(torch.autograd.Function):
     """(cost [B, Do, Ho, Wo], disp [B, 1, Ho, Wo]) of a low-resolution cost [B, Di, Hi, Wi].  Differentiable through the
     disparity (the path every PSMNet loss takes, without the full-size gradient volume) and through the volume itself."""

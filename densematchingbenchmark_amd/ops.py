@@ -159,6 +159,23 @@ def fast_dif_fms(left, right, disp_sample, normalize=False, p=1.0):
     return out
 
 
+def fast_fms_bwd(left, right, disp_sample, dvol, dif=False):
+    """Backward of fast_cat_fms / fast_dif_fms (normalize=False): (d left, d right), each [B, C, H, W]."""
+    lib = _lib.load()
+    left, right = _feature_pair(left, right, "fast_fms_bwd")
+    ds, D, per_pixel = _fast_samples(left, disp_sample)
+    dvol = _f32c(dvol, "grad_output")
+    B, C, H, W = left.shape
+    want = (B, C if dif else 2 * C, D, H, W)
+    if tuple(dvol.shape) != want:
+        raise _lib.DmbLibraryError("fast_fms_bwd: grad_output is %s, expected %s" % (tuple(dvol.shape), want))
+    dl, dr = torch.empty_like(left), torch.empty_like(right)
+    part = torch.empty((B, C, H, 2, W), dtype=torch.float32, device=left.device)
+    check(lib.dmb_fast_fms_bwd_f32(dev_ptr(left), dev_ptr(right), dev_ptr(ds), dev_ptr(dvol), dev_ptr(dl), dev_ptr(dr), dev_ptr(part),
+                                   B, C, D, H, W, per_pixel, 1 if dif else 0, stream_ptr(left.device)), "dmb_fast_fms_bwd_f32")
+    return dl, dr
+
+
 def gwc_fms(left, right, disp_idx, num_groups, out=None, out_ch_offset=0):
     lib = _lib.load()
     left, right = _feature_pair(left, right, "gwc_fms")

@@ -70,6 +70,16 @@ int dmb_fast_cat_fms_f32(const float* L, const float* R, const float* disp_sampl
 int dmb_fast_dif_fms_f32(const float* L, const float* R, const float* disp_sample, float* out, int B, int C, int D, int H,
                          int W, int per_pixel, int normalize, float p, void* stream);
 
+/* Backward of fast_cat_fms (dif == 0) / fast_dif_fms without normalisation (dif != 0): what the reference obtains from
+ * torch.autograd through F.grid_sample and the expand of inverse_warp_3d.py:19-20 (cat_fms.py:51-82, dif_fms.py:49-86).
+ *   dvol: gradient of the builder's output ([B, 2C, D, H, W] / [B, C, D, H, W]);  dL, dR: [B, C, H, W];
+ *   partial: workspace of B * C * H * 2 * W floats (per output row the gradient rows of its two source rows).
+ *   dL = sum_k dvol_ref * (T > 0);  dR = the sampler's adjoint of dvol_tgt (cat) or of -dvol (dif).
+ * Sums along x go through LDS atomics (their order is the hardware's, as in the reference's own GPU backward); no gradient
+ * with respect to disp_sample.  Same D, H, W >= 2 rule as the forward. */
+int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol, float* dL, float* dR,
+                         float* partial, int B, int C, int D, int H, int W, int per_pixel, int dif, void* stream);
+
 /* Group-wise correlation volume (GwcNet).  ABSENT from the reference (README.md:16 only names it);
  * occupies the COR_FUNCS slot of cost_processors/utils/correlation1d_cost.py:29-31.  Spec:
  *   out[b, g, k, y, x] = (1/(C/G)) * sum_{c in group g} L[b,c,y,x] * R[b,c,y,x-d_k]  if in range else 0

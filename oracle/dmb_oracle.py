@@ -169,6 +169,30 @@ def fast_dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1
     return dif
 
 
+def fast_volume_grads(reference_fm, target_fm, grad_out, max_disp=192, start_disp=0, dilation=1, disp_sample=None, kind="cat",
+                      dtype=torch.float32):
+    """Gradients of fast_cat_fms / fast_dif_fms (``kind``) with respect to the two feature maps for an upstream gradient
+    ``grad_out``, the way the reference gets them: torch.autograd through the sampler of layers/inverse_warp_3d.py:19-50 (the
+    image expanded over the D planes, a (size - 1)-normalised grid, F.grid_sample with its align_corners=False default).  The
+    mask ``(warped > 0)`` is a constant (cat_fms.py:77 builds it with ``.type_as``: no gradient path).  Pinned by
+    tests/golden/fast_volumes_grad.npz (the reference's own functions under autograd).  ``dtype=torch.float64`` = yardstick."""
+    L = reference_fm.detach().to(dtype).requires_grad_()
+    R = target_fm.detach().to(dtype).requires_grad_()
+    ds = _fast_samples(reference_fm, max_disp, start_disp, dilation, disp_sample).to(dtype)
+    B, D, H, W = ds.shape
+    C = R.shape[1]
+    img = R.unsqueeze(2).expand(B, C, D, H, W)
+    gd = torch.linspace(0, D - 1, D, dtype=dtype).view(1, D, 1, 1).expand(B, D, H, W)
+    gh = torch.linspace(0, H - 1, H, dtype=dtype).view(1, 1, H, 1).expand(B, D, H, W)
+    gw = torch.linspace(0, W - 1, W, dtype=dtype).view(1, 1, 1, W).expand(B, D, H, W) + (-ds)
+    grid = torch.stack(((gw / (W - 1) * 2) - 1, (gh / (H - 1) * 2) - 1, (gd / (D - 1) * 2) - 1), dim=4)
+    tgt = F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    ref = L.unsqueeze(2) * (tgt > 0).to(dtype)
+    vol = torch.cat((ref, tgt), dim=1) if kind == "cat" else ref - tgt
+    vol.backward(grad_out.to(dtype))
+    return L.grad, R.grad
+
+
 def correlation1d_cost(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):
     """cost_processors/utils/correlation1d_cost.py:7-27.  The arithmetic lives in SpatialCorrelationSampler
     (ClementPinard/Pytorch-Correlation-extension, branch fix_1.7 per INSTALL.md:60-66; no version pin in requirements.txt),

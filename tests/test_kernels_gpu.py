@@ -130,8 +130,44 @@ def test_fast_mode_argument_errors(dev):
     with pytest.raises(_lib.DmbLibraryError):
         ops.fast_cat_fms(a, a, torch.zeros(1, device=dev))               # D = 1: the reference divides by D - 1
     from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import fast_cat_fms
+    with pytest.raises(NotImplementedError):   # the samples are constants on the HIP path: a sample tensor that wants a gradient is refused
+        fast_cat_fms(a, a, 4, disp_sample=torch.zeros(1, 3, 4, 6, device=dev).requires_grad_())
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.dif_fms import fast_dif_fms
     with pytest.raises(NotImplementedError):
-        fast_cat_fms(a.requires_grad_(), a, 4)
+        fast_dif_fms(a.clone().requires_grad_(), a, 4, normalize=True)
+
+
+def test_fast_volume_builders_backward(dev):
+    """Backward of fast_cat_fms / fast_dif_fms (csrc/warp_volume.hip, the sampler's adjoint) through the module-level builders
+    under torch.autograd, against gradients of the REFERENCE's builders under its own autograd (tests/golden/
+    fast_volumes_grad.npz): per-pixel samples and the builders' linspace samples; and against an FP64 evaluation of the oracle
+    (error no larger than 4x the FP32 reference's own)."""
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import fast_cat_fms
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.dif_fms import fast_dif_fms
+    g = golden("fast_volumes_grad.npz")
+    for i, row in enumerate(g["cases"]):
+        sh, D, seed = tuple(int(v) for v in row[:4]), int(row[4]), int(row[5])
+        a, b = _rand(sh, seed), _rand(sh, seed + 1000)
+        gen = torch.Generator().manual_seed(seed + 2000)
+        ds = torch.rand((sh[0], D, sh[2], sh[3]), generator=gen) * sh[3] * 0.6 - 2.0
+        for kind, fn in (("cat", fast_cat_fms), ("dif", fast_dif_fms)):
+            ch = 2 * sh[1] if kind == "cat" else sh[1]
+            for mode in ("pixel", "default"):
+                nd = D if mode == "pixel" else 12
+                up = _rand((sh[0], ch, nd, sh[2], sh[3]), seed + 3000 + (0 if kind == "cat" else 1))
+                L, R = a.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+                kw = dict(disp_sample=ds.to(dev)) if mode == "pixel" else dict(max_disp=24, start_disp=-3, dilation=2)
+                vol = fn(L, R, **kw)
+                vol.backward(up.to(dev))
+                okw = dict(disp_sample=ds) if mode == "pixel" else dict(max_disp=24, start_disp=-3, dilation=2)
+                t64 = O.fast_volume_grads(a, b, up, kind=kind, dtype=torch.float64, **okw)
+                for got, name, truth in ((L.grad, "dL", t64[0]), (R.grad, "dR", t64[1])):
+                    ref = torch.as_tensor(g["%s_%s_%s_%d" % (kind, mode, name, i)])
+                    scale = max(1.0, ref.abs().max().item())
+                    assert (got.cpu() - ref).abs().max().item() <= 2e-5 * scale, (kind, mode, name, i)
+                    e_got = (got.cpu().double() - truth).abs().max().item()
+                    e_ref = (ref.double() - truth).abs().max().item()
+                    assert e_got <= max(4 * e_ref, 1e-6 * scale), (kind, mode, name, i, e_got, e_ref)
 
 
 @pytest.mark.parametrize("C,G", [(16, 2), (32, 8), (12, 12), (320, 40)])

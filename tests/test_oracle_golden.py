@@ -526,6 +526,27 @@ def test_oracle_correlation1d_cost_is_the_samplers_published_semantics():
     assert (got[:, :, :, 0] == torch.nn.functional.leaky_relu(torch.cat([torch.zeros(B, D - 1, H), (L[..., 0] * R[..., 0]).sum(1, keepdim=True)], 1), 0.1)).all()
 
 
+def test_oracle_fast_volume_gradients_match_the_reference_autograd():
+    """The gradients of the sample-based builders: the oracle's differentiable restatement of the sampler against
+    gradients of the REFERENCE's fast_cat_fms / fast_dif_fms under torch.autograd (oracle/gen_golden_fast_grad.py), per-pixel
+    samples and the builders' own linspace samples."""
+    g = golden("fast_volumes_grad.npz")
+    for i, row in enumerate(g["cases"]):
+        sh, D, seed = tuple(int(v) for v in row[:4]), int(row[4]), int(row[5])
+        a, b = rand(sh, seed), rand(sh, seed + 1000)
+        gen = torch.Generator().manual_seed(seed + 2000)
+        ds = torch.rand((sh[0], D, sh[2], sh[3]), generator=gen) * sh[3] * 0.6 - 2.0
+        for kind in ("cat", "dif"):
+            ch = 2 * sh[1] if kind == "cat" else sh[1]
+            for mode in ("pixel", "default"):
+                nd = D if mode == "pixel" else 12
+                up = rand((sh[0], ch, nd, sh[2], sh[3]), seed + 3000 + (0 if kind == "cat" else 1))
+                kw = dict(disp_sample=ds) if mode == "pixel" else dict(max_disp=24, start_disp=-3, dilation=2)
+                dL, dR = O.fast_volume_grads(a, b, up, kind=kind, **kw)
+                assert maxdiff(dL, g["%s_%s_dL_%d" % (kind, mode, i)]) <= 1e-5
+                assert maxdiff(dR, g["%s_%s_dR_%d" % (kind, mode, i)]) <= 1e-5
+
+
 def test_oracle_gwc_has_two_witnesses():
     """Second witness for the UNPINNED group-wise correlation volume: two statements that share no code pin
     each other, and one of them is pinned to the reference.
