@@ -174,7 +174,12 @@ __device__ __forceinline__ void store_tile(const f32x16 (&a)[VEC], const float (
   }
 }
 
-template <class C>
+// WITH_RES: the residual operand is a compile-time property of the launch (two instantiations per tile shape).  The vector
+// epilogue with its residual ring needs 3 - 5 registers more than the 168 that three workgroups per CU leave; as a run-time
+// branch that meant spills -- a scratch segment -- for EVERY launch of the kernel, and a kernel with a scratch segment costs
+// about 6 us of dispatch gap on either side of each launch (five of the six 32 -> 32 launches of a PSMNet step carry no
+// residual).
+template <class C, bool WITH_RES>
 __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
@@ -318,31 +323,33 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
       sc4[k] = scale ? scale[co] : 1.f;
       sh4[k] = shift ? shift[co] : 0.f;
     }
-    auto offsets = [&](int mt, unsigned (&off)[4]) {
+    // a tile's four 16-byte words per lane are 8 channels apart: one per-lane offset per tile (out of range for lanes outside
+    // the volume; adding the channel steps keeps it out of range) instead of four -- the eight offset registers of two tiles in
+    // flight were what pushed this epilogue past 168 registers (3 spills = a scratch segment for the kernel, and a kernel with
+    // a scratch segment costs ~6 us of dispatch gap on either side of every launch)
+    const unsigned kstep = 8u * DHW * 4u;
+    auto offset0 = [&](int mt) {
       const int gy = y0 + C::GR * (mt / C::XS) + px / C::G, gxo = x0 + (mt % C::XS) * C::G + px % C::G;
       const bool inb = gz < D && gy < H && gxo < W;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        off[k] = inb ? ((unsigned)(wn * 32 + k * 8 + (lane >> 3)) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxo) * 4u
-                     : DMA_OOB;
+      return inb ? ((unsigned)(wn * 32 + (lane >> 3)) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxo) * 4u : DMA_OOB;
     };
     auto run = [&](auto has_res) {
       constexpr bool HAS_RES = decltype(has_res)::value;
-      unsigned off[2][4];
+      unsigned off0[2];
       u32x4 rv[2][4];
-      offsets(0, off[0]);
+      off0[0] = offset0(0);
       if constexpr (HAS_RES) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rv[0][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[0][k], 0, 0);
+        for (int k = 0; k < 4; ++k) rv[0][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(off0[0] + k * kstep), 0, 0);
       }
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) {
         if (mt + 1 < C::MT) {
-          offsets(mt + 1, off[(mt + 1) & 1]);
+          off0[(mt + 1) & 1] = offset0(mt + 1);
           if constexpr (HAS_RES) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              rv[(mt + 1) & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off[(mt + 1) & 1][k], 0, 0);
+              rv[(mt + 1) & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(off0[(mt + 1) & 1] + k * kstep), 0, 0);
           }
         }
 #pragma unroll
@@ -365,14 +372,11 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
           o.y = __float_as_uint(fmaxf(v.y, lo));
           o.z = __float_as_uint(fmaxf(v.z, lo));
           o.w = __float_as_uint(fmaxf(v.w, lo));
-          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)off[mt & 1][k], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(off0[mt & 1] + k * kstep), 0, 0);
         }
       }
     };
-    if (res)
-      run(std::true_type{});
-    else
-      run(std::false_type{});
+    run(std::integral_constant<bool, WITH_RES>{});
     return;
   }
   if (gz >= D) return;
@@ -1336,9 +1340,15 @@ static int launch_s1(const float* x, const float* wp, const float* scale, const 
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  DMB_ENSURE_LDS((&conv3d_s1_kernel<C>), (size_t)(lds));
-  hipLaunchKernelGGL((conv3d_s1_kernel<C>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
-                     H, W, ntx, nty, ntz, relu);
+  if (res) {
+    DMB_ENSURE_LDS((&conv3d_s1_kernel<C, true>), (size_t)(lds));
+    hipLaunchKernelGGL((conv3d_s1_kernel<C, true>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
+                       H, W, ntx, nty, ntz, relu);
+  } else {
+    DMB_ENSURE_LDS((&conv3d_s1_kernel<C, false>), (size_t)(lds));
+    hipLaunchKernelGGL((conv3d_s1_kernel<C, false>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
+                       H, W, ntx, nty, ntz, relu);
+  }
   return launch_status("conv3d stride-1 launch failed");
 }
 
