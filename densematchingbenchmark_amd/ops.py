@@ -1247,3 +1247,37 @@ def map_loss_bwd(x, gt, loss_out, grad_out, lower, upper, mode):
     check(lib.dmb_map_loss_bwd_f32(dev_ptr(x), dev_ptr(gt), dev_ptr(loss_out), dev_ptr(go), 1.0, dev_ptr(gx), x.numel(),
                                    float(lower), float(upper), int(mode), stream_ptr(x.device)), "dmb_map_loss_bwd_f32")
     return gx
+
+
+# ---------------------------------------------------------------------------------------------- spatial propagation (dmb.ops.spn)
+def spn_gaterecurrent2d(X, G1, G2, G3, horizontal, reverse):
+    """dmb/ops/spn/functions/gaterecurrent2dnoind.py:10-24 (forward): the whole scan in one launch (csrc/spn.hip)."""
+    lib = _lib.load()
+    X = _f32c(X, "X")
+    ts = [_f32c(g, "gate") for g in (G1, G2, G3)]
+    for g in ts:
+        _same_shape(X, g, "spn")
+    if X.dim() != 4:
+        raise _lib.DmbLibraryError("spn: X must be [N, C, H, W], got %s" % (tuple(X.shape),))
+    N, C, H, W = X.shape
+    out = torch.empty_like(X)
+    check(lib.dmb_spn_gaterecurrent2d_f32(dev_ptr(X), dev_ptr(ts[0]), dev_ptr(ts[1]), dev_ptr(ts[2]), dev_ptr(out), N, C, H, W,
+                                          1 if horizontal else 0, 1 if reverse else 0, stream_ptr(X.device)), "dmb_spn_gaterecurrent2d_f32")
+    return out
+
+
+def spn_gaterecurrent2d_bwd(X, G1, G2, G3, H_fwd, grad_out, horizontal, reverse):
+    """gaterecurrent2dnoind.py:26-44 (backward): (dX, dG1, dG2, dG3)."""
+    lib = _lib.load()
+    ops_in = [_f32c(t, "spn operand") for t in (X, G1, G2, G3, H_fwd, grad_out)]
+    for t in ops_in[1:]:
+        _same_shape(ops_in[0], t, "spn_bwd")
+    N, C, H, W = ops_in[0].shape
+    outs = [torch.empty_like(ops_in[0]) for _ in range(4)]
+    check(lib.dmb_spn_gaterecurrent2d_bwd_f32(*[dev_ptr(t) for t in ops_in], *[dev_ptr(t) for t in outs], N, C, H, W,
+                                              1 if horizontal else 0, 1 if reverse else 0, stream_ptr(ops_in[0].device)),
+          "dmb_spn_gaterecurrent2d_bwd_f32")
+    return tuple(outs)
+
+
+from .spn import GateRecurrent2dnoind  # noqa: E402,F401  (``dmb.ops.GateRecurrent2dnoind``: dmb/ops/__init__.py:1)

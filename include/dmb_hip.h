@@ -80,6 +80,20 @@ int dmb_fast_dif_fms_f32(const float* L, const float* R, const float* disp_sampl
 int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol, float* dL, float* dR,
                          float* partial, int B, int C, int D, int H, int W, int per_pixel, int dif, void* stream);
 
+/* Spatial propagation scan: dmb/ops/spn (GateRecurrent2dnoind: functions/gaterecurrent2dnoind.py:10-44 on
+ * src/gaterecurrent2dnoind_kernel.cu:10-166,288-345,535-552), the reference's only native op (CUDA; one kernel launch per
+ * scanned line there, ONE launch here).  X, G1, G2, G3, H: [N, C, H, W].
+ *   H[s, t] = (1 - g1 - g2 - g3) * X[s, t] + g1 * H[s', t - 1] + g2 * H[s', t] + g3 * H[s', t + 1],   g_k = G_k[s, t] where
+ *   the neighbour lies inside the image, else 0; s along the columns if horizontal else along the rows, s' = s - 1 (s + 1 if
+ *   reverse).  The line across the scan direction may hold at most 2048 positions.
+ * Backward: dH = gradient of the output; writes dX, dG1, dG2, dG3 (zero where a link leaves the image).  Unlike the reference
+ * (kernel.cu:317) it does not overwrite dH.  Parity UNPINNED: the reference op cannot be built here (CUDA). */
+int dmb_spn_gaterecurrent2d_f32(const float* X, const float* G1, const float* G2, const float* G3, float* H_out, int N, int C,
+                                int H, int W, int horizontal, int reverse, void* stream);
+int dmb_spn_gaterecurrent2d_bwd_f32(const float* X, const float* G1, const float* G2, const float* G3, const float* H_fwd,
+                                    const float* dH, float* dX, float* dG1, float* dG2, float* dG3, int N, int C, int H, int W,
+                                    int horizontal, int reverse, void* stream);
+
 /* Group-wise correlation volume (GwcNet).  ABSENT from the reference (README.md:16 only names it);
  * occupies the COR_FUNCS slot of cost_processors/utils/correlation1d_cost.py:29-31.  Spec:
  *   out[b, g, k, y, x] = (1/(C/G)) * sum_{c in group g} L[b,c,y,x] * R[b,c,y,x-d_k]  if in range else 0

@@ -268,6 +268,41 @@ def gwc_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, num
 
 
 # ------------------------------------------------------------------------------------------------------------
+# spatial propagation scan: dmb/ops/spn (the reference's only native op; CUDA-only there: PARITY UNPINNED)
+# ------------------------------------------------------------------------------------------------------------
+def spn_gaterecurrent2d(X, G1, G2, G3, horizontal, reverse):
+    """dmb/ops/spn/src/gaterecurrent2dnoind_kernel.cu:130-166 (one scanned line; the other three directions :168-286 differ in
+    the index arithmetic only) driven by :535-552: restated with differentiable torch ops, one line at a time --
+        H[s, t] = (1 - g1 - g2 - g3) * X[s, t] + g1 * H[s', t-1] + g2 * H[s', t] + g3 * H[s', t+1]
+    with s' the line scanned before s and g_k = G_k[s, t] where the neighbour exists, else 0 (get_gate_sf, :85-98: the gate of a
+    link is stored at the later of its two positions, :10-66).  The reference cannot be run here (no CUDA; its Python wrapper
+    refuses CPU tensors, functions/gaterecurrent2dnoind.py:14-16): this restatement is UNPINNED; its autograd is what the HIP
+    backward is checked against (an independent derivation of kernel.cu:288-345)."""
+    if not horizontal:   # scan along the rows: the same recurrence on the transposed planes
+        return spn_gaterecurrent2d(X.transpose(2, 3), G1.transpose(2, 3), G2.transpose(2, 3), G3.transpose(2, 3), True,
+                                   reverse).transpose(2, 3)
+    N, C, H, W = X.shape
+    order = range(W - 1, -1, -1) if reverse else range(W)
+    lines = {}
+    prev = None
+    for i, w in enumerate(order):
+        x = X[..., w]
+        if prev is None:
+            h = x * 1.0
+        else:
+            zero = torch.zeros_like(x[..., :1])
+            up = torch.cat([zero, prev[..., :-1]], dim=-1)      # H[s', t - 1]
+            dn = torch.cat([prev[..., 1:], zero], dim=-1)       # H[s', t + 1]
+            g1 = torch.cat([zero, G1[..., 1:, w]], dim=-1)      # no neighbour above row 0
+            g2 = G2[..., w]
+            g3 = torch.cat([G3[..., :-1, w], zero], dim=-1)     # none below the last row
+            h = (((1.0 - g1) - g2) - g3) * x + ((g1 * up + g2 * prev) + g3 * dn)
+        lines[w] = h
+        prev = h
+    return torch.stack([lines[w] for w in range(W)], dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # conv + BN (+ReLU) units: layers/basic_layers.py:68-100,160-177
 # ------------------------------------------------------------------------------------------------------------
 _BN_TRAINING = [False]

@@ -967,3 +967,47 @@ def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shap
         assert torch.equal(again, ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True))
     finally:
         lib.dmb_dev_set_option(4, 0)
+
+
+# ------------------------------------------------------------------------------------- spatial propagation scan (dmb.ops.spn)
+@pytest.mark.parametrize("horizontal,reverse", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("shape", [(2, 3, 6, 9), (1, 2, 64, 80), (1, 1, 1100, 5), (1, 2, 7, 1500)])
+def test_spn_gaterecurrent2d(dev, horizontal, reverse, shape):
+    """GateRecurrent2dnoind (dmb/ops/spn, the reference's only native op; ONE launch per scan here instead of one per scanned
+    line) against the oracle's restatement of the recurrence (UNPINNED: the CUDA reference cannot run here), forward and --
+    through torch.autograd -- backward against the oracle's own autograd with an FP64 evaluation as yardstick.  Lines across
+    the scan longer than 1024 positions take two positions per thread; longer than 2048 are refused."""
+    from densematchingbenchmark_amd.ops import GateRecurrent2dnoind
+    N, C, H, W = shape
+    if (H if horizontal else W) > 2048:
+        pytest.skip("line too long")
+    g = torch.Generator().manual_seed(41)
+    X = torch.randn(shape, generator=g)
+    Gs = [torch.rand(shape, generator=g) * 0.33 for _ in range(3)]     # gates sum below 1: a contraction, as after AnyNet's normalisation
+    up = torch.randn(shape, generator=g)
+    leaves = [t.clone().to(dev).requires_grad_() for t in [X] + Gs]
+    out = GateRecurrent2dnoind(horizontal, reverse)(*leaves)
+    ref = O.spn_gaterecurrent2d(X, *Gs, horizontal, reverse)
+    assert out.shape == ref.shape and (out.detach().cpu() - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+    out.backward(up.to(dev))
+    def grads(dtype):
+        ls = [t.clone().to(dtype).requires_grad_() for t in [X] + Gs]
+        O.spn_gaterecurrent2d(*ls, horizontal, reverse).backward(up.to(dtype))
+        return [t.grad for t in ls]
+    g32, g64 = grads(torch.float32), grads(torch.float64)
+    for got, r32, r64 in zip(leaves, g32, g64):
+        scale = max(1.0, r64.abs().max().item())
+        e_got = (got.grad.cpu().double() - r64).abs().max().item()
+        e_ref = (r32.double() - r64).abs().max().item()
+        assert e_got <= max(4 * e_ref, 2e-6 * scale), (e_got, e_ref)
+
+
+def test_spn_refuses_cpu_tensors_and_long_lines(dev):
+    from densematchingbenchmark_amd import _lib
+    from densematchingbenchmark_amd.ops import GateRecurrent2dnoind
+    x = torch.zeros(1, 1, 4, 4)
+    with pytest.raises(_lib.DmbLibraryError):
+        GateRecurrent2dnoind(True, False)(x, x, x, x)
+    y = torch.zeros(1, 1, 2100, 3, device=dev)
+    with pytest.raises(_lib.DmbLibraryError):
+        GateRecurrent2dnoind(True, False)(y, y, y, y)

@@ -581,3 +581,52 @@ def test_first_layer_from_maps_is_the_3d_convolution_of_the_volume(kind):
     want = torch.nn.functional.conv3d(vol, w, padding=1)
     got = O.first_layer_from_maps(L, R, w, D, kind)
     assert got.shape == want.shape and (got - want).abs().max().item() <= 1e-12
+
+
+def _spn_literal(X, G1, G2, G3, horizontal, reverse):
+    """Per-element statement of the scan from the kernel source's index arithmetic (gaterecurrent2dnoind_kernel.cu: gate lookup
+    :10-98, one line per direction :130-286, line order :535-600): the second witness of the oracle's vectorised restatement."""
+    N, C, H, W = X.shape
+    out = torch.zeros_like(X)
+
+    def get(d, h, w):
+        return d[h, w] if 0 <= h < H and 0 <= w < W else 0.0
+
+    def gate(G, h1, w1, h2, w2):
+        if not (0 <= h1 < H and 0 <= w1 < W and 0 <= h2 < H and 0 <= w2 < W):
+            return 0.0
+        if horizontal:
+            first = (w1 > w2) if not reverse else (w1 < w2)
+        else:
+            first = (h1 > h2) if not reverse else (h1 < h2)
+        return G[h1, w1] if first else G[h2, w2]
+
+    for n in range(N):
+        for c in range(C):
+            x, g1, g2, g3, o = X[n, c], G1[n, c], G2[n, c], G3[n, c], out[n, c]
+            S = W if horizontal else H
+            for s in (range(S - 1, -1, -1) if reverse else range(S)):
+                p = s + 1 if reverse else s - 1
+                for t in range(H if horizontal else W):
+                    h, w = (t, s) if horizontal else (s, t)
+                    nb = [(t - 1, p), (t, p), (t + 1, p)] if horizontal else [(p, t - 1), (p, t), (p, t + 1)]
+                    a, b, cc = (gate(g, h, w, nh, nw) for g, (nh, nw) in zip((g1, g2, g3), nb))
+                    o[h, w] = (1 - a - b - cc) * x[h, w] + a * get(o, *nb[0]) + b * get(o, *nb[1]) + cc * get(o, *nb[2])
+    return out
+
+
+@pytest.mark.parametrize("horizontal", [True, False])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_oracle_spn_scan_has_a_literal_witness(horizontal, reverse):
+    """The spatial propagation scan (dmb/ops/spn, the reference's only native op -- CUDA, cannot be run here: UNPINNED): the
+    oracle's line-at-a-time restatement against a per-element loop written from the kernel source's index arithmetic, all four
+    scan directions; and the properties the recurrence implies: the first scanned line is a copy of X, zero gates give H = X."""
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(1, 2, 5, 7, generator=g, dtype=torch.float64)
+    Gs = [torch.rand(1, 2, 5, 7, generator=g, dtype=torch.float64) * 0.33 for _ in range(3)]
+    got = O.spn_gaterecurrent2d(X, *Gs, horizontal, reverse)
+    assert (got - _spn_literal(X, *Gs, horizontal, reverse)).abs().max().item() <= 1e-14
+    first = (slice(None), slice(None), slice(None), -1 if reverse else 0) if horizontal else (slice(None), slice(None), -1 if reverse else 0)
+    assert torch.equal(got[first], X[first])
+    zero = [torch.zeros_like(X)] * 3
+    assert torch.equal(O.spn_gaterecurrent2d(X, *zero, horizontal, reverse), X)
