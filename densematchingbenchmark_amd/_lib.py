@@ -32,6 +32,7 @@ SIGNATURES = {
     "dmb_fast_fms_bwd_f32": (_c_int, [_P] * 7 + [_c_int] * 7 + [_P]),
     "dmb_spn_gaterecurrent2d_f32": (_c_int, [_P] * 5 + [_c_int] * 6 + [_P]),
     "dmb_spn_gaterecurrent2d_bwd_f32": (_c_int, [_P] * 10 + [_c_int] * 6 + [_P]),
+    "dmb_conv2d_k3_multi_f32": (_c_int, [_c_int, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "dmb_cat_fms_into_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
     "dmb_correlation1d_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _P]),
     "dmb_copy_window_f32": (_c_int, [_P, _P, _c_ll, _c_int, _c_int, _c_int, _P]),

@@ -97,12 +97,25 @@ __device__ __forceinline__ void noalias_step(const float* __restrict__ cur, floa
 // that one XCD owns a contiguous tile range).  The chunk pipeline runs ACROSS tiles: the first chunk of the next tile
 // is in flight while the last chunk of the current one is multiplied, and a tile's stores drain while the next tile's
 // first chunk is multiplied.
-template <class C>
+// MULTI: one launch walks the tiles of several independent convolutions ("jobs") that share the layer shape (Ci, Co, H, kernel)
+// and differ in input, weights, output and image WIDTH: the five 2-D convolutions of the volume-free first layer
+// (csrc/catconv.hip), three of which are 52-column border maps of 272 tiles each -- one after the other they take a round of
+// the chip apiece for a tenth of a round's arithmetic.
+constexpr int C2_MAXJOBS = 6;
+struct C2Jobs {
+  const float* x[C2_MAXJOBS];
+  const float* wp[C2_MAXJOBS];
+  float* y[C2_MAXJOBS];
+  int W[C2_MAXJOBS], out_ctot[C2_MAXJOBS], ntx[C2_MAXJOBS], tile_begin[C2_MAXJOBS];
+  int njobs;
+};
+
+template <class C, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, float* __restrict__ y, int Ci,
                                                         int Co, int H, int W, int relu, int in_ctot, int out_ctot,
-                                                        int res_ctot, int ntx, int nty, int ntiles) {
+                                                        int res_ctot, int ntx, int nty, int ntiles, const C2Jobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int G = gridDim.x;
   if ((int)blockIdx.x >= ntiles) return;
@@ -110,25 +123,39 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wy = wave / C::WN, wn = wave % C::WN;
-  const unsigned HW = (unsigned)H * W;
   const int Cipad = cdiv(Ci, C2_CK) * C2_CK;
-  const int Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
-  const unsigned HWo = (unsigned)Ho * Wo;
+  const int Ho = (H - 1) / C::S + 1;
 
   struct Tile {
     int b, x0, y0;   // batch item, output coordinates of the tile origin
     int p;           // DOT: which of the launch's weight sets (pairs of phases); 0 otherwise
+    int job;         // MULTI: which convolution of the launch
   };
+  // per-tile view of what MULTI makes job-dependent (wave-uniform: scalar loads from the kernel arguments)
+  auto W_of = [&](const Tile& tl) { return MULTI ? jobs.W[tl.job] : W; };
+  auto x_of = [&](const Tile& tl) { return MULTI ? jobs.x[tl.job] : x; };
+  auto y_of = [&](const Tile& tl) { return MULTI ? jobs.y[tl.job] : y; };
+  auto wp_of = [&](const Tile& tl) { return MULTI ? jobs.wp[tl.job] : wp; };
+  auto octot_of = [&](const Tile& tl) { return MULTI ? jobs.out_ctot[tl.job] : out_ctot; };
   auto tile_at = [&](int it) {
     int t = xcd_remap((int)blockIdx.x + it * G, ntiles);
     Tile tl;
     tl.p = 0;
+    tl.job = 0;
+    int ntx_ = ntx;
+    if constexpr (MULTI) {
+#pragma unroll
+      for (int q = 1; q < C2_MAXJOBS; ++q)
+        if (q < jobs.njobs && t >= jobs.tile_begin[q]) tl.job = q;
+      t -= jobs.tile_begin[tl.job];
+      ntx_ = jobs.ntx[tl.job];
+    }
     if constexpr (C::DOT) {   // res_ctot = number of weight sets; the set is the fastest index: 8 consecutive work items
       tl.p = t % res_ctot;    // share one input tile
       t /= res_ctot;
     }
-    tl.x0 = (t % ntx) * C::TX;
-    t /= ntx;
+    tl.x0 = (t % ntx_) * C::TX;
+    t /= ntx_;
     tl.y0 = (t % nty) * C::TY;
     tl.b = t / nty;
     return tl;
@@ -136,9 +163,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
 
   constexpr int WPW = C::W_FLOATS / 16;      // 16-byte weight words per wave
   constexpr int WI = (WPW + 63) / 64;
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (unsigned)((C::DOT ? res_ctot : 1) * (Cipad / 2) * C::KK * C::NTT * 64) * 4u);
   auto stage = [&](const Tile& tl, int c0, float* buf) {
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * in_ctot * HW, (unsigned)Ci * HW * 4u);
+    const int W = W_of(tl);   // (shadows the launch's W: everything below is per tile)
+    const unsigned HW = (unsigned)H * W;
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp_of(tl), (unsigned)((C::DOT ? res_ctot : 1) * (Cipad / 2) * C::KK * C::NTT * 64) * 4u);
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x_of(tl) + (size_t)tl.b * in_ctot * HW, (unsigned)Ci * HW * 4u);
     if constexpr (C::V16) {
       // unit u = 4 consecutive floats of the staged chunk, linear in LDS: u -> (channel, tile row, 16-byte column)
       constexpr int IPW = (C::VUNITS + 255) / 256;   // instructions per wave
@@ -202,7 +231,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
   // epilogue: BN scale/shift -> + residual -> ReLU (basic_layers.py:219-243 adds the skip AFTER conv2's BN, no ReLU)
   auto epilogue = [&](auto has_res, const Tile& tl, float* scratch) {
     constexpr bool HAS_RES = decltype(has_res)::value;
-    float* yb = y + (size_t)tl.b * out_ctot * HWo;
+    const int Wo = (W_of(tl) - 1) / C::S + 1, out_ctot = octot_of(tl);   // (shadow the launch's: per tile)
+    const unsigned HWo = (unsigned)Ho * Wo;
+    float* yb = y_of(tl) + (size_t)tl.b * out_ctot * HWo;
     const float* rb = res ? res + (size_t)tl.b * res_ctot * HWo : nullptr;
     if constexpr (C::V16) {
       // accumulator tile -> scratch[channel][pixel] -> a lane owns 4 consecutive pixels of one channel.  Loads and
@@ -294,6 +325,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
 
   // DOT epilogue: lane (j, h) of wave wn holds, for pixel j of each row-pair tile, channels wn * 32 + cd_row(r, h)
   auto dot_epilogue = [&](const Tile& tl, float* scratch) {
+    const int Wo = (W - 1) / C::S + 1;
+    const unsigned HWo = (unsigned)Ho * Wo;
     float w2r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) w2r[r] = res[(wn & 1) * 32 + cd_row(r, h)];
@@ -342,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict_
           st_t.x0 = same ? cur_t.x0 : next_t.x0;
           st_t.y0 = same ? cur_t.y0 : next_t.y0;
           st_t.p = same ? cur_t.p : next_t.p;
+          st_t.job = same ? cur_t.job : next_t.job;
           if (same || has_next) stage(st_t, same ? (ci + 1) * C::CK : 0, nxt);
         }
         const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
@@ -475,8 +509,31 @@ static int launch_conv2d(const float* x, const float* wp, const float* scale, co
   const long long slots = 2LL * num_cus();   // two workgroups per CU, a multiple of the 8 XCDs
   const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
   hipLaunchKernelGGL((conv2d_kernel<C>), dim3(grid), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, Co, H, W, relu,
-                     in_ctot, out_ctot, res_ctot, ntx, nty, (int)ntiles);
+                     in_ctot, out_ctot, res_ctot, ntx, nty, (int)ntiles, C2Jobs{});
   return launch_status("conv2d launch failed");
+}
+
+// Several convolutions of one layer shape in ONE launch (see C2Jobs): no affine, no residual, no ReLU, stride 1.
+template <class C>
+static int launch_conv2d_multi(const C2Jobs& jobs_in, int B, int Ci, int Co, int H, hipStream_t st) {
+  static_assert(C::S == 1 && !C::DOT, "multi-job launches are stride-1 convolutions");
+  C2Jobs jobs = jobs_in;
+  const int nty = cdiv(H, C::TY);
+  long long ntiles = 0;
+  for (int q = 0; q < jobs.njobs; ++q) {
+    jobs.ntx[q] = cdiv(jobs.W[q], C::TX);
+    jobs.tile_begin[q] = (int)ntiles;
+    ntiles += (long long)B * jobs.ntx[q] * nty;
+    if (ntiles > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d_multi: grid too large");
+  }
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  DMB_ENSURE_LDS((&conv2d_kernel<C, true>), (size_t)(lds));
+  const long long slots = 2LL * num_cus();
+  const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+  hipLaunchKernelGGL((conv2d_kernel<C, true>), dim3(grid), dim3(256), lds, st, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, Ci, Co, H, 0, 0, Ci,
+                     0, 0, 0, nty, (int)ntiles, jobs);
+  return launch_status("conv2d_multi launch failed");
 }
 
 }  // namespace dmb
@@ -554,6 +611,32 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
 #undef DMB_C2
   return fail(DMB_EUNSUPPORTED, "conv2d: stride 1 with kernel 1 | 3, dilation 1 | 2 (4 | 8 up to 32 output channels), output channels <= 128; "
                                 "stride 2 with kernel 1 | 3 (<= 64 output channels) or 5 (<= 32), dilation 1");
+}
+
+extern "C" int dmb_conv2d_k3_multi_f32(int njobs, const float* const* x, const float* const* wpack, float* const* y, const int* W,
+                                       const int* out_channels_total, int B, int Ci, int Co, int H, void* stream) {
+  if (njobs <= 0 || njobs > C2_MAXJOBS || !x || !wpack || !y || !W || !out_channels_total || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0)
+    return fail(DMB_EINVAL, "conv2d_multi: bad argument");
+  C2Jobs jobs = {};
+  jobs.njobs = njobs;
+  for (int q = 0; q < njobs; ++q) {
+    if (!x[q] || !wpack[q] || !y[q] || W[q] <= 0 || out_channels_total[q] < Co) return fail(DMB_EINVAL, "conv2d_multi: bad job");
+    if (W[q] % 4 != 0 || (((uintptr_t)x[q] | (uintptr_t)y[q]) & 15) != 0)
+      return fail(DMB_EUNSUPPORTED, "conv2d_multi: rows must be 16-byte aligned (W % 4 == 0)");
+    if ((long long)Ci * H * W[q] * 4 >= 0x7fffffffLL || (long long)out_channels_total[q] * H * W[q] * 4 >= 0x7fffffffLL)
+      return fail(DMB_EUNSUPPORTED, "conv2d_multi: one batch item must stay below 2 GiB");
+    jobs.x[q] = x[q];
+    jobs.wp[q] = wpack[q];
+    jobs.y[q] = y[q];
+    jobs.W[q] = W[q];
+    jobs.out_ctot[q] = out_channels_total[q];
+  }
+  const int NTT = cdiv(Co, 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (NTT == 1) return launch_conv2d_multi<C2Cfg<1, 3, 1, 1, true>>(jobs, B, Ci, Co, H, st);
+  if (NTT == 2) return launch_conv2d_multi<C2Cfg<2, 3, 1, 1, true>>(jobs, B, Ci, Co, H, st);
+  if (NTT == 4) return launch_conv2d_multi<C2Cfg<4, 3, 1, 1, true>>(jobs, B, Ci, Co, H, st);
+  return fail(DMB_EUNSUPPORTED, "conv2d_multi: output channels <= 64 or 97 .. 128");
 }
 
 extern "C" int dmb_conf_phase_conv2d_f32(const float* c, const float* wpack, const float* scale, const float* shift,

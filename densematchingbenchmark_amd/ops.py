@@ -307,13 +307,21 @@ def side_stream(device, which=0):
     return _side_streams[key]
 
 
-_first_layer_streams = True
+_first_layer_mode = "merged"
+
+
+def set_first_layer_mode(mode):
+    """How catconv_first issues its five 2-D convolutions: "merged" (one multi-job launch, default), "streams" (the three border
+    maps on two side streams) or "serial" (five launches on one stream).  Same kernels' arithmetic, identical results."""
+    global _first_layer_mode
+    if mode not in ("merged", "streams", "serial"):
+        raise ValueError("first-layer mode must be 'merged', 'streams' or 'serial'")
+    _first_layer_mode = mode
 
 
 def set_first_layer_streams(flag):
-    """The five 2-D convolutions of the volume-free first layer (catconv_first) on three streams (default) or on one."""
-    global _first_layer_streams
-    _first_layer_streams = bool(flag)
+    """(round-3 interim switch, kept for scripts) True -> "streams", False -> "serial"."""
+    set_first_layer_mode("streams" if flag else "serial")
 
 
 def copy_window(src, Wd, xs):
@@ -378,44 +386,41 @@ def catconv_first(L, R, D, packs, scale=None, shift=None, relu=False):
     dev = L.device
     # The five 2-D convolutions are independent and three of them are small (the 52-column border maps: 272 tiles each
     # for 512 workgroup slots): one after the other they take six rounds of the chip where their arithmetic fills less than
-    # four.  The border maps run on two side streams next to the two big ones (fork / join by events; same kernels on the
-    # same operands: identical results); ``set_first_layer_streams(False)`` issues them on one stream.
-    def big():
-        fa = conv2d(L, packs["A"], CA, 3)                                          # F_{dz, 0}          [B, CA, H, W]
-        hc = conv2d(copy_window(R, W + 4, -4), packs["HC"], CA, 3)                 # H_dz at n = j - 4  [B, CA, H, W + 4]
-        return fa, hc
-
-    def left_border():
-        lc = copy_window(L, Wc, 0)                                                 # columns [0, D + 4)
-        fb = torch.empty((B, 2 * CA, H, Wc), dtype=torch.float32, device=dev)
-        conv2d(lc, packs["B1"], CA, 3, out=fb, out_ch_offset=0)                    # F_{dz, 1}
-        conv2d(lc, packs["B2"], CA, 3, out=fb, out_ch_offset=CA)                   # F_{dz, 2}
-        return fb
-
-    def right_border():
-        return conv2d(copy_window(R, Wc, W - Wc), packs["HD"], CA, 3)              # border variant     [B, CA, H, Wc]
-
-    if _first_layer_streams:
+    # four.  ``set_first_layer_mode``: "merged" (default) = ONE multi-job launch walks all their tiles; "streams" = the border
+    # maps on two side streams next to the two big ones; "serial" = five launches on one stream.  Same arithmetic every way.
+    Lc, Rw, Rl = copy_window(L, Wc, 0), copy_window(R, W + 4, -4), copy_window(R, Wc, W - Wc)
+    if _first_layer_mode == "merged":
+        FA = torch.empty((B, CA, H, W), dtype=torch.float32, device=dev)              # F_{dz, 0}
+        HC = torch.empty((B, CA, H, W + 4), dtype=torch.float32, device=dev)          # H_dz at n = j - 4
+        FB = torch.empty((B, 2 * CA, H, Wc), dtype=torch.float32, device=dev)         # F_{dz, 1} | F_{dz, 2}
+        HD = torch.empty((B, CA, H, Wc), dtype=torch.float32, device=dev)             # border variant
+        conv2d_k3_multi([(Rw, packs["HC"], HC, 0), (L, packs["A"], FA, 0), (Lc, packs["B1"], FB, 0), (Lc, packs["B2"], FB, CA),
+                         (Rl, packs["HD"], HD, 0)], CA)
+    elif _first_layer_mode == "streams":
         main = torch.cuda.current_stream(dev)
         s1, s2 = side_stream(dev), side_stream(dev, 1)
         fork = main.record_event()
         with torch.cuda.stream(s1):
             s1.wait_event(fork)
-            FB = left_border()
+            FB = torch.empty((B, 2 * CA, H, Wc), dtype=torch.float32, device=dev)
+            conv2d(Lc, packs["B1"], CA, 3, out=FB, out_ch_offset=0)
+            conv2d(Lc, packs["B2"], CA, 3, out=FB, out_ch_offset=CA)
             FB.record_stream(main)      # allocated on the side stream, read (and released) on the caller's
             j1 = s1.record_event()
         with torch.cuda.stream(s2):
             s2.wait_event(fork)
-            HD = right_border()
+            HD = conv2d(Rl, packs["HD"], CA, 3)
             HD.record_stream(main)
             j2 = s2.record_event()
-        FA, HC = big()
+        FA, HC = conv2d(L, packs["A"], CA, 3), conv2d(Rw, packs["HC"], CA, 3)
         main.wait_event(j1)
         main.wait_event(j2)
     else:
-        FA, HC = big()
-        FB = left_border()
-        HD = right_border()
+        FA, HC = conv2d(L, packs["A"], CA, 3), conv2d(Rw, packs["HC"], CA, 3)
+        FB = torch.empty((B, 2 * CA, H, Wc), dtype=torch.float32, device=dev)
+        conv2d(Lc, packs["B1"], CA, 3, out=FB, out_ch_offset=0)
+        conv2d(Lc, packs["B2"], CA, 3, out=FB, out_ch_offset=CA)
+        HD = conv2d(Rl, packs["HD"], CA, 3)
     FM = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
     BAND = torch.empty((B, Co, H, D, 4), dtype=torch.float32, device=dev)
     GM = torch.empty((B, Co, H, W + 4), dtype=torch.float32, device=dev)
@@ -1136,6 +1141,29 @@ def conv2d(x, wpack, Co, ksize, stride=1, dilation=1, scale=None, shift=None, re
                              Cx, out.shape[1], residual.shape[1] if residual is not None else 0, stream_ptr(x.device)),
           "dmb_conv2d_f32")
     return out
+
+
+def conv2d_k3_multi(jobs, Co):
+    """``jobs``: list of (x [B, Ci, H, W_q], wpack, out [B, Ctot_q, H, W_q], out_ch_offset): independent 3x3 stride-1 convolutions
+    of one layer shape in ONE launch (csrc/conv2d.hip, MULTI); no affine / residual / ReLU."""
+    import ctypes
+    lib = _lib.load()
+    n = len(jobs)
+    x0 = _f32c(jobs[0][0], "x")
+    B, Ci, H = x0.shape[0], x0.shape[1], x0.shape[2]
+    xs, ws, ys, Ws, cts = [], [], [], [], []
+    for x, wp, out, off in jobs:
+        x = _f32c(x, "x")
+        if tuple(x.shape[:3]) != (B, Ci, H) or tuple(out.shape[2:]) != tuple(x.shape[2:]) or out.shape[0] != B or off + Co > out.shape[1]:
+            raise _lib.DmbLibraryError("conv2d_k3_multi: job shapes %s -> %s do not fit" % (tuple(x.shape), tuple(out.shape)))
+        xs.append(dev_ptr(x).value)
+        ws.append(dev_ptr(wp).value)
+        ys.append(_window_ptr(out, off).value)
+        Ws.append(x.shape[3])
+        cts.append(out.shape[1])
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    check(lib.dmb_conv2d_k3_multi_f32(n, PA(*xs), PA(*ws), PA(*ys), IA(*Ws), IA(*cts), B, Ci, Co, H, stream_ptr(x0.device)),
+          "dmb_conv2d_k3_multi_f32")
 
 
 def avgpool2d(x, k, in_window=None):

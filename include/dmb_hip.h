@@ -308,6 +308,14 @@ int dmb_conv2d_f32(const float* x, const float* wpack, const float* scale, const
                    float* y, int B, int Ci, int Co, int H, int W, int ksize, int stride, int dilation, int relu,
                    int in_channels_total, int out_channels_total, int res_channels_total, void* stream);
 
+/* njobs (<= 6) independent 3x3 stride-1 convolutions of ONE layer shape (B, Ci -> Co, H) in one launch: job q convolves
+ * x[q] [B, Ci, H, W[q]] with wpack[q] into y[q] (a channel window of a tensor with out_channels_total[q] channels); no affine,
+ * no residual, no ReLU; W[q] % 4 == 0 and 16-byte aligned bases.  The arrays are HOST arrays of device pointers / sizes.
+ * Used by the volume-free first layer (cat_fms.py:7-48 + aggregators/PSMNet.py:31-33 without the volume): its five 2-D
+ * convolutions, three of them 52-column border maps that would each take a round of the chip on their own. */
+int dmb_conv2d_k3_multi_f32(int njobs, const float* const* x, const float* const* wpack, float* const* y, const int* W,
+                            const int* out_channels_total, int B, int Ci, int Co, int H, void* stream);
+
 /* nn.AvgPool2d(k, stride=k) (PSMNet.py:43-58): channels [in_ch_offset, in_ch_offset + C) of x [B, in_channels_total,
  * H, W] -> y [B, C, H/k, W/k]. */
 int dmb_avgpool2d_f32(const float* x, float* y, int B, int C, int H, int W, int k, int in_channels_total,

@@ -23,15 +23,15 @@ def _parse(kv):
 
 
 def _set(k, v):
-    if k == "fls":
-        ops.set_first_layer_streams(bool(v))
+    if k == "fls":     # 2 = merged launch (default), 1 = three streams, 0 = serial
+        ops.set_first_layer_mode({2: "merged", 1: "streams", 0: "serial"}[v])
     elif k == "ovl":
         ops.set_branch_overlap(bool(v))
     else:
         lib.dmb_dev_set_option(k, v)
 
 
-_DEFAULT = {"fls": 1, "ovl": 0}
+_DEFAULT = {"fls": 2, "ovl": 0}
 variants = [("default", [])] + [(a, [_parse(kv) for kv in a.split(",")]) for a in sys.argv[1:]]
 
 

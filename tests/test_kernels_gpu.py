@@ -775,13 +775,15 @@ def test_catconv_first_layer(dev, B, C, Co, D, H, W):
         mat = ops.conv3d_k3(ops.cat_fms(L.to(dev), R.to(dev), idx), ops.pack_conv3d_weights(w.to(dev)), Co, sc.to(dev), sh.to(dev),
                             None, 1, True).cpu()
         assert (got - mat).abs().max().item() <= 4e-5      # two FP32 evaluations, each within 2e-5 of the FP64 value
-    # the five 2-D convolutions on three streams (default) and on one: the same kernels on the same operands
-    ops.set_first_layer_streams(False)
-    try:
-        one = ops.catconv_first(L.to(dev), R.to(dev), D, ops.catconv_pack(w.to(dev)), sc.to(dev), sh.to(dev), True).cpu()
-    finally:
-        ops.set_first_layer_streams(True)
-    assert torch.equal(one, got)
+    # the five 2-D convolutions as one multi-job launch (default), on three streams, and one after the other: the same
+    # arithmetic on the same operands
+    for mode in ("streams", "serial"):
+        ops.set_first_layer_mode(mode)
+        try:
+            other = ops.catconv_first(L.to(dev), R.to(dev), D, ops.catconv_pack(w.to(dev)), sc.to(dev), sh.to(dev), True).cpu()
+        finally:
+            ops.set_first_layer_mode("merged")
+        assert torch.equal(other, got), mode
 
 
 def test_catconv_not_applicable_shapes(dev):
