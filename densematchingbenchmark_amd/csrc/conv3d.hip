@@ -70,9 +70,15 @@ struct Affine {
 // ---------------------------------------------------------------------------------------------------------
 // Stride-1 kernel.
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, int SCHED_ = 1, int G_ = 0, int PMIN_ = 0>
+// LIN (with G = 16, TX = W, TY = 3): the wave's 32-voxel column tiles are 32 CONSECUTIVE voxels of the (y, x) plane in memory
+// order, a workgroup = TZ planes x 64 consecutive voxels (two column tiles per wave).  For the quarter-resolution layer of the
+// hourglass ([4, 64, 12, 34, 60]: 97 920 voxels = 382.5 per CU) no box tiling comes near a multiple of 256 equal workgroups (216
+// boxes of 4 x 4 x 60 = 84 % of the chip, one wave per SIMD); 64-voxel runs give 4 x 6 x 32 = 768 equal workgroups = exactly three
+// per CU, 99.6 % of their column tiles real.  The staged tile is the 3 + 2 rows a 64-voxel run can touch (W >= 32), full width.
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, int SCHED_ = 1, int G_ = 0, int PMIN_ = 0, bool LIN_ = false>
 struct S1Cfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_, SCHED = SCHED_;
+  static constexpr bool LIN = LIN_;
   static constexpr int G = G_;                  // row-group width: 0 = flattened tiles, 16 = row pairs, 8 = row quads
   static constexpr bool ROWPAIR = G_ != 0;     // any row-group mapping (takes the 16-byte vector path)
   static constexpr int GR = G_ ? 32 / G_ : 1;  // rows per group
@@ -96,7 +102,7 @@ struct S1Cfg {
   //  - row group (TX % G == 0, TY % (32 / G) == 0): G columns of 32 / G consecutive rows -- row pairs of 16 (lanes 0-15 =
   //    row r, 16-31 = row r + 1) or row quads of 8: every computed voxel is a real output.  Used when W % TX == 0.
   static constexpr int XS = ROWPAIR ? TX / (G_ ? G_ : 1) : 1;
-  static constexpr int MT = ROWPAIR ? (TY / GR) * XS : (TY * P + 31) / 32;  // 32-voxel column tiles per wave
+  static constexpr int MT = LIN ? 2 : (ROWPAIR ? (TY / GR) * XS : (TY * P + 31) / 32);  // 32-voxel column tiles per wave
   __device__ static constexpr int lane_off(int j) { return ROWPAIR ? (j / (G_ ? G_ : 1)) * P + (j % (G_ ? G_ : 1)) : j; }
   __device__ static constexpr int tile_off(int mt) { return ROWPAIR ? GR * (mt / XS) * P + (mt % XS) * G_ : mt * 32; }
   __device__ static void decode(int mt, int j, int& ly, int& lx, bool& valid) {
@@ -123,7 +129,8 @@ struct S1Cfg {
   static constexpr int WPE = (ROWPAIR && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2;
   static_assert(ROWPAIR || P <= 64, "one wave stages one tile row per instruction");
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
-  static_assert(!ROWPAIR || (G_ % 4 == 0 && TX % (G_ ? G_ : 1) == 0 && TY % GR == 0), "row-group tiles need TX % G == 0 and TY % (32 / G) == 0");
+  static_assert(!ROWPAIR || LIN || (G_ % 4 == 0 && TX % (G_ ? G_ : 1) == 0 && TY % GR == 0), "row-group tiles need TX % G == 0 and TY % (32 / G) == 0");
+  static_assert(!LIN || (ROWPAIR && TY == 3 && TX % 4 == 0 && TX >= 32), "linear tiles: vector path, 3 + 2 staged rows, full-width rows");
   static_assert(!ROWPAIR || ((CK * IPC) % 4 == 0 && NT == 1 && LDS_FLOATS >= 4 * 32 * TR_PITCH), "row-pair staging / scratch");
 };
 
@@ -189,13 +196,14 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
   const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
   relu &= 0xff;
   int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = t % ntx;
+  const int tx = t % ntx;     // LIN: ntx = 64-voxel runs per plane, nty = 1
   t /= ntx;
   const int ty = t % nty;
   t /= nty;
   const int tz = t % ntz;
   const int b = t / ntz;
-  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
+  const int p0 = C::LIN ? tx * 64 : 0;                                   // LIN: first voxel of the run in its plane
+  const int x0 = C::LIN ? 0 : tx * C::TX, y0 = C::LIN ? p0 / W : ty * C::TY, z0 = tz * C::TZ;
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
@@ -267,6 +275,13 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
     }
   };
 
+  // LIN: where this lane's voxel of each column tile sits in the staged tile (rows y0 - 1 .. y0 + 3, full width)
+  int lin_off[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+    const int pos = p0 + mt * 32 + j, py = pos / W;
+    lin_off[mt] = C::LIN ? (py - y0) * C::P + (pos - py * W) : 0;
+  }
   const int NC = cdiv(Ci, C::CK);  // a partial last chunk reads zeros (bounds check) against zero-padded weights
   stage(0, lds);
   __syncthreads();
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
     if (ci + 1 < NC && !(dbg & 2)) stage((ci + 1) * C::CK, lds + ((ci + 1) & 1) * C::BUF_FLOATS);  // lands while we compute
     // ---- NK k-steps on the current buffer; A and B fragments register double-buffered one k-step ahead ----
     const float* abase = cur + C::IN_FLOATS + (wn * C::NT) * 64 + lane;
-    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + C::lane_off(j) + C::XOFF;
+    const float* bbase = cur + h * C::CH_STRIDE + wz * C::PLANE + (C::LIN ? 0 : C::lane_off(j)) + C::XOFF;
     float af[2][C::NT], bf[2][C::MT];
     auto load_frag = [&](int ks, float (&a)[C::NT], float (&bq)[C::MT]) {
       const int cp = ks / 27, tap = ks % 27;
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
       for (int nt = 0; nt < C::NT; ++nt) a[nt] = abase[(ks * C::NTT + nt) * 64];
       const float* bp = bbase + 2 * cp * C::CH_STRIDE + dz * C::PLANE + dy * C::P + dx;
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[C::tile_off(mt)];
+      for (int mt = 0; mt < C::MT; ++mt) bq[mt] = bp[C::LIN ? lin_off[mt] : C::tile_off(mt)];
     };
     load_frag(0, af[0], bf[0]);
 #pragma unroll
@@ -329,6 +344,10 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
     // a scratch segment costs ~6 us of dispatch gap on either side of every launch)
     const unsigned kstep = 8u * DHW * 4u;
     auto offset0 = [&](int mt) {
+      if constexpr (C::LIN) {   // 4 consecutive voxels of the run (H * W % 4 == 0: a word never straddles the end of the plane)
+        const unsigned pos = (unsigned)(p0 + mt * 32 + px);
+        return (gz < D && pos < HW) ? ((unsigned)(wn * 32 + (lane >> 3)) * DHW + (unsigned)gz * HW + pos) * 4u : DMA_OOB;
+      }
       const int gy = y0 + C::GR * (mt / C::XS) + px / C::G, gxo = x0 + (mt % C::XS) * C::G + px % C::G;
       const bool inb = gz < D && gy < H && gxo < W;
       return inb ? ((unsigned)(wn * 32 + (lane >> 3)) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxo) * 4u : DMA_OOB;
@@ -1336,7 +1355,7 @@ static int s1_num_cus() {
 template <class C>
 static int launch_s1(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                      float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
-  const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
+  const int ntx = C::LIN ? cdiv(H * W, 64) : cdiv(W, C::TX), nty = C::LIN ? 1 : cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
@@ -1468,6 +1487,9 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       // of which two widths exist: 40 and 24.  A launch here is only a few "rounds" of workgroups deep (W = 120, batch
       // 4: 2448 tiles of 40 columns on 2 x 256 slots = 4.8 rounds, measured 128 TF/s; 4080 tiles of 24 = 7.97 rounds, 145
       // TF/s), so the width is picked per launch by rounds x columns.
+      // quarter resolution of the BASELINE shape (W = 60): 64-voxel runs, exactly three equal workgroups per CU (see S1Cfg)
+      if (aligned && out_small && g_dev_opts[2] == 0 && g_dev_opts[13] == 0 && W == 60 && (H * W) % 4 == 0)
+        return launch_s1<S1Cfg<0, 64, 3, 60, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
       if (aligned && out_small && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0 || W % 32 == 0)) {
         const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 3LL * s1_num_cus();   // 3 workgroups per CU
         const long long c40 = W % 40 == 0 ? cdiv_ll(per * (W / 40), slots) * 40 : (1LL << 60);

@@ -81,6 +81,9 @@ for _rep in range(1 if diag else 2):
   deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv 64->64 quarter->half", res=True)
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv 64->32 half->full", res=False)
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv 64->32 half->full", res=True)
+  lib.dmb_dev_set_option(13, 1)   # A/B: quarter-resolution stride-1 layer on 4 x 4 x 60 boxes (216 workgroups) instead of 64-voxel runs (768)
+  conv_case(64, 64, 1, D // 4, H // 4, W // 4, "conv4 s1 64->64 quarter (box tiles)")
+  lib.dmb_dev_set_option(13, 0)
   lib.dmb_dev_set_option(10, 1)   # A/B: stride-2 layers on four-wave workgroups (two waves per SIMD)
   conv_case(32, 64, 2, D, H, W, "conv1 s2 32->64 (4-wave workgroups)")
   conv_case(64, 64, 2, D // 2, H // 2, W // 2, "conv3 s2 64->64 (4-wave workgroups)")

@@ -1013,3 +1013,32 @@ def test_spn_refuses_cpu_tensors_and_long_lines(dev):
     y = torch.zeros(1, 1, 2100, 3, device=dev)
     with pytest.raises(_lib.DmbLibraryError):
         GateRecurrent2dnoind(True, False)(y, y, y, y)
+
+
+@pytest.mark.parametrize("Ci,shape", [(64, (1, 4, 5, 60)), (64, (2, 3, 34, 60)), (20, (1, 2, 1, 60)), (64, (4, 12, 34, 60))])
+def test_conv3d_quarter_resolution_linear_runs(dev, Ci, shape):
+    """The 64-channel stride-1 layer at the BASELINE quarter resolution (W = 60) on 64-voxel runs of the (y, x) plane (S1Cfg LIN:
+    768 equal workgroups for [4, 64, 12, 34, 60], exactly three per CU) against the box-tiled form (development option 13) --
+    the same ascending (channel, tap) fma chain per output, so BIT-identical, with residual and both ReLU placements -- and
+    against the CPU convolution.  Runs that cross row ends, a last run shorter than 64, odd plane counts, a single row."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, D, H, W = shape
+    xc = _rand((B, Ci, D, H, W), 621)
+    wc = _rand((64, Ci, 3, 3, 3), 622, 1.0 / math.sqrt(Ci * 27))
+    sc, sh = _affine(64, 623)
+    x, wp = xc.to(dev), ops.pack_conv3d_weights(wc.to(dev))
+    res = _rand((B, 64, D, H, W), 624).to(dev)
+    lib = _lib.load()
+    for r, relu in ((None, False), (None, True), (res, True), (res, "pre")):
+        outs = []
+        for boxes in (0, 1):
+            lib.dmb_dev_set_option(13, boxes)
+            try:
+                outs.append(ops.conv3d_k3(x, wp, 64, sc.to(dev), sh.to(dev), r, 1, relu))
+            finally:
+                lib.dmb_dev_set_option(13, 0)
+        assert torch.equal(outs[0], outs[1]), (r is not None, relu, (outs[0] - outs[1]).abs().max().item())
+    ref = F.conv3d(xc, wc, None, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+    got = ops.conv3d_k3(x, wp, 64, sc.to(dev), sh.to(dev), None, 1, False).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5
