@@ -57,8 +57,9 @@ with torch.no_grad():
             acc[name].append(run(8))
             for k, _ in opts:
                 _set(k, _DEFAULT.get(k, 0))
-print("# whole PSMNet step (batch 4, 544x960, D = 192) under development options, variants alternated in one process on one chip;")
-print("# 4=1: deconv3d_kernel (round-2 transposed convolution) instead of deconv3d_zy_kernel; 10=1: four-wave stride-2 workgroups; fls=0: "
-      "first-layer convolutions on one stream; 11=2: sixteen-wave transposed convolution for the half -> full resolution layer; ovl=1: branch overlap")
+print("# whole PSMNet step (batch 4, 544x960, D = 192) under development options, variants alternated in one process on one chip (4 x 8 steps each);")
+print("# 13=1: quarter-resolution stride-1 layer on box tiles instead of 64-voxel runs; 4=1: deconv3d_kernel (round-2 transposed convolution) instead of "
+      "deconv3d_zy_kernel; 10=1: four-wave stride-2 workgroups; fls=0 / 1: first-layer convolutions as five launches on one stream / on three streams "
+      "(default: one multi-job launch); 11=2: sixteen-wave transposed convolution for the half -> full resolution layer; ovl=1: branch overlap")
 for name, ts in acc.items():
     print("%-24s %s  -> min %.3f ms, median %.3f ms" % (name, " ".join("%.3f" % t for t in ts), min(ts), sorted(ts)[len(ts) // 2]))
