@@ -340,23 +340,30 @@ __global__ __launch_bounds__(W16Cfg::NTHREADS, 4) void deconv3d_w16_kernel(W16Ar
 struct W16Ticket {
   int* counter;
   unsigned base;
+  bool* dirty;
 };
-static W16Ticket w16_ticket(unsigned advance) {
-  static int* ring[64] = {};
-  static unsigned basev[64][256] = {};
-  static unsigned seq = 0;
+static W16Ticket w16_ticket(unsigned advance, hipStream_t st) {
   constexpr int RING = 256;
+  static int* ring[64] = {};
+  static unsigned basev[64][RING] = {};
+  static bool dirty[64][RING] = {};
+  static unsigned seq = 0;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u};
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u, nullptr};
   if (!ring[dev]) {
     if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), RING * sizeof(int)) != hipSuccess ||
         hipMemset(ring[dev], 0, RING * sizeof(int)) != hipSuccess) {
       ring[dev] = nullptr;
-      return {nullptr, 0u};
+      return {nullptr, 0u, nullptr};
     }
   }
   const unsigned s = seq++ % RING;
-  W16Ticket t{ring[dev] + s, basev[dev][s]};
+  if (dirty[dev][s]) {   // a launch on this slot failed: zero it before it is trusted again
+    if (hipMemsetAsync(ring[dev] + s, 0, sizeof(int), st) != hipSuccess) return {nullptr, 0u, nullptr};
+    basev[dev][s] = 0;
+    dirty[dev][s] = false;
+  }
+  W16Ticket t{ring[dev] + s, basev[dev][s], &dirty[dev][s]};
   basev[dev][s] += advance;
   return t;
 }
@@ -391,11 +398,13 @@ int deconv3d_w16_try(const float* x, const float* wp, const float* scale, const 
   DMB_ENSURE_LDS((&deconv3d_w16_kernel), lds);
   long long grid = ntiles < ncu ? ntiles : ncu;
   if (g_dev_opts[9] > 0 && g_dev_opts[9] < grid) grid = g_dev_opts[9];
-  const W16Ticket tk = w16_ticket((unsigned)(ntiles + grid));
+  const W16Ticket tk = w16_ticket((unsigned)(ntiles + grid), st);
   if (!tk.counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
   W16Args a{x, wp, res, y, tk.counter, tk.base, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8, g_dev_opts[12]};
   hipLaunchKernelGGL(deconv3d_w16_kernel, dim3((unsigned)grid), dim3(C::NTHREADS), lds, st, a, scale, shift);
-  return launch_status("deconv3d (sixteen-wave workgroups) launch failed");
+  const int rc = launch_status("deconv3d (sixteen-wave workgroups) launch failed");
+  if (rc != DMB_OK) *tk.dirty = true;
+  return rc;
 }
 
 }  // namespace dmb

@@ -389,28 +389,32 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
 struct ZYTicket {
   int* counter;
   unsigned base;
+  unsigned* base_slot;   // host copy of where the counter will stand after this launch
+  bool* dirty;           // set when the launch is not known to have run: the slot is zeroed before its next use
 };
-static unsigned* zy_slot_base(int dev) {
-  static unsigned base[64][1024] = {};
-  return base[dev];
-}
-static ZYTicket zy_ticket(unsigned advance) {
-  static int* ring[64] = {};
-  static unsigned seq = 0;
+static ZYTicket zy_ticket(unsigned advance, hipStream_t st) {
   constexpr int RING = 1024;
+  static int* ring[64] = {};
+  static unsigned base[64][RING] = {};
+  static bool dirty[64][RING] = {};
+  static unsigned seq = 0;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u};
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u, nullptr, nullptr};
   if (!ring[dev]) {
     if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), RING * sizeof(int)) != hipSuccess ||
         hipMemset(ring[dev], 0, RING * sizeof(int)) != hipSuccess) {
       ring[dev] = nullptr;
-      return {nullptr, 0u};
+      return {nullptr, 0u, nullptr, nullptr};
     }
   }
   const unsigned slot = seq++ % RING;
-  unsigned* base = zy_slot_base(dev);
-  ZYTicket t{ring[dev] + slot, base[slot]};
-  base[slot] += advance;
+  if (dirty[dev][slot]) {   // a launch on this slot failed: its counter and our copy may disagree
+    if (hipMemsetAsync(ring[dev] + slot, 0, sizeof(int), st) != hipSuccess) return {nullptr, 0u, nullptr, nullptr};
+    base[dev][slot] = 0;
+    dirty[dev][slot] = false;
+  }
+  ZYTicket t{ring[dev] + slot, base[dev][slot], &base[dev][slot], &dirty[dev][slot]};
+  base[dev][slot] += advance;
   return t;
 }
 
@@ -432,11 +436,13 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
   const long long slots = 3LL * ncu * (g_dev_opts[8] > 0 ? g_dev_opts[8] : 1);
   long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
   if (g_dev_opts[9] > 0 && g_dev_opts[9] < grid) grid = g_dev_opts[9];   // development: few workgroups walk many items
-  const ZYTicket tk = zy_ticket((unsigned)(4 * ntiles + grid));
+  const ZYTicket tk = zy_ticket((unsigned)(4 * ntiles + grid), st);
   if (!tk.counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
   ZYArgs a{x, wp, res, y, tk.counter, tk.base, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8, g_dev_opts[12]};
   hipLaunchKernelGGL((deconv3d_zy_kernel<C>), dim3((unsigned)grid), dim3(256), lds, st, a, scale, shift);
-  return launch_status("deconv3d (z/y-parity items) launch failed");
+  const int rc = launch_status("deconv3d (z/y-parity items) launch failed");
+  if (rc != DMB_OK) *tk.dirty = true;
+  return rc;
 }
 
 // Entry for dmb_deconv3d_k3s2_f32 (conv3d.hip): returns -1 when this form does not apply (the caller falls back to
