@@ -193,8 +193,16 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
                                                            const float* __restrict__ res, float* __restrict__ y, int Ci,
                                                            int D, int H, int W, int ntx, int nty, int ntz, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
+  // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk, 32 = no barrier in the chunk loop
+  const int dbg = (relu >> 8) & 0xff;
+  const int stg = relu >> 16;           // development: start-up stagger unit (g_dev_opts[14])
   relu &= 0xff;
+  if (stg > 0 && blockIdx.x < 256u * C::WPE) {
+    // the first round's workgroups of a CU start together: delay them by their slot on the CU (HW_ID.TG_ID) x stg x 3.4 us so that
+    // set-up and epilogue of one fall under the matrix work of the others (scripts/s1_stagger_probe.py: -0.3 % at best)
+    const int n = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 15u) * stg;   // HW_REG_HW_ID bits 19:16
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;     // LIN: ntx = 64-voxel runs per plane, nty = 1
   t /= ntx;
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
         for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(af[ks & 1][nt], bf[ks & 1][mt], acc[mt][nt]);
       if (C::SCHED != 0) __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();  // the compiler drains the DMA (vmcnt(0)) here: next buffer complete, current one free
+    if (!(dbg & 32)) __syncthreads();  // the compiler drains the DMA (vmcnt(0)) here: next buffer complete, current one free
   }
 
   // ---- epilogue ----
@@ -1468,14 +1476,15 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     return fail(DMB_EUNSUPPORTED, "conv3d: 8 channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   const bool out_small = (long long)Co * D * H * W * 4 < 0x7fffffffLL;   // the vector epilogue addresses the whole output item
   hipStream_t st = (hipStream_t)stream;
-  relu |= g_dev_opts[6] << 8;   // development diagnostics (see the kernels)
-#define DMB_S1(CO, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st)
+  relu |= (g_dev_opts[6] & 0xff) << 8;   // development diagnostics (see the kernels)
+  const int relu_s1 = relu | (g_dev_opts[14] << 16);   // stride-1 kernels: + start-up stagger unit
+#define DMB_S1(CO, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st)
   if (stride == 1) {
     const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path
     const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0 && aligned && out_small;
     const int tx = flat_tx(W);
     if (Co == 32) {
-      if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
       if (rp) return DMB_S1(32, 48, 1, 16, 0);
       // widths of the training crops (512 / 4 = 128) and other multiples of 32: 32-column row-pair tiles, nothing discarded
       if (W % 32 == 0 && g_dev_opts[2] == 0 && aligned && out_small) return DMB_S1(32, 32, 1, 16, 0);
@@ -1489,7 +1498,7 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       // TF/s), so the width is picked per launch by rounds x columns.
       // quarter resolution of the BASELINE shape (W = 60): 64-voxel runs, exactly three equal workgroups per CU (see S1Cfg)
       if (aligned && out_small && g_dev_opts[2] == 0 && g_dev_opts[13] == 0 && W == 60 && (H * W) % 4 == 0)
-        return launch_s1<S1Cfg<0, 64, 3, 60, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+        return launch_s1<S1Cfg<0, 64, 3, 60, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
       if (aligned && out_small && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0 || W % 32 == 0)) {
         const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 3LL * s1_num_cus();   // 3 workgroups per CU
         const long long c40 = W % 40 == 0 ? cdiv_ll(per * (W / 40), slots) * 40 : (1LL << 60);
@@ -1502,7 +1511,7 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       return tx == 52 ? DMB_S1(64, 52, 2, 0, 0) : DMB_S1(64, 60, 2, 0, 0);
     }
     if (Co == 128)   // GC-Net's deepest level: 2 waves x 2 row tiles, 2-row tiles keep the accumulators at 160 registers
-      return launch_s1<S1Cfg<0, 128, 2, 60, 2, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      return launch_s1<S1Cfg<0, 128, 2, 60, 2, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
   } else if (stride == 2) {
     const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned input rows
     if (Co == 64 && v16) {

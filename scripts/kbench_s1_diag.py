@@ -20,7 +20,7 @@ x64 = torch.randn(B, 64, D // 2, H // 2, W // 2, device=dev)
 wp64 = ops.pack_conv3d_weights(torch.randn(64, 64, 3, 3, 3, device=dev) * 0.03)
 sc64, sh64 = torch.ones(64, device=dev), torch.zeros(64, device=dev)
 for rep in range(2):
-    for opt in (0, 1, 2, 3):
+    for opt in (0, 1, 2, 3, 35):
         lib.dmb_dev_set_option(6, opt)
         a = timeit(lambda: ops.conv3d_k3(x, wp, 32, sc, sh, None, 1, True))
         b = timeit(lambda: ops.conv3d_k3(x64, wp64, 64, sc64, sh64, None, 1, True))
