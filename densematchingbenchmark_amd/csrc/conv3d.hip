@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
           o.y = __float_as_uint(fmaxf(v.y, lo));
           o.z = __float_as_uint(fmaxf(v.z, lo));
           o.w = __float_as_uint(fmaxf(v.w, lo));
-          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(off0[mt & 1] + k * kstep), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(off0[mt & 1] + k * kstep), 0, 0);   // (streaming stores: step +0.3 %)
         }
       }
     };
