@@ -44,6 +44,8 @@ SIGNATURES = {
     "dmb_deconv3d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conv3d_k3_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 8 + [_P]),
     "dmb_conv3d_k3_c1_f32": (_c_int, [_P, _P, _c_float, _P, _P] + [_c_int] * 5 + [_P]),
+    "dmb_conv3d_k3_c1_multi_f32": (_c_int, [_c_int, _P, _P, _P, _P] + [_c_int] * 5 + [_P]),
+    "dmb_cost_chain_f32": (_c_int, [_P, _c_int, _c_ll, _P]),
     "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 7 + [_P]),
     "dmb_trilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),
     "dmb_deconv3d_k8s4_c1_f32": (_c_int, [_P, _P, _P] + [_c_int] * 4 + [_P]),

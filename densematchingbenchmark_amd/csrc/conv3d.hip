@@ -1217,10 +1217,22 @@ __device__ __forceinline__ float dpp_row_shl1(float v) {   // lane i <- lane i +
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
 
+// MULTI: several heads in one launch (PSMNet's three classifiers: 3 x 1632 workgroups fill the 512 slots in 9.6 rounds instead of
+// three times 3.2, the last of each a fifth full): batch item b of the stacked output belongs to job b / bper, which names its own
+// input, weights and bias; no skip operand (the cumulative cost sums are a separate pass over the three small outputs).
+constexpr int C1_MAXJOBS = 4;
+struct C1Jobs {
+  const float* x[C1_MAXJOBS];
+  const float* w[C1_MAXJOBS];
+  float bias[C1_MAXJOBS];
+  int bper;
+};
+
+template <bool MULTI>
 __global__ __launch_bounds__(256, 2) void conv3d_c1v_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float bias, const float* __restrict__ res,
                                                             float* __restrict__ y, int Ci, int D, int H, int W, int ntx,
-                                                            int nty, int ntz) {
+                                                            int nty, int ntz, C1Jobs jobs) {
   __shared__ __attribute__((aligned(16))) float tile[C1V_ZS * C1V_ROWS * C1V_P];
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
@@ -1231,7 +1243,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1v_kernel(const float* __restr
   const int b = t / ntz;
   const int x0 = tx * C1V_TX, y0 = ty * C1V_TY, z0 = tz * C1V_TZ;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
-  const float* xb = x + (size_t)b * Ci * DHW;
+  int bx = b;                         // batch item within its input
+  if constexpr (MULTI) {
+    const int job = b / jobs.bper;
+    bx = b - job * jobs.bper;
+    x = jobs.x[job];
+    w = jobs.w[job];
+    bias = jobs.bias[job];
+  }
+  const float* xb = x + (size_t)bx * Ci * DHW;
   const int tid = threadIdx.x;
   const int lq = tid & 15;            // word of the row: columns 4 lq .. 4 lq + 3 of the staged row = x0 - 4 + 4 lq ...
   const int lyp = (tid >> 4) & 3;     // output rows y0 + 2 lyp, + 1
@@ -1574,11 +1594,76 @@ extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, 
   if ((long long)2 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: tensor too large for 32-bit offsets");
   if (W % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) && !g_dev_opts[3]) {   // 16-byte rows
     const int vx = cdiv(W, C1V_TX), vy = cdiv(H, C1V_TY), vz = cdiv(D, C1V_TZ);
-    hipLaunchKernelGGL(conv3d_c1v_kernel, dim3((unsigned)((long long)B * vx * vy * vz)), dim3(256), 0, (hipStream_t)stream, x, w,
-                       bias, residual, y, Ci, D, H, W, vx, vy, vz);
+    hipLaunchKernelGGL(conv3d_c1v_kernel<false>, dim3((unsigned)((long long)B * vx * vy * vz)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, residual, y, Ci, D, H, W, vx, vy, vz, C1Jobs{});
     return launch_status("conv3d_c1 launch failed");
   }
   hipLaunchKernelGGL(conv3d_c1_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, x, w, bias, residual, y,
                      Ci, D, H, W, ntx, nty, ntz);
   return launch_status("conv3d_c1 launch failed");
+}
+
+// Several 32 -> 1 heads in ONE launch (see conv3d_c1v_kernel<true>): job j convolves x[j] ([B, Ci, D, H, W]) with w[j] ([Ci, 27]) and
+// bias[j] (host array) into items [j B, (j + 1) B) of y ([njobs B, 1, D, H, W]).  Shapes the 16-byte kernel does not take run as
+// njobs launches of dmb_conv3d_k3_c1_f32: same results either way (the kernels are bit-identical).
+extern "C" int dmb_conv3d_k3_c1_multi_f32(int njobs, const float* const* x, const float* const* w, const float* bias, float* y,
+                                          int B, int Ci, int D, int H, int W, void* stream) {
+  if (njobs <= 0 || njobs > C1_MAXJOBS || !x || !w || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(DMB_EINVAL, "conv3d_c1_multi: bad argument (1 .. 4 jobs)");
+  const size_t item = (size_t)D * H * W;
+  bool vec = W % 4 == 0 && (((uintptr_t)y) & 15) == 0 && !g_dev_opts[3] && (long long)2 * D * H * W * 4 < 0x7fffffffLL;
+  C1Jobs jobs{};
+  jobs.bper = B;
+  for (int j = 0; j < njobs; ++j) {
+    if (!x[j] || !w[j]) return fail(DMB_EINVAL, "conv3d_c1_multi: null job operand");
+    jobs.x[j] = x[j];
+    jobs.w[j] = w[j];
+    jobs.bias[j] = bias ? bias[j] : 0.f;
+    vec = vec && (((uintptr_t)x[j]) & 15) == 0;
+  }
+  const int vx = cdiv(W, C1V_TX), vy = cdiv(H, C1V_TY), vz = cdiv(D, C1V_TZ);
+  const long long nblk = (long long)njobs * B * vx * vy * vz;
+  if (!vec || nblk > 0x7fffffffLL || g_dev_opts[15]) {   // (development option 15: one launch per head)
+    for (int j = 0; j < njobs; ++j) {
+      const int rc = dmb_conv3d_k3_c1_f32(x[j], w[j], jobs.bias[j], nullptr, y + (size_t)j * B * item, B, Ci, D, H, W, stream);
+      if (rc != DMB_OK) return rc;
+    }
+    return DMB_OK;
+  }
+  hipLaunchKernelGGL(conv3d_c1v_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, 0.f, nullptr,
+                     y, Ci, D, H, W, vx, vy, vz, jobs);
+  return launch_status("conv3d_c1_multi launch failed");
+}
+
+// PSMNet.py:70-72's cumulative costs on a stack of n head outputs: y[j] += y[j - 1] for j = 1 .. n - 1, in place, in that order
+// (cost2 = classif2(out2) + cost1, cost3 = classif3(out3) + cost2: the same FP32 adds the fused skip operand performs).
+__global__ __launch_bounds__(256) void cost_chain_kernel(float* __restrict__ y, int n, long long count4, long long tail0,
+                                                         long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count4) {
+    float4 v = reinterpret_cast<const float4*>(y)[i];
+    for (int j = 1; j < n; ++j) {
+      float4* p = reinterpret_cast<float4*>(y + (size_t)j * count) + i;
+      const float4 c = *p;
+      v = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
+      *p = v;
+    }
+  } else if (tail0 + (i - count4) < count) {
+    const long long e = tail0 + (i - count4);
+    float v = y[e];
+    for (int j = 1; j < n; ++j) {
+      v = y[(size_t)j * count + e] + v;
+      y[(size_t)j * count + e] = v;
+    }
+  }
+}
+
+extern "C" int dmb_cost_chain_f32(float* y, int n, long long count, void* stream) {
+  if (!y || n <= 0 || count <= 0) return fail(DMB_EINVAL, "cost_chain: bad argument");
+  if (n == 1) return DMB_OK;
+  const bool vec = count % 4 == 0 && (((uintptr_t)y) & 15) == 0;
+  const long long count4 = vec ? count / 4 : 0, tail0 = count4 * 4, threads = count4 + (count - tail0);
+  hipLaunchKernelGGL(cost_chain_kernel, dim3((unsigned)cdiv_ll(threads, 256)), dim3(256), 0, (hipStream_t)stream, y, n, count4, tail0,
+                     count);
+  return launch_status("cost_chain launch failed");
 }

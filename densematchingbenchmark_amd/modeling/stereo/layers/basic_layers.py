@@ -155,13 +155,15 @@ class HeadConv3d(nn.Conv3d):
             x = x.materialize()
         if train_fn.wants_grad(self, x, residual):
             return train_fn.HeadConvFn.apply(x, self.weight, self.bias, residual)
-        b = 0.0
-        if self.bias is not None:
-            key = _versions(self.bias)
-            if key != self._bias_key:  # one device->host read per weight load, not per call
-                self._bias_key, self._bias_val = key, float(self.bias.detach().cpu()[0])
-            b = self._bias_val
-        return ops.conv3d_k3_c1(x, self.weight.detach(), b, residual)
+        return ops.conv3d_k3_c1(x, self.weight.detach(), self.bias_value(), residual)
+
+    def bias_value(self):
+        if self.bias is None:
+            return 0.0
+        key = _versions(self.bias)
+        if key != self._bias_key:  # one device->host read per weight load, not per call
+            self._bias_key, self._bias_val = key, float(self.bias.detach().cpu()[0])
+        return self._bias_val
 
 
 class HeadDeconv3d(nn.ConvTranspose3d):

@@ -487,6 +487,55 @@ def conv3d_k3_x6(x, wpack, Co, scale=None, shift=None, residual=None, relu=False
     return y
 
 
+def conv3d_k3_c1_multi(xs, ws, biases=None):
+    """Several 32 -> 1 heads in one launch: ``xs`` [B, Ci, D, H, W] each, ``ws`` [1, Ci, 3, 3, 3] each, ``biases`` floats ->
+    [n, B, 1, D, H, W] (job j in slice j).  Bit-identical to n ``conv3d_k3_c1`` calls without skip operand."""
+    import ctypes
+    lib = _lib.load()
+    n = len(xs)
+    if n < 1 or n > 4 or len(ws) != n or (biases is not None and len(biases) != n):
+        raise _lib.DmbLibraryError("conv3d_k3_c1_multi: 1 .. 4 jobs, one weight (and bias) per job")
+    xs = [_f32c(x, "x") for x in xs]
+    ws = [_f32c(w, "weight") for w in ws]
+    B, Ci, D, H, W = xs[0].shape
+    for x, w in zip(xs, ws):
+        if tuple(x.shape) != (B, Ci, D, H, W) or w.numel() != Ci * 27 or x.device != xs[0].device:
+            raise _lib.DmbLibraryError("conv3d_k3_c1_multi: job %s x %s does not match the first job's %s"
+                                       % (tuple(x.shape), tuple(w.shape), (B, Ci, D, H, W)))
+    y = torch.empty((n, B, 1, D, H, W), dtype=torch.float32, device=xs[0].device)
+    PA, FA = ctypes.c_void_p * n, ctypes.c_float * n
+    check(lib.dmb_conv3d_k3_c1_multi_f32(n, PA(*[dev_ptr(x).value for x in xs]), PA(*[dev_ptr(w).value for w in ws]),
+                                         FA(*[float(b) for b in (biases or [0.0] * n)]), dev_ptr(y), B, Ci, D, H, W,
+                                         stream_ptr(y.device)), "dmb_conv3d_k3_c1_multi_f32")
+    return y
+
+
+def cost_chain_(y):
+    """In place on a stack y[n, ...]: y[j] += y[j - 1], j = 1 .. n - 1 (PSMNet.py:70-72's cumulative costs)."""
+    lib = _lib.load()
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise _lib.DmbLibraryError("cost_chain_: contiguous float32 stack expected")
+    n = y.shape[0]
+    check(lib.dmb_cost_chain_f32(dev_ptr(y), n, y.numel() // n, stream_ptr(y.device)), "dmb_cost_chain_f32")
+    return y
+
+
+# PSMNet's three classifier heads and their three up-sampling + regression passes as ONE launch each (eval): 9.6 rounds of tiles
+# instead of 3 x 3.2.  Opt-in: in isolation the merged launches are 0.1 ms faster (scripts/merge_probe.py), inside the step they
+# are not (26.859 against 26.842 ms, profiles/r03_ab_step3.log): a head that runs right after its classifier's first convolution
+# finds part of that output in the 256 MB memory-side cache, three heads at the end of the step do not.
+_merged_heads = False
+
+
+def set_merged_heads(flag):
+    global _merged_heads
+    _merged_heads = bool(flag)
+
+
+def merged_heads():
+    return _merged_heads
+
+
 def conv3d_k3_c1(x, w, bias=0.0, residual=None):
     lib = _lib.load()
     x, w = _f32c(x, "x"), _f32c(w, "weight")

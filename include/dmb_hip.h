@@ -180,6 +180,18 @@ int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, co
 int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float* residual, float* y,
                          int B, int Ci, int D, int H, int W, void* stream);
 
+/* Up to 4 such heads in ONE launch (PSMNet.py:46,50,54: classif1[1], classif2[1], classif3[1] of one forward): job j
+ * convolves x[j] ([B, Ci, D, H, W]) with w[j] ([1, Ci, 3, 3, 3]) and bias_host[j] into items [j B, (j + 1) B) of
+ * y ([njobs B, 1, D, H, W]).  x / w: HOST arrays of njobs device pointers; bias_host: host array or NULL.  No skip
+ * operand: the cumulative sums are dmb_cost_chain_f32.  Results are bit-identical to njobs dmb_conv3d_k3_c1_f32 calls. */
+int dmb_conv3d_k3_c1_multi_f32(int njobs, const float* const* x, const float* const* w, const float* bias_host, float* y,
+                               int B, int Ci, int D, int H, int W, void* stream);
+
+/* PSMNet.py:70-72's cumulative costs (cost2 = classif2(out2) + cost1, cost3 = classif3(out3) + cost2) on a stack of n
+ * head outputs y: [n, count], in place: y[j] += y[j - 1] for j = 1 .. n - 1, in that order -- the FP32 adds the
+ * skip operand of dmb_conv3d_k3_c1_f32 performs, same bits. */
+int dmb_cost_chain_f32(float* y, int n, long long count, void* stream);
+
 /* ConvTranspose3d kernel 3, stride 2, padding 1, output_padding 1 (hourglass.py:52-60):
  * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, 2W];  y[o] += x[i] * w[k] with o = 2i - 1 + k.  Co = 64 or any Co <= 32
  * (fewer than 32: zero-padded weight rows, e.g. GC-Net's 1-channel output layer, aggregators/GCNet.py:63-67). */

@@ -19,7 +19,7 @@ batch = dict(leftFeature=left, rightFeature=right)
 # an option is "<development option index>=<value>", or "fls=0" (first-layer convolutions on one stream), "ovl=1" (branch overlap)
 def _parse(kv):
     k, v = kv.split("=")
-    return (k if k in ("fls", "ovl") else int(k), int(v))
+    return (k if k in ("fls", "ovl", "mh") else int(k), int(v))
 
 
 def _set(k, v):
@@ -27,11 +27,13 @@ def _set(k, v):
         ops.set_first_layer_mode({2: "merged", 1: "streams", 0: "serial"}[v])
     elif k == "ovl":
         ops.set_branch_overlap(bool(v))
+    elif k == "mh":    # 1 = the three classifier heads / up-samplings as one launch each (default: one per branch)
+        ops.set_merged_heads(bool(v))
     else:
         lib.dmb_dev_set_option(k, v)
 
 
-_DEFAULT = {"fls": 2, "ovl": 0}
+_DEFAULT = {"fls": 2, "ovl": 0, "mh": 0}
 variants = [("default", [])] + [(a, [_parse(kv) for kv in a.split(",")]) for a in sys.argv[1:]]
 
 

@@ -302,6 +302,47 @@ def test_conv3d_c1(dev, Ci):
     assert (got - ref).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("shape,njobs", [((2, 6, 9, 72), 3), ((1, 17, 10, 240), 2), ((2, 5, 7, 30), 3), ((1, 9, 8, 124), 4), ((3, 4, 4, 8), 1)])
+def test_conv3d_c1_multi_and_cost_chain(dev, shape, njobs):
+    """Several heads in one launch (conv3d_c1v_kernel<true>: job = batch item / B picks input, weights, bias) against one
+    dmb_conv3d_k3_c1_f32 call per head: bit-identical, also through the dword fallback (W = 30); then the in-place cumulative sums
+    against the skip-operand form cost_j = head_j(x_j) + cost_{j-1}: the same FP32 adds, bit-identical."""
+    ops = _ops()
+    B, D, H, W = shape
+    xs = [_rand((B, 32, D, H, W), 40 + j).to(dev) for j in range(njobs)]
+    ws = [_rand((1, 32, 3, 3, 3), 50 + j, 1.0 / math.sqrt(32 * 27)).to(dev) for j in range(njobs)]
+    bs = [0.25 * j - 0.5 for j in range(njobs)]
+    stack = ops.conv3d_k3_c1_multi(xs, ws, bs)
+    assert stack.shape == (njobs, B, 1, D, H, W)
+    singles = [ops.conv3d_k3_c1(x, w, b, None) for x, w, b in zip(xs, ws, bs)]
+    for j in range(njobs):
+        assert torch.equal(stack[j], singles[j])
+        ref = F.conv3d(xs[j].cpu(), ws[j].cpu(), torch.tensor([bs[j]]), padding=1)
+        assert (stack[j].cpu() - ref).abs().max().item() <= 1e-5
+    chained, prev = [], None
+    for x, w, b in zip(xs, ws, bs):
+        prev = ops.conv3d_k3_c1(x, w, b, prev)
+        chained.append(prev)
+    ops.cost_chain_(stack)
+    for j in range(njobs):
+        assert torch.equal(stack[j], chained[j])
+
+
+def test_cost_chain_odd_sizes(dev):
+    """dmb_cost_chain_f32 on counts that are not multiples of 4 and on a misaligned base: exactly torch's running FP32 sum."""
+    ops = _ops()
+    for n, count, skip in ((3, 1001, 0), (2, 7, 0), (4, 64, 1), (1, 5, 0)):
+        buf = _rand((n * count + skip,), 60 + n).to(dev)
+        y = buf[skip:].view(n, count)
+        want = y.clone()
+        for j in range(1, n):
+            want[j] = want[j] + want[j - 1]
+        if skip:   # a misaligned view is not a contiguous allocation start, but it is contiguous: the scalar path takes it
+            assert y.is_contiguous()
+        ops.cost_chain_(y)
+        assert torch.equal(y, want)
+
+
 @pytest.mark.parametrize("shape", [(2, 6, 9, 72), (1, 17, 10, 240), (1, 3, 19, 64), (1, 9, 8, 124)])
 def test_conv3d_c1_vector_rows(dev, shape):
     """Rows that are 16-byte aligned (W % 4 == 0) take the register-staged kernel (16-byte fetches, one LDS word per input
