@@ -1386,7 +1386,8 @@ static int launch_s1(const float* x, const float* wp, const float* scale, const 
   const int ntx = C::LIN ? cdiv(H * W, 64) : cdiv(W, C::TX), nty = C::LIN ? 1 : cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
-  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  // (development option 17: extra KB of LDS per workgroup -- fewer workgroups per CU, for occupancy experiments)
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + (size_t)g_dev_opts[17] * 1024;
   if (res) {
     DMB_ENSURE_LDS((&conv3d_s1_kernel<C, true>), (size_t)(lds));
     hipLaunchKernelGGL((conv3d_s1_kernel<C, true>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,

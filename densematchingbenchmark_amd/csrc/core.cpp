@@ -7,13 +7,13 @@ void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 }  // namespace dmb
 
 namespace dmb {
-int g_dev_opts[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // development knobs (kernel variant selection in micro-benchmarks)
+int g_dev_opts[32] = {1};  // development knobs (kernel variant selection in micro-benchmarks)
 }
 // Development knob, NOT part of the ABI (absent from include/dmb_hip.h): key 0 = conv scheduling variant,
 // key 1 = 1 forces the VALU form of the group-wise correlation, key 2 = 1 forces flattened conv3d tiles,
 // key 3 = 1 forces the scalar (dword) staging / store paths (conv2d, stride-2 and transposed conv3d).
 extern "C" void dmb_dev_set_option(int key, int value) {
-  if (key >= 0 && key < 16) dmb::g_dev_opts[key] = value;
+  if (key >= 0 && key < 32) dmb::g_dev_opts[key] = value;
 }
 
 extern "C" int dmb_abi_version(void) { return 2; }
