@@ -1388,6 +1388,10 @@ static int launch_s1(const float* x, const float* wp, const float* scale, const 
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   // (development option 17: extra KB of LDS per workgroup -- fewer workgroups per CU, for occupancy experiments)
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + (size_t)g_dev_opts[17] * 1024;
+  if (g_dev_opts[17]) {   // the experiment raises the cap itself (DMB_ENSURE_LDS sets it once, to the kernel's own need)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (res) {
     DMB_ENSURE_LDS((&conv3d_s1_kernel<C, true>), (size_t)(lds));
     hipLaunchKernelGGL((conv3d_s1_kernel<C, true>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,

@@ -33,8 +33,7 @@ inline int ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned long lo
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   const unsigned long long bit = 1ull << (dev & 63);
   if (*seen & bit) return DMB_OK;
-  // the cap is raised to the whole 160 KB of a gfx950 CU once per kernel and device (a launch then asks for what it needs)
-  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes > 160 * 1024 ? (int)bytes : 160 * 1024);
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   *seen |= bit;
   return DMB_OK;
