@@ -442,10 +442,15 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
 // WM: wave groups along the output positions.  WM = 2 makes a workgroup of EIGHT waves on the same LDS tile, each with half of
 // the tile's 32-position column tiles (32 instead of 64 accumulator registers): two workgroups per CU (the LDS bound) then
 // put four waves on every SIMD instead of two, so that one wave's staging waits and epilogue hide behind three others.
-template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false, int WM_ = 1>
+// VEP (with V16): the epilogue goes through a per-wave LDS scratch so that a lane owns TWO adjacent output columns of one channel
+// and stores them as one 8-byte word (16 bytes would need 4-column alignment, and a 30-column tile starts on an odd pair in every
+// second tile): a CU retires vector-memory lanes at about one per clock whatever their width, and the dword epilogue's 50 M lane
+// stores of the 32 -> 64 layer were 0.08 of its 0.72 ms (diagnostic switch 1).
+template <int CIN_, int COUT_, int TY_, int TX_, int CK_, int WN_, bool V16_ = false, int WM_ = 1, bool VEP_ = false>
 struct S2Cfg {
   static constexpr int CIN = CIN_, COUT = COUT_, TY = TY_, TX = TX_, CK = CK_, WN = WN_;
-  static constexpr bool V16 = V16_;
+  static constexpr bool V16 = V16_, VEP = V16_ && VEP_;
+  static constexpr int TR_PITCH = 40;          // epilogue transposition scratch [32 channels][32 + 8]: = 8 (mod 16), see the kernel
   static constexpr int WM = WM_, NWAVES = 4 * WM_, NTHREADS = 64 * NWAVES;
   static constexpr int WZ = 4 / WN;
   static constexpr int TZ = WZ;
@@ -472,6 +477,7 @@ struct S2Cfg {
   static_assert(CK % 2 == 0 && COUT % (32 * WN) == 0 && IN_FLOATS % 4 == 0, "shape");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
   static_assert(MT % WM == 0, "the column tiles are dealt evenly to the wave groups");
+  static_assert(!VEP || (PO % 2 == 0 && TX % 2 == 0 && LDS_FLOATS >= NWAVES * 32 * TR_PITCH), "pair epilogue: even tiles, scratch");
 };
 
 template <class C>
@@ -618,6 +624,59 @@ __global__ __launch_bounds__(C::NTHREADS, C::WPE * C::WM) void conv3d_s2_kernel(
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = (unsigned)Do * HWo;
   float* yb = y + (size_t)b * C::COUT * DHWo;
   const float* rb = res ? res + (size_t)b * C::COUT * DHWo : nullptr;
+  if constexpr (C::VEP) {
+    // Each 32 x 32 accumulator tile (32 positions of one output row x 32 channels) goes through this wave's scratch (the chunk
+    // buffers are free after the last barrier): lane = (channel c4 of a group of 4, position pair p2), 8 groups = 8 words of 8
+    // bytes.  Scratch pitch 40: the two lane halves of the write (channel rows 4 apart) and the four channel rows of a read land
+    // on disjoint bank groups.  Branch-free: lanes outside the tile / volume get an out-of-range buffer offset.
+    float* my = lds + wave * (32 * C::TR_PITCH);
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(yb, (unsigned)C::COUT * DHWo * 4u);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(rb ? rb : yb, (unsigned)C::COUT * DHWo * 4u);
+    const int p2 = (lane & 15) * 2, c4 = lane >> 4;
+    const float lo = relu == 1 ? 0.f : -__builtin_inff();    // ReLU after the residual add
+    const float lo2 = relu == 2 ? 0.f : -__builtin_inff();   // ReLU before it (GC-Net)
+    const unsigned kstep = 4u * DHWo * 4u;                   // the 8 words of a lane are 4 channels apart
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+      const int co0 = (wn * C::NT + nt) * 32;
+      float sc8[8], sh8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        sc8[k] = scale ? scale[co0 + k * 4 + c4] : 1.f;
+        sh8[k] = shift ? shift[co0 + k * 4 + c4] : 0.f;
+      }
+#pragma unroll
+      for (int mt = 0; mt < C::MTW; ++mt) {
+        const int m = (wm * C::MTW + mt) * 32 + p2;
+        const int ly = m / C::PO, lx = m - ly * C::PO;
+        const int gy = y0 + ly, gxo = x0 + lx;
+        const bool ok = m < C::TY * C::PO && lx < C::TX && gy < Ho && gxo < Wo;   // (PO, TX, Wo even: a pair is in or out as a whole)
+        const unsigned off = ok ? ((unsigned)(co0 + c4) * DHWo + (unsigned)gz * HWo + (unsigned)gy * Wo + (unsigned)gxo) * 4u : DMA_OOB;
+        u32x2 rv[8];
+        if (rb) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rv[k] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(off + k * kstep), 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my[cd_row(r, h) * C::TR_PITCH + j] = acc[mt][nt][r];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float2 v = *reinterpret_cast<const float2*>(my + (k * 4 + c4) * C::TR_PITCH + p2);
+          v.x = fmaxf(fmaf(v.x, sc8[k], sh8[k]), lo2);
+          v.y = fmaxf(fmaf(v.y, sc8[k], sh8[k]), lo2);
+          if (rb) {
+            v.x += __uint_as_float(rv[k].x);
+            v.y += __uint_as_float(rv[k].y);
+          }
+          u32x2 o;
+          o.x = __float_as_uint(fmaxf(v.x, lo));
+          o.y = __float_as_uint(fmaxf(v.y, lo));
+          __builtin_amdgcn_raw_buffer_store_b64(o, yrs, (int)(off + k * kstep), 0, 0);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < C::NT; ++nt) {
     const int co0 = (wn * C::NT + nt) * 32;
@@ -1547,6 +1606,11 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
         return launch_s2<S2Cfg<0, 64, 4, 22, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
       if (g_dev_opts[10] == 1)   // A/B: four-wave workgroups
         return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      // 8-byte epilogue: W % 4 == 0 makes Wo even; the output (and skip operand) base must be 8-byte aligned and one batch item
+      // of the output addressable with 32-bit byte offsets
+      const bool pair_ok = ((((uintptr_t)y | (uintptr_t)residual) & 7) == 0) && (long long)Co * ((D - 1) / 2 + 1) * ((H - 1) / 2 + 1) * Wo * 4 < 0x7fffffffLL;
+      if (pair_ok && g_dev_opts[10] != 2)   // (A/B: 10 = 2 keeps the dword epilogue)
+        return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
       return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     }
     if (Co == 64) return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);

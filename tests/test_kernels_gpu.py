@@ -791,6 +791,40 @@ def test_conv3d_vector_and_scalar_staging_agree(dev, kind, shape):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("Ci,shape", [(32, (1, 8, 16, 120)), (64, (2, 5, 9, 60)), (32, (1, 6, 8, 240)), (32, (1, 4, 4, 124))])
+@pytest.mark.parametrize("mode", ["plain", "skip_relu", "relu_then_skip"])
+def test_conv3d_s2_pair_epilogue_is_bit_identical(dev, Ci, shape, mode):
+    """The stride-2 kernel's 8-byte epilogue (S2Cfg VEP: 32 x 32 accumulator tiles through a per-wave LDS scratch, a lane stores two
+    adjacent columns of one channel) against the dword epilogue (development option 10 = 2): the same FP32 operations per output,
+    so bit-identical -- with folded BatchNorm, with the skip operand before / after the ReLU, over partial tiles in x, y and z --
+    and within 2e-5 of the CPU convolution."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 221)
+    w = _rand((64, Ci, 3, 3, 3), 222, 1.0 / math.sqrt(Ci * 27))
+    sc, sh = _affine(64, 223)
+    Do, Ho, Wo = (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    res = None if mode == "plain" else _rand((B, 64, Do, Ho, Wo), 224)
+    relu = {"plain": False, "skip_relu": True, "relu_then_skip": "pre"}[mode]
+    ref = F.conv3d(x, w, None, stride=2, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+    if mode == "skip_relu":
+        ref = F.relu(ref + res)
+    elif mode == "relu_then_skip":
+        ref = F.relu(ref) + res
+    lib = _lib.load()
+    wp = ops.pack_conv3d_weights(w.to(dev))
+    outs = []
+    for opt in (0, 2):
+        lib.dmb_dev_set_option(10, opt)
+        try:
+            outs.append(ops.conv3d_k3(x.to(dev), wp, 64, sc.to(dev), sh.to(dev), None if res is None else res.to(dev), 2, relu))
+        finally:
+            lib.dmb_dev_set_option(10, 0)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].cpu() - ref).abs().max().item() <= 2e-5
+
+
 # ------------------------------------------------------------------------------- first conv on a cat volume, 2-D form
 @pytest.mark.parametrize("B,C,Co,D,H,W", [(2, 32, 32, 16, 12, 64), (1, 32, 32, 48, 9, 240), (1, 8, 32, 4, 5, 12),
                                           (2, 6, 20, 8, 7, 16), (1, 32, 32, 2 * 4, 6, 20)])
