@@ -183,7 +183,8 @@ __device__ __forceinline__ void catconv_combine_body(const float* __restrict__ F
 #pragma unroll
     for (int k = 0; k < ZB; ++k) {
       const int z = z0 + k < D ? z0 + k : D - 1;
-      if (NEAR) bq[k] = band[z];
+      // the band values matter for x + e - z in [-2, 2) only: lanes further from the diagonal skip the load
+      if (NEAR) bq[k] = (x - z >= -5 && x - z <= 1) ? band[z] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (!NEAR) gq[k] = gb[z];
     }
   };

@@ -21,7 +21,7 @@ for it in range(N):
     try:
         if kind in ("s1", "s2", "deconv", "x6"):
             D, H = rng.randint(1, 9), rng.randint(1, 11)
-            W = rng.choice([rng.randint(1, 70), 24, 40, 48, 72, 80, 96, 120])
+            W = rng.choice([rng.randint(1, 70), 24, 40, 48, 60, 60, 72, 80, 96, 120])
             Ci = rng.choice([1, 3, 7, 8, 16, 32, 33, 64])
             Co = rng.choice([32, 64] if kind != "s1" else [32, 64, 128])
             relu = rng.choice([False, True, "pre"])
