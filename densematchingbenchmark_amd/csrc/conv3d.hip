@@ -362,23 +362,26 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
     };
     auto run = [&](auto has_res) {
       constexpr bool HAS_RES = decltype(has_res)::value;
-      unsigned off0[2];
-      u32x4 rv[2][4];
-      off0[0] = offset0(0);
-      if constexpr (HAS_RES) {
+      // Skip-operand loads run ahead of the stores in a ring of three register sets: tile 1 is requested when tile 0 is
+      // processed, from then on TWO tiles ahead -- the accumulator registers of the tiles already written out pay for the third
+      // set, so the register peak stays where the first tile puts it (96 accumulators + 2 sets).
+      unsigned off0[C::MT];
+      u32x4 rv[3][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rv[0][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(off0[0] + k * kstep), 0, 0);
-      }
+      for (int mt = 0; mt < C::MT; ++mt) off0[mt] = 0;
+      off0[0] = offset0(0);
+      auto request = [&](int t) {
+        off0[t] = offset0(t);
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rv[t % 3][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(off0[t] + k * kstep), 0, 0);
+        }
+      };
+      request(0);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) {
-        if (mt + 1 < C::MT) {
-          off0[(mt + 1) & 1] = offset0(mt + 1);
-          if constexpr (HAS_RES) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              rv[(mt + 1) & 1][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(off0[(mt + 1) & 1] + k * kstep), 0, 0);
-          }
-        }
+        if (mt <= 1 && mt + 1 < C::MT) request(mt + 1);   // tiles 1 and 2: one ahead (at mt = 0 all six accumulator tiles are live)
+        if (mt >= 1 && mt + 2 < C::MT) request(mt + 2);   // from tile 3 on: two ahead
 #pragma unroll
         for (int r = 0; r < 16; ++r) my[cd_row(r, h) * C::TR_PITCH + j] = acc[mt][0][r];
 #pragma unroll
@@ -389,17 +392,17 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
           v.z = fmaxf(fmaf(v.z, sc4[k], sh4[k]), lo2);
           v.w = fmaxf(fmaf(v.w, sc4[k], sh4[k]), lo2);
           if constexpr (HAS_RES) {   // (not __builtin_bit_cast on a vector element: this clang reads element 0 for every index)
-            v.x += __uint_as_float(rv[mt & 1][k].x);
-            v.y += __uint_as_float(rv[mt & 1][k].y);
-            v.z += __uint_as_float(rv[mt & 1][k].z);
-            v.w += __uint_as_float(rv[mt & 1][k].w);
+            v.x += __uint_as_float(rv[mt % 3][k].x);
+            v.y += __uint_as_float(rv[mt % 3][k].y);
+            v.z += __uint_as_float(rv[mt % 3][k].z);
+            v.w += __uint_as_float(rv[mt % 3][k].w);
           }
           u32x4 o;
           o.x = __float_as_uint(fmaxf(v.x, lo));
           o.y = __float_as_uint(fmaxf(v.y, lo));
           o.z = __float_as_uint(fmaxf(v.z, lo));
           o.w = __float_as_uint(fmaxf(v.w, lo));
-          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(off0[mt & 1] + k * kstep), 0, 0);   // (streaming stores: step +0.3 %)
+          __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(off0[mt] + k * kstep), 0, 0);   // (streaming stores: step +0.3 %)
         }
       }
     };
