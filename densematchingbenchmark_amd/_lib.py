@@ -68,6 +68,7 @@ SIGNATURES = {
     "dmb_bilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 8 + [_P]),
     "dmb_bilinear_scale_f32": (_c_int, [_P, _P] + [_c_int] * 6 + [_c_float] + [_c_int] * 2 + [_P]),
     "dmb_epe_accum_f64": (_c_int, [_P, _P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
+    "dmb_epe_accum_multi_f64": (_c_int, [_c_int, _P, _P, _P, _P] + [_c_int] * 5 + [_c_float, _c_float, _P]),
     "dmb_conv3d_x6_packed_bytes": (_c_ll, [_c_int, _c_int]),
     "dmb_conv3d_x6_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conv3d_k3_x6_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 7 + [_P]),

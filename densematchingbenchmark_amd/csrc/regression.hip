@@ -485,10 +485,19 @@ __global__ __launch_bounds__(256) void deconv_k8s4_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------
 constexpr int EPE_SLICES = 64;
 
-__global__ __launch_bounds__(256) void epe_partial_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+// Several estimates against ONE ground truth in a launch (the three disparity maps of a PSMNet / AcfNet forward): blockIdx.z picks
+// the estimate and its block of B workspace rows.
+constexpr int EPE_MAXMAPS = 4;
+struct EpeMaps {
+  const float* est[EPE_MAXMAPS];
+};
+
+__global__ __launch_bounds__(256) void epe_partial_kernel(EpeMaps maps, const float* __restrict__ gt,
                                                           double* __restrict__ ws, int Hp, int Wp, int H0, int W0,
                                                           float lb, float ub) {
   const int b = blockIdx.y;
+  const float* __restrict__ est = maps.est[blockIdx.z];
+  ws += (size_t)blockIdx.z * gridDim.y * 6;
   // eval.py:24-29: pad_top = Hp - H0; the crop [pad_top:, :W0] is applied only when pad_top >= 0
   const bool crop = Hp - H0 >= 0;
   const int top = crop ? Hp - H0 : 0;
@@ -531,7 +540,8 @@ __global__ __launch_bounds__(256) void epe_partial_kernel(const float* __restric
 __global__ void epe_finalize_kernel(const double* __restrict__ ws, double* __restrict__ acc, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const double* r = ws + b * 6;
+  const double* r = ws + ((size_t)blockIdx.y * B + b) * 6;   // blockIdx.y: the estimate; its accumulator row follows
+  acc += blockIdx.y * 6;
   atomicAdd(&acc[0], 1.0);
   if (r[0] >= 1.0) {  // pixel_error.py:48: an empty mask yields all-zero errors for this image
     atomicAdd(&acc[1], r[1] / r[0]);
@@ -806,7 +816,27 @@ extern "C" int dmb_epe_accum_f64(const float* est, const float* gt, double* acc,
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 6 * B, st);
   if (e != hipSuccess) return fail((int)e, "epe_accum: workspace memset failed");
-  hipLaunchKernelGGL(epe_partial_kernel, dim3(EPE_SLICES, B), dim3(256), 0, st, est, gt, workspace, Hp, Wp, H0, W0, lb, ub);
+  EpeMaps maps{};
+  maps.est[0] = est;
+  hipLaunchKernelGGL(epe_partial_kernel, dim3(EPE_SLICES, B), dim3(256), 0, st, maps, gt, workspace, Hp, Wp, H0, W0, lb, ub);
   hipLaunchKernelGGL(epe_finalize_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, workspace, acc, B);
   return launch_status("epe_accum launch failed");
+}
+
+extern "C" int dmb_epe_accum_multi_f64(int nmaps, const float* const* est, const float* gt, double* acc, double* workspace, int B,
+                                       int Hp, int Wp, int H0, int W0, float lb, float ub, void* stream) {
+  if (nmaps <= 0 || nmaps > EPE_MAXMAPS || !est || !gt || !acc || !workspace || B <= 0 || B > 65535 || Hp <= 0 || Wp <= 0 ||
+      H0 <= 0 || W0 <= 0)
+    return fail(DMB_EINVAL, "epe_accum_multi: bad argument (1 .. 4 estimates)");
+  EpeMaps maps{};
+  for (int i = 0; i < nmaps; ++i) {
+    if (!est[i]) return fail(DMB_EINVAL, "epe_accum_multi: null estimate");
+    maps.est[i] = est[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 6 * B * nmaps, st);
+  if (e != hipSuccess) return fail((int)e, "epe_accum_multi: workspace memset failed");
+  hipLaunchKernelGGL(epe_partial_kernel, dim3(EPE_SLICES, B, nmaps), dim3(256), 0, st, maps, gt, workspace, Hp, Wp, H0, W0, lb, ub);
+  hipLaunchKernelGGL(epe_finalize_kernel, dim3(cdiv(B, 64), nmaps), dim3(64), 0, st, workspace, acc, B);
+  return launch_status("epe_accum_multi launch failed");
 }

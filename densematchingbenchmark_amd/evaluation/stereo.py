@@ -38,6 +38,11 @@ class EpeAccumulator:
         """est_disps: list (one per disparity id) of PADDED [B, 1, Hp, Wp] maps; gt_disp padded the same way."""
         if isinstance(est_disps, torch.Tensor):
             est_disps = [est_disps]
+        est_disps = list(est_disps)
+        if 1 < len(est_disps) <= 4 and len(est_disps) == self.acc.shape[0] and all(e.shape == gt_disp.shape for e in est_disps):
+            # the maps of one forward against the same ground truth: one pass instead of one per map (same sums per map)
+            ops.epe_accumulate_multi(est_disps, gt_disp, self.acc, original_size, self.lb, self.ub)
+            return
         for i, est in enumerate(est_disps):
             ops.epe_accumulate(est, gt_disp, self.acc[i], original_size, self.lb, self.ub)
 

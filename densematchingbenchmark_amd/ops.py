@@ -1148,6 +1148,32 @@ def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
     return acc
 
 
+def epe_accumulate_multi(ests, gt, acc, original_size, lower_bound, upper_bound):
+    """``ests``: 1 .. 4 maps [B, 1, Hp, Wp] evaluated against the same ``gt`` in one pass; acc: float64[len(ests), 6] (contiguous
+    rows of a device tensor), row i updated from ests[i] exactly as ``epe_accumulate`` would."""
+    import ctypes
+    lib = _lib.load()
+    n = len(ests)
+    ests = [_f32c(e, "est_disp") for e in ests]
+    gt = _f32c(gt, "gt_disp")
+    B = gt.shape[0]
+    Hp, Wp = gt.shape[-2:]
+    H0, W0 = original_size
+    if n < 1 or n > 4 or acc.dtype != torch.float64 or tuple(acc.shape) != (n, 6) or not acc.is_contiguous():
+        raise _lib.DmbLibraryError("epe_accumulate_multi: 1 .. 4 estimates and a contiguous float64[n, 6] accumulator")
+    for e in ests:
+        _same_shape(e, gt, "epe_accumulate_multi: estimate and ground truth")
+    if gt.numel() != B * Hp * Wp or not (0 < int(H0) <= Hp and 0 < int(W0) <= Wp):
+        raise _lib.DmbLibraryError("epe_accumulate_multi: maps must be [B, 1, Hp, Wp] with the original size inside, got %s / %s"
+                                   % (tuple(gt.shape), (H0, W0)))
+    ws = torch.empty((n, B, 6), dtype=torch.float64, device=gt.device)
+    PA = ctypes.c_void_p * n
+    check(lib.dmb_epe_accum_multi_f64(n, PA(*[dev_ptr(e).value for e in ests]), dev_ptr(gt), dev_ptr(acc), dev_ptr(ws), B, Hp, Wp,
+                                      int(H0), int(W0), float(lower_bound), float(upper_bound), stream_ptr(gt.device)),
+          "dmb_epe_accum_multi_f64")
+    return acc
+
+
 # ---------------------------------------------------------------------------------------------- 2-D backbone ops
 def _window_ptr(t, ch_offset):
     """Pointer to channel ``ch_offset`` of batch item 0 of a contiguous [B, C, H, W] tensor."""

@@ -299,6 +299,13 @@ int dmb_conf_ring_f32(const float* cost, const float* w1t, const float* scale, c
 int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* workspace, int B, int Hp, int Wp,
                       int H0, int W0, float lb, float ub, void* stream);
 
+/* The same for up to 4 estimates against ONE ground truth in a single pass (the disparity maps of one forward:
+ * tools/test.py evaluates every entry of results['disps'] against the same batch['leftDisp']): est: HOST array of
+ * nmaps device pointers; acc: [nmaps, 6] doubles, row i accumulated from est[i]; workspace: 6*B*nmaps doubles.
+ * Per estimate the arithmetic is dmb_epe_accum_f64's. */
+int dmb_epe_accum_multi_f64(int nmaps, const float* const* est, const float* gt, double* acc, double* workspace, int B,
+                            int Hp, int Wp, int H0, int W0, float lb, float ub, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * "Next" rows: the 2-D networks either side of the path.
  * dmb/modeling/stereo/backbones/PSMNet.py:8-129 and backbones/StereoNet.py:7-106 with

@@ -500,6 +500,31 @@ def test_epe_accumulate(dev):
         assert abs(acc[1 + i].item() / 3 - ref[k]) <= 1e-5 * max(1.0, abs(ref[k]))
 
 
+def test_epe_accumulate_multi_matches_single(dev):
+    """dmb_epe_accum_multi_f64 (the disparity maps of one forward against the same ground truth in one pass) against one
+    dmb_epe_accum_f64 call per map: counts identical, means equal to FP64 rounding of the slice-wise atomic sums (1e-12), over two
+    updates; and through EpeAccumulator.update, which picks the one-pass form for 2 .. 4 maps."""
+    ops = _ops()
+    from densematchingbenchmark_amd.evaluation import EpeAccumulator
+    g = torch.Generator().manual_seed(29)
+    acc_m = torch.zeros((3, 6), dtype=torch.float64, device=dev)
+    acc_s = torch.zeros((3, 6), dtype=torch.float64, device=dev)
+    holder = EpeAccumulator(dev, 3, 0, 192)
+    for rep in range(2):
+        gt = torch.rand((2, 1, 24, 40), generator=g) * 220 - 10
+        ests = [gt + torch.randn((2, 1, 24, 40), generator=g) * (1 + i) for i in range(3)]
+        if rep == 1:
+            gt[1] = 500.0   # empty mask
+        gd, ed = gt.to(dev), [e.to(dev) for e in ests]
+        ops.epe_accumulate_multi(ed, gd, acc_m, (21, 37), 0, 192)
+        for i in range(3):
+            ops.epe_accumulate(ed[i], gd, acc_s[i], (21, 37), 0, 192)
+        holder.update(ed, gd, (21, 37))
+    assert torch.equal(acc_m[:, 0], acc_s[:, 0]) and acc_m[0, 0].item() == 4
+    assert (acc_m - acc_s).abs().max().item() <= 1e-12 * acc_s.abs().max().item()
+    assert (holder.acc - acc_s).abs().max().item() <= 1e-12 * acc_s.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------- 2-D backbone ops
 @pytest.mark.parametrize("Ci,Co,k,stride,dil,shape", [
     (3, 32, 3, 2, 1, (2, 20, 70)),       # firstconv.0: 3 input channels (zero-padded fragments), stride 2
