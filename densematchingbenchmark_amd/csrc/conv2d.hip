@@ -41,7 +41,11 @@ __global__ void pack_conv2d_kernel(const float* __restrict__ w, float* __restric
 // Both cut the vector-memory INSTRUCTION count 4x: measured on MI355X these layers are bound by the rate at which a CU
 // issues 64-lane memory instructions (a 3x3 layer has 3x less arithmetic per staged byte than the 3x3x3 ones), not by
 // bytes: 32->32 at 384x1248 ran 1.65 ms with dword copies / stores against 0.97 ms with neither.
-template <int NTT_, int KS_, int DIL_, int S_ = 1, bool V16_ = true, bool DOT_ = false>
+// RYO: output rows per wave, 0 = the default (4 at stride 1).  The persistent grid is two workgroups per CU and a launch of the
+// backbone is a few tile rounds deep, so the tile HEIGHT is picked per launch by rounds x rows (launch_conv2d_auto): 8 images of
+// 136 x 240 at 64 channels are 680 tiles of 8 rows = 1.33 rounds on 512 slots (the chip works for 2) or 1360 tiles of 4 rows
+// = 2.66 rounds (it works for 3 half-sized ones): 0.195 -> 0.16 ms for each of PSMNet's 31 layer2 convolutions.
+template <int NTT_, int KS_, int DIL_, int S_ = 1, bool V16_ = true, bool DOT_ = false, int RYO_ = 0>
 struct C2Cfg {
   static constexpr int NTT = NTT_, KS = KS_, DIL = DIL_, S = S_;
   static constexpr bool V16 = V16_;
@@ -54,7 +58,7 @@ struct C2Cfg {
   static constexpr bool DOT = DOT_;
   static constexpr int WN = NTT;               // one 32-channel row tile per wave column (1, 2 or 4)
   static constexpr int WY = 4 / WN;            // waves stacked along y
-  static constexpr int RY = (S == 1) ? 4 : 2;  // output rows per wave (row pairs); strided tiles read 2x2 the input
+  static constexpr int RY = RYO_ > 0 ? RYO_ : ((S == 1) ? 4 : 2);  // output rows per wave (row pairs); strided tiles read 2x2 the input
   static constexpr int TY = RY * WY, TX = 48;
   static constexpr int HALO = (KS / 2) * DIL;
   static constexpr int LP = V16 ? (HALO + 3) / 4 * 4 : HALO;           // staged columns left of the tile origin
@@ -513,6 +517,21 @@ static int launch_conv2d(const float* x, const float* wp, const float* scale, co
   return launch_status("conv2d launch failed");
 }
 
+// Tile height by rounds x rows (see C2Cfg): the default 4 rows per wave, or 2 where that takes less of the chip's time.
+template <int N, int K, int DL, bool V16>
+static int launch_conv2d_auto(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                              float* y, int B, int Ci, int Co, int H, int W, int relu, int in_ctot, int out_ctot,
+                              int res_ctot, hipStream_t st) {
+  using C4 = C2Cfg<N, K, DL, 1, V16, false, 0>;
+  using C2 = C2Cfg<N, K, DL, 1, V16, false, 2>;
+  const long long slots = 2LL * num_cus();
+  const long long t4 = (long long)B * cdiv(W, C4::TX) * cdiv(H, C4::TY), t2 = (long long)B * cdiv(W, C2::TX) * cdiv(H, C2::TY);
+  const long long cost4 = ((t4 + slots - 1) / slots) * C4::RY, cost2 = ((t2 + slots - 1) / slots) * C2::RY;
+  if (cost2 < cost4 && !g_dev_opts[18])   // (development option 18: always the default height)
+    return launch_conv2d<C2>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
+  return launch_conv2d<C4>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
+}
+
 // Several convolutions of one layer shape in ONE launch (see C2Jobs): no affine, no residual, no ReLU, stride 1.
 template <class C>
 static int launch_conv2d_multi(const C2Jobs& jobs_in, int B, int Ci, int Co, int H, hipStream_t st) {
@@ -582,7 +601,11 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
   if (stride == 1) {
     if (ksize == 3 && dilation == 1) {
       if (NTT == 1) DMB_C2(1, 3, 1, 1);
-      if (NTT == 2) DMB_C2(2, 3, 1, 1);
+      if (NTT == 2) {   // PSMNet layer2 / StereoNet trunk widths: the tile height follows the launch's size
+        if (v16) return launch_conv2d_auto<2, 3, 1, true>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu, in_channels_total,
+                                                          out_channels_total, res_channels_total, st);
+        DMB_C2(2, 3, 1, 1);
+      }
       if (NTT == 4) DMB_C2(4, 3, 1, 1);
     } else if (ksize == 3 && dilation == 2) {
       if (NTT == 1) DMB_C2(1, 3, 2, 1);

@@ -606,6 +606,32 @@ def test_conv2d_vector_path(dev, Ci, Co, k, stride, dil, shape):
     assert (got - F.conv2d(x, w, None, stride=stride, padding=pad, dilation=dil)).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("shape", [(8, 136, 240), (2, 20, 48), (3, 9, 100)])
+def test_conv2d_tile_height_variants_are_bit_identical(dev, shape):
+    """64-channel 3x3 layers pick their tile height per launch (4 or 2 output rows per wave, by rounds x rows on the persistent
+    grid): the same MFMA sequence per output, so the launch-size-dependent choice must not change a bit (development option 18
+    forces the default height) -- with folded BatchNorm, skip operand and ReLU."""
+    ops = _ops()
+    from densematchingbenchmark_amd import _lib
+    B, H, W = shape
+    x = _rand((B, 64, H, W), 301).to(dev)
+    w = _rand((64, 64, 3, 3), 302, 1.0 / math.sqrt(64 * 9))
+    sc, sh = _affine(64, 303)
+    res = _rand((B, 64, H, W), 304).to(dev)
+    wp = ops.pack_conv2d_weights(w.to(dev))
+    lib = _lib.load()
+    outs = []
+    for opt in (0, 1):
+        lib.dmb_dev_set_option(18, opt)
+        try:
+            outs.append(ops.conv2d(x, wp, 64, 3, 1, 1, sc.to(dev), sh.to(dev), res, True))
+        finally:
+            lib.dmb_dev_set_option(18, 0)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.relu(F.conv2d(x.cpu(), w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res.cpu())
+    assert (outs[0].cpu() - ref).abs().max().item() <= 2e-5
+
+
 def test_conv2d_unsupported_combinations_fail_loudly(dev):
     ops = _ops()
     from densematchingbenchmark_amd._lib import DmbLibraryError
