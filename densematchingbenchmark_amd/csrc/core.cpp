@@ -16,5 +16,5 @@ extern "C" void dmb_dev_set_option(int key, int value) {
   if (key >= 0 && key < 32) dmb::g_dev_opts[key] = value;
 }
 
-extern "C" int dmb_abi_version(void) { return 2; }
+extern "C" int dmb_abi_version(void) { return 3; }
 extern "C" const char* dmb_last_error(void) { return dmb::g_last_error; }

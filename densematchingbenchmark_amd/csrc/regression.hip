@@ -480,8 +480,9 @@ __global__ __launch_bounds__(256) void deconv_k8s4_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// EPE accumulator.  Pass 1: EPE_SLICES workgroups per image reduce a slice each and add six partial sums to the
-// per-image workspace; pass 2: one thread per image turns them into the image's means and adds those to acc.
+// EPE accumulator.  Pass 1: EPE_SLICES workgroups per image reduce a slice each and write six partial sums to the slice's
+// workspace row; pass 2: one thread per image adds the slices in ascending order, turns the sums into the image's means and
+// adds those to acc.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int EPE_SLICES = 64;
 
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256) void epe_partial_kernel(EpeMaps maps, const fl
                                                           float lb, float ub) {
   const int b = blockIdx.y;
   const float* __restrict__ est = maps.est[blockIdx.z];
-  ws += (size_t)blockIdx.z * gridDim.y * 6;
+  ws += (size_t)blockIdx.z * gridDim.y * EPE_SLICES * 6;
   // eval.py:24-29: pad_top = Hp - H0; the crop [pad_top:, :W0] is applied only when pad_top >= 0
   const bool crop = Hp - H0 >= 0;
   const int top = crop ? Hp - H0 : 0;
@@ -531,24 +532,37 @@ __global__ __launch_bounds__(256) void epe_partial_kernel(EpeMaps maps, const fl
     if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < 6) {   // this slice's six sums, in its own workspace row: no atomics, no clearing, a fixed summation order
     const int k = threadIdx.x;
-    atomicAdd(&ws[b * 6 + k], sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3]);
+    ws[((size_t)b * EPE_SLICES + blockIdx.x) * 6 + k] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
   }
 }
 
-__global__ void epe_finalize_kernel(const double* __restrict__ ws, double* __restrict__ acc, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const double* r = ws + ((size_t)blockIdx.y * B + b) * 6;   // blockIdx.y: the estimate; its accumulator row follows
-  acc += blockIdx.y * 6;
-  atomicAdd(&acc[0], 1.0);
-  if (r[0] >= 1.0) {  // pixel_error.py:48: an empty mask yields all-zero errors for this image
-    atomicAdd(&acc[1], r[1] / r[0]);
-    atomicAdd(&acc[2], 100.0 * r[2] / r[0]);
-    atomicAdd(&acc[3], 100.0 * r[3] / r[0]);
-    atomicAdd(&acc[4], 100.0 * r[4] / r[0]);
-    atomicAdd(&acc[5], 100.0 * r[5] / r[0]);
+// One 64-lane wave per estimate: lane l takes images l, l + 64, ... in ascending order, the lanes' sums are combined by a fixed
+// butterfly and lane 0 adds the six totals to the accumulator row -- no atomics anywhere: the metrics of a run are reproducible
+// bit for bit, whatever the dispatch order.
+__global__ __launch_bounds__(64) void epe_finalize_kernel(const double* __restrict__ ws, double* __restrict__ acc, int B) {
+  const double* maps = ws + (size_t)blockIdx.x * B * EPE_SLICES * 6;   // blockIdx.x: the estimate; its accumulator row follows
+  acc += blockIdx.x * 6;
+  double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const double* slices = maps + (size_t)b * EPE_SLICES * 6;
+    double r[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int sl = 0; sl < EPE_SLICES; ++sl)   // slices in ascending order
+#pragma unroll
+      for (int k = 0; k < 6; ++k) r[k] += slices[sl * 6 + k];
+    tot[0] += 1.0;
+    if (r[0] >= 1.0) {  // pixel_error.py:48: an empty mask yields all-zero errors for this image
+      tot[1] += r[1] / r[0];
+#pragma unroll
+      for (int k = 2; k < 6; ++k) tot[k] += 100.0 * r[k] / r[0];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double t = tot[k];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (threadIdx.x == 0) acc[k] += t;
   }
 }
 
@@ -814,12 +828,10 @@ extern "C" int dmb_epe_accum_f64(const float* est, const float* gt, double* acc,
   if (!est || !gt || !acc || !workspace || B <= 0 || B > 65535 || Hp <= 0 || Wp <= 0 || H0 <= 0 || W0 <= 0)
     return fail(DMB_EINVAL, "epe_accum: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 6 * B, st);
-  if (e != hipSuccess) return fail((int)e, "epe_accum: workspace memset failed");
   EpeMaps maps{};
   maps.est[0] = est;
   hipLaunchKernelGGL(epe_partial_kernel, dim3(EPE_SLICES, B), dim3(256), 0, st, maps, gt, workspace, Hp, Wp, H0, W0, lb, ub);
-  hipLaunchKernelGGL(epe_finalize_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, workspace, acc, B);
+  hipLaunchKernelGGL(epe_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, acc, B);
   return launch_status("epe_accum launch failed");
 }
 
@@ -834,9 +846,7 @@ extern "C" int dmb_epe_accum_multi_f64(int nmaps, const float* const* est, const
     maps.est[i] = est[i];
   }
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 6 * B * nmaps, st);
-  if (e != hipSuccess) return fail((int)e, "epe_accum_multi: workspace memset failed");
   hipLaunchKernelGGL(epe_partial_kernel, dim3(EPE_SLICES, B, nmaps), dim3(256), 0, st, maps, gt, workspace, Hp, Wp, H0, W0, lb, ub);
-  hipLaunchKernelGGL(epe_finalize_kernel, dim3(cdiv(B, 64), nmaps), dim3(64), 0, st, workspace, acc, B);
+  hipLaunchKernelGGL(epe_finalize_kernel, dim3(nmaps), dim3(64), 0, st, workspace, acc, B);
   return launch_status("epe_accum_multi launch failed");
 }

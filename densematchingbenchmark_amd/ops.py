@@ -1129,6 +1129,9 @@ def conf_head_from_source(cost, comp, scale, shift, w2):
     return conf
 
 
+EPE_WORKSPACE_DOUBLES_PER_IMAGE = 64 * 6   # include/dmb_hip.h: 64 slices x 6 sums per image (and estimate)
+
+
 def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
     """acc: float64[6] device tensor updated in place; est/gt: [B, 1, Hp, Wp]."""
     lib = _lib.load()
@@ -1142,7 +1145,7 @@ def epe_accumulate(est, gt, acc, original_size, lower_bound, upper_bound):
     if est.numel() != B * Hp * Wp or not (0 < int(H0) <= Hp and 0 < int(W0) <= Wp):
         raise _lib.DmbLibraryError("epe_accumulate: maps must be [B, 1, Hp, Wp] with the original size inside, got %s / %s"
                                    % (tuple(est.shape), (H0, W0)))
-    ws = torch.empty((B, 6), dtype=torch.float64, device=est.device)
+    ws = torch.empty((B, EPE_WORKSPACE_DOUBLES_PER_IMAGE), dtype=torch.float64, device=est.device)
     check(lib.dmb_epe_accum_f64(dev_ptr(est), dev_ptr(gt), dev_ptr(acc), dev_ptr(ws), B, Hp, Wp, int(H0), int(W0),
                                 float(lower_bound), float(upper_bound), stream_ptr(est.device)), "dmb_epe_accum_f64")
     return acc
@@ -1166,7 +1169,7 @@ def epe_accumulate_multi(ests, gt, acc, original_size, lower_bound, upper_bound)
     if gt.numel() != B * Hp * Wp or not (0 < int(H0) <= Hp and 0 < int(W0) <= Wp):
         raise _lib.DmbLibraryError("epe_accumulate_multi: maps must be [B, 1, Hp, Wp] with the original size inside, got %s / %s"
                                    % (tuple(gt.shape), (H0, W0)))
-    ws = torch.empty((n, B, 6), dtype=torch.float64, device=gt.device)
+    ws = torch.empty((n, B, EPE_WORKSPACE_DOUBLES_PER_IMAGE), dtype=torch.float64, device=gt.device)
     PA = ctypes.c_void_p * n
     check(lib.dmb_epe_accum_multi_f64(n, PA(*[dev_ptr(e).value for e in ests]), dev_ptr(gt), dev_ptr(acc), dev_ptr(ws), B, Hp, Wp,
                                       int(H0), int(W0), float(lower_bound), float(upper_bound), stream_ptr(gt.device)),

@@ -294,14 +294,17 @@ int dmb_conf_ring_f32(const float* cost, const float* w1t, const float* scale, c
  * columns [0, W0); mask = gt > lb && gt < ub; if the mask is non-empty
  *     acc[0] += 1; acc[1] += mean|gt-est|; acc[2..5] += 100 * mean(|gt-est| > {1,2,3,5})
  * (an empty mask contributes an image with all-zero errors, pixel_error.py:48-55).  acc: 6 doubles on
- * the device, accumulated atomically; the caller zeroes it and all-reduces it across ranks.  workspace: 6*B
- * doubles of caller-owned device scratch (cleared by the call on `stream`). */
+ * the device, updated in stream order (no atomics); the caller zeroes it and all-reduces it across
+ * ranks.  workspace: DMB_EPE_WORKSPACE_DOUBLES * B doubles of caller-owned device scratch, fully overwritten by the
+ * call: every image is reduced in 64 slices whose sums are added in a fixed order, so the per-image means are
+ * reproducible bit for bit (ABI version 3; version 2 took 6*B doubles and summed the slices atomically). */
+#define DMB_EPE_WORKSPACE_DOUBLES 384
 int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* workspace, int B, int Hp, int Wp,
                       int H0, int W0, float lb, float ub, void* stream);
 
 /* The same for up to 4 estimates against ONE ground truth in a single pass (the disparity maps of one forward:
  * tools/test.py evaluates every entry of results['disps'] against the same batch['leftDisp']): est: HOST array of
- * nmaps device pointers; acc: [nmaps, 6] doubles, row i accumulated from est[i]; workspace: 6*B*nmaps doubles.
+ * nmaps device pointers; acc: [nmaps, 6] doubles, row i accumulated from est[i]; workspace: DMB_EPE_WORKSPACE_DOUBLES*B*nmaps doubles.
  * Per estimate the arithmetic is dmb_epe_accum_f64's. */
 int dmb_epe_accum_multi_f64(int nmaps, const float* const* est, const float* gt, double* acc, double* workspace, int B,
                             int Hp, int Wp, int H0, int W0, float lb, float ub, void* stream);

@@ -38,7 +38,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libdmb_hip.so does not export %s" % s
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and include/dmb_hip.h disagree"
-    assert lib.dmb_abi_version() == 2
+    assert lib.dmb_abi_version() == 3
     assert lib.dmb_conv3d_packed_floats(32, 64) == 32 * 64 * 27
 
 

@@ -502,8 +502,9 @@ def test_epe_accumulate(dev):
 
 def test_epe_accumulate_multi_matches_single(dev):
     """dmb_epe_accum_multi_f64 (the disparity maps of one forward against the same ground truth in one pass) against one
-    dmb_epe_accum_f64 call per map: counts identical, means equal to FP64 rounding of the slice-wise atomic sums (1e-12), over two
-    updates; and through EpeAccumulator.update, which picks the one-pass form for 2 .. 4 maps."""
+    dmb_epe_accum_f64 call per map, over two updates, and through EpeAccumulator.update, which picks the one-pass form for
+    2 .. 4 maps: bit-identical accumulators (no atomics: 64 slice sums per image added in ascending order, images by a fixed
+    butterfly)."""
     ops = _ops()
     from densematchingbenchmark_amd.evaluation import EpeAccumulator
     g = torch.Generator().manual_seed(29)
@@ -520,9 +521,8 @@ def test_epe_accumulate_multi_matches_single(dev):
         for i in range(3):
             ops.epe_accumulate(ed[i], gd, acc_s[i], (21, 37), 0, 192)
         holder.update(ed, gd, (21, 37))
-    assert torch.equal(acc_m[:, 0], acc_s[:, 0]) and acc_m[0, 0].item() == 4
-    assert (acc_m - acc_s).abs().max().item() <= 1e-12 * acc_s.abs().max().item()
-    assert (holder.acc - acc_s).abs().max().item() <= 1e-12 * acc_s.abs().max().item()
+    # slice sums are written, not added atomically, and combined in a fixed order: the three forms agree bit for bit
+    assert acc_m[0, 0].item() == 4 and torch.equal(acc_m, acc_s) and torch.equal(holder.acc, acc_s)
 
 
 # ------------------------------------------------------------------------------------------- 2-D backbone ops
