@@ -25,6 +25,8 @@
 // STATUS: an experiment kept behind development option 11 (tested bit-identical; see deconv3d_w16_try for the measurement).
 #include <type_traits>
 
+#include <mutex>
+
 #include "dmb_common.h"
 
 namespace dmb {
@@ -348,6 +350,8 @@ static W16Ticket w16_ticket(unsigned advance, hipStream_t st) {
   static unsigned basev[64][RING] = {};
   static bool dirty[64][RING] = {};
   static unsigned seq = 0;
+  static std::mutex mu;   // (see zy_ticket)
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u, nullptr};
   if (!ring[dev]) {

@@ -25,6 +25,8 @@
 // other two forms: bit-identical results.
 #include <type_traits>
 
+#include <mutex>
+
 #include "dmb_common.h"
 
 namespace dmb {
@@ -398,6 +400,8 @@ static ZYTicket zy_ticket(unsigned advance, hipStream_t st) {
   static unsigned base[64][RING] = {};
   static bool dirty[64][RING] = {};
   static unsigned seq = 0;
+  static std::mutex mu;   // host threads may share the library: the ring bookkeeping is serialised
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u, nullptr, nullptr};
   if (!ring[dev]) {
