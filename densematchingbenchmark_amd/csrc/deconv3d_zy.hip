@@ -174,13 +174,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
     Tile next_t = cur_t;
     int fetched = 0;
 
-    f32x16 acc[2][C::MT];   // [x parity][column tile]
-#pragma unroll
-    for (int px = 0; px < 2; ++px)
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[px][mt][r] = 0.f;
+    f32x16 acc[2][C::MT];   // [x parity][column tile]; started by the item's first unit (constant 0 operand, see below)
 
 #pragma clang loop unroll(disable)   // (and no peeling of the first chunk: one copy of the multiply loop per class)
     for (int ci = 0; ci < NC; ++ci, ++g) {
@@ -221,11 +215,23 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
         __builtin_amdgcn_sched_barrier(0);
         const auto& fa = af[u & 1];
         const auto& fb = bf[u & 1];
+        if (u == 0 && ci == 0) {
+          // the item's first products start the accumulators from the MFMA's constant 0 operand: no 64 v_mov per item to clear
+          // them (a wave-uniform branch around the first unit only; the loop itself stays one copy per class)
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          acc[0][mt] = DMB_MFMA(fa[1], fb[0][mt], acc[0][mt]);   // even x: kx = 1 from input x
-          acc[1][mt] = DMB_MFMA(fa[2], fb[0][mt], acc[1][mt]);   // odd x:  kx = 2 from input x
-          acc[1][mt] = DMB_MFMA(fa[0], fb[1][mt], acc[1][mt]);   //         kx = 0 from input x + 1
+          for (int mt = 0; mt < C::MT; ++mt) {
+            acc[0][mt] = DMB_MFMA(fa[1], fb[0][mt], zero);
+            acc[1][mt] = DMB_MFMA(fa[2], fb[0][mt], zero);
+            acc[1][mt] = DMB_MFMA(fa[0], fb[1][mt], acc[1][mt]);
+          }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            acc[0][mt] = DMB_MFMA(fa[1], fb[0][mt], acc[0][mt]);   // even x: kx = 1 from input x
+            acc[1][mt] = DMB_MFMA(fa[2], fb[0][mt], acc[1][mt]);   // odd x:  kx = 2 from input x
+            acc[1][mt] = DMB_MFMA(fa[0], fb[1][mt], acc[1][mt]);   //         kx = 0 from input x + 1
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -256,7 +262,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
       const __amdgpu_buffer_rsrc_t rrs = make_rsrc(a.res ? a.res + (size_t)cur_t.b * C::COUT * DHWo : yb, (unsigned)C::COUT * DHWo * 4u);
       const int rl = lane >> 4, x4 = (lane & 15) * 4;
       const float lo = a.relu == 1 ? 0.f : -__builtin_inff();    // ReLU after the residual add
-      const float lo2 = a.relu == 2 ? 0.f : -__builtin_inff();   // ReLU before it (GC-Net)
+      const bool pre_relu = a.relu == 2;                          // ReLU before it (GC-Net)
       constexpr int QP = 32 / C::PCH, KP = C::PCH / 4;          // passes per 32-channel tile, 16-byte words per lane and pass
       constexpr int NPASS = C::MT * QP;
       // Addressing: a word's byte offset = lane part (channel row rl of the pass, 4 consecutive x: ONE register per column
@@ -279,6 +285,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
       };
       const float* affl = aff + wn * 32 + rl;                     // + 8 q + 4 k: immediate offsets
       float* swr = scr + 4 * h * C::SCR_PITCH + 2 * j;           // + rr * pitch
+      const unsigned swr_addr = (unsigned)(uintptr_t)swr;          // LDS byte address (the low 32 bits of the generic pointer)
       const float* srd = scr + rl * C::SCR_PITCH + x4;           // + 4 k * pitch
       auto run = [&](auto has_res) {
         constexpr bool HAS_RES = decltype(has_res)::value;
@@ -297,16 +304,30 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
 #pragma unroll
           for (int rr = 0; rr < C::PCH / 2; ++rr) {
             const int r = q * (C::PCH / 2) + rr;   // accumulator register r of lane half h = channel 8 q + rr + 4 h of the tile
-            *reinterpret_cast<float2*>(swr + rr * C::SCR_PITCH) = make_float2(acc[0][mt][r], acc[1][mt][r]);
+            // ds_write2_b32 by hand: its two data registers need not be adjacent.  Written as an 8-byte (or two adjacent dword)
+            // stores the compiler first copies the pair into adjacent registers -- 128 v_mov per work item, and vector
+            // instructions cost this kernel a sixth of its matrix time (profiles/r03_pmc_hg.log).  LDS operations of a wave
+            // complete in order, so the float4 reads below see these writes; "memory" keeps the compiler from moving them.
+            static_assert((C::PCH / 2 - 1) * C::SCR_PITCH + 1 <= 255, "ds_write2_b32 offsets are 8 bits of dwords");
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4"
+                         :
+                         : "v"(swr_addr), "v"(acc[0][mt][r]), "v"(acc[1][mt][r]), "n"(rr * C::SCR_PITCH), "n"(rr * C::SCR_PITCH + 1)
+                         : "memory");
           }
 #pragma unroll
           for (int k = 0; k < KP; ++k) {
             float4 v = *reinterpret_cast<const float4*>(srd + 4 * k * C::SCR_PITCH);
             const float sc = affl[q * C::PCH + 4 * k], sh = affl[C::COUT + q * C::PCH + 4 * k];
-            v.x = fmaxf(fmaf(v.x, sc, sh), lo2);
-            v.y = fmaxf(fmaf(v.y, sc, sh), lo2);
-            v.z = fmaxf(fmaf(v.z, sc, sh), lo2);
-            v.w = fmaxf(fmaf(v.w, sc, sh), lo2);
+            v.x = fmaf(v.x, sc, sh);
+            v.y = fmaf(v.y, sc, sh);
+            v.z = fmaf(v.z, sc, sh);
+            v.w = fmaf(v.w, sc, sh);
+            if (pre_relu) {   // wave-uniform (GC-Net's ReLU before the skip add): a scalar branch instead of 64 v_max per work item
+              v.x = fmaxf(v.x, 0.f);
+              v.y = fmaxf(v.y, 0.f);
+              v.z = fmaxf(v.z, 0.f);
+              v.w = fmaxf(v.w, 0.f);
+            }
             if constexpr (HAS_RES) {   // (not __builtin_bit_cast on a vector element: this clang reads element 0 for every index)
               v.x += __uint_as_float(rv[sl][k].x);
               v.y += __uint_as_float(rv[sl][k].y);
