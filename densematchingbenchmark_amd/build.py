@@ -53,7 +53,9 @@ def build_library(force=False, verbose=True):
                 print("[dmb build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        # -Bsymbolic: references between the library's own translation units bind inside the library (two builds of it can then
+        # be loaded side by side: scripts/ab_lib.py times a kernel change against the previous build in ONE process on ONE chip)
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB_PATH] + objs
         if verbose:
             print("[dmb build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
