@@ -306,7 +306,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
             const int r = q * (C::PCH / 2) + rr;   // accumulator register r of lane half h = channel 8 q + rr + 4 h of the tile
             // ds_write2_b32 by hand: its two data registers need not be adjacent.  Written as an 8-byte (or two adjacent dword)
             // stores the compiler first copies the pair into adjacent registers -- 128 v_mov per work item, and vector
-            // instructions cost this kernel a sixth of its matrix time (profiles/r03_pmc_hg.log).  LDS operations of a wave
+            // instructions cost this kernel a tenth of its matrix time (profiles/r03_pmc_hg.log: SQ_INSTS_VALU counts the MFMAs too).  LDS operations of a wave
             // complete in order, so the float4 reads below see these writes; "memory" keeps the compiler from moving them.
             static_assert((C::PCH / 2 - 1) * C::SCR_PITCH + 1 <= 255, "ds_write2_b32 offsets are 8 bits of dwords");
             asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4"
