@@ -1,5 +1,5 @@
 """Development aid: run ONE layer of the cost path a few times (for rocprofv3 counter passes).
-    python scripts/kcase.py deconv6|deconv5|s2_1|s2_3|s1q|s1f|s1h|c1|gwc|tri [reps]"""
+    python scripts/kcase.py deconv6|deconv5|s2_1|s2_3|s1q|s1f|s1h|c1|gwc|tri|c2d32|c2d64|c2d128 [reps]"""
 import os
 import sys
 
@@ -39,6 +39,11 @@ elif name == "tri":
     c = g(B, D, H, W)
     vals = ops.disp_sample_values(192, 0, 1)
     fn = lambda: ops.trilinear_ac_soft_argmin(c, (192, 544, 960), vals, 1.0)
+elif name in ("c2d64", "c2d128", "c2d32"):   # backbone layers (8 images): layer2 64 -> 64 at 1/4, layer3 128 -> 128 at 1/4, layer1 32 -> 32 at 1/2
+    C, h, w = {"c2d64": (64, H, W), "c2d128": (128, H, W), "c2d32": (32, 2 * H, 2 * W)}[name]
+    x, wp2 = g(8, C, h, w), ops.pack_conv2d_weights(g(C, C, 3, 3) * 0.05)
+    sc, sh = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    fn = lambda: ops.conv2d(x, wp2, C, 3, 1, 1, sc, sh, None, True)
 else:
     raise SystemExit("unknown case " + name)
 for _ in range(reps):

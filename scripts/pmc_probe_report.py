@@ -18,7 +18,7 @@ for path in sorted(glob.glob(os.path.join(root, "g*", "**", "*counter_collection
         for c, v in cs.items():
             vals[names[d]][c].append(v)
 for k, cs in vals.items():
-    if not any(s in k for s in ("conv3d", "deconv3d", "trilinear", "volume", "soft_argmin", "gwc", "conv_c1")):
+    if not any(s in k for s in ("conv3d", "deconv3d", "trilinear", "volume", "soft_argmin", "gwc", "conv_c1", "conv2d_kernel")):
         continue
     print(k)
     for c, v in cs.items():
