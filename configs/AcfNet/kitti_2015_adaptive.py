@@ -1,0 +1,28 @@
+# AcfNet (adaptive unimodal cost filtering) at the KITTI operating point: 375x1242 padded to 384x1248 (reference
+# configs/AcfNet/kitti_2015_adaptive.py:145-162).  Same model block as scene_flow_adaptive.py.
+import os, runpy
+_c = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_common.py"))
+task = 'stereo'
+max_disp = 192
+model = dict(
+    meta_architecture="GeneralizedStereoModel",
+    max_disp=max_disp,
+    batch_norm=True,
+    backbone=dict(type="PSMNet", in_planes=3),
+    cost_processor=dict(
+        type='Concatenation',
+        cost_computation=_c['volume']("default", max_disp, 4),
+        cost_aggregator=dict(type="AcfNet", max_disp=max_disp, in_planes=64),
+    ),
+    cmn=dict(num=3, alpha=1.0, beta=1.0, in_planes=max_disp,
+             losses=dict(nll_loss=dict(max_disp=max_disp, start_disp=0, weight=8.0, weights=(1.0, 0.7, 0.5)))),
+    disp_predictor=_c['predictor']('FASTER', max_disp),
+    losses=dict(
+        focal_loss=dict(max_disp=max_disp, start_disp=0, dilation=1, weight=1.0, weights=(1.0, 0.7, 0.5), coefficient=5.0),
+        l1_loss=dict(max_disp=max_disp, weight=0.1, weights=(1.0, 0.7, 0.5)),
+    ),
+    eval=_c['evaluation'](max_disp),
+)
+data = dict(sparse=True, eval=dict(input_shape=[384, 1248], original_shape=[375, 1242]))
+eval_disparity_id = [0, 1, 2]
+dist_params = dict(backend='nccl')

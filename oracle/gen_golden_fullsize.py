@@ -7,6 +7,7 @@ files at the sizes the CPU suite can afford).
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py          (about five minutes on 8 cores)
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py round3   (only the families added in round 3)
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py kitti    (round 4: the reference's KITTI operating point)
 
 Round 3 added (parity): PSMNet pair 0 at classifier gain 30 (fullsize_psmnet_gain30.npz); one FULL AcfNet
 disparity / confidence map instead of every 64th pixel (fullsize_acfnet_map.npz); and the regression tail -- trilinear x4
@@ -94,11 +95,89 @@ def round3():
                             cost_rows=G.npy(full[CROWS]))
 
 
+def kitti():
+    """Round 4: the reference's PUBLISHED operating point for PSMNet / AcfNet -- KITTI, 384x1248
+    (configs/PSMNet/kitti_2015.py:113,122,129; configs/PSMNet/ResultOfPSMNet.md:15-19: 384x1248, 599 ms) -- through the
+    reference's OWN KITTI config files: features [1, 32, 96, 312], 48 disparity samples at 1/4 resolution.  Stored: the sampled
+    maps and cost rows of every level, plus the FULL best-level disparity map of PSMNet (479 232 pixels).  Also the full
+    best-level map of PSMNet pair 0 at 544x960 (a whole map, not every 64th pixel)."""
+    from dmb.modeling.stereo.cost_processors import build_cost_processor
+    from dmb.modeling.stereo.disp_predictors import build_disp_predictor
+    from dmb.modeling.stereo.cmn.cmn import Cmn, ConfHead
+    from densematchingbenchmark_amd import synthetic
+
+    crows = (slice(None), slice(7, None, 48), slice(11, None, 24), slice(None))   # costs [1, 192, 384, 1248] -> 4 planes x 16 rows
+    with torch.no_grad():
+        cfg = G.load_cfg("configs/PSMNet/kitti_2015.py")
+        assert list(cfg.data.eval.input_shape) == [384, 1248]
+        m = _M()
+        m.cost_processor = build_cost_processor(cfg)
+        m.disp_predictor = build_disp_predictor(cfg)
+        m.eval()
+        synthetic.init_params_(m, seed=0, classif_gain=10.0)
+        out = {}
+        for i in range(2):
+            lf, rf = synthetic.feature_pair(i, 32, 96, 312)
+            costs = m.cost_processor(lf, rf)
+            disps = [m.disp_predictor(c) for c in costs]
+            for lvl, (d, c) in enumerate(zip(disps, costs)):
+                out["pair%d_disp%d" % (i, 3 - lvl)] = G.npy(d[SUB])
+                if i == 0:
+                    out["pair0_cost%d_rows" % (3 - lvl)] = G.npy(c[crows])
+            if i == 0:
+                out["pair0_disp3_full"] = G.npy(disps[0])
+            print("psmnet kitti pair", i, "disp3 range %.2f..%.2f" % (disps[0].min().item(), disps[0].max().item()), flush=True)
+            del costs, disps
+        np.savez_compressed(os.path.join(OUT, "fullsize_psmnet_kitti.npz"), **out)
+
+        cfg = G.load_cfg("configs/AcfNet/kitti_2015_adaptive.py")
+        assert list(cfg.data.eval.input_shape) == [384, 1248]
+        m = _M()
+        m.cost_processor = build_cost_processor(cfg)
+        m.disp_predictor = build_disp_predictor(cfg)
+        m.cmn = Cmn.__new__(Cmn)
+        torch.nn.Module.__init__(m.cmn)
+        m.cmn.conf_heads = torch.nn.ModuleList([ConfHead(cfg.model.cmn.in_planes, True) for _ in range(3)])
+        m.cmn.alpha, m.cmn.beta = cfg.model.cmn.alpha, cfg.model.cmn.beta
+        m.eval()
+        synthetic.init_params_(m, seed=5, classif_gain=10.0)
+        lf, rf = synthetic.feature_pair(0, 32, 96, 312)
+        costs = m.cost_processor(lf, rf)
+        disps = [m.disp_predictor(c) for c in costs]
+        confs, cost_vars, _ = Cmn.get_confidence(m.cmn, costs)
+        out = {}
+        for lvl in range(3):
+            out["disp%d" % (3 - lvl)] = G.npy(disps[lvl][SUB])
+            out["conf%d" % (3 - lvl)] = G.npy(confs[lvl][SUB])
+            out["var%d" % (3 - lvl)] = G.npy(cost_vars[lvl][SUB])
+            out["cost%d_rows" % (3 - lvl)] = G.npy(costs[lvl][crows])
+        print("acfnet kitti disp3 range %.2f..%.2f conf3 range %.3f..%.3f" % (disps[0].min().item(), disps[0].max().item(),
+                                                                           confs[0].min().item(), confs[0].max().item()), flush=True)
+        np.savez_compressed(os.path.join(OUT, "fullsize_acfnet_kitti.npz"), **out)
+        del costs, disps, confs, cost_vars
+
+        # ---- the WHOLE best-level map of PSMNet pair 0 at 544x960 (the sampled fixture holds every 64th pixel) -------------
+        cfg = G.load_cfg("configs/PSMNet/scene_flow.py")
+        m = _M()
+        m.cost_processor = build_cost_processor(cfg)
+        m.disp_predictor = build_disp_predictor(cfg)
+        m.eval()
+        synthetic.init_params_(m, seed=0, classif_gain=10.0)
+        lf, rf = synthetic.feature_pair(0, 32, 136, 240)
+        costs = m.cost_processor(lf, rf)
+        d3 = m.disp_predictor(costs[0])
+        np.savez_compressed(os.path.join(OUT, "fullsize_psmnet_map.npz"), disp3=G.npy(d3))
+        print("psmnet full map: disp3 range %.2f..%.2f" % (d3.min().item(), d3.max().item()), flush=True)
+
+
 def main():
     G.import_reference()
     torch.set_num_threads(int(os.environ.get("DMB_THREADS", "8")))
     if "round3" in sys.argv[1:]:
         round3()
+        return
+    if "kitti" in sys.argv[1:]:
+        kitti()
         return
     from dmb.modeling.stereo.cost_processors import build_cost_processor
     from dmb.modeling.stereo.disp_predictors import build_disp_predictor
@@ -165,6 +244,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, "fullsize_stereonet.npz"), disp=G.npy(d), cost=G.npy(costs[0][:, :, 1::2, :]))
         print("stereonet disp range %.2f..%.2f" % (d.min().item(), d.max().item()), flush=True)
     round3()
+    kitti()
     for f in sorted(os.listdir(OUT)):
         if f.startswith("fullsize"):
             print("%-28s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
