@@ -12,13 +12,18 @@ import re
 import torch  # imported first on purpose: the library then binds to the HIP runtime torch already loaded
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libdmb_hip.so")
+# DMB_LIB=dev (development scripts only): the build with the kernel-variant switches, lib/libdmb_hip_dev.so (build.py dev=True)
+DEV_BUILD = os.environ.get("DMB_LIB", "") == "dev"
+LIB_PATH = os.path.join(_PKG, "lib", "libdmb_hip_dev.so" if DEV_BUILD else "libdmb_hip.so")
+DECONV3D_WORKSPACE_BYTES = 64   # include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dmb_hip.h")
 
 _c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 _P = _c_void_p  # device pointer
 _HI = ctypes.POINTER(ctypes.c_int)  # host int array
 _HF = ctypes.POINTER(ctypes.c_float)  # host float array
+
+ABI_VERSION = 4
 
 # name -> (restype, argtypes)
 SIGNATURES = {
@@ -44,9 +49,7 @@ SIGNATURES = {
     "dmb_deconv3d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conv3d_k3_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 8 + [_P]),
     "dmb_conv3d_k3_c1_f32": (_c_int, [_P, _P, _c_float, _P, _P] + [_c_int] * 5 + [_P]),
-    "dmb_conv3d_k3_c1_multi_f32": (_c_int, [_c_int, _P, _P, _P, _P] + [_c_int] * 5 + [_P]),
-    "dmb_cost_chain_f32": (_c_int, [_P, _c_int, _c_ll, _P]),
-    "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 7 + [_P]),
+    "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 7 + [_P, _P]),
     "dmb_trilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),
     "dmb_deconv3d_k8s4_c1_f32": (_c_int, [_P, _P, _P] + [_c_int] * 4 + [_P]),
     "dmb_deconv3d_k8s4_c1_soft_argmin_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 4 + [_c_float, _HF, _P]),
@@ -130,6 +133,12 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.dmb_abi_version() != ABI_VERSION:
+        raise DmbLibraryError("%s reports ABI version %d, this binding is written for %d: rebuild it (python -m "
+                              "densematchingbenchmark_amd.build)" % (LIB_PATH, lib.dmb_abi_version(), ABI_VERSION))
+    if DEV_BUILD:
+        lib.dmb_dev_set_option.restype = None
+        lib.dmb_dev_set_option.argtypes = [_c_int, _c_int]
     _lib = lib
     return lib
 

@@ -14,7 +14,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmb_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip", "path_bwd.hip", "catconv.hip", "warp_volume.hip", "deconv3d_zy.hip", "deconv3d_w16.hip", "spn.hip"]
+SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip", "path_bwd.hip", "catconv.hip", "warp_volume.hip", "deconv3d_zy.hip", "spn.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # warp_volume.hip restates the reference's FP32 sampler arithmetic operation by operation: no fused multiply-adds there
@@ -35,33 +35,45 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
-    """Compile every HIP source for gfx950 and link libdmb_hip.so.  Returns the library path."""
+def build_library(force=False, verbose=True, dev=False):
+    """Compile every HIP source for gfx950 and link libdmb_hip.so.  Returns the library path.
+
+    ``dev=True`` builds the DEVELOPMENT variant instead: the same sources with -DDMB_DEV (kernel-variant switches and diagnostic
+    branches for the A/B measurements of scripts/, reached through ``dmb_dev_set_option``) into lib/libdmb_hip_dev.so.  Nothing in
+    the package, the tests or bench.py loads it (scripts select it with DMB_LIB=dev); __graft_entry__.build() does not build it."""
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()
+    lib_path = os.path.join(LIB_DIR, "libdmb_hip_dev.so") if dev else LIB_PATH
+    suffix, extra = (".dev.o", ["-DDMB_DEV"]) if dev else (".o", [])
     headers = [os.path.join(CSRC, "dmb_common.h"), os.path.join(CSRC, "interp.h"), os.path.join(INCLUDE, "dmb_hip.h")]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             raise FileNotFoundError("libdmb_hip.so source listed in build.SOURCES is missing: %s" % sp)
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + suffix)
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
+            cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + extra + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
+            jobs.append(cmd)
+    if jobs:   # the translation units are independent: compile them side by side (bounded by the host's cores)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[dmb build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(LIB_PATH, objs):
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+            list(pool.map(run, jobs))
+    if force or _stale(lib_path, objs):
         # -Bsymbolic: references between the library's own translation units bind inside the library (two builds of it can then
-        # be loaded side by side: scripts/ab_lib.py times a kernel change against the previous build in ONE process on ONE chip)
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB_PATH] + objs
+        # be loaded side by side in one process)
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", lib_path] + objs
         if verbose:
             print("[dmb build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(LIB_PATH)
+    print(build_library(force="--force" in sys.argv, dev="--dev" in sys.argv))

@@ -489,17 +489,6 @@ __global__ __launch_bounds__(256) void bilinear_hp_kernel(const float* __restric
   y[(((size_t)b * out_ctot + out_coff + c) * Ho + yo) * Wo + xo] = fmaf(a1, ly, a0 * (1.f - ly)) * mult;
 }
 
-static int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
-
 template <class C>
 static int launch_conv2d(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                          float* y, int B, int Ci, int Co, int H, int W, int relu, int in_ctot, int out_ctot,
@@ -527,7 +516,7 @@ static int launch_conv2d_auto(const float* x, const float* wp, const float* scal
   const long long slots = 2LL * num_cus();
   const long long t4 = (long long)B * cdiv(W, C4::TX) * cdiv(H, C4::TY), t2 = (long long)B * cdiv(W, C2::TX) * cdiv(H, C2::TY);
   const long long cost4 = ((t4 + slots - 1) / slots) * C4::RY, cost2 = ((t2 + slots - 1) / slots) * C2::RY;
-  if (cost2 < cost4 && !g_dev_opts[18])   // (development option 18: always the default height)
+  if (cost2 < cost4 && !DMB_OPT(18))   // (development option 18: always the default height)
     return launch_conv2d<C2>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
   return launch_conv2d<C4>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
 }
@@ -591,7 +580,7 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
   hipStream_t st = (hipStream_t)stream;
   // vector path: every row of x, y and residual starts on a 16-byte boundary
   const int Wo_ = (W - 1) / stride + 1;
-  const bool v16 = W % 4 == 0 && Wo_ % 4 == 0 && !g_dev_opts[3] &&
+  const bool v16 = W % 4 == 0 && Wo_ % 4 == 0 && !DMB_OPT(3) &&
                    (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
 #define DMB_C2(N, K, DL, S)                                                                                           \
   return v16 ? launch_conv2d<C2Cfg<N, K, DL, S, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu,     \
@@ -669,7 +658,7 @@ extern "C" int dmb_conf_phase_conv2d_f32(const float* c, const float* wpack, con
   if ((long long)Ci * Hq * Wq * 4 >= 0x7fffffffLL || (long long)16 * Hq * Wq * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "conf_phase_conv2d: one batch item must stay below 2 GiB");
   hipStream_t st = (hipStream_t)stream;
-  const bool v16 = Wq % 4 == 0 && !g_dev_opts[3] && (((uintptr_t)c) & 15) == 0;
+  const bool v16 = Wq % 4 == 0 && !DMB_OPT(3) && (((uintptr_t)c) & 15) == 0;
   // (`res` carries the 64 dot weights, `y` the confidence map, `res_ctot` the number of weight sets: see C2Cfg::DOT)
   return v16 ? launch_conv2d<C2Cfg<4, 3, 1, 1, true, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, 0, nsets, st)
              : launch_conv2d<C2Cfg<4, 3, 1, 1, false, true>>(c, wpack, scale, shift, w2, conf, B, Ci, 128, Hq, Wq, 1, Ci, 0, nsets, st);

@@ -193,9 +193,10 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
                                                            const float* __restrict__ res, float* __restrict__ y, int Ci,
                                                            int D, int H, int W, int ntx, int nty, int ntz, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk, 32 = no barrier in the chunk loop
-  const int dbg = (relu >> 8) & 0xff;
-  const int stg = relu >> 16;           // development: start-up stagger unit (g_dev_opts[14])
+  // development build only (DMB_DBG is the constant 0 in the release build: these branches do not exist there) -- diagnostics
+  // (option 6): 1 = no stores, 2 = no staging after the first chunk, 32 = no barrier in the chunk loop; option 14: start-up stagger
+  const int dbg = DMB_DBG((relu >> 8) & 0xff);
+  const int stg = DMB_DBG(relu >> 16);
   relu &= 0xff;
   if (stg > 0 && blockIdx.x < 256u * C::WPE) {
     // the first round's workgroups of a CU start together: delay them by their slot on the CU (HW_ID.TG_ID) x stg x 3.4 us so that
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::WPE * C::WM) void conv3d_s2_kernel(
   const int tz = t % ntz;
   const int b = t / ntz;
   const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;  // output coordinates
-  const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
+  const int dbg = DMB_DBG(relu >> 8);   // development build only (option 6): 1 = no stores, 2 = no staging after the first chunk
   relu &= 0xff;
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -778,7 +779,7 @@ __device__ __forceinline__ void deconv_body(float* lds, const float* __restrict_
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + stride - 1) / stride;
-  const int dbg = relu >> 8;   // development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging after the first chunk
+  const int dbg = DMB_DBG(relu >> 8);   // development build only (option 6)
   relu &= 0xff;
 
   struct Tile {
@@ -1286,22 +1287,10 @@ __device__ __forceinline__ float dpp_row_shl1(float v) {   // lane i <- lane i +
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
 
-// MULTI: several heads in one launch (PSMNet's three classifiers: 3 x 1632 workgroups fill the 512 slots in 9.6 rounds instead of
-// three times 3.2, the last of each a fifth full): batch item b of the stacked output belongs to job b / bper, which names its own
-// input, weights and bias; no skip operand (the cumulative cost sums are a separate pass over the three small outputs).
-constexpr int C1_MAXJOBS = 4;
-struct C1Jobs {
-  const float* x[C1_MAXJOBS];
-  const float* w[C1_MAXJOBS];
-  float bias[C1_MAXJOBS];
-  int bper;
-};
-
-template <bool MULTI>
 __global__ __launch_bounds__(256, 2) void conv3d_c1v_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float bias, const float* __restrict__ res,
                                                             float* __restrict__ y, int Ci, int D, int H, int W, int ntx,
-                                                            int nty, int ntz, C1Jobs jobs) {
+                                                            int nty, int ntz) {
   __shared__ __attribute__((aligned(16))) float tile[C1V_ZS * C1V_ROWS * C1V_P];
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % ntx;
@@ -1312,15 +1301,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1v_kernel(const float* __restr
   const int b = t / ntz;
   const int x0 = tx * C1V_TX, y0 = ty * C1V_TY, z0 = tz * C1V_TZ;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
-  int bx = b;                         // batch item within its input
-  if constexpr (MULTI) {
-    const int job = b / jobs.bper;
-    bx = b - job * jobs.bper;
-    x = jobs.x[job];
-    w = jobs.w[job];
-    bias = jobs.bias[job];
-  }
-  const float* xb = x + (size_t)bx * Ci * DHW;
+  const float* xb = x + (size_t)b * Ci * DHW;
   const int tid = threadIdx.x;
   const int lq = tid & 15;            // word of the row: columns 4 lq .. 4 lq + 3 of the staged row = x0 - 4 + 4 lq ...
   const int lyp = (tid >> 4) & 3;     // output rows y0 + 2 lyp, + 1
@@ -1438,17 +1419,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1v_kernel(const float* __restr
 // channels ascending -- identical to the MFMA kernels' k order up to their channel pairing.
 
 static long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
-static int s1_num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
-
 template <class C>
 static int launch_s1(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
                      float* y, int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
@@ -1456,8 +1426,8 @@ static int launch_s1(const float* x, const float* wp, const float* scale, const 
   const long long nblk = (long long)B * ntx * nty * ntz;
   if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   // (development option 17: extra KB of LDS per workgroup -- fewer workgroups per CU, for occupancy experiments)
-  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + (size_t)g_dev_opts[17] * 1024;
-  if (g_dev_opts[17]) {   // the experiment raises the cap itself (DMB_ENSURE_LDS sets it once, to the kernel's own need)
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + (size_t)DMB_OPT(17) * 1024;
+  if (DMB_OPT(17)) {   // the experiment raises the cap itself (DMB_ENSURE_LDS sets it once, to the kernel's own need)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_s1_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
@@ -1495,15 +1465,7 @@ static int launch_deconv(const float* x, const float* wp, const float* scale, co
   if (ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
   const size_t lds = (size_t)(C::LDS_FLOATS + C::AFF_FLOATS + C::SCR_FLOATS) * sizeof(float);
   DMB_ENSURE_LDS((&deconv3d_kernel<C>), (size_t)(lds));
-  static int ncu = 0;
-  if (!ncu) {
-    
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-  }
+  const int ncu = num_cus();
   // persistent grid: C::WPE workgroups per CU; a third of them walk the even-z items, two thirds the odd-z items
   // (twice the work each).  With fewer items than slots every workgroup gets exactly one item.
   const long long slots = (long long)C::WPE * ncu;
@@ -1552,8 +1514,37 @@ extern "C" int dmb_conv3d_pack_dgrad_weights_f32(const float* w, float* wpack, i
   return pack_common(w, wpack, Ci, Co, 2, stream);   // a convolution Co -> Ci
 }
 
-// Tile choice for the stride-1 kernel.  Row-pair tiles (TX = 48) when W is a multiple of 48: nothing is discarded.
-// Otherwise the flattened mapping with the TX (60 or 52) that wastes fewer columns for this W.
+// ---- Tile choice for the stride-1 kernel ---------------------------------------------------------------------------
+// Every row-group tile shape works for ANY volume with 16-byte rows (W % 4 == 0, aligned bases): partial tiles are zero-filled
+// by the staging's bounds checks and masked in the epilogue.  Which one runs is a cost estimate over the instantiated shapes --
+// rounds of workgroups the launch needs on this chip x resident workgroups per CU x the matrix work of one workgroup -- not a
+// table of image widths: e.g. 240 columns -> 48-column row pairs (5 tiles, nothing discarded), 312 columns (KITTI, 1248 / 4) ->
+// 24-column row quads of 8 rows (13 tiles, nothing discarded), 156 -> 40-column row quads (4 tiles, 2.5 % discarded).
+// Without 16-byte rows: the flattened mapping (dword staging) with the TX (60 or 52) that wastes fewer columns.
+struct S1Tile {
+  int tx, ty, tz, mt, wpe;   // tile extent, 32-voxel column tiles per wave, workgroups per CU
+  bool lin;                  // 64-voxel runs of the (y, x) plane instead of boxes
+};
+static double s1_cost(const S1Tile& t, int B, int D, int H, int W) {
+  const long long n = t.lin ? (long long)B * cdiv(D, t.tz) * cdiv(H * W, 64)
+                            : (long long)B * cdiv(D, t.tz) * cdiv(H, t.ty) * cdiv(W, t.tx);
+  const long long slots = (long long)t.wpe * num_cus();
+  // a round of `wpe` co-resident workgroups shares the CU's matrix cores; + 0.5: set-up and epilogue of a workgroup in units of
+  // one column tile's arithmetic (launches here are 1 .. 15 rounds deep, so the last, partly filled round matters)
+  return (double)cdiv_ll(n, slots) * t.wpe * (t.mt + 0.5);
+}
+// index of the cheapest candidate (ties: the earlier one); DMB_OPT(19) = k > 0 forces candidate k - 1 (development build)
+static int s1_pick(const S1Tile* cand, const bool* ok, int n, int B, int D, int H, int W) {
+  if (DMB_OPT(19) > 0 && DMB_OPT(19) <= n && ok[DMB_OPT(19) - 1]) return DMB_OPT(19) - 1;
+  int best = -1;
+  double bc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (!ok[i]) continue;
+    const double c = s1_cost(cand[i], B, D, H, W);
+    if (best < 0 || c < bc) best = i, bc = c;
+  }
+  return best;
+}
 static int flat_tx(int W) {
   const int w60 = cdiv(W, 60) * 60, w52 = cdiv(W, 52) * 52;
   // useful fraction = W / padded width * (TX / (TX + 2)) * (TY*P / (MT*32))
@@ -1570,56 +1561,65 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     return fail(DMB_EUNSUPPORTED, "conv3d: 8 channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   const bool out_small = (long long)Co * D * H * W * 4 < 0x7fffffffLL;   // the vector epilogue addresses the whole output item
   hipStream_t st = (hipStream_t)stream;
-  relu |= (g_dev_opts[6] & 0xff) << 8;   // development diagnostics (see the kernels)
-  const int relu_s1 = relu | (g_dev_opts[14] << 16);   // stride-1 kernels: + start-up stagger unit
-#define DMB_S1(CO, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, 4, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st)
+  relu &= 0xff;
+  relu |= (DMB_OPT(6) & 0xff) << 8;                    // (development build: diagnostics, see the kernels)
+  const int relu_s1 = relu | (DMB_OPT(14) << 16);      // (development build: start-up stagger unit of the stride-1 kernels)
+#define DMB_S1(CO, TY, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, TY, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st)
   if (stride == 1) {
-    const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;   // 16-byte rows for the vector path
-    const bool rp = (W % 48 == 0) && g_dev_opts[2] == 0 && aligned && out_small;
+    // the vector path: 16-byte rows for staging, skip operand and stores
+    const bool vec = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 && out_small && DMB_OPT(2) == 0;
     const int tx = flat_tx(W);
     if (Co == 32) {
-      if (g_dev_opts[0] == 0) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
-      if (rp) return DMB_S1(32, 48, 1, 16, 0);
-      // widths of the training crops (512 / 4 = 128) and other multiples of 32: 32-column row-pair tiles, nothing discarded
-      if (W % 32 == 0 && g_dev_opts[2] == 0 && aligned && out_small) return DMB_S1(32, 32, 1, 16, 0);
-      return tx == 52 ? DMB_S1(32, 52, 1, 0, 0) : DMB_S1(32, 60, 1, 0, 0);
+#ifdef DMB_DEV
+      if (DMB_OPT(0) == 1) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
+#endif
+      if (vec) {
+        // row pairs (16 columns x 2 rows per 32-voxel column tile) of 48 or 32 columns x 4 rows, row quads (8 x 4) of 24 columns x 8
+        // rows; one z-slice per wave, three workgroups per CU each
+        static const S1Tile cand[3] = {{48, 4, 4, 6, 3, false}, {24, 8, 4, 6, 3, false}, {32, 4, 4, 4, 3, false}};
+        const bool ok[3] = {true, true, true};
+        switch (s1_pick(cand, ok, 3, B, D, H, W)) {
+          case 0: return DMB_S1(32, 4, 48, 1, 16, 0);
+          case 1: return DMB_S1(32, 8, 24, 1, 8, 40);
+          default: return DMB_S1(32, 4, 32, 1, 16, 0);
+        }
+      }
+      return tx == 52 ? DMB_S1(32, 4, 52, 1, 0, 0) : DMB_S1(32, 4, 60, 1, 0, 0);
     }
     if (Co == 64) {
-      // row quads (8 columns x 4 rows) of 40-column tiles: no discarded halo columns and 5/8 of the flattened tile's
-      // work per workgroup, which at half resolution (W = 120) also quantises better over the 512 workgroup slots
-      // of which two widths exist: 40 and 24.  A launch here is only a few "rounds" of workgroups deep (W = 120, batch
-      // 4: 2448 tiles of 40 columns on 2 x 256 slots = 4.8 rounds, measured 128 TF/s; 4080 tiles of 24 = 7.97 rounds, 145
-      // TF/s), so the width is picked per launch by rounds x columns.
-      // quarter resolution of the BASELINE shape (W = 60): 64-voxel runs, exactly three equal workgroups per CU (see S1Cfg)
-      if (aligned && out_small && g_dev_opts[2] == 0 && g_dev_opts[13] == 0 && W == 60 && (H * W) % 4 == 0)
-        return launch_s1<S1Cfg<0, 64, 3, 60, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
-      if (aligned && out_small && g_dev_opts[2] == 0 && (W % 40 == 0 || W % 24 == 0 || W % 32 == 0)) {
-        const long long per = (long long)B * cdiv(D, 2) * cdiv(H, 4), slots = 3LL * s1_num_cus();   // 3 workgroups per CU
-        const long long c40 = W % 40 == 0 ? cdiv_ll(per * (W / 40), slots) * 40 : (1LL << 60);
-        const long long c32 = W % 32 == 0 ? cdiv_ll(per * (W / 32), slots) * 32 : (1LL << 60);
-        const long long c24 = W % 24 == 0 ? cdiv_ll(per * (W / 24), slots) * 24 : (1LL << 60);
-        if (c24 < c40 && c24 <= c32) return DMB_S1(64, 24, 2, 8, 40);
-        if (c32 < c40) return DMB_S1(64, 32, 2, 8, 40);   // (training crops: W = 64 at half resolution)
-        return DMB_S1(64, 40, 2, 8, 56);
+      if (vec) {
+        // 64-voxel runs of the plane in memory order for rows of up to 64 voxels (planes no box tiling fills the chip with: the
+        // deepest hourglass level), row quads of 40 / 24 / 32 columns x 4 rows otherwise; two z-slices x two channel tiles per
+        // workgroup.  A launch here is only a few rounds of workgroups deep, so the estimate decides per launch.
+        static const S1Tile cand[4] = {{64, 3, 2, 2, 3, true}, {40, 4, 2, 5, 3, false}, {24, 4, 2, 3, 3, false}, {32, 4, 2, 4, 3, false}};
+        const bool ok[4] = {W >= 32 && W <= 64 && (H * W) % 4 == 0 && DMB_OPT(13) == 0, true, true, true};
+        switch (s1_pick(cand, ok, 4, B, D, H, W)) {
+          case 0: return launch_s1<S1Cfg<0, 64, 3, 64, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
+          case 1: return DMB_S1(64, 4, 40, 2, 8, 56);
+          case 2: return DMB_S1(64, 4, 24, 2, 8, 40);
+          default: return DMB_S1(64, 4, 32, 2, 8, 40);
+        }
       }
-      return tx == 52 ? DMB_S1(64, 52, 2, 0, 0) : DMB_S1(64, 60, 2, 0, 0);
+      return tx == 52 ? DMB_S1(64, 4, 52, 2, 0, 0) : DMB_S1(64, 4, 60, 2, 0, 0);
     }
     if (Co == 128)   // GC-Net's deepest level: 2 waves x 2 row tiles, 2-row tiles keep the accumulators at 160 registers
       return launch_s1<S1Cfg<0, 128, 2, 60, 2, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
   } else if (stride == 2) {
-    const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned input rows
+    const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !DMB_OPT(3);   // 16-byte aligned input rows
     if (Co == 64 && v16) {
       // output positions computed per tile row: 32 with 30-column tiles, 24 with 22-column ones; the narrower tile wins at
       // the training-crop widths (Wo = 64: 3 x 96 against 3 x 128 positions per 4 rows, Wo = 32: 2 x 96 against 2 x 128)
       const int Wo = (W - 1) / 2 + 1;
       if (cdiv(Wo, 22) * 96 < cdiv(Wo, 30) * 128)
         return launch_s2<S2Cfg<0, 64, 4, 22, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
-      if (g_dev_opts[10] == 1)   // A/B: four-wave workgroups
+#ifdef DMB_DEV
+      if (DMB_OPT(10) == 1)   // A/B: four-wave workgroups
         return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+#endif
       // 8-byte epilogue: W % 4 == 0 makes Wo even; the output (and skip operand) base must be 8-byte aligned and one batch item
       // of the output addressable with 32-bit byte offsets
       const bool pair_ok = ((((uintptr_t)y | (uintptr_t)residual) & 7) == 0) && (long long)Co * ((D - 1) / 2 + 1) * ((H - 1) / 2 + 1) * Wo * 4 < 0x7fffffffLL;
-      if (pair_ok && g_dev_opts[10] != 2)   // (A/B: 10 = 2 keeps the dword epilogue)
+      if (pair_ok && DMB_OPT(10) != 2)   // (A/B: 10 = 2 keeps the dword epilogue)
         return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
       return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
     }
@@ -1633,22 +1633,21 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
 
 extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                      const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
-                                     int relu, void* stream) {
+                                     int relu, void* workspace, void* stream) {
   if (!x || !wpack || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv3d: bad argument");
   if ((long long)8 * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "deconv3d: 8 input channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
-  relu |= g_dev_opts[6] << 8;
-  if (!g_dev_opts[3] && !g_dev_opts[7]) {   // three workgroups per CU where the shape admits it (csrc/deconv3d_zy.hip)
-    int rc = deconv3d_w16_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);   // many tiles per CU
-    if (rc != -1) return rc;
-    rc = deconv3d_zy_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, st);
+  relu &= 0xff;
+  relu |= DMB_OPT(6) << 8;   // (development build: diagnostics)
+  if (workspace && !DMB_OPT(3) && !DMB_OPT(7)) {   // three workgroups per CU where the shape admits it (csrc/deconv3d_zy.hip)
+    const int rc = deconv3d_zy_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, static_cast<int*>(workspace), st);
     if (rc != -1) return rc;
   }
-  const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !g_dev_opts[3];   // 16-byte aligned rows
+  const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !DMB_OPT(3);   // 16-byte aligned rows
   // 16-byte epilogue: aligned output / residual rows, every channel real, one batch item of the output below 2 GiB
   const bool vepi = v16 && Co % 32 == 0 && ((((uintptr_t)y | (uintptr_t)residual) & 15) == 0) &&
-                    (long long)Co * 8 * D * H * W * 4 < 0x7fffffffLL && !g_dev_opts[7];
+                    (long long)Co * 8 * D * H * W * 4 < 0x7fffffffLL && !DMB_OPT(7);
   // 2 rows x 28 columns per item instead of 1 x 60 where that computes fewer positions (input W = 64: 3 x 32 against
   // 2 x 64 per row; the tile width stays a multiple of 4 for the 16-byte staging)
   const bool narrow = v16 && cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
@@ -1671,78 +1670,13 @@ extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, 
   const size_t lds = (size_t)2 * C1_BUF * sizeof(float);
   DMB_ENSURE_LDS((&conv3d_c1_kernel), (size_t)(lds));
   if ((long long)2 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: tensor too large for 32-bit offsets");
-  if (W % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) && !g_dev_opts[3]) {   // 16-byte rows
+  if (W % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) && !DMB_OPT(3)) {   // 16-byte rows
     const int vx = cdiv(W, C1V_TX), vy = cdiv(H, C1V_TY), vz = cdiv(D, C1V_TZ);
-    hipLaunchKernelGGL(conv3d_c1v_kernel<false>, dim3((unsigned)((long long)B * vx * vy * vz)), dim3(256), 0, (hipStream_t)stream, x, w,
-                       bias, residual, y, Ci, D, H, W, vx, vy, vz, C1Jobs{});
+    hipLaunchKernelGGL(conv3d_c1v_kernel, dim3((unsigned)((long long)B * vx * vy * vz)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, residual, y, Ci, D, H, W, vx, vy, vz);
     return launch_status("conv3d_c1 launch failed");
   }
   hipLaunchKernelGGL(conv3d_c1_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, x, w, bias, residual, y,
                      Ci, D, H, W, ntx, nty, ntz);
   return launch_status("conv3d_c1 launch failed");
-}
-
-// Several 32 -> 1 heads in ONE launch (see conv3d_c1v_kernel<true>): job j convolves x[j] ([B, Ci, D, H, W]) with w[j] ([Ci, 27]) and
-// bias[j] (host array) into items [j B, (j + 1) B) of y ([njobs B, 1, D, H, W]).  Shapes the 16-byte kernel does not take run as
-// njobs launches of dmb_conv3d_k3_c1_f32: same results either way (the kernels are bit-identical).
-extern "C" int dmb_conv3d_k3_c1_multi_f32(int njobs, const float* const* x, const float* const* w, const float* bias, float* y,
-                                          int B, int Ci, int D, int H, int W, void* stream) {
-  if (njobs <= 0 || njobs > C1_MAXJOBS || !x || !w || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0)
-    return fail(DMB_EINVAL, "conv3d_c1_multi: bad argument (1 .. 4 jobs)");
-  const size_t item = (size_t)D * H * W;
-  bool vec = W % 4 == 0 && (((uintptr_t)y) & 15) == 0 && !g_dev_opts[3] && (long long)2 * D * H * W * 4 < 0x7fffffffLL;
-  C1Jobs jobs{};
-  jobs.bper = B;
-  for (int j = 0; j < njobs; ++j) {
-    if (!x[j] || !w[j]) return fail(DMB_EINVAL, "conv3d_c1_multi: null job operand");
-    jobs.x[j] = x[j];
-    jobs.w[j] = w[j];
-    jobs.bias[j] = bias ? bias[j] : 0.f;
-    vec = vec && (((uintptr_t)x[j]) & 15) == 0;
-  }
-  const int vx = cdiv(W, C1V_TX), vy = cdiv(H, C1V_TY), vz = cdiv(D, C1V_TZ);
-  const long long nblk = (long long)njobs * B * vx * vy * vz;
-  if (!vec || nblk > 0x7fffffffLL || g_dev_opts[15]) {   // (development option 15: one launch per head)
-    for (int j = 0; j < njobs; ++j) {
-      const int rc = dmb_conv3d_k3_c1_f32(x[j], w[j], jobs.bias[j], nullptr, y + (size_t)j * B * item, B, Ci, D, H, W, stream);
-      if (rc != DMB_OK) return rc;
-    }
-    return DMB_OK;
-  }
-  hipLaunchKernelGGL(conv3d_c1v_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, 0.f, nullptr,
-                     y, Ci, D, H, W, vx, vy, vz, jobs);
-  return launch_status("conv3d_c1_multi launch failed");
-}
-
-// PSMNet.py:70-72's cumulative costs on a stack of n head outputs: y[j] += y[j - 1] for j = 1 .. n - 1, in place, in that order
-// (cost2 = classif2(out2) + cost1, cost3 = classif3(out3) + cost2: the same FP32 adds the fused skip operand performs).
-__global__ __launch_bounds__(256) void cost_chain_kernel(float* __restrict__ y, int n, long long count4, long long tail0,
-                                                         long long count) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < count4) {
-    float4 v = reinterpret_cast<const float4*>(y)[i];
-    for (int j = 1; j < n; ++j) {
-      float4* p = reinterpret_cast<float4*>(y + (size_t)j * count) + i;
-      const float4 c = *p;
-      v = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
-      *p = v;
-    }
-  } else if (tail0 + (i - count4) < count) {
-    const long long e = tail0 + (i - count4);
-    float v = y[e];
-    for (int j = 1; j < n; ++j) {
-      v = y[(size_t)j * count + e] + v;
-      y[(size_t)j * count + e] = v;
-    }
-  }
-}
-
-extern "C" int dmb_cost_chain_f32(float* y, int n, long long count, void* stream) {
-  if (!y || n <= 0 || count <= 0) return fail(DMB_EINVAL, "cost_chain: bad argument");
-  if (n == 1) return DMB_OK;
-  const bool vec = count % 4 == 0 && (((uintptr_t)y) & 15) == 0;
-  const long long count4 = vec ? count / 4 : 0, tail0 = count4 * 4, threads = count4 + (count - tail0);
-  hipLaunchKernelGGL(cost_chain_kernel, dim3((unsigned)cdiv_ll(threads, 256)), dim3(256), 0, (hipStream_t)stream, y, n, count4, tail0,
-                     count);
-  return launch_status("cost_chain launch failed");
 }

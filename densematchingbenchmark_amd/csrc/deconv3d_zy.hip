@@ -14,9 +14,21 @@
 // The four (z parity, y parity) classes carry 1 : 2 : 2 : 4 of the arithmetic (number of (kz, ky) pairs an output of the
 // class sees).  Each class is its own instantiation of the body -- its own input halo ((TZ + pz) planes x (1 + py) rows),
 // its own channel chunk (16 / 8 / 8 / 4 input channels, so that every class runs 48 MFMAs per wave between two barriers and
-// double-buffers within the same LDS budget) -- and the items of all classes form ONE list, heaviest class first, handed
-// out through an atomic counter: a persistent workgroup takes the next item while it multiplies the current one, and the
-// chunk pipeline (LDS-DMA of chunk i + 1 under the MFMAs of chunk i) runs across items of a class.
+// double-buffers within the same LDS budget).  Items are handed out through atomic counters: a persistent workgroup takes the
+// next item while it multiplies the current one, and the chunk pipeline (LDS-DMA of chunk i + 1 under the MFMAs of chunk i)
+// runs across consecutive items of a class.
+//
+// Item order (round 4).  The four classes of a tile stage (almost) the same input voxels.  In one class-major list over the
+// whole layer (round 3) they ran a whole pass over the input apart: every input byte came from HBM four times (counters: 2.7 GB
+// fetched for 1.0 GB of operands).  Now the tiles are split into eight contiguous ranges, one per XCD (a workgroup reads
+// HW_REG_XCC_ID and draws from ITS range's counter first: speed only -- when that range is exhausted it draws from the others,
+// so the result does not depend on where the hardware places workgroups), and inside a range the list goes group by group:
+// RUN consecutive tiles x the four classes, heaviest class first.  The four stagings of a tile then happen on one XCD within
+// a few items of each other and three of them are served by that XCD's L2.
+//
+// The counters live in a caller-provided workspace (include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES, zeroed once by the
+// caller).  The last workgroup to leave resets them, so every launch finds and leaves zeros: nothing is predicted on the
+// host, a launch captured in a HIP graph replays correctly, and the library allocates nothing.
 //
 // Everything else is the design of deconv3d_kernel: A = weights (rows = output channels), B = input voxels, both x
 // parities in one wave so that a lane pair of accumulators is two adjacent outputs; 16-byte LDS-DMA staging; the epilogue
@@ -24,8 +36,6 @@
 // operand, ReLU in the reference's order).  Same FP32 products, same ascending (channel, tap) fma chain per output as the
 // other two forms: bit-identical results.
 #include <type_traits>
-
-#include <mutex>
 
 #include "dmb_common.h"
 
@@ -70,21 +80,47 @@ struct ZYCfg {
   static_assert(LDS_FLOATS * 4 * 3 <= 160 * 1024, "three workgroups per CU");
 };
 
+constexpr int ZY_RUN = 2;     // tiles per group of the item order (DMB_OPT(16) overrides it in the development build)
+constexpr int ZY_PARTS = 8;   // tile ranges = item counters (one per XCD); workspace: [ZY_PARTS] counters, [ZY_PARTS] = workgroups done
+
 struct ZYArgs {
   const float* x;
   const float* wp;
   const float* res;
   float* y;
-  int* counter;
-  unsigned base;   // value of the counter when this launch starts (see zy_ticket)
+  int* ws;       // the caller's workspace: zeros on entry, zeros again when the last workgroup has left
   int Ci, D, H, W, ntx, nty, ntz, ntiles, relu, dbg;
-  int stagger;   // start-up delay unit (see the kernel)
+  int run;       // tiles per group of the item order (>= 1)
+  int nparts;    // tile ranges in use (ZY_PARTS; 1 in the development build's single-list mode)
+  int stagger;   // development build: start-up delay unit (see the kernel)
 };
+
+// Draws the next work item for this workgroup (called by ONE thread): returns cls * ntiles + tile, or 4 * ntiles when every
+// range is exhausted.  `part` = the range to try first (the workgroup's XCD), `skip` = ranges already found exhausted (state of
+// the calling thread).  Range k holds tiles [k q + min(k, r), ...) with q = ntiles / nparts, r = ntiles % nparts; its counter
+// value t names group t / (4 run), and inside the group class-major: (t % (4 run)) / (tiles in the group), heaviest class first.
+__device__ __forceinline__ int zy_draw(const ZYArgs& a, int part, int& skip) {
+  const int q = a.ntiles / a.nparts, r = a.ntiles % a.nparts;
+  for (; skip < a.nparts; ++skip) {
+    int k = part + skip;
+    if (k >= a.nparts) k -= a.nparts;
+    const int nk = q + (k < r ? 1 : 0);
+    if (nk == 0) continue;
+    const unsigned t = (unsigned)__hip_atomic_fetch_add(a.ws + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 4u * (unsigned)nk) {
+      const int g = (int)t / (4 * a.run), first = g * a.run;
+      const int ng = min(a.run, nk - first), rr = (int)t - g * 4 * a.run;
+      const int cls = rr / ng, tile = k * q + min(k, r) + first + (rr - cls * ng);
+      return cls * a.ntiles + tile;
+    }
+  }
+  return 4 * a.ntiles;
+}
 
 // One class: processes `item` and every following item the counter hands out as long as it belongs to the same class;
 // returns the first item that does not (>= 4 * ntiles: the list is exhausted).
 template <class C, int PZ, int PY>
-__device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, int item) {
+__device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, int item, int part, int& skip) {
   using K = typename C::template Cls<PZ, PY>;
   // The four class bodies are inlined into one loop over items: without this barrier the compiler hoists every body's
   // per-lane constants (copy offsets, epilogue lane coordinates) to the kernel entry and keeps all four sets live -- 190
@@ -98,8 +134,8 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   const int Ho = 2 * H, Wo = 2 * W;
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = 2u * D * HWo;
-  constexpr int CLS = 3 - (2 * PZ + PY);   // position of the class in the item list: heaviest first
-  const int hi = (CLS + 1) * a.ntiles;
+  constexpr int CLS = 3 - (2 * PZ + PY);   // class number of the item code cls * ntiles + tile: heaviest first
+  const int lo_item = CLS * a.ntiles, hi = (CLS + 1) * a.ntiles;
   float* aff = lds + 2 * C::BUF_MAX;
 
   struct Tile {
@@ -160,7 +196,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
         dma16(wrs, woff[i], (unsigned)(c0 / 2) * (27 * C::NTT * 64 * 4), buf + K::IN_FLOATS + (i * 256 + wave * 64) * 4);
   };
 
-  const int NC = (a.dbg & 64) ? 2 : Ci / K::CK;   // (development: two chunks per item -- the memory side of an item almost alone)
+  const int NC = DMB_DBG(a.dbg & 64) ? 2 : Ci / K::CK;   // (development: two chunks per item -- the memory side of an item almost alone)
   Tile cur_t = tile_at(item);
   unsigned coff[K::IPC], noff[K::IPC];
   tile_offsets(cur_t, coff);
@@ -169,7 +205,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
   __syncthreads();
   int g = 0;          // chunks consumed so far: selects the LDS buffer
   for (;;) {
-    int next = hi;    // published after the first chunk's barrier
+    int next = 4 * a.ntiles;    // published after the first chunk's barrier
     bool has_next = false;
     Tile next_t = cur_t;
     int fetched = 0;
@@ -180,19 +216,19 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
     for (int ci = 0; ci < NC; ++ci, ++g) {
       const float* cur = lds + (g & 1) * C::BUF_MAX;
       float* nxt = lds + ((g + 1) & 1) * C::BUF_MAX;
-      if (ci == 0 && tid == 0) fetched = (int)((unsigned)atomicAdd(a.counter, 1) - a.base);   // consumed just before this chunk's barrier
+      if (ci == 0 && tid == 0) fetched = zy_draw(a, part, skip);   // consumed just before this chunk's barrier
       // the next chunk's copies (of this item, or the first chunk of the next one) are dealt out over the first SU units
       constexpr int SU = K::NU - 2, PPU = (K::NPIECE + SU - 1) / SU;
       const bool more = ci + 1 < NC;
-      const bool staging = !(a.dbg & 2) && (more || has_next);
+      const bool staging = !DMB_DBG(a.dbg & 2) && (more || has_next);
       const int st_c0 = more ? (ci + 1) * K::CK : 0;
       const __amdgpu_buffer_rsrc_t st_rs = in_rsrc(more ? cur_t : next_t, st_c0);
       unsigned st_off[K::IPC];
 #pragma unroll
       for (int q = 0; q < K::IPC; ++q) st_off[q] = more ? coff[q] : noff[q];
       auto deal = [&](int u) {
-        if (staging && !(a.dbg & 32)) stage(st_rs, st_off, st_c0, nxt, u * PPU, (u + 1) * PPU);
-        if (staging && (a.dbg & 32) && u == 0) stage(st_rs, st_off, st_c0, nxt, 0, K::NPIECE);
+        if (staging && !DMB_DBG(a.dbg & 32)) stage(st_rs, st_off, st_c0, nxt, u * PPU, (u + 1) * PPU);
+        if (staging && DMB_DBG(a.dbg & 32) && u == 0) stage(st_rs, st_off, st_c0, nxt, 0, K::NPIECE);
       };
       const float* abase = cur + K::IN_FLOATS + wn * 64 + lane;
       const float* bbase = cur + h * K::CH_STRIDE + wz * K::PLANE + j;
@@ -239,7 +275,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
       __syncthreads();
       if (ci == 0) {
         next = __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED));   // wave-uniform: tiles, resources and branches derived from it stay scalar
-        has_next = next < hi && !(a.dbg & 16);
+        has_next = next >= lo_item && next < hi && !DMB_DBG(a.dbg & 16);   // the next item continues this class: pipeline across it
         if (has_next) {
           next_t = tile_at(next);
           tile_offsets(next_t, noff);
@@ -253,7 +289,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
     // offset: branch-free).  Residual loads run RD passes ahead of the stores.
     // (g has been advanced past the last chunk: buffer (g & 1) is being filled for the next item, ((g - 1) & 1) is the one
     // just consumed; every wave's reads of it completed before the barrier that ended the chunk loop)
-    if (!(a.dbg & 1)) {
+    if (!DMB_DBG(a.dbg & 1)) {
       float* scr = K::SCR_PRIVATE ? lds + ((g - 1) & 1) * C::BUF_MAX + wave * (K::CPW * K::CH_STRIDE)
                                   : aff + C::AFF_FLOATS + wave * (C::PCH * C::SCR_PITCH);
       const int gzi = cur_t.z0 + wz;
@@ -273,15 +309,15 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) {
         const int lx = mt * 32 + x4 / 2;
-        const bool ok = gzi < D && lx < C::TX && cur_t.x0 + lx < W && !(a.dbg & 4);
-        voff[mt] = ok ? ((a.dbg & 8) ? (unsigned)lane * 16u : ((unsigned)rl * DHWo + (unsigned)(2 * mt * 32 + x4)) * 4u) : DMA_OOB;
+        const bool ok = gzi < D && lx < C::TX && cur_t.x0 + lx < W && !DMB_DBG(a.dbg & 4);
+        voff[mt] = ok ? (DMB_DBG(a.dbg & 8) ? (unsigned)lane * 16u : ((unsigned)rl * DHWo + (unsigned)(2 * mt * 32 + x4)) * 4u) : DMA_OOB;
       }
       const unsigned sbase = ((unsigned)(wn * 32) * DHWo + (unsigned)(2 * gzi + PZ) * HWo + (unsigned)(2 * cur_t.y0 + PY) * Wo +
                               2u * (unsigned)cur_t.x0) * 4u;
       const unsigned sstep = 4u * DHWo * 4u;                      // four channels on
       auto soff = [&](int t, int k) {
         const unsigned o = sbase + (unsigned)((t % QP) * KP + k) * sstep;
-        return (a.dbg & 8) ? (o & 0x1fff80u) : o;   // development: epilogue traffic confined to a 2 MiB window
+        return DMB_DBG(a.dbg & 8) ? (o & 0x1fff80u) : o;   // development: epilogue traffic confined to a 2 MiB window
       };
       const float* affl = aff + wn * 32 + rl;                     // + 8 q + 4 k: immediate offsets
       float* swr = scr + 4 * h * C::SCR_PITCH + 2 * j;           // + rr * pitch
@@ -374,100 +410,65 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* aff = lds + 2 * C::BUF_MAX;
   __shared__ int slot[1];   // the next item, published by thread 0
-  // De-phase the workgroups ACROSS THE CHIP.  All workgroups start together on equal items, so they all reach their
-  // epilogues together: the layer's output and skip traffic arrives as chip-wide bursts during which every workgroup waits
-  // on memory and no CU multiplies, and the memory system idles in between -- the memory phase ADDS to the multiply time
-  // instead of hiding under it.  A start-up delay of (workgroup index mod 16) x stagger x 3.4 us spreads the phases.
+#ifdef DMB_DEV
+  // (development option 12) a start-up delay of (workgroup index mod 16) x stagger x 3.4 us: measured, no gain
   if (a.stagger > 0) {
     const int n = (int)((blockIdx.x * 7u) & 15u) * a.stagger;
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }
+#endif
   // per-channel affine, staged once (LDS reads count on lgkmcnt and cost no registers across the item loop; see
   // deconv3d_kernel)
   if (threadIdx.x < C::COUT) {
     aff[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
     aff[C::COUT + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
   }
-  if (threadIdx.x == 0) __atomic_store_n(slot, (int)((unsigned)atomicAdd(a.counter, 1) - a.base), __ATOMIC_RELAXED);
+  // the tile range this workgroup draws from first: its XCD's (HW_REG_XCC_ID, bits 3:0 of hardware register 20) -- locality
+  // only; zy_draw moves on to the other ranges when this one is exhausted, so any placement computes every item exactly once
+  const int part = a.nparts > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) % a.nparts : 0;
+  int skip = 0;   // (state of thread 0, the only caller of zy_draw)
+  if (threadIdx.x == 0) __atomic_store_n(slot, zy_draw(a, part, skip), __ATOMIC_RELAXED);
   __syncthreads();
   int item = __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED));
   const int total = 4 * a.ntiles;
-  while (item < total) {
+  while (item >= 0 && item < total) {
     const int cls = item / a.ntiles;   // 0 = (odd z, odd y): four (kz, ky) pairs ... 3 = (even z, even y): one
     if (cls == 0)
-      item = zy_body<C, 1, 1>(lds, slot, a, item);
+      item = zy_body<C, 1, 1>(lds, slot, a, item, part, skip);
     else if (cls == 1)
-      item = zy_body<C, 1, 0>(lds, slot, a, item);
+      item = zy_body<C, 1, 0>(lds, slot, a, item, part, skip);
     else if (cls == 2)
-      item = zy_body<C, 0, 1>(lds, slot, a, item);
+      item = zy_body<C, 0, 1>(lds, slot, a, item, part, skip);
     else
-      item = zy_body<C, 0, 0>(lds, slot, a, item);
+      item = zy_body<C, 0, 0>(lds, slot, a, item, part, skip);
   }
-}
-
-// Item counters: one counter per launch out of a small per-device ring, so that launches in flight on different streams
-// never share one.  A counter is never reset: every workgroup takes items until it draws one past the end, so a launch of
-// `total` items on `grid` workgroups advances its counter by exactly total + grid, and the next launch on that slot is
-// told where the counter stands (`base`; unsigned arithmetic, wrap-around included).  No memset launch per convolution.
-struct ZYTicket {
-  int* counter;
-  unsigned base;
-  unsigned* base_slot;   // host copy of where the counter will stand after this launch
-  bool* dirty;           // set when the launch is not known to have run: the slot is zeroed before its next use
-};
-static ZYTicket zy_ticket(unsigned advance, hipStream_t st) {
-  constexpr int RING = 1024;
-  static int* ring[64] = {};
-  static unsigned base[64][RING] = {};
-  static bool dirty[64][RING] = {};
-  static unsigned seq = 0;
-  static std::mutex mu;   // host threads may share the library: the ring bookkeeping is serialised
-  std::lock_guard<std::mutex> lock(mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return {nullptr, 0u, nullptr, nullptr};
-  if (!ring[dev]) {
-    if (hipMalloc(reinterpret_cast<void**>(&ring[dev]), RING * sizeof(int)) != hipSuccess ||
-        hipMemset(ring[dev], 0, RING * sizeof(int)) != hipSuccess) {
-      ring[dev] = nullptr;
-      return {nullptr, 0u, nullptr, nullptr};
+  // Leave the workspace as it was found.  A workgroup draws nothing after this point; the last one to arrive knows that every
+  // other one has drawn its last ticket (release / acquire through the `done` counter) and zeroes counters and `done`.
+  if (threadIdx.x == 0) {
+    int* done = a.ws + ZY_PARTS;
+    if (__hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      for (int k = 0; k < ZY_PARTS; ++k) __hip_atomic_store(a.ws + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  const unsigned slot = seq++ % RING;
-  if (dirty[dev][slot]) {   // a launch on this slot failed: its counter and our copy may disagree
-    if (hipMemsetAsync(ring[dev] + slot, 0, sizeof(int), st) != hipSuccess) return {nullptr, 0u, nullptr, nullptr};
-    base[dev][slot] = 0;
-    dirty[dev][slot] = false;
-  }
-  ZYTicket t{ring[dev] + slot, base[dev][slot], &base[dev][slot], &dirty[dev][slot]};
-  base[dev][slot] += advance;
-  return t;
 }
 
 template <class C>
 static int launch_zy(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int Ci, int D, int H, int W, int relu, hipStream_t st) {
+                     int B, int Ci, int D, int H, int W, int relu, int* ws, hipStream_t st) {
   const int ntx = cdiv(W, C::TX), nty = H, ntz = cdiv(D, C::TZ);
   const long long ntiles = (long long)B * ntx * nty * ntz;
   if (4 * ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   DMB_ENSURE_LDS((&deconv3d_zy_kernel<C>), lds);
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-  }
-  const long long slots = 3LL * ncu * (g_dev_opts[8] > 0 ? g_dev_opts[8] : 1);
+  const long long slots = 3LL * num_cus() * (DMB_OPT(8) > 0 ? DMB_OPT(8) : 1);
   long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
-  if (g_dev_opts[9] > 0 && g_dev_opts[9] < grid) grid = g_dev_opts[9];   // development: few workgroups walk many items
-  const ZYTicket tk = zy_ticket((unsigned)(4 * ntiles + grid), st);
-  if (!tk.counter) return fail(DMB_EINVAL, "deconv3d: could not set up the work-item counter");
-  ZYArgs a{x, wp, res, y, tk.counter, tk.base, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8, g_dev_opts[12]};
+  if (DMB_OPT(9) > 0 && DMB_OPT(9) < grid) grid = DMB_OPT(9);   // development: few workgroups walk many items
+  const int run = DMB_OPT(16) > 0 ? DMB_OPT(16) : ZY_RUN;
+  ZYArgs a{x, wp, res, y, ws, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8, run, DMB_OPT(20) ? 1 : ZY_PARTS, DMB_OPT(12)};
+  if (DMB_OPT(20)) a.run = (int)ntiles;   // development: ONE class-major list over the whole layer (the round-3 order)
   hipLaunchKernelGGL((deconv3d_zy_kernel<C>), dim3((unsigned)grid), dim3(256), lds, st, a, scale, shift);
-  const int rc = launch_status("deconv3d (z/y-parity items) launch failed");
-  if (rc != DMB_OK) *tk.dirty = true;
-  return rc;
+  return launch_status("deconv3d (z/y-parity items) launch failed");
 }
 
 // Entry for dmb_deconv3d_k3s2_f32 (conv3d.hip): returns -1 when this form does not apply (the caller falls back to
@@ -475,14 +476,15 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
 // 64 output channels real, whole 16-channel chunks and at least two of them, 16 input channels of one batch item and one batch item of the output
 // below 2 GiB (32-bit buffer offsets).
 int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                    int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st) {
-  if (g_dev_opts[4] == 1) return -1;   // (development option 4: 1 = deconv3d_kernel, 2 = this form even where the sixteen-wave one applies)
+                    int B, int Ci, int Co, int D, int H, int W, int relu, int* ws, hipStream_t st) {
+  if (DMB_OPT(4) == 1 || !ws) return -1;   // (development option 4 = 1: deconv3d_kernel)
+  if ((((uintptr_t)ws) & 3) != 0) return fail(DMB_EINVAL, "deconv3d: misaligned workspace");
   if (!(Co == 32 || Co == 64) || Ci % 16 != 0 || Ci < 32 || W % 4 != 0) return -1;   // (>= 2 chunks in every class)
   if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) != 0) return -1;
   if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;
   if (cdiv(W, 28) * 32 < cdiv(W, 60) * 64) return -1;   // narrow images: deconv3d_kernel's 2 x 28 tiles compute fewer positions
-  if (Co == 32) return launch_zy<ZYCfg<32>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, st);
-  return launch_zy<ZYCfg<64>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, st);
+  if (Co == 32) return launch_zy<ZYCfg<32>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, ws, st);
+  return launch_zy<ZYCfg<64>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, ws, st);
 }
 
 }  // namespace dmb

@@ -6,7 +6,21 @@
 namespace dmb {
 
 void set_last_error(const char* msg);
+
+// Development knobs exist only in the DEVELOPMENT build of the library (-DDMB_DEV: lib/libdmb_hip_dev.so, loaded by scripts/
+// through DMB_LIB=dev, never by the package, the tests or bench.py).  In the release build DMB_OPT(k) is the constant 0 and
+// DMB_DBG(expr) the constant 0: no global option table, no diagnostic branch in any kernel, dmb_dev_set_option not exported.
+#ifdef DMB_DEV
 extern int g_dev_opts[32];
+#define DMB_OPT(k) (::dmb::g_dev_opts[(k)])
+#define DMB_DBG(expr) (expr)
+#else
+#define DMB_OPT(k) 0
+#define DMB_DBG(expr) 0
+#endif
+
+// Compute units of the CURRENT device (cached per device ordinal; a process may drive several GPUs).
+int num_cus();
 
 inline int fail(int code, const char* msg) {
   set_last_error(msg);
@@ -96,12 +110,9 @@ __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >>
 
 #endif  // __HIPCC__
 
-// csrc/deconv3d_zy.hip: the (tile, z parity, y parity) form of the transposed convolution; -1 = does not apply
+// csrc/deconv3d_zy.hip: the (tile, z parity, y parity) form of the transposed convolution; -1 = does not apply.
+// `workspace`: DMB_DECONV3D_WORKSPACE_BYTES of device memory holding zeros (see include/dmb_hip.h); the launch leaves it zeroed.
 int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                    int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st);
-
-// csrc/deconv3d_w16.hip: one sixteen-wave workgroup per CU computes all eight parity classes of a tile; -1 = does not apply
-int deconv3d_w16_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int Ci, int Co, int D, int H, int W, int relu, hipStream_t st);
+                    int B, int Ci, int Co, int D, int H, int W, int relu, int* workspace, hipStream_t st);
 
 }  // namespace dmb

@@ -23,8 +23,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int CG>
 __global__ __launch_bounds__(256, 3) void gwc_mfma_kernel(const float* __restrict__ L, const float* __restrict__ R,
                                                           float* __restrict__ out, int C, int G, int H, int W, int D,
-                                                          DispIdx idx, int out_channels, int och_off, int rpw, int dmax, int dbg) {
-  // dbg: development diagnostics (g_dev_opts[6]): 1 = no stores, 2 = no staging
+                                                          DispIdx idx, int out_channels, int och_off, int rpw, int dmax, int dbg_arg) {
+  // dbg: development build only (option 6; the constant 0 in the release build): 1 = no stores, 2 = no staging
+  const int dbg = DMB_DBG(dbg_arg);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lrow = lds;                        // [CG][GW_LROW]
   float* rrow = lds + CG * GW_LROW;         // [CG][GW_RROW]
@@ -159,12 +160,12 @@ static int launch_gwc_mfma(const float* L, const float* R, float* out, int B, in
                            const DispIdx& idx, int out_channels, int och_off, hipStream_t st) {
   const size_t lds = (size_t)(CG * (GW_LROW + GW_RROW) + 4 * GW_SCR + DMB_MAX_DISP_SAMPLES) * sizeof(float);
   DMB_ENSURE_LDS((&gwc_mfma_kernel<CG>), (size_t)(lds));
-  const int rpw = g_dev_opts[5] > 0 ? g_dev_opts[5] : 2;   // rows per workgroup (g_dev_opts[5]: development knob)
+  const int rpw = DMB_OPT(5) > 0 ? DMB_OPT(5) : 2;   // rows per workgroup (DMB_OPT(5): development knob)
   int dmax = 0;
   for (int k = 0; k < D; ++k) dmax = idx.d[k] > dmax ? idx.d[k] : dmax;
   dim3 grid(cdiv(H, rpw) * cdiv(W, GW_LROW), G, B);
   hipLaunchKernelGGL((gwc_mfma_kernel<CG>), grid, dim3(256), lds, st, L, R, out, C, G, H, W, D, idx, out_channels, och_off, rpw,
-                     dmax, g_dev_opts[6]);
+                     dmax, DMB_OPT(6));
   return launch_status("gwc_mfma launch failed");
 }
 

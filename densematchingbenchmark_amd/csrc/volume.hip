@@ -235,7 +235,7 @@ extern "C" int dmb_gwc_fms_f32(const float* L, const float* R, float* out, int B
   int dpos, dneg;
   if (int e = disp_range(disp_idx_host, D, idx, dpos, dneg)) return e;
   const int CG = C / G;
-  if (!g_dev_opts[1]) {  // matrix-core form whenever it applies (0 <= d_k <= 64, even channels per group)
+  if (!DMB_OPT(1)) {  // matrix-core form whenever it applies (0 <= d_k <= 64, even channels per group)
     const int rc = gwc_mfma_dispatch(L, R, out, B, C, G, H, W, D, idx, out_channels, out_ch_offset, (hipStream_t)stream);
     if (rc != DMB_EUNSUPPORTED) return rc;
   }

@@ -554,7 +554,7 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
       }
     }
   }
-  if (g_dev_opts[5] > 0) zseg = cdiv(D, g_dev_opts[5]);   // development knob: number of z segments
+  if (DMB_OPT(5) > 0) zseg = cdiv(D, DMB_OPT(5));   // development knob: number of z segments
   const int nzs = cdiv(D, zseg);
   const bool v16 = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)dc) & 15) == 0;
   DMB_ENSURE_LDS((&conv3d_wgrad_s1_kernel<true, 24>), (size_t)(WgCfg<24>::LDS_FLOATS * 4));

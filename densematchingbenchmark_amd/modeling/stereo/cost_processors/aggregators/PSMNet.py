@@ -80,31 +80,10 @@ class PSMAggregator(nn.Module):
         main.wait_event(done)
         return [up3, up2, up1]
 
-    def _forward_merged_heads(self, raw_cost):
-        """Eval only: trunk() + the up-sampling loop with the three 32 -> 1 heads as one launch, the cumulative cost sums
-        (PSMNet.py:71-72) as one pass over the three quarter-resolution outputs, and the three up-sampling + regression passes as
-        one launch over the stack.  The same FP32 operations in the same order per output: bit-identical to forward()'s
-        launch-per-branch form (tests/test_modules_gpu.py)."""
-        B, C, D, H, W = raw_cost.shape
-        cost0 = self.dres0(raw_cost)
-        cost0 = self.dres1[1](self.dres1[0](cost0), residual=cost0)
-        out1, pre1, post1 = self.dres2(cost0, None, None, skip=cost0)
-        out2, pre2, post2 = self.dres3(out1, pre1, post1, skip=cost0)
-        out3, pre3, post3 = self.dres4(out2, pre2, post2, skip=cost0)
-        heads = (self.classif1, self.classif2, self.classif3)
-        stack = ops.conv3d_k3_c1_multi([h[0](o) for h, o in zip(heads, (out1, out2, out3))],
-                                       [h[1].weight.detach() for h in heads], [h[1].bias_value() for h in heads])
-        ops.cost_chain_(stack)                                           # [3, B, 1, D/4, H/4, W/4]: cost1, cost2, cost3
-        vals = ops.disp_sample_values(self.max_disp, 0, 1)
-        cost, disp = ops.trilinear_ac_soft_argmin(stack.view(3 * B, *stack.shape[3:]), (self.max_disp, H * 4, W * 4), vals, 1.0)
-        return [ops.RegressionHint.attach(cost[k * B:(k + 1) * B], vals, 1.0, disp[k * B:(k + 1) * B]) for k in (2, 1, 0)]
-
     def forward(self, raw_cost):
         B, C, D, H, W = raw_cost.shape
         if ops.branch_overlap() and raw_cost.device.type == "cuda" and not train_fn.wants_grad(self, raw_cost):
             return self._forward_overlapped(raw_cost)
-        if ops.merged_heads() and raw_cost.device.type == "cuda" and not train_fn.wants_grad(self, raw_cost):
-            return self._forward_merged_heads(raw_cost)
         cost1, cost2, cost3 = self.trunk(raw_cost)
         size = (self.max_disp, H * 4, W * 4)                             # PSMNet.py:75-88, align_corners=True
         # The up-sampling kernel also regresses the standard soft-argmin (alpha 1, samples 0..max_disp-1) of the volume

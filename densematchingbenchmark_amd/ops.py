@@ -4,6 +4,8 @@ Only shape bookkeeping and output allocation happen here (PyTorch as the device 
 produced by a HIP kernel of libdmb_hip.so.  All functions raise ``DmbLibraryError`` on CPU tensors -- the
 product path has no fallback.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -240,12 +242,22 @@ def _relu_mode(relu):
     return int(relu) if relu in (0, 1, 2) else int(bool(relu))
 
 
-def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, relu=False):
+def _out_tensor(out, shape, device, what):
+    """The caller's pre-allocated output (as the reference's native op takes it, ops/spn/functions/gaterecurrent2dnoind.py:8-39)
+    or a fresh one."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != device:
+        raise _lib.DmbLibraryError("%s: out must be a contiguous float32 tensor of shape %s on %s" % (what, tuple(shape), device))
+    return out
+
+
+def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, relu=False, out=None):
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Ci, D, H, W = x.shape
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
-    y = torch.empty((B, Co, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    y = _out_tensor(out, (B, Co, Do, Ho, Wo), x.device, "conv3d_k3")
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
     _affine_ok(scale, shift, Co, "conv3d_k3")
@@ -487,55 +499,6 @@ def conv3d_k3_x6(x, wpack, Co, scale=None, shift=None, residual=None, relu=False
     return y
 
 
-def conv3d_k3_c1_multi(xs, ws, biases=None):
-    """Several 32 -> 1 heads in one launch: ``xs`` [B, Ci, D, H, W] each, ``ws`` [1, Ci, 3, 3, 3] each, ``biases`` floats ->
-    [n, B, 1, D, H, W] (job j in slice j).  Bit-identical to n ``conv3d_k3_c1`` calls without skip operand."""
-    import ctypes
-    lib = _lib.load()
-    n = len(xs)
-    if n < 1 or n > 4 or len(ws) != n or (biases is not None and len(biases) != n):
-        raise _lib.DmbLibraryError("conv3d_k3_c1_multi: 1 .. 4 jobs, one weight (and bias) per job")
-    xs = [_f32c(x, "x") for x in xs]
-    ws = [_f32c(w, "weight") for w in ws]
-    B, Ci, D, H, W = xs[0].shape
-    for x, w in zip(xs, ws):
-        if tuple(x.shape) != (B, Ci, D, H, W) or w.numel() != Ci * 27 or x.device != xs[0].device:
-            raise _lib.DmbLibraryError("conv3d_k3_c1_multi: job %s x %s does not match the first job's %s"
-                                       % (tuple(x.shape), tuple(w.shape), (B, Ci, D, H, W)))
-    y = torch.empty((n, B, 1, D, H, W), dtype=torch.float32, device=xs[0].device)
-    PA, FA = ctypes.c_void_p * n, ctypes.c_float * n
-    check(lib.dmb_conv3d_k3_c1_multi_f32(n, PA(*[dev_ptr(x).value for x in xs]), PA(*[dev_ptr(w).value for w in ws]),
-                                         FA(*[float(b) for b in (biases or [0.0] * n)]), dev_ptr(y), B, Ci, D, H, W,
-                                         stream_ptr(y.device)), "dmb_conv3d_k3_c1_multi_f32")
-    return y
-
-
-def cost_chain_(y):
-    """In place on a stack y[n, ...]: y[j] += y[j - 1], j = 1 .. n - 1 (PSMNet.py:70-72's cumulative costs)."""
-    lib = _lib.load()
-    if y.dtype != torch.float32 or not y.is_contiguous():
-        raise _lib.DmbLibraryError("cost_chain_: contiguous float32 stack expected")
-    n = y.shape[0]
-    check(lib.dmb_cost_chain_f32(dev_ptr(y), n, y.numel() // n, stream_ptr(y.device)), "dmb_cost_chain_f32")
-    return y
-
-
-# PSMNet's three classifier heads and their three up-sampling + regression passes as ONE launch each (eval): 9.6 rounds of tiles
-# instead of 3 x 3.2.  Opt-in: in isolation the merged launches are 0.1 ms faster (scripts/merge_probe.py), inside the step they
-# are not (26.859 against 26.842 ms, profiles/r03_ab_step3.log): a head that runs right after its classifier's first convolution
-# finds part of that output in the 256 MB memory-side cache, three heads at the end of the step do not.
-_merged_heads = False
-
-
-def set_merged_heads(flag):
-    global _merged_heads
-    _merged_heads = bool(flag)
-
-
-def merged_heads():
-    return _merged_heads
-
-
 def conv3d_k3_c1(x, w, bias=0.0, residual=None):
     lib = _lib.load()
     x, w = _f32c(x, "x"), _f32c(w, "weight")
@@ -550,20 +513,46 @@ def conv3d_k3_c1(x, w, bias=0.0, residual=None):
     return y
 
 
-def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=False):
+# Work-item counters of the transposed convolution (include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES): the library allocates
+# nothing, so the host layer keeps ONE zeroed workspace per (device, stream) -- launches on one stream run one after the other
+# and each leaves the workspace zeroed; launches on different streams may overlap and get different workspaces.  Allocated
+# during a graph capture it comes from the graph's pool, zero fill included.
+_deconv_ws = {}
+
+
+def deconv3d_workspace(device):
+    st = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), st.cuda_stream)
+    ws = _deconv_ws.get(key)
+    if ws is None:
+        ws = torch.zeros((_lib.DECONV3D_WORKSPACE_BYTES // 4,), dtype=torch.int32, device=device)
+        _deconv_ws[key] = ws
+    return ws
+
+
+def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=False, workspace="auto", out=None):
+    """``workspace``: "auto" = the per-stream workspace above; None = the kernel form without counters; or an int32 tensor of
+    DECONV3D_WORKSPACE_BYTES holding zeros."""
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Ci, D, H, W = x.shape
-    y = torch.empty((B, Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    y = _out_tensor(out, (B, Co, 2 * D, 2 * H, 2 * W), x.device, "deconv3d_k3s2")
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
     _affine_ok(scale, shift, Co, "deconv3d_k3s2")
     if wpack.numel() != lib.dmb_deconv3d_packed_floats(Ci, Co):
         raise _lib.DmbLibraryError("deconv3d_k3s2: packed weights hold %d floats, %d -> %d channels need %d"
                                    % (wpack.numel(), Ci, Co, lib.dmb_deconv3d_packed_floats(Ci, Co)))
+    if isinstance(workspace, str):
+        workspace = deconv3d_workspace(x.device)
+    if workspace is not None and (workspace.dtype != torch.int32 or workspace.numel() * 4 < _lib.DECONV3D_WORKSPACE_BYTES
+                                  or workspace.device != x.device or not workspace.is_contiguous()):
+        raise _lib.DmbLibraryError("deconv3d_k3s2: workspace must be a contiguous int32 tensor of %d bytes on %s"
+                                   % (_lib.DECONV3D_WORKSPACE_BYTES, x.device))
     check(lib.dmb_deconv3d_k3s2_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                     dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
-                                    B, Ci, Co, D, H, W, _relu_mode(relu), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
+                                    B, Ci, Co, D, H, W, _relu_mode(relu),
+                                    None if workspace is None else ctypes.c_void_p(workspace.data_ptr()), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
     return y
 
 
@@ -1227,13 +1216,21 @@ def conv2d_k3_multi(jobs, Co):
     import ctypes
     lib = _lib.load()
     n = len(jobs)
+    if n < 1 or n > 6:
+        raise _lib.DmbLibraryError("conv2d_k3_multi: 1 .. 6 jobs per launch, got %d" % n)
     x0 = _f32c(jobs[0][0], "x")
     B, Ci, H = x0.shape[0], x0.shape[1], x0.shape[2]
     xs, ws, ys, Ws, cts = [], [], [], [], []
+    keep = []   # converted inputs stay alive until the launch is enqueued (a freed temporary's block could be handed to the next job)
     for x, wp, out, off in jobs:
         x = _f32c(x, "x")
+        keep.append(x)
         if tuple(x.shape[:3]) != (B, Ci, H) or tuple(out.shape[2:]) != tuple(x.shape[2:]) or out.shape[0] != B or off + Co > out.shape[1]:
             raise _lib.DmbLibraryError("conv2d_k3_multi: job shapes %s -> %s do not fit" % (tuple(x.shape), tuple(out.shape)))
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.device != x0.device or x.device != x0.device:
+            raise _lib.DmbLibraryError("conv2d_k3_multi: outputs must be contiguous float32 tensors on %s" % (x0.device,))
+        if wp.dtype != torch.float32 or not wp.is_contiguous() or wp.device != x0.device:
+            raise _lib.DmbLibraryError("conv2d_k3_multi: packed weights must be contiguous float32 tensors on %s" % (x0.device,))
         xs.append(dev_ptr(x).value)
         ws.append(dev_ptr(wp).value)
         ys.append(_window_ptr(out, off).value)

@@ -7,11 +7,25 @@
  *     allocator in the Python host layer) unless the parameter name ends in `_host`;
  *   - all tensors are FP32, contiguous, NC(D)HW exactly as the reference lays them out;
  *   - `stream` is the caller's hipStream_t (NULL = the legacy default stream); every entry
- *     point only enqueues work on that stream, never synchronises, never allocates;
+ *     point only enqueues kernel launches on that stream: no synchronisation, no allocation, no
+ *     memset / memcpy -- so a sequence of calls can be captured into a HIP graph and replayed
+ *     (tests/test_graph_gpu.py captures a whole PSMNet step).  Scratch memory a kernel needs is a
+ *     caller-provided workspace argument (dmb_*_workspace_bytes / DMB_*_WORKSPACE_BYTES), as the
+ *     reference's own native op takes caller-allocated tensors only
+ *     (dmb/ops/spn/functions/gaterecurrent2dnoind.py:8-39);
  *   - return value 0 = success, otherwise the hipError_t value of the failing launch or one of
  *     the DMB_E* codes below.  Nothing here calls exit() (the reference's only native op,
  *     dmb/ops/spn/src/gaterecurrent2dnoind_kernel.cu:544-549, does; this library does not);
- *   - no global state; safe to call concurrently on distinct streams.
+ *   - host-side state, all of it: a thread-local pointer to the last error string, and two
+ *     per-device read-mostly caches filled on first use (the device's compute-unit count; which
+ *     kernels have had their dynamic-LDS limit raised on which device, a per-device attribute
+ *     that hipFuncSetAttribute requires before a launch with more than 64 KB of LDS).  No
+ *     option table, no device allocations, nothing a launch depends on besides its arguments:
+ *     calls from several host threads on distinct streams are safe (the workspace of
+ *     dmb_deconv3d_k3s2_f32 must then be distinct per stream, see there).  The release library
+ *     exports exactly the functions declared here (tests/test_host_logic.py compares the two lists);
+ *     kernel-variant switches exist only in the development build (build.py dev=True ->
+ *     lib/libdmb_hip_dev.so, used by scripts/, never by the package, the tests or bench.py).
  *
  * Each entry point names the reference interface it replaces (file:line under the reference
  * tree).  The reference is pure PyTorch on this path, so "replaces" means: the same
@@ -30,7 +44,8 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes. */
+/* ABI version: bumped whenever a signature below changes (4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads
+ * entry points of version 3 removed). */
 int dmb_abi_version(void);
 /* Static string describing the last DMB_E* code returned on this thread ("" if none). */
 const char* dmb_last_error(void);
@@ -180,24 +195,18 @@ int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, co
 int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float* residual, float* y,
                          int B, int Ci, int D, int H, int W, void* stream);
 
-/* Up to 4 such heads in ONE launch (PSMNet.py:46,50,54: classif1[1], classif2[1], classif3[1] of one forward): job j
- * convolves x[j] ([B, Ci, D, H, W]) with w[j] ([1, Ci, 3, 3, 3]) and bias_host[j] into items [j B, (j + 1) B) of
- * y ([njobs B, 1, D, H, W]).  x / w: HOST arrays of njobs device pointers; bias_host: host array or NULL.  No skip
- * operand: the cumulative sums are dmb_cost_chain_f32.  Results are bit-identical to njobs dmb_conv3d_k3_c1_f32 calls. */
-int dmb_conv3d_k3_c1_multi_f32(int njobs, const float* const* x, const float* const* w, const float* bias_host, float* y,
-                               int B, int Ci, int D, int H, int W, void* stream);
-
-/* PSMNet.py:70-72's cumulative costs (cost2 = classif2(out2) + cost1, cost3 = classif3(out3) + cost2) on a stack of n
- * head outputs y: [n, count], in place: y[j] += y[j - 1] for j = 1 .. n - 1, in that order -- the FP32 adds the
- * skip operand of dmb_conv3d_k3_c1_f32 performs, same bits. */
-int dmb_cost_chain_f32(float* y, int n, long long count, void* stream);
-
 /* ConvTranspose3d kernel 3, stride 2, padding 1, output_padding 1 (hourglass.py:52-60):
  * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, 2W];  y[o] += x[i] * w[k] with o = 2i - 1 + k.  Co = 64 or any Co <= 32
- * (fewer than 32: zero-padded weight rows, e.g. GC-Net's 1-channel output layer, aggregators/GCNet.py:63-67). */
+ * (fewer than 32: zero-padded weight rows, e.g. GC-Net's 1-channel output layer, aggregators/GCNet.py:63-67).
+ * workspace: DMB_DECONV3D_WORKSPACE_BYTES of device memory, 4-byte aligned, holding ZEROS (the caller zeroes it once, e.g.
+ * at allocation); the launch uses it for its work-item counters and leaves it zeroed again, so the same workspace serves
+ * every later call on that stream, eager or replayed from a captured graph.  Launches that may be in flight at the same
+ * time (different streams) need different workspaces.  NULL selects the kernel form without counters (static tile walk:
+ * same results bit for bit, slower). */
+#define DMB_DECONV3D_WORKSPACE_BYTES 64
 int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                           const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
-                          int relu, void* stream);
+                          int relu, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cost up-sampling
@@ -297,7 +306,7 @@ int dmb_conf_ring_f32(const float* cost, const float* w1t, const float* scale, c
  * the device, updated in stream order (no atomics); the caller zeroes it and all-reduces it across
  * ranks.  workspace: DMB_EPE_WORKSPACE_DOUBLES * B doubles of caller-owned device scratch, fully overwritten by the
  * call: every image is reduced in 64 slices whose sums are added in a fixed order, so the per-image means are
- * reproducible bit for bit (ABI version 3; version 2 took 6*B doubles and summed the slices atomically). */
+ * reproducible bit for bit (since ABI version 3; version 2 took 6*B doubles and summed the slices atomically). */
 #define DMB_EPE_WORKSPACE_DOUBLES 384
 int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* workspace, int B, int Hp, int Wp,
                       int H0, int W0, float lb, float ub, void* stream);

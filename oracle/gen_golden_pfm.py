@@ -40,7 +40,9 @@ def main():
         out[name + "_data"] = np.ascontiguousarray(got).astype(np.float32)
         out[name + "_scale"] = np.float64(s)
         out[name + "_dtype"] = np.array(got.dtype.str)
-    path = os.path.join(ROOT, "tests", "golden", "pfm_files.npz")
+    out_dir = os.environ.get("DMB_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))   # as the other generators
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "pfm_files.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")
 

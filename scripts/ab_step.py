@@ -2,6 +2,7 @@
 inside ONE process on ONE chip (numbers from different gpurun boxes differ by ~1 %).
     python scripts/ab_step.py "4=1" "10=1" "4=1,10=1"      each argument: comma-separated option=value pairs of a variant"""
 import os, sys
+os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from densematchingbenchmark_amd import _lib, ops, synthetic
@@ -10,16 +11,17 @@ from densematchingbenchmark_amd.modeling import build_model
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
-cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "PSMNet", "scene_flow.py"))
+cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", *os.environ.get("AB_CONFIG", "PSMNet/scene_flow.py").split("/")))
 model = build_model(cfg).eval()
 synthetic.init_params_(model, seed=0, classif_gain=10.0)
 model = model.to(dev)
-left, right = synthetic.feature_batch(0, 1, 4, 32, 136, 240, dev)
+_Hp, _Wp = cfg.data.eval.input_shape
+left, right = synthetic.feature_batch(0, 1, 4, 32, _Hp // 4, _Wp // 4, dev)
 batch = dict(leftFeature=left, rightFeature=right)
 # an option is "<development option index>=<value>", or "fls=0" (first-layer convolutions on one stream), "ovl=1" (branch overlap)
 def _parse(kv):
     k, v = kv.split("=")
-    return (k if k in ("fls", "ovl", "mh") else int(k), int(v))
+    return (k if k in ("fls", "ovl") else int(k), int(v))
 
 
 def _set(k, v):
@@ -27,13 +29,11 @@ def _set(k, v):
         ops.set_first_layer_mode({2: "merged", 1: "streams", 0: "serial"}[v])
     elif k == "ovl":
         ops.set_branch_overlap(bool(v))
-    elif k == "mh":    # 1 = the three classifier heads / up-samplings as one launch each (default: one per branch)
-        ops.set_merged_heads(bool(v))
     else:
         lib.dmb_dev_set_option(k, v)
 
 
-_DEFAULT = {"fls": 2, "ovl": 0, "mh": 0}
+_DEFAULT = {"fls": 2, "ovl": 0}
 variants = [("default", [])] + [(a, [_parse(kv) for kv in a.split(",")]) for a in sys.argv[1:]]
 
 
@@ -59,9 +59,9 @@ with torch.no_grad():
             acc[name].append(run(8))
             for k, _ in opts:
                 _set(k, _DEFAULT.get(k, 0))
-print("# whole PSMNet step (batch 4, 544x960, D = 192) under development options, variants alternated in one process on one chip (4 x 8 steps each);")
-print("# 13=1: quarter-resolution stride-1 layer on box tiles instead of 64-voxel runs; 4=1: deconv3d_kernel (round-2 transposed convolution) instead of "
-      "deconv3d_zy_kernel; 10=1: four-wave stride-2 workgroups; fls=0 / 1: first-layer convolutions as five launches on one stream / on three streams "
-      "(default: one multi-job launch); 11=2: sixteen-wave transposed convolution for the half -> full resolution layer; ovl=1: branch overlap")
+print("# whole PSMNet step (batch 4, %dx%d, D = 192) under development options, variants alternated in one process on one chip (4 x 8 steps each);" % (_Hp, _Wp))
+print("# 13=1: narrow stride-1 planes on box tiles instead of 64-voxel runs; 4=1: deconv3d_kernel (round-2 transposed convolution) instead of "
+      "deconv3d_zy_kernel; 16=R: zy item order in groups of R tiles; 20=1: ONE class-major zy item list (round-3 order); 10=1: four-wave stride-2 "
+      "workgroups; 19=k: stride-1 tile candidate k - 1; fls=0 / 1: first-layer convolutions as five launches on one stream / on three streams; ovl=1: branch overlap")
 for name, ts in acc.items():
     print("%-24s %s  -> min %.3f ms, median %.3f ms" % (name, " ".join("%.3f" % t for t in ts), min(ts), sorted(ts)[len(ts) // 2]))

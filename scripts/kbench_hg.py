@@ -1,8 +1,10 @@
-"""Development aid: the hourglass layers that sit below the MFMA roofline (stride-2, transposed, quarter resolution) at the
-BASELINE cfg2 shapes, with the residual operands they carry in the real step and with diagnostic switches
-(g_dev_opts[6]: 1 = no stores, 2 = no staging after the first chunk) to see which part of a kernel is exposed.
+"""Development aid: the hourglass layers that sit below the MFMA roofline (stride-2, transposed, quarter resolution) with the
+residual operands they carry in the real step, and (``diag``) with diagnostic switches (development option 6: 1 = no stores,
+2 = no staging after the first chunk) to see which part of a kernel is exposed.  Shape: KB_SHAPE = D,H,W of the FULL-resolution
+feature volume (default 48,136,240 = BASELINE cfg2; 48,96,312 = the reference's KITTI operating point), KB_B pairs.
     python scripts/kbench_hg.py [diag]"""
 import os
+os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +14,7 @@ from densematchingbenchmark_amd import _lib, ops
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("KB_B", "4"))
-D, H, W = 48, 136, 240
+D, H, W = [int(v) for v in os.environ.get("KB_SHAPE", "48,136,240").split(",")]
 lib = _lib.load()
 diag = len(sys.argv) > 1 and sys.argv[1] == "diag"
 
@@ -65,7 +67,7 @@ def deconv_case(Ci, Co, d, h, w, name, res=False):
     lib.dmb_dev_set_option(6, 0)
 
 
-print("B =", B)
+print("B =", B, " full-resolution volume D, H, W =", (D, H, W))
 # the chip clocks by its power budget: bring it to a steady state first, and run the list twice
 _x = torch.randn(B, 32, D, H, W, device=dev)
 _wp = ops.pack_conv3d_weights(torch.randn(32, 32, 3, 3, 3, device=dev) * 0.03)
@@ -74,6 +76,17 @@ for _ in range(150):
 torch.cuda.synchronize()
 del _x
 for _rep in range(1 if diag else 2):
+  conv_case(32, 32, 1, D, H, W, "classif / dres 32->32 full (dominant)")
+  conv_case(32, 32, 1, D, H, W, "classif / dres 32->32 full (dominant)", res=True)
+  if not diag:
+    for cand, name in ((1, "48 x 4 row pairs"), (2, "24 x 8 row quads"), (3, "32 x 4 row pairs")):   # development option 19: tile candidate
+      lib.dmb_dev_set_option(19, cand)
+      conv_case(32, 32, 1, D, H, W, "  32->32 full on %s" % name)
+    for cand, name in ((1, "64-voxel runs"), (2, "40 x 4 row quads"), (3, "24 x 4 row quads"), (4, "32 x 4 row quads")):
+      lib.dmb_dev_set_option(19, cand)
+      conv_case(64, 64, 1, D // 2, H // 2, W // 2, "  64->64 half on %s" % name, res=True)
+      conv_case(64, 64, 1, D // 4, H // 4, W // 4, "  64->64 quarter on %s" % name)
+    lib.dmb_dev_set_option(19, 0)
   conv_case(32, 64, 2, D, H, W, "conv1 s2 32->64 full->half")
   conv_case(64, 64, 1, D // 2, H // 2, W // 2, "conv2 s1 64->64 half", res=True)
   conv_case(64, 64, 2, D // 2, H // 2, W // 2, "conv3 s2 64->64 half->quarter")
@@ -88,10 +101,16 @@ for _rep in range(1 if diag else 2):
   conv_case(32, 64, 2, D, H, W, "conv1 s2 32->64 (4-wave workgroups)")
   conv_case(64, 64, 2, D // 2, H // 2, W // 2, "conv3 s2 64->64 (4-wave workgroups)")
   lib.dmb_dev_set_option(10, 0)
-  lib.dmb_dev_set_option(11, 1)   # A/B: one sixteen-wave workgroup per CU computes all eight parity classes of a tile (opt-in)
-  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (sixteen-wave workgroups)", res=False)
-  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (sixteen-wave workgroups)", res=True)
-  lib.dmb_dev_set_option(11, 0)
+  for run in (1, 4, 16):           # A/B: zy item order in groups of `run` tiles (default: deconv3d_zy.hip ZY_RUN)
+    lib.dmb_dev_set_option(16, run)
+    deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv (zy groups of %d tiles)" % run, res=True)
+    deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (zy groups of %d tiles)" % run, res=True)
+  lib.dmb_dev_set_option(16, 0)
+  lib.dmb_dev_set_option(20, 1)    # A/B: ONE class-major item list over the whole layer (the round-3 order)
+  deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv (one class-major list)", res=True)
+  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (one class-major list)", res=False)
+  deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (one class-major list)", res=True)
+  lib.dmb_dev_set_option(20, 0)
   lib.dmb_dev_set_option(4, 1)   # A/B: the two-parity form (both y parities per item, two workgroups per CU)
   deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv (items with both y parities)", res=True)
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (items with both y parities)", res=False)

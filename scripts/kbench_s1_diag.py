@@ -1,5 +1,6 @@
 """Development aid: the two stride-1 layers of the step with the diagnostic switches (g_dev_opts[6]: 1 = no stores, 2 = no staging\nafter the first chunk): how far the full kernels are from their multiply-only structure.   python scripts/kbench_s1_diag.py"""
 import os, sys
+os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from densematchingbenchmark_amd import _lib, ops

@@ -2,6 +2,7 @@
 workgroup), complete and as bare MFMA + LDS-read structure (option 6 = 35): how much of the matrix pipe ONE wave per SIMD can use --
 i.e. whether a workgroup in its set-up / epilogue costs its third of the CU or nothing.   python scripts/occupancy_probe.py"""
 import os, sys
+os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from densematchingbenchmark_amd import _lib, ops

@@ -2,6 +2,7 @@
 stagger of the first round's workgroups by their slot on the CU (g_dev_opts[14], unit 3.4 us), alternated inside one process; and
 the launch at 2, 4 and 8 pairs (fixed cost per launch against cost per workgroup).   python scripts/s1_stagger_probe.py"""
 import os, sys
+os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from densematchingbenchmark_amd import _lib, ops

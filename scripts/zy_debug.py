@@ -2,6 +2,7 @@
 optionally with a forced small grid (few workgroups walk many items: cross-item pipelining and class switches), and say WHERE
 they differ.   python scripts/zy_debug.py Ci Co B D H W [grid]"""
 import os
+os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,13 +24,13 @@ ref = ops.deconv3d_k3s2(x, wp, Co, None, None, None, False)
 lib.dmb_dev_set_option(4, 0)
 lib.dmb_dev_set_option(9, grid)
 lib.dmb_dev_set_option(6, dbg)
-lib.dmb_dev_set_option(11, int(os.environ.get("W16", "0")))    # W16=1: the sixteen-wave form wherever its shape constraints allow
-lib.dmb_dev_set_option(4, int(os.environ.get("FORM", "0")))    # FORM=2: the z/y-parity item form
+lib.dmb_dev_set_option(16, int(os.environ.get("RUN", "0")))    # RUN=R: item order in groups of R tiles (0 = the default)
+lib.dmb_dev_set_option(20, int(os.environ.get("ONE", "0")))    # ONE=1: one class-major list over the whole layer (round-3 order)
 got = ops.deconv3d_k3s2(x, wp, Co, None, None, None, False)
 lib.dmb_dev_set_option(9, 0)
 lib.dmb_dev_set_option(6, 0)
-lib.dmb_dev_set_option(11, 0)
-lib.dmb_dev_set_option(4, 0)
+lib.dmb_dev_set_option(16, 0)
+lib.dmb_dev_set_option(20, 0)
 torch.cuda.synchronize()
 bad = (got != ref)
 print("shape", (Ci, Co, B, D, H, W), "grid", grid, "dbg", dbg, "mismatching elements:", int(bad.sum()), "of", bad.numel(), "max diff", float((got - ref).abs().max()))

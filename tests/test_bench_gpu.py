@@ -39,6 +39,10 @@ def test_bench_gpus_flag_launches_the_ranks(dev):
     for k in ("epe", "1px", "3px"):
         assert abs(one["epe_accumulator"][k] - two["epe_accumulator"][k]) <= 1e-9 * max(1.0, abs(one["epe_accumulator"][k]))
     assert two["value"] > 0 and two["ms_per_step"] > 0
+    # every rank's own clock is in the line, the metric uses the slowest (MAX over ranks)
+    assert len(two["per_rank_ms"]) == 2 and len(one["per_rank_ms"]) == 1
+    assert abs(max(two["per_rank_ms"]) - two["ms_per_step"]) <= 1e-3 * two["ms_per_step"] + 2e-3
+    assert "pinned" in two["host_affinity"]
 
 
 def test_bench_one_rank_through_rccl(dev):
@@ -55,3 +59,4 @@ def test_bench_one_rank_through_rccl(dev):
     for k in ("epe", "1px", "3px"):   # the all-reduced accumulator of a one-rank group is the rank's own
         assert rccl["epe_accumulator"][k] == plain["epe_accumulator"][k]
     assert rccl["value"] > 0
+    assert rccl.get("rccl_version") and "rccl_version" not in plain     # e.g. "2.26.6": read from the library the job ran on

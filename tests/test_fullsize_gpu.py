@@ -242,7 +242,7 @@ def test_fullsize_psmnet_gain30_vs_reference(dev):
     from densematchingbenchmark_amd import synthetic
     from densematchingbenchmark_amd.config import Config
     from densematchingbenchmark_amd.modeling import build_model
-    g = golden("fullsize_psmnet_gain30.npz")
+    g, g10 = golden("fullsize_psmnet_gain30.npz"), golden("fullsize_psmnet.npz")
     cfg = Config.fromfile(os.path.join(ROOT, "configs", "PSMNet/scene_flow.py"))
     model = build_model(cfg).eval()
     synthetic.init_params_(model, seed=0, classif_gain=30.0)
@@ -264,8 +264,13 @@ def test_fullsize_psmnet_gain30_vs_reference(dev):
               (3 - lvl, maxdiff(gpu[lvl][SUB], ref), err_gpu, err_ref))
         assert maxdiff(ref32[lvl][SUB], ref) <= 2e-5          # the oracle IS the reference here too
         assert err_gpu <= max(DISP_TOL, YARD_MARGIN * err_ref)
-        assert maxdiff(gpu[lvl][SUB], ref) <= 6e-4 and _meandiff(gpu[lvl][SUB], ref) <= 1e-4
-        assert maxdiff(results["costs"][lvl][CROWS], g["pair0_cost%d_rows" % (3 - lvl)]) <= 3 * COST_TOL
+        # measured against the reference's outputs (round 3, gpurun_out/r3e): 1.07e-4 .. 1.53e-4 at the worst sampled pixel, 2e-5
+        # on average -- the bounds are those figures + 10 %, as for the gain-10 family (a 3x regression must not pass)
+        assert maxdiff(gpu[lvl][SUB], ref) <= 1.7e-4 and _meandiff(gpu[lvl][SUB], ref) <= DISP_MEAN_FULL
+        # cost rows: the gain-10 bound scaled by the ratio of the two families' cost ranges (both read from the fixtures)
+        rows30, rows10 = g["pair0_cost%d_rows" % (3 - lvl)], g10["pair0_cost%d_rows" % (3 - lvl)]
+        scale = max(1.0, float(abs(rows30).max()) / float(abs(rows10).max()))
+        assert maxdiff(results["costs"][lvl][CROWS], rows30) <= COST_TOL * scale, (lvl, scale)
 
 
 def test_fullsize_acfnet_full_map_vs_reference(dev):
@@ -306,3 +311,94 @@ def test_fullsize_regression_at_the_ends_of_the_range(dev):
     assert maxdiff(disp[SUB], g["faster"]) <= max(DISP_TOL, 1.5 * e_fast) and maxdiff(disp[SUB], g["plain"]) <= max(DISP_TOL, 1.5 * e_plain)
     two = ops.soft_argmin(ops.trilinear_ac(q, (192, 544, 960)), vals, 1.0)
     assert torch.equal(two, disp)                                    # fused and two-kernel forms are bit-identical
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 4: the reference's PUBLISHED operating point for PSMNet / AcfNet -- KITTI, 384x1248 (375x1242 padded): features
+# [B, 32, 96, 312], 48 samples at 1/4 resolution (configs/PSMNet/kitti_2015.py:113,122,129; ResultOfPSMNet.md:15-19) -- against
+# outputs of the REAL reference through its own kitti_2015 config files (oracle/gen_golden_fullsize.py kitti), and one WHOLE
+# 544x960 PSMNet map.  None of the three widths 312 / 156 / 78 is a multiple of the BASELINE tile widths: these shapes run on
+# the 24-column row quads, 40-column row quads with a partial tile, and the dword paths (78 is not a multiple of 4).
+# ----------------------------------------------------------------------------------------------------------------------
+KROWS = (slice(None), slice(7, None, 48), slice(11, None, 24), slice(None))   # as in oracle/gen_golden_fullsize.py kitti()
+
+
+def test_fullsize_psmnet_kitti_vs_reference(dev):
+    """Two pairs as one batch through configs/PSMNet/kitti_2015.py: every level's sampled disparity maps, pair 0's cost rows and
+    the WHOLE best-level map of pair 0 (479 232 pixels)."""
+    from densematchingbenchmark_amd import synthetic
+    g = golden("fullsize_psmnet_kitti.npz")
+    cfg, model = _built("PSMNet/kitti_2015.py", 0)
+    assert list(cfg.data.eval.input_shape) == [384, 1248]
+    model = model.to(dev)
+    left, right = synthetic.feature_batch(0, 1, 2, 32, 96, 312, dev)
+    results, _ = model(dict(leftFeature=left, rightFeature=right))
+    assert [tuple(d.shape) for d in results["disps"]] == [(2, 1, 384, 1248)] * 3
+    worst = 0.0
+    for lvl in range(3):
+        for i in range(2):
+            d = results["disps"][lvl][i:i + 1][SUB]
+            ref = g["pair%d_disp%d" % (i, 3 - lvl)]
+            worst = max(worst, maxdiff(d, ref))
+            assert maxdiff(d, ref) <= DISP_MAX_FULL, (lvl, i, maxdiff(d, ref))
+            assert _meandiff(d, ref) <= DISP_MEAN_FULL
+        assert maxdiff(results["costs"][lvl][0:1][KROWS], g["pair0_cost%d_rows" % (3 - lvl)]) <= COST_TOL
+    full = maxdiff(results["disps"][0][0:1], g["pair0_disp3_full"])
+    print("KITTI PSMNet: worst sampled |disp - reference| = %.3g, whole best-level map = %.3g" % (worst, full))
+    assert full <= DISP_MAX_FULL and _meandiff(results["disps"][0][0:1], g["pair0_disp3_full"]) <= DISP_MEAN_FULL
+
+
+def test_fullsize_acfnet_kitti_vs_reference(dev):
+    """configs/AcfNet/kitti_2015_adaptive.py: learned 4x up-sampling and the confidence network at 384x1248."""
+    from densematchingbenchmark_amd import synthetic
+    g = golden("fullsize_acfnet_kitti.npz")
+    cfg, model = _built("AcfNet/kitti_2015_adaptive.py", 5)
+    model = model.to(dev)
+    lf, rf = synthetic.feature_pair(0, 32, 96, 312)
+    results, _ = model(dict(leftFeature=lf.to(dev), rightFeature=rf.to(dev)))
+    assert set(results) == {"disps", "costs", "confs"}
+    with torch.no_grad():
+        variance, _ = model.cmn(results["costs"])
+    for lvl in range(3):
+        k = 3 - lvl
+        print("KITTI AcfNet level %d: |disp - reference| = %.3g, conf %.3g" % (k, maxdiff(results["disps"][lvl][SUB], g["disp%d" % k]),
+                                                                             maxdiff(results["confs"][lvl][SUB], g["conf%d" % k])))
+        assert maxdiff(results["disps"][lvl][SUB], g["disp%d" % k]) <= DISP_MAX_FULL
+        assert _meandiff(results["disps"][lvl][SUB], g["disp%d" % k]) <= DISP_MEAN_FULL
+        assert maxdiff(results["confs"][lvl][SUB], g["conf%d" % k]) <= 2e-5
+        assert maxdiff(variance[lvl][SUB], g["var%d" % k]) <= 2e-5
+        assert maxdiff(results["costs"][lvl][KROWS], g["cost%d_rows" % k]) <= COST_TOL
+
+
+def test_fp64_yardstick_psmnet_kitti(dev):
+    """The FP32-floor contract (see above) at the KITTI operating point, both pairs."""
+    from densematchingbenchmark_amd import synthetic
+    cfg, model = _built("PSMNet/kitti_2015.py", 0)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    left, right = synthetic.feature_batch(0, 1, 2, 32, 96, 312, dev)
+    results, _ = model(dict(leftFeature=left, rightFeature=right))
+    gpu = [d.cpu() for d in results["disps"]]
+    del results
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    with torch.no_grad():
+        for i in range(2):
+            lf, rf = synthetic.feature_pair(i, 32, 96, 312)
+            ref32, _ = O.psmnet_path(lf, rf, p, 192)
+            c64 = _truth(lambda d: O.psm_aggregator(O.cat_fms(lf, rf, 48, 0, 1).double().to(d), _f64(p, d), 192, "cost_processor.aggregator."), dev)
+            _assert_yardstick("psmnet kitti pair %d" % i, [d[i:i + 1] for d in gpu], ref32, c64)
+            del c64
+
+
+def test_fullsize_psmnet_full_map_vs_reference(dev):
+    """BASELINE configs[1], pair 0: the WHOLE best-level disparity map (522 240 pixels) against the reference's, not every 64th
+    pixel."""
+    from densematchingbenchmark_amd import synthetic
+    g = golden("fullsize_psmnet_map.npz")
+    cfg, model = _built("PSMNet/scene_flow.py", 0)
+    model = model.to(dev)
+    lf, rf = synthetic.feature_pair(0, 32, 136, 240)
+    results, _ = model(dict(leftFeature=lf.to(dev), rightFeature=rf.to(dev)))
+    d = maxdiff(results["disps"][0], g["disp3"])
+    print("psmnet full map: max |disp - reference| over %d pixels = %.3g" % (g["disp3"].size, d))
+    assert d <= DISP_MAX_FULL and _meandiff(results["disps"][0], g["disp3"]) <= DISP_MEAN_FULL

@@ -1,0 +1,118 @@
+"""The library's launch contract (include/dmb_hip.h, boundary rules): every entry point only enqueues kernel launches that
+depend on nothing but their arguments -- so a whole step can be captured into a HIP graph and replayed, and launches from
+several host threads on distinct streams do not interfere.  Round 3's transposed convolution broke both (a host-predicted
+counter base as a kernel argument, a lazily allocated counter ring); its counters now live in a caller-provided workspace the
+kernel itself resets."""
+import os
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(dev, cfg_rel="PSMNet/scene_flow.py"):
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", cfg_rel))
+    model = build_model(cfg).eval()
+    synthetic.init_params_(model, seed=0, classif_gain=10.0)
+    return model.to(dev)
+
+
+def test_psmnet_step_captured_in_a_hip_graph_replays_bit_identically(dev):
+    """One PSMNet step at 544x960 / max_disp 192 (two pairs) captured in torch.cuda.CUDAGraph (= hipGraph), replayed three times
+    on fresh inputs: disparity maps AND full-resolution costs equal, bit for bit, to the eager evaluation of the same inputs."""
+    from densematchingbenchmark_amd import synthetic
+    model = _model(dev)
+    B = 2
+    left, right = synthetic.feature_batch(0, 1, B, 32, 136, 240, dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():      # warm-up off the default stream: weight packing, per-device attributes
+        for _ in range(2):
+            model(dict(leftFeature=left, rightFeature=right))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        results, _ = model(dict(leftFeature=left, rightFeature=right))
+        captured = list(results["disps"]) + list(results["costs"])
+    for rep in range(3):
+        l2, r2 = synthetic.feature_batch(10 + 2 * rep, 1, B, 32, 136, 240, dev)
+        left.copy_(l2)
+        right.copy_(r2)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in captured]
+        with torch.no_grad():
+            eager, _ = model(dict(leftFeature=l2, rightFeature=r2))
+        want = list(eager["disps"]) + list(eager["costs"])
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (rep, k, (a - b).abs().max().item())
+        del eager, want, got
+
+
+def test_deconv3d_replays_from_a_graph_many_times(dev):
+    """The transposed convolution alone, 50 replays: every replay finds the workspace zeroed by the previous one."""
+    from densematchingbenchmark_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 64, 6, 17, 60), generator=g).to(dev)
+    w = (torch.randn((64, 32, 3, 3, 3), generator=g) * 0.05).to(dev)
+    res = torch.randn((2, 32, 12, 34, 120), generator=g).to(dev)
+    wp = ops.pack_deconv3d_weights(w)
+    ws = torch.zeros(16, dtype=torch.int32, device=dev)
+    want = ops.deconv3d_k3s2(x, wp, 32, None, None, res, True, workspace=None)      # the form without counters
+    out = torch.empty_like(want)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.deconv3d_k3s2(x, wp, 32, None, None, res, True, workspace=ws, out=out)
+    for rep in range(50):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), rep
+        assert int(ws.abs().sum().item()) == 0
+
+
+def test_deconv3d_from_two_host_threads_on_two_streams(dev):
+    """dmb_deconv3d_k3s2_f32 called concurrently from two host threads, each on its own stream (ctypes releases the GIL around
+    the call) with its own workspace: 40 launches each, every result equal to the sequential one."""
+    from densematchingbenchmark_amd import ops
+    g = torch.Generator().manual_seed(6)
+    cases = []
+    for k in range(2):
+        x = torch.randn((2, 64, 6, 34, 60), generator=g).to(dev)
+        w = (torch.randn((64, 64, 3, 3, 3), generator=g) * 0.05).to(dev)
+        res = torch.randn((2, 64, 12, 68, 120), generator=g).to(dev)
+        wp = ops.pack_deconv3d_weights(w)
+        cases.append((x, wp, res, ops.deconv3d_k3s2(x, wp, 64, None, None, res, True, workspace=None)))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(dev)
+            x, wp, res, want = cases[k]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                outs = [ops.deconv3d_k3s2(x, wp, 64, None, None, res, True) for _ in range(40)]
+            st.synchronize()
+            for i, o in enumerate(outs):
+                if not torch.equal(o, want):
+                    errors.append((k, i, (o - want).abs().max().item()))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    # the two streams got two workspaces
+    assert len({ws.data_ptr() for ws in ops._deconv_ws.values()}) == len(ops._deconv_ws) >= 2

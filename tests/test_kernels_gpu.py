@@ -26,6 +26,17 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
+def _misaligned(t, dev):
+    """The same values on the device at an address that is only 4-byte aligned.  The library picks its 16-byte (vector) paths
+    from the operands' alignment, so a misaligned operand is how a caller reaches the dword (scalar) paths -- the release library
+    has no switch for it (kernel-variant options exist only in the development build, which the tests never load)."""
+    buf = torch.empty(t.numel() + 1, dtype=torch.float32, device=dev)
+    v = buf[1:].view(t.shape)
+    v.copy_(t)
+    assert v.data_ptr() % 16 == 4 and v.is_contiguous()
+    return v
+
+
 # ------------------------------------------------------------------------------------------- volumes (bit-exact)
 @pytest.mark.parametrize("shape,md,sd,dil", [
     ((1, 1, 3, 4), 5, -2, 2),       # reference known-answer shape (tests/.../test_cat_fms.py:30-40)
@@ -173,22 +184,14 @@ def test_fast_volume_builders_backward(dev):
 @pytest.mark.parametrize("C,G", [(16, 2), (32, 8), (12, 12), (320, 40)])
 @pytest.mark.parametrize("W,md,sd", [(40, 9, 0), (300, 48, 0), (70, 12, -3)])
 def test_gwc(dev, C, G, W, md, sd):
-    """MFMA form (0 <= d <= 64, even channels/group) and VALU form (everything else) against the oracle, and --
-    where both apply -- against each other bit for bit (same ascending-channel FMA chain)."""
-    from densematchingbenchmark_amd import _lib
+    """MFMA form (0 <= d <= 64, even channels/group) and VALU form (everything else: negative disparities, one channel per
+    group) against the oracle."""
     ops = _ops()
     L, R = _rand((2, C, 5, W), 3), _rand((2, C, 5, W), 4)
     idx = ops.disp_index_list(md, sd, 1)
     got = ops.gwc_fms(L.to(dev), R.to(dev), idx, G).cpu()
     ref = O.gwc_fms(L, R, md, sd, 1, G)
     assert (got - ref).abs().max().item() <= 3e-6  # <= C/G FP32 products, different summation order
-    lib = _lib.load()
-    lib.dmb_dev_set_option(1, 1)   # force the VALU kernel
-    try:
-        valu = ops.gwc_fms(L.to(dev), R.to(dev), idx, G).cpu()
-    finally:
-        lib.dmb_dev_set_option(1, 0)
-    assert torch.equal(valu, got)
 
 
 @pytest.mark.parametrize("C,W,D", [(8, 40, 9), (32, 300, 48), (4, 23, 9)])
@@ -302,54 +305,12 @@ def test_conv3d_c1(dev, Ci):
     assert (got - ref).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("shape,njobs", [((2, 6, 9, 72), 3), ((1, 17, 10, 240), 2), ((2, 5, 7, 30), 3), ((1, 9, 8, 124), 4), ((3, 4, 4, 8), 1)])
-def test_conv3d_c1_multi_and_cost_chain(dev, shape, njobs):
-    """Several heads in one launch (conv3d_c1v_kernel<true>: job = batch item / B picks input, weights, bias) against one
-    dmb_conv3d_k3_c1_f32 call per head: bit-identical, also through the dword fallback (W = 30); then the in-place cumulative sums
-    against the skip-operand form cost_j = head_j(x_j) + cost_{j-1}: the same FP32 adds, bit-identical."""
-    ops = _ops()
-    B, D, H, W = shape
-    xs = [_rand((B, 32, D, H, W), 40 + j).to(dev) for j in range(njobs)]
-    ws = [_rand((1, 32, 3, 3, 3), 50 + j, 1.0 / math.sqrt(32 * 27)).to(dev) for j in range(njobs)]
-    bs = [0.25 * j - 0.5 for j in range(njobs)]
-    stack = ops.conv3d_k3_c1_multi(xs, ws, bs)
-    assert stack.shape == (njobs, B, 1, D, H, W)
-    singles = [ops.conv3d_k3_c1(x, w, b, None) for x, w, b in zip(xs, ws, bs)]
-    for j in range(njobs):
-        assert torch.equal(stack[j], singles[j])
-        ref = F.conv3d(xs[j].cpu(), ws[j].cpu(), torch.tensor([bs[j]]), padding=1)
-        assert (stack[j].cpu() - ref).abs().max().item() <= 1e-5
-    chained, prev = [], None
-    for x, w, b in zip(xs, ws, bs):
-        prev = ops.conv3d_k3_c1(x, w, b, prev)
-        chained.append(prev)
-    ops.cost_chain_(stack)
-    for j in range(njobs):
-        assert torch.equal(stack[j], chained[j])
-
-
-def test_cost_chain_odd_sizes(dev):
-    """dmb_cost_chain_f32 on counts that are not multiples of 4 and on a misaligned base: exactly torch's running FP32 sum."""
-    ops = _ops()
-    for n, count, skip in ((3, 1001, 0), (2, 7, 0), (4, 64, 1), (1, 5, 0)):
-        buf = _rand((n * count + skip,), 60 + n).to(dev)
-        y = buf[skip:].view(n, count)
-        want = y.clone()
-        for j in range(1, n):
-            want[j] = want[j] + want[j - 1]
-        if skip:   # a misaligned view is not a contiguous allocation start, but it is contiguous: the scalar path takes it
-            assert y.is_contiguous()
-        ops.cost_chain_(y)
-        assert torch.equal(y, want)
-
-
 @pytest.mark.parametrize("shape", [(2, 6, 9, 72), (1, 17, 10, 240), (1, 3, 19, 64), (1, 9, 8, 124)])
 def test_conv3d_c1_vector_rows(dev, shape):
     """Rows that are 16-byte aligned (W % 4 == 0) take the register-staged kernel (16-byte fetches, one LDS word per input
     row and thread, halo columns by lane shifts): same accumulation order as the dword kernel -> BIT-identical to it, and
     within 1e-5 of the CPU convolution; tile edges in every direction (8 z x 8 y x 60 x tiles)."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, D, H, W = shape
     x = _rand((B, 32, D, H, W), 16)
     w = _rand((1, 32, 3, 3, 3), 17, 1.0 / math.sqrt(32 * 27))
@@ -357,12 +318,7 @@ def test_conv3d_c1_vector_rows(dev, shape):
     ref = F.conv3d(x, w, torch.tensor([-0.5]), padding=1) + res
     got = ops.conv3d_k3_c1(x.to(dev), w.to(dev), -0.5, res.to(dev))
     assert (got.cpu() - ref).abs().max().item() <= 1e-5
-    lib = _lib.load()
-    lib.dmb_dev_set_option(3, 1)     # force the dword kernel
-    try:
-        old = ops.conv3d_k3_c1(x.to(dev), w.to(dev), -0.5, res.to(dev))
-    finally:
-        lib.dmb_dev_set_option(3, 0)
+    old = ops.conv3d_k3_c1(_misaligned(x, dev), w.to(dev), -0.5, res.to(dev))     # a misaligned input takes the dword kernel
     assert torch.equal(got, old)
     assert (ops.conv3d_k3_c1(x.to(dev), w.to(dev), 0.0, None).cpu() - (ref - res + 0.5)).abs().max().item() <= 1e-5
 
@@ -583,7 +539,6 @@ def test_conv2d_vector_path(dev, Ci, Co, k, stride, dil, shape):
     """Widths that are multiples of 4 take the 16-byte staging + transposed-store path; it must agree bit for bit with the
     scalar path (same MFMA sequence, same epilogue arithmetic) and with torch within the FP32 tolerance."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, H, W = shape
     x = _rand((B, Ci, H, W), 151)
     w = _rand((Co, Ci, k, k), 152, 1.0 / math.sqrt(Ci * k * k))
@@ -594,12 +549,7 @@ def test_conv2d_vector_path(dev, Ci, Co, k, stride, dil, shape):
     wp = ops.pack_conv2d_weights(w.to(dev))
     args = (x.to(dev), wp, Co, k, stride, dil, sc.to(dev), sh.to(dev), res.to(dev), True)
     got = ops.conv2d(*args)
-    lib = _lib.load()
-    lib.dmb_dev_set_option(3, 1)      # development knob: force the scalar path
-    try:
-        scalar = ops.conv2d(*args)
-    finally:
-        lib.dmb_dev_set_option(3, 0)
+    scalar = ops.conv2d(_misaligned(x, dev), *args[1:])      # a misaligned input takes the scalar path
     assert torch.equal(got, scalar)
     assert (got.cpu() - F.relu(ref + res)).abs().max().item() <= 2e-5
     got = ops.conv2d(x.to(dev), wp, Co, k, stride, dil).cpu()
@@ -607,29 +557,24 @@ def test_conv2d_vector_path(dev, Ci, Co, k, stride, dil, shape):
 
 
 @pytest.mark.parametrize("shape", [(8, 136, 240), (2, 20, 48), (3, 9, 100)])
-def test_conv2d_tile_height_variants_are_bit_identical(dev, shape):
+def test_conv2d_tile_height_is_picked_per_launch(dev, shape):
     """64-channel 3x3 layers pick their tile height per launch (4 or 2 output rows per wave, by rounds x rows on the persistent
-    grid): the same MFMA sequence per output, so the launch-size-dependent choice must not change a bit (development option 18
-    forces the default height) -- with folded BatchNorm, skip operand and ReLU."""
+    grid): launch sizes on either side of the choice against the CPU convolution -- with folded BatchNorm, skip operand and
+    ReLU -- and a batch against its own items one at a time (a different launch size, possibly a different height: the same
+    MFMA sequence per output, so not a bit may change)."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, H, W = shape
     x = _rand((B, 64, H, W), 301).to(dev)
     w = _rand((64, 64, 3, 3), 302, 1.0 / math.sqrt(64 * 9))
     sc, sh = _affine(64, 303)
     res = _rand((B, 64, H, W), 304).to(dev)
     wp = ops.pack_conv2d_weights(w.to(dev))
-    lib = _lib.load()
-    outs = []
-    for opt in (0, 1):
-        lib.dmb_dev_set_option(18, opt)
-        try:
-            outs.append(ops.conv2d(x, wp, 64, 3, 1, 1, sc.to(dev), sh.to(dev), res, True))
-        finally:
-            lib.dmb_dev_set_option(18, 0)
-    assert torch.equal(outs[0], outs[1])
+    whole = ops.conv2d(x, wp, 64, 3, 1, 1, sc.to(dev), sh.to(dev), res, True)
+    for b in range(B):
+        one = ops.conv2d(x[b:b + 1].contiguous(), wp, 64, 3, 1, 1, sc.to(dev), sh.to(dev), res[b:b + 1].contiguous(), True)
+        assert torch.equal(one[0], whole[b])
     ref = F.relu(F.conv2d(x.cpu(), w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res.cpu())
-    assert (outs[0].cpu() - ref).abs().max().item() <= 2e-5
+    assert (whole.cpu() - ref).abs().max().item() <= 2e-5
 
 
 def test_conv2d_unsupported_combinations_fail_loudly(dev):
@@ -817,28 +762,25 @@ def test_conv3d_bf16x6_is_as_accurate_as_fp32(dev, Ci, Co, shape):
     assert (plain - F.conv3d(x.double(), w.double(), None, padding=1)).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("kind,shape", [("s2", (1, 6, 9, 48)), ("s2", (2, 5, 8, 120)), ("deconv", (1, 3, 5, 60)), ("deconv", (2, 2, 3, 24))])
+@pytest.mark.parametrize("kind,shape", [("s2", (1, 6, 9, 48)), ("s2", (2, 5, 8, 120)), ("deconv", (1, 3, 5, 60)), ("deconv", (2, 2, 3, 24)),
+                                        ("s1_32", (1, 5, 9, 312)), ("s1_32", (2, 4, 12, 48)), ("s1_64", (1, 4, 8, 156)), ("s1_64", (1, 3, 7, 40))])
 def test_conv3d_vector_and_scalar_staging_agree(dev, kind, shape):
     """Rows that are 16-byte aligned are staged with 16-byte LDS-DMA words; the result must be bit-identical to the dword
-    staging path (same MFMA sequence, same epilogue), which stays in use for other widths."""
+    staging path (same MFMA sequence, same epilogue), which stays in use for other widths and for misaligned operands -- a
+    misaligned input is how the dword path is reached here."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, D, H, W = shape
-    x = _rand((B, 32, D, H, W), 211).to(dev)
-    sc, sh = _affine(64, 213)
-    lib = _lib.load()
+    xc = _rand((B, 32, D, H, W), 211)
+    Co = 32 if kind == "s1_32" else 64
+    sc, sh = _affine(Co, 213)
     outs = []
-    for force_scalar in (0, 1):
-        lib.dmb_dev_set_option(3, force_scalar)
-        try:
-            if kind == "s2":
-                w = _rand((64, 32, 3, 3, 3), 212, 0.03).to(dev)
-                outs.append(ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 64, sc.to(dev), sh.to(dev), None, 2, True))
-            else:
-                w = _rand((32, 64, 3, 3, 3), 212, 0.1).to(dev)
-                outs.append(ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(w), 64, sc.to(dev), sh.to(dev), None, True))
-        finally:
-            lib.dmb_dev_set_option(3, 0)
+    for x in (xc.to(dev), _misaligned(xc, dev)):
+        if kind == "deconv":
+            w = _rand((32, 64, 3, 3, 3), 212, 0.1).to(dev)
+            outs.append(ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(w), 64, sc.to(dev), sh.to(dev), None, True))
+        else:
+            w = _rand((Co, 32, 3, 3, 3), 212, 0.03).to(dev)
+            outs.append(ops.conv3d_k3(x, ops.pack_conv3d_weights(w), Co, sc.to(dev), sh.to(dev), None, 2 if kind == "s2" else 1, True))
     assert torch.equal(outs[0], outs[1])
 
 
@@ -846,11 +788,10 @@ def test_conv3d_vector_and_scalar_staging_agree(dev, kind, shape):
 @pytest.mark.parametrize("mode", ["plain", "skip_relu", "relu_then_skip"])
 def test_conv3d_s2_pair_epilogue_is_bit_identical(dev, Ci, shape, mode):
     """The stride-2 kernel's 8-byte epilogue (S2Cfg VEP: 32 x 32 accumulator tiles through a per-wave LDS scratch, a lane stores two
-    adjacent columns of one channel) against the dword epilogue (development option 10 = 2): the same FP32 operations per output,
-    so bit-identical -- with folded BatchNorm, with the skip operand before / after the ReLU, over partial tiles in x, y and z --
-    and within 2e-5 of the CPU convolution."""
+    adjacent columns of one channel) against the dword epilogue (taken when the output is not 8-byte aligned: the caller's ``out``
+    here): the same FP32 operations per output, so bit-identical -- with folded BatchNorm, with the skip operand before / after the
+    ReLU, over partial tiles in x, y and z -- and within 2e-5 of the CPU convolution."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, D, H, W = shape
     x = _rand((B, Ci, D, H, W), 221)
     w = _rand((64, Ci, 3, 3, 3), 222, 1.0 / math.sqrt(Ci * 27))
@@ -863,15 +804,10 @@ def test_conv3d_s2_pair_epilogue_is_bit_identical(dev, Ci, shape, mode):
         ref = F.relu(ref + res)
     elif mode == "relu_then_skip":
         ref = F.relu(ref) + res
-    lib = _lib.load()
     wp = ops.pack_conv3d_weights(w.to(dev))
     outs = []
-    for opt in (0, 2):
-        lib.dmb_dev_set_option(10, opt)
-        try:
-            outs.append(ops.conv3d_k3(x.to(dev), wp, 64, sc.to(dev), sh.to(dev), None if res is None else res.to(dev), 2, relu))
-        finally:
-            lib.dmb_dev_set_option(10, 0)
+    for out in (None, _misaligned(torch.zeros(B, 64, Do, Ho, Wo), dev)):
+        outs.append(ops.conv3d_k3(x.to(dev), wp, 64, sc.to(dev), sh.to(dev), None if res is None else res.to(dev), 2, relu, out=out))
     assert torch.equal(outs[0], outs[1])
     assert (outs[0].cpu() - ref).abs().max().item() <= 2e-5
 
@@ -985,13 +921,12 @@ def test_conf_head_composed_with_learned_upsampling(dev, B, Hq, Wq):
     finally:
         ops.set_conf_dot_epilogue(True)
     assert (via_hidden.double() - want).abs().max().item() <= 5e-6 and (via_hidden - got).abs().max().item() <= 2e-6
-    # ... and with the dword staging path of the convolution kernel (development option 3), which the fused epilogue shares
-    from densematchingbenchmark_amd import _lib
-    _lib.load().dmb_dev_set_option(3, 1)
-    try:
-        scalar_path = ops.conf_head_from_source(cost, comp, sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
-    finally:
-        _lib.load().dmb_dev_set_option(3, 0)
+    # ... and with the dword staging path of the convolution kernel (a misaligned quarter-resolution source), which the fused
+    # epilogue shares
+    cqm = _misaligned(c, dev)
+    cost_m = ops.deconv3d_k8s4_c1(cqm, w8d.view(8, 8, 8))
+    ops.UpsampleSource.attach(cost_m, cqm, w8d)
+    scalar_path = ops.conf_head_from_source(cost_m, comp, sc.to(dev), sh.to(dev), w2.to(dev)).cpu()
     assert torch.equal(scalar_path, got)
     cost.add_(0.0)                                        # a modified tensor no longer matches its note
     assert not ops.conf_head_composite_applicable(cost, M)
@@ -1018,24 +953,18 @@ def test_deconv_k8s4_zcol_with_regression_is_bit_identical(dev, shape):
 def test_deconv3d_vector_and_scalar_epilogues_agree(dev, Co, shape):
     """The transposed convolution's 16-byte epilogue (two x parities interleaved through a per-wave LDS scratch, residual
     ring) against its 8-byte scattered form: same fma / add / max sequence per output -> bit-identical, with and without the
-    skip operand, both ReLU placements."""
+    skip operand, both ReLU placements.  The scattered form is what a misaligned output takes (the caller's ``out``)."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, D, H, W = shape
     x = _rand((B, 64, D, H, W), 601).to(dev)
     w = _rand((64, Co, 3, 3, 3), 602, 0.05).to(dev)
     wp = ops.pack_deconv3d_weights(w)
     sc, sh = _affine(Co, 603)
     res = _rand((B, Co, 2 * D, 2 * H, 2 * W), 604).to(dev)
-    lib = _lib.load()
     for r, relu in ((None, True), (res, True), (res, False), (res, "pre")):
         outs = []
-        for scalar in (0, 1):
-            lib.dmb_dev_set_option(7, scalar)
-            try:
-                outs.append(ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu))
-            finally:
-                lib.dmb_dev_set_option(7, 0)
+        for out in (None, _misaligned(torch.zeros(B, Co, 2 * D, 2 * H, 2 * W), dev)):
+            outs.append(ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu, out=out))
         assert torch.equal(outs[0], outs[1])
 
 
@@ -1044,12 +973,12 @@ def test_deconv3d_vector_and_scalar_epilogues_agree(dev, Co, shape):
                                          (64, 64, (4, 12, 34, 60)), (64, 32, (2, 24, 68, 120))])
 def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shape):
     """csrc/deconv3d_zy.hip -- work items (tile, z parity, y parity), four class bodies with their own chunk sizes, items handed
-    out through an atomic counter, three workgroups per CU -- against deconv3d_kernel (both y parities per item; development
-    option 4 selects it): the same ascending (channel, tap) fma chain per output, so BIT-identical, with and without the skip
-    operand and for both ReLU placements; and against the CPU transposed convolution.  Shapes: partial tiles in x (124, 116)
-    and z (D = 5, 3, 1), a single row, 2 .. 8 chunks per class, the hourglass's quarter-resolution layer."""
+    out through per-XCD counters in the caller's workspace, three workgroups per CU -- against deconv3d_kernel (both y parities
+    per item, static tile walk: what ``workspace=None`` selects): the same ascending (channel, tap) fma chain per output, so
+    BIT-identical, with and without the skip operand and for both ReLU placements; and against the CPU transposed convolution.
+    Shapes: partial tiles in x (124, 116) and z (D = 5, 3, 1), a single row, 2 .. 8 chunks per class, the hourglass's
+    quarter-resolution layer.  The workspace must come back zeroed from every launch."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, D, H, W = shape
     xc = _rand((B, Ci, D, H, W), 611)
     wc = _rand((Ci, Co, 3, 3, 3), 612, 1.0 / math.sqrt(Ci * 27 / 8))
@@ -1057,44 +986,19 @@ def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shap
     x, w = xc.to(dev), wc.to(dev)
     wp = ops.pack_deconv3d_weights(w)
     res = _rand((B, Co, 2 * D, 2 * H, 2 * W), 614).to(dev)
-    lib = _lib.load()
+    ws = torch.zeros(16, dtype=torch.int32, device=dev)
     ref = F.conv_transpose3d(xc, wc, None, stride=2, padding=1, output_padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
     for r, relu in ((None, False), (None, True), (res, True), (res, False), (res, "pre")):
-        outs = []
-        for form in (2, 1):   # development option 4: 2 = this form, 1 = deconv3d_kernel
-            lib.dmb_dev_set_option(4, form)
-            try:
-                outs.append(ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu))
-            finally:
-                lib.dmb_dev_set_option(4, 0)
-        assert torch.equal(outs[0], outs[1]), (r is not None, relu, (outs[0] - outs[1]).abs().max().item())
+        new = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu, workspace=ws)
+        assert int(ws.abs().sum().item()) == 0          # the last workgroup to leave has reset every counter
+        old = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu, workspace=None)
+        assert torch.equal(new, old), (r is not None, relu, (new - old).abs().max().item())
         if r is None and relu is False:
-            assert (outs[0].cpu() - ref).abs().max().item() <= 2e-5
-    # ... and, where it applies (64 -> 32 with many tiles per CU; development option 11 forces it on the small test shapes),
-    # the sixteen-wave form of csrc/deconv3d_w16.hip: all eight parity classes from one staged tile, bit-identical again
-    if Co == 32:
-        for grid in (0, 3):
-            lib.dmb_dev_set_option(11, 1)
-            lib.dmb_dev_set_option(9, grid)
-            try:
-                for r, relu in ((None, False), (res, True), (res, "pre")):
-                    w16 = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu)
-                    lib.dmb_dev_set_option(4, 1)
-                    old_form = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu)
-                    lib.dmb_dev_set_option(4, 0)
-                    assert torch.equal(w16, old_form), (grid, r is not None, relu, (w16 - old_form).abs().max().item())
-            finally:
-                lib.dmb_dev_set_option(11, 0)
-                lib.dmb_dev_set_option(9, 0)
-                lib.dmb_dev_set_option(4, 0)
-    # the launch really took the new form (same call twice in a row: the counter ring hands out a fresh counter each time)
-    lib.dmb_dev_set_option(4, 2)
-    again = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True)
-    lib.dmb_dev_set_option(4, 1)
-    try:
-        assert torch.equal(again, ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True))
-    finally:
-        lib.dmb_dev_set_option(4, 0)
+            assert (new.cpu() - ref).abs().max().item() <= 2e-5
+    # the same call again on the same workspace, and on the host layer's per-stream workspace
+    again = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True, workspace=ws)
+    auto = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True)
+    assert torch.equal(again, auto) and torch.equal(again, ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), res, True, workspace=None))
 
 
 # ------------------------------------------------------------------------------------- spatial propagation scan (dmb.ops.spn)
@@ -1141,29 +1045,24 @@ def test_spn_refuses_cpu_tensors_and_long_lines(dev):
         GateRecurrent2dnoind(True, False)(y, y, y, y)
 
 
-@pytest.mark.parametrize("Ci,shape", [(64, (1, 4, 5, 60)), (64, (2, 3, 34, 60)), (20, (1, 2, 1, 60)), (64, (4, 12, 34, 60))])
-def test_conv3d_quarter_resolution_linear_runs(dev, Ci, shape):
-    """The 64-channel stride-1 layer at the BASELINE quarter resolution (W = 60) on 64-voxel runs of the (y, x) plane (S1Cfg LIN:
-    768 equal workgroups for [4, 64, 12, 34, 60], exactly three per CU) against the box-tiled form (development option 13) --
-    the same ascending (channel, tap) fma chain per output, so BIT-identical, with residual and both ReLU placements -- and
-    against the CPU convolution.  Runs that cross row ends, a last run shorter than 64, odd plane counts, a single row."""
+@pytest.mark.parametrize("Ci,shape", [(64, (1, 4, 5, 60)), (64, (2, 3, 34, 60)), (20, (1, 2, 1, 60)), (64, (4, 12, 34, 60)),
+                                      (64, (1, 3, 9, 32)), (64, (2, 5, 7, 44)), (64, (1, 2, 24, 64))])
+def test_conv3d_linear_runs_for_narrow_planes(dev, Ci, shape):
+    """The 64-channel stride-1 layer on 64-voxel runs of the (y, x) plane (S1Cfg LIN: rows of 32 .. 64 voxels -- the deepest
+    hourglass level; 768 equal workgroups for [4, 64, 12, 34, 60], exactly three per CU) against the flattened dword form (what a
+    misaligned input takes) -- the same ascending (channel, tap) fma chain per output, so BIT-identical, with residual and both
+    ReLU placements -- and against the CPU convolution.  Runs that cross row ends, a last run shorter than 64, odd plane
+    counts, a single row, widths below and at the capacity of the staged rows."""
     ops = _ops()
-    from densematchingbenchmark_amd import _lib
     B, D, H, W = shape
     xc = _rand((B, Ci, D, H, W), 621)
     wc = _rand((64, Ci, 3, 3, 3), 622, 1.0 / math.sqrt(Ci * 27))
     sc, sh = _affine(64, 623)
     x, wp = xc.to(dev), ops.pack_conv3d_weights(wc.to(dev))
+    xm = _misaligned(xc, dev)
     res = _rand((B, 64, D, H, W), 624).to(dev)
-    lib = _lib.load()
     for r, relu in ((None, False), (None, True), (res, True), (res, "pre")):
-        outs = []
-        for boxes in (0, 1):
-            lib.dmb_dev_set_option(13, boxes)
-            try:
-                outs.append(ops.conv3d_k3(x, wp, 64, sc.to(dev), sh.to(dev), r, 1, relu))
-            finally:
-                lib.dmb_dev_set_option(13, 0)
+        outs = [ops.conv3d_k3(xx, wp, 64, sc.to(dev), sh.to(dev), r, 1, relu) for xx in (x, xm)]
         assert torch.equal(outs[0], outs[1]), (r is not None, relu, (outs[0] - outs[1]).abs().max().item())
     ref = F.conv3d(xc, wc, None, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
     got = ops.conv3d_k3(x, wp, 64, sc.to(dev), sh.to(dev), None, 1, False).cpu()

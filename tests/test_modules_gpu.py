@@ -129,31 +129,6 @@ def test_branch_overlap_is_identical(dev):
             ops.set_branch_overlap(False)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 8, 16, 32), (1, 64, 12, 20, 124), (1, 64, 8, 12, 28)])
-def test_merged_heads_are_identical(dev, shape):
-    """The opt-in eval form of the PSMNet aggregator (ops.set_merged_heads(True): three 32 -> 1 heads in one launch, the cumulative
-    cost sums as one pass, the three up-sampling + regression passes as one launch) against the default launch-per-branch form:
-    the same FP32 operations in the same order, so volumes, regression hints and disparities are bit-identical, across tile edges."""
-    from densematchingbenchmark_amd import ops
-    from densematchingbenchmark_amd.modeling.stereo.cost_processors.aggregators import PSMAggregator
-    m = _load(PSMAggregator(max_disp=4 * shape[2], in_planes=64), O.random_params_psm(seed=7, classif_gain=10.0)).to(dev).eval()
-    raw = rand(shape, 306).to(dev)
-    vals = ops.disp_sample_values(4 * shape[2], 0, 1)
-    with torch.no_grad():
-        assert not ops.merged_heads()
-        want = m(raw)
-        ops.set_merged_heads(True)
-        try:
-            got = m(raw)
-        finally:
-            ops.set_merged_heads(False)
-    assert len(got) == 3
-    for a, b in zip(got, want):
-        assert a.shape == b.shape and torch.equal(a, b)
-        ha, hb = ops.RegressionHint.lookup(a, vals, 1.0, True), ops.RegressionHint.lookup(b, vals, 1.0, True)
-        assert ha is not None and hb is not None and torch.equal(ha, hb)
-
-
 def test_fast_mode_cost_processor_through_builders(dev):
     """cost_computation.type='fast_mode' (the AnyNet config's builder, configs/AnyNet/scene_flow.py:34-35) through
     build_cost_processor: the warped volume feeds the same aggregator; with and without explicit per-pixel samples."""
