@@ -13,9 +13,9 @@ import torch  # imported first on purpose: the library then binds to the HIP run
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # DMB_LIB=dev (development scripts only): the build with the kernel-variant switches, lib/libdmb_hip_dev.so (build.py dev=True)
-DEV_BUILD = os.environ.get("DMB_LIB", "") == "dev"
-LIB_PATH = os.path.join(_PKG, "lib", "libdmb_hip_dev.so" if DEV_BUILD else "libdmb_hip.so")
-DECONV3D_WORKSPACE_BYTES = 64   # include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES
+DEV_BUILD = os.environ.get("DMB_LIB", "").startswith("dev")    # "dev" or "dev_<tag>" (a build-time experiment, build.py)
+LIB_PATH = os.path.join(_PKG, "lib", "libdmb_hip_%s.so" % os.environ["DMB_LIB"] if DEV_BUILD else "libdmb_hip.so")
+DECONV3D_WORKSPACE_BYTES = 2048   # include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dmb_hip.h")
 
 _c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
@@ -49,7 +49,8 @@ SIGNATURES = {
     "dmb_deconv3d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conv3d_k3_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 8 + [_P]),
     "dmb_conv3d_k3_c1_f32": (_c_int, [_P, _P, _c_float, _P, _P] + [_c_int] * 5 + [_P]),
-    "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 7 + [_P, _P]),
+    "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 8 + [_P, _P]),
+    "dmb_zero_columns_f32": (_c_int, [_P, _c_ll, _c_int, _c_int, _P]),
     "dmb_trilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),
     "dmb_deconv3d_k8s4_c1_f32": (_c_int, [_P, _P, _P] + [_c_int] * 4 + [_P]),
     "dmb_deconv3d_k8s4_c1_soft_argmin_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 4 + [_c_float, _HF, _P]),

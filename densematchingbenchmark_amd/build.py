@@ -45,6 +45,12 @@ def build_library(force=False, verbose=True, dev=False):
     hipcc = _hipcc()
     lib_path = os.path.join(LIB_DIR, "libdmb_hip_dev.so") if dev else LIB_PATH
     suffix, extra = (".dev.o", ["-DDMB_DEV"]) if dev else (".o", [])
+    # build-time experiments (development build only): DMB_BUILD_TAG=st16 DMB_BUILD_DEFS="-DDMB_ZY_ST=16" -> lib/libdmb_hip_dev_st16.so,
+    # loaded by scripts with DMB_LIB=dev_st16
+    tag = os.environ.get("DMB_BUILD_TAG", "") if dev else ""
+    if tag:
+        lib_path = os.path.join(LIB_DIR, "libdmb_hip_dev_%s.so" % tag)
+        suffix, extra = ".dev_%s.o" % tag, extra + os.environ.get("DMB_BUILD_DEFS", "").split()
     headers = [os.path.join(CSRC, "dmb_common.h"), os.path.join(CSRC, "interp.h"), os.path.join(INCLUDE, "dmb_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:

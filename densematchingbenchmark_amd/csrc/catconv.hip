@@ -33,6 +33,16 @@ __global__ __launch_bounds__(256) void copy_window_kernel(const float* __restric
   }
 }
 
+// t[r, x0 .. pitch) = 0 for every row r: the padding columns of a tensor whose rows are padded to a 16-byte multiple
+__global__ __launch_bounds__(256) void zero_columns_kernel(float* __restrict__ t, long long rows, int pitch, int x0) {
+  const int n = pitch - x0;
+  const long long total = rows * n;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / n;
+    t[r * pitch + x0 + (int)(i - r * n)] = 0.f;
+  }
+}
+
 __device__ __forceinline__ bool z_tap_valid(int v, int dz) { return v == 0 ? dz >= 1 : (v == 2 ? dz <= 1 : true); }
 
 // 2-D summations over dz, one workgroup per (b, co, y) row.  Z(z): z = 0 -> taps dz in {1, 2}; interior -> {0, 1, 2};
@@ -253,6 +263,15 @@ extern "C" int dmb_copy_window_f32(const float* src, float* dst, long long rows,
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   hipLaunchKernelGGL(copy_window_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, rows, W, Wd, xs);
   return launch_status("copy_window launch failed");
+}
+
+extern "C" int dmb_zero_columns_f32(float* t, long long rows, int pitch, int x0, void* stream) {
+  if (!t || rows <= 0 || pitch <= 0 || x0 < 0 || x0 > pitch) return fail(DMB_EINVAL, "zero_columns: bad argument");
+  if (x0 == pitch) return DMB_OK;
+  const long long total = rows * (pitch - x0);
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(zero_columns_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, rows, pitch, x0);
+  return launch_status("zero_columns launch failed");
 }
 
 extern "C" int dmb_catconv_finalize_f32(const float* FA, const float* FB, const float* HC, const float* HD, float* FM,

@@ -1524,14 +1524,16 @@ extern "C" int dmb_conv3d_pack_dgrad_weights_f32(const float* w, float* wpack, i
 struct S1Tile {
   int tx, ty, tz, mt, wpe;   // tile extent, 32-voxel column tiles per wave, workgroups per CU
   bool lin;                  // 64-voxel runs of the (y, x) plane instead of boxes
+  double eff;                // measured rate of the shape on volumes it tiles exactly, relative to the 48 x 4 row pairs
 };
 static double s1_cost(const S1Tile& t, int B, int D, int H, int W) {
   const long long n = t.lin ? (long long)B * cdiv(D, t.tz) * cdiv(H * W, 64)
                             : (long long)B * cdiv(D, t.tz) * cdiv(H, t.ty) * cdiv(W, t.tx);
   const long long slots = (long long)t.wpe * num_cus();
-  // a round of `wpe` co-resident workgroups shares the CU's matrix cores; + 0.5: set-up and epilogue of a workgroup in units of
-  // one column tile's arithmetic (launches here are 1 .. 15 rounds deep, so the last, partly filled round matters)
-  return (double)cdiv_ll(n, slots) * t.wpe * (t.mt + 0.5);
+  // a round of `wpe` co-resident workgroups shares the CU's matrix cores; + 0.1: set-up and epilogue of a workgroup in units of
+  // one column tile's arithmetic (launches here are 1 .. 15 rounds deep, so the last, partly filled round matters).  Checked
+  // against profiles/r04_kbench_hg*.log: the estimate ranks the candidates as measured on 240 / 120 / 60 and 312 / 156 columns.
+  return (double)cdiv_ll(n, slots) * t.wpe * (t.mt + 0.1) / t.eff;
 }
 // index of the cheapest candidate (ties: the earlier one); DMB_OPT(19) = k > 0 forces candidate k - 1 (development build)
 static int s1_pick(const S1Tile* cand, const bool* ok, int n, int B, int D, int H, int W) {
@@ -1576,7 +1578,8 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       if (vec) {
         // row pairs (16 columns x 2 rows per 32-voxel column tile) of 48 or 32 columns x 4 rows, row quads (8 x 4) of 24 columns x 8
         // rows; one z-slice per wave, three workgroups per CU each
-        static const S1Tile cand[3] = {{48, 4, 4, 6, 3, false}, {24, 8, 4, 6, 3, false}, {32, 4, 4, 4, 3, false}};
+        // (8-row quads stage a quarter more halo rows per byte of output and store 32-byte instead of 64-byte runs: 0.972)
+        static const S1Tile cand[3] = {{48, 4, 4, 6, 3, false, 1.0}, {24, 8, 4, 6, 3, false, 0.972}, {32, 4, 4, 4, 3, false, 1.0}};
         const bool ok[3] = {true, true, true};
         switch (s1_pick(cand, ok, 3, B, D, H, W)) {
           case 0: return DMB_S1(32, 4, 48, 1, 16, 0);
@@ -1591,7 +1594,7 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
         // 64-voxel runs of the plane in memory order for rows of up to 64 voxels (planes no box tiling fills the chip with: the
         // deepest hourglass level), row quads of 40 / 24 / 32 columns x 4 rows otherwise; two z-slices x two channel tiles per
         // workgroup.  A launch here is only a few rounds of workgroups deep, so the estimate decides per launch.
-        static const S1Tile cand[4] = {{64, 3, 2, 2, 3, true}, {40, 4, 2, 5, 3, false}, {24, 4, 2, 3, 3, false}, {32, 4, 2, 4, 3, false}};
+        static const S1Tile cand[4] = {{64, 3, 2, 2, 3, true, 1.0}, {40, 4, 2, 5, 3, false, 1.0}, {24, 4, 2, 3, 3, false, 1.0}, {32, 4, 2, 4, 3, false, 1.0}};
         const bool ok[4] = {W >= 32 && W <= 64 && (H * W) % 4 == 0 && DMB_OPT(13) == 0, true, true, true};
         switch (s1_pick(cand, ok, 4, B, D, H, W)) {
           case 0: return launch_s1<S1Cfg<0, 64, 3, 64, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
@@ -1632,18 +1635,20 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
 }
 
 extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
-                                     const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
+                                     const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W, int Wout,
                                      int relu, void* workspace, void* stream) {
   if (!x || !wpack || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "deconv3d: bad argument");
+  if (Wout <= 0 || Wout > 2 * W || Wout <= 2 * W - 8 || (Wout & 1)) return fail(DMB_EINVAL, "deconv3d: Wout must be 2 W, or 2 W minus the (at most 3) doubled padding columns");
   if ((long long)8 * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "deconv3d: 8 input channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
   relu &= 0xff;
   relu |= DMB_OPT(6) << 8;   // (development build: diagnostics)
   if (workspace && !DMB_OPT(3) && !DMB_OPT(7)) {   // three workgroups per CU where the shape admits it (csrc/deconv3d_zy.hip)
-    const int rc = deconv3d_zy_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, relu, static_cast<int*>(workspace), st);
+    const int rc = deconv3d_zy_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, Wout, relu, static_cast<int*>(workspace), st);
     if (rc != -1) return rc;
   }
+  if (Wout != 2 * W) return fail(DMB_EUNSUPPORTED, "deconv3d: a row-padded input (Wout < 2 W) needs the workspace form: Co 32 or 64, Ci % 16 == 0, Wout % 4 == 0, aligned operands");
   const bool v16 = W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !DMB_OPT(3);   // 16-byte aligned rows
   // 16-byte epilogue: aligned output / residual rows, every channel real, one batch item of the output below 2 GiB
   const bool vepi = v16 && Co % 32 == 0 && ((((uintptr_t)y | (uintptr_t)residual) & 15) == 0) &&

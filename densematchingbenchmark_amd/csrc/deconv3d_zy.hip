@@ -23,7 +23,7 @@
 // fetched for 1.0 GB of operands).  Now the tiles are split into eight contiguous ranges, one per XCD (a workgroup reads
 // HW_REG_XCC_ID and draws from ITS range's counter first: speed only -- when that range is exhausted it draws from the others,
 // so the result does not depend on where the hardware places workgroups), and inside a range the list goes group by group:
-// RUN consecutive tiles x the four classes, heaviest class first.  The four stagings of a tile then happen on one XCD within
+// RUN = 2^k consecutive tiles x the four classes, heaviest class first.  The four stagings of a tile then happen on one XCD within
 // a few items of each other and three of them are served by that XCD's L2.
 //
 // The counters live in a caller-provided workspace (include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES, zeroed once by the
@@ -38,6 +38,18 @@
 #include <type_traits>
 
 #include "dmb_common.h"
+
+// Cache policy of the epilogue's stores / skip-operand loads (the aux operand of the buffer instructions on gfx950: 1 = sc0,
+// 2 = nt, 16 = sc1; build-time knobs, build.py: DMB_BUILD_DEFS).  The output is 8x the input and is not read again by this
+// launch: written `nt sc1` it does not stay in the XCD's L2, where the four classes of a tile find each other's input tiles.
+// Measured (profiles/r04_zy_policy.log, min of 3 passes): quarter -> half resolution 0.265 -> 0.238 ms, half -> full 0.778 ->
+// 0.767 ms, with the skip operand 0.856 either way; `nt` on the skip operand's loads changes nothing.
+#ifndef DMB_ZY_ST
+#define DMB_ZY_ST 18
+#endif
+#ifndef DMB_ZY_LD
+#define DMB_ZY_LD 0
+#endif
 
 namespace dmb {
 
@@ -80,8 +92,11 @@ struct ZYCfg {
   static_assert(LDS_FLOATS * 4 * 3 <= 160 * 1024, "three workgroups per CU");
 };
 
-constexpr int ZY_RUN = 2;     // tiles per group of the item order (DMB_OPT(16) overrides it in the development build)
-constexpr int ZY_PARTS = 8;   // tile ranges = item counters (one per XCD); workspace: [ZY_PARTS] counters, [ZY_PARTS] = workgroups done
+constexpr int ZY_RUN_LOG2 = 1;   // tiles per group of the item order = 2 (DMB_OPT(16) overrides the log2 in the development build)
+constexpr int ZY_PARTS = 8;      // tile ranges = item counters (one per XCD)
+constexpr int ZY_STRIDE = 32;    // ints between two counters: each on its own 128-byte line (eight XCDs hammer eight lines, not one)
+// workspace (ints): counter k at [k * ZY_STRIDE], workgroups-done counter at [ZY_PARTS * ZY_STRIDE]
+static_assert((ZY_PARTS * ZY_STRIDE + 1) * 4 <= DMB_DECONV3D_WORKSPACE_BYTES, "workspace layout");
 
 struct ZYArgs {
   const float* x;
@@ -90,31 +105,48 @@ struct ZYArgs {
   float* y;
   int* ws;       // the caller's workspace: zeros on entry, zeros again when the last workgroup has left
   int Ci, D, H, W, ntx, nty, ntz, ntiles, relu, dbg;
-  int run;       // tiles per group of the item order (>= 1)
+  int Wout;      // output row length: 2 W, or less when the input's last columns are zero padding (multiple of 4)
+  int lrun;      // log2 of the tiles per group of the item order
   int nparts;    // tile ranges in use (ZY_PARTS; 1 in the development build's single-list mode)
+  int q, r;      // ntiles = q * nparts + r: range k holds q + (k < r) tiles from k q + min(k, r)
   int stagger;   // development build: start-up delay unit (see the kernel)
 };
 
-// Draws the next work item for this workgroup (called by ONE thread): returns cls * ntiles + tile, or 4 * ntiles when every
-// range is exhausted.  `part` = the range to try first (the workgroup's XCD), `skip` = ranges already found exhausted (state of
-// the calling thread).  Range k holds tiles [k q + min(k, r), ...) with q = ntiles / nparts, r = ntiles % nparts; its counter
-// value t names group t / (4 run), and inside the group class-major: (t % (4 run)) / (tiles in the group), heaviest class first.
-__device__ __forceinline__ int zy_draw(const ZYArgs& a, int part, int& skip) {
-  const int q = a.ntiles / a.nparts, r = a.ntiles % a.nparts;
-  for (; skip < a.nparts; ++skip) {
-    int k = part + skip;
-    if (k >= a.nparts) k -= a.nparts;
-    const int nk = q + (k < r ? 1 : 0);
-    if (nk == 0) continue;
-    const unsigned t = (unsigned)__hip_atomic_fetch_add(a.ws + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t < 4u * (unsigned)nk) {
-      const int g = (int)t / (4 * a.run), first = g * a.run;
-      const int ng = min(a.run, nk - first), rr = (int)t - g * 4 * a.run;
-      const int cls = rr / ng, tile = k * q + min(k, r) + first + (rr - cls * ng);
-      return cls * a.ntiles + tile;
-    }
+// ---- drawing work items ---------------------------------------------------------------------------------------------------
+// Range k's counter value t names group t >> (lrun + 2) of RUN = 1 << lrun tiles and, inside the group, class-major (heaviest
+// class first): class (t mod 4 RUN) / (tiles in the group), tile (t mod 4 RUN) mod (tiles in the group).
+// A draw is split in three so that NOTHING waits on the atomic's round trip: thread 0 ISSUES the fetch-add before the item's
+// first multiply loop (zy_issue), turns the returned ticket into a published (range, ticket) pair after that loop (zy_finish;
+// only when its range is exhausted -- the tail of the launch -- does it draw from the other ranges there, synchronously), and
+// every wave DECODES the pair into (class, tile) after the barrier, in scalar arithmetic (zy_decode).
+__device__ __forceinline__ int zy_range(const ZYArgs& a, int part, int skip) {
+  const int k = part + skip;
+  return k >= a.nparts ? k - a.nparts : k;
+}
+__device__ __forceinline__ unsigned zy_issue(const ZYArgs& a, int part, int skip) {
+  if (skip >= a.nparts) return 0xffffffffu;
+  return (unsigned)__hip_atomic_fetch_add(a.ws + zy_range(a, part, skip) * ZY_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// -> (range << 27) | ticket, or -1 when every range is exhausted (tickets stay below 2^27: checked on the host)
+__device__ __forceinline__ int zy_finish(const ZYArgs& a, int part, int& skip, unsigned t) {
+  while (skip < a.nparts) {
+    const int k = zy_range(a, part, skip);
+    const unsigned nk = (unsigned)(a.q + (k < a.r ? 1 : 0));
+    if (t < 4u * nk) return (k << 27) | (int)t;
+    ++skip;   // this range is exhausted for good (its counter only grows)
+    t = zy_issue(a, part, skip);
   }
-  return 4 * a.ntiles;
+  return -1;
+}
+// -> item code cls * ntiles + tile (4 * ntiles = no item)
+__device__ __forceinline__ int zy_decode(const ZYArgs& a, int code) {
+  if (code < 0) return 4 * a.ntiles;
+  const int k = code >> 27, t = code & ((1 << 27) - 1);
+  const int nk = a.q + (k < a.r ? 1 : 0), base = k * a.q + min(k, a.r);
+  const int run = 1 << a.lrun, first = (t >> (a.lrun + 2)) << a.lrun, rr = t & (4 * run - 1);
+  const int ng = min(run, nk - first);
+  const int cls = ng == run ? rr >> a.lrun : rr / ng;   // (the division: last, partial group of a range only)
+  return cls * a.ntiles + base + first + (rr - cls * ng);
 }
 
 // One class: processes `item` and every following item the counter hands out as long as it belongs to the same class;
@@ -132,7 +164,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
   const int wz = wave / C::WN, wn = wave % C::WN;
   const int D = a.D, H = a.H, W = a.W, Ci = a.Ci;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
-  const int Ho = 2 * H, Wo = 2 * W;
+  const int Ho = 2 * H, Wo = a.Wout;
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = 2u * D * HWo;
   constexpr int CLS = 3 - (2 * PZ + PY);   // class number of the item code cls * ntiles + tile: heaviest first
   const int lo_item = CLS * a.ntiles, hi = (CLS + 1) * a.ntiles;
@@ -208,7 +240,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
     int next = 4 * a.ntiles;    // published after the first chunk's barrier
     bool has_next = false;
     Tile next_t = cur_t;
-    int fetched = 0;
+    unsigned ticket = 0;
 
     f32x16 acc[2][C::MT];   // [x parity][column tile]; started by the item's first unit (constant 0 operand, see below)
 
@@ -216,7 +248,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
     for (int ci = 0; ci < NC; ++ci, ++g) {
       const float* cur = lds + (g & 1) * C::BUF_MAX;
       float* nxt = lds + ((g + 1) & 1) * C::BUF_MAX;
-      if (ci == 0 && tid == 0) fetched = zy_draw(a, part, skip);   // consumed just before this chunk's barrier
+      if (ci == 0 && tid == 0) ticket = zy_issue(a, part, skip);   // in flight during this chunk's multiply loop
       // the next chunk's copies (of this item, or the first chunk of the next one) are dealt out over the first SU units
       constexpr int SU = K::NU - 2, PPU = (K::NPIECE + SU - 1) / SU;
       const bool more = ci + 1 < NC;
@@ -271,10 +303,11 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (ci == 0 && tid == 0) __atomic_store_n(slot, fetched, __ATOMIC_RELAXED);
+      if (ci == 0 && tid == 0) __atomic_store_n(slot, zy_finish(a, part, skip, ticket), __ATOMIC_RELAXED);
       __syncthreads();
       if (ci == 0) {
-        next = __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED));   // wave-uniform: tiles, resources and branches derived from it stay scalar
+        // wave-uniform: tiles, resources and branches derived from it stay scalar
+        next = zy_decode(a, __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED)));
         has_next = next >= lo_item && next < hi && !DMB_DBG(a.dbg & 16);   // the next item continues this class: pipeline across it
         if (has_next) {
           next_t = tile_at(next);
@@ -309,7 +342,8 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) {
         const int lx = mt * 32 + x4 / 2;
-        const bool ok = gzi < D && lx < C::TX && cur_t.x0 + lx < W && !DMB_DBG(a.dbg & 4);
+        // (a lane's word = output columns 2 (x0 + lx) .. + 3; Wo % 4 == 0: inside or outside as a whole)
+        const bool ok = gzi < D && lx < C::TX && 2 * (cur_t.x0 + lx) < Wo && !DMB_DBG(a.dbg & 4);
         voff[mt] = ok ? (DMB_DBG(a.dbg & 8) ? (unsigned)lane * 16u : ((unsigned)rl * DHWo + (unsigned)(2 * mt * 32 + x4)) * 4u) : DMA_OOB;
       }
       const unsigned sbase = ((unsigned)(wn * 32) * DHWo + (unsigned)(2 * gzi + PZ) * HWo + (unsigned)(2 * cur_t.y0 + PY) * Wo +
@@ -331,7 +365,7 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
 #pragma unroll
           for (int t = 0; t < RD; ++t)
 #pragma unroll
-            for (int k = 0; k < KP; ++k) rv[t][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voff[t / QP], (int)soff(t, k), 0);
+            for (int k = 0; k < KP; ++k) rv[t][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voff[t / QP], (int)soff(t, k), DMB_ZY_LD);
         }
 #pragma unroll
         for (int t = 0; t < NPASS; ++t) {
@@ -381,13 +415,13 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
             // (three workgroups per CU) lanes 12..15 of each 16 stored the NEXT pass's accumulator values (found with
             // scripts/zy_debug.py: one wrong float in 10^3, only with more than one workgroup per CU).  With a literal
             // soffset the compiler inserts the wait states itself.
-            __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(voff[mt] + soff(t, k)), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(voff[mt] + soff(t, k)), 0, DMB_ZY_ST);
           }
           if constexpr (HAS_RES) {
             if (t + RD < NPASS) {   // refill the slot just consumed
 #pragma unroll
               for (int k = 0; k < KP; ++k)
-                rv[sl][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voff[(t + RD) / QP], (int)soff(t + RD, k), 0);
+                rv[sl][k] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voff[(t + RD) / QP], (int)soff(t + RD, k), DMB_ZY_LD);
             }
           }
         }
@@ -424,12 +458,12 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
     aff[C::COUT + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
   }
   // the tile range this workgroup draws from first: its XCD's (HW_REG_XCC_ID, bits 3:0 of hardware register 20) -- locality
-  // only; zy_draw moves on to the other ranges when this one is exhausted, so any placement computes every item exactly once
+  // only; zy_finish moves on to the other ranges when this one is exhausted, so any placement computes every item exactly once
   const int part = a.nparts > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) % a.nparts : 0;
-  int skip = 0;   // (state of thread 0, the only caller of zy_draw)
-  if (threadIdx.x == 0) __atomic_store_n(slot, zy_draw(a, part, skip), __ATOMIC_RELAXED);
+  int skip = 0;   // (state of thread 0, the only caller of zy_issue / zy_finish)
+  if (threadIdx.x == 0) __atomic_store_n(slot, zy_finish(a, part, skip, zy_issue(a, part, skip)), __ATOMIC_RELAXED);
   __syncthreads();
-  int item = __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED));
+  int item = zy_decode(a, __builtin_amdgcn_readfirstlane(__atomic_load_n(slot, __ATOMIC_RELAXED)));
   const int total = 4 * a.ntiles;
   while (item >= 0 && item < total) {
     const int cls = item / a.ntiles;   // 0 = (odd z, odd y): four (kz, ky) pairs ... 3 = (even z, even y): one
@@ -445,9 +479,9 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
   // Leave the workspace as it was found.  A workgroup draws nothing after this point; the last one to arrive knows that every
   // other one has drawn its last ticket (release / acquire through the `done` counter) and zeroes counters and `done`.
   if (threadIdx.x == 0) {
-    int* done = a.ws + ZY_PARTS;
+    int* done = a.ws + ZY_PARTS * ZY_STRIDE;
     if (__hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-      for (int k = 0; k < ZY_PARTS; ++k) __hip_atomic_store(a.ws + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < ZY_PARTS; ++k) __hip_atomic_store(a.ws + k * ZY_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(done, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -455,7 +489,7 @@ __global__ __launch_bounds__(256, 3) void deconv3d_zy_kernel(ZYArgs a, const flo
 
 template <class C>
 static int launch_zy(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                     int B, int Ci, int D, int H, int W, int relu, int* ws, hipStream_t st) {
+                     int B, int Ci, int D, int H, int W, int Wout, int relu, int* ws, hipStream_t st) {
   const int ntx = cdiv(W, C::TX), nty = H, ntz = cdiv(D, C::TZ);
   const long long ntiles = (long long)B * ntx * nty * ntz;
   if (4 * ntiles > 0x3fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
@@ -464,9 +498,16 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
   const long long slots = 3LL * num_cus() * (DMB_OPT(8) > 0 ? DMB_OPT(8) : 1);
   long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
   if (DMB_OPT(9) > 0 && DMB_OPT(9) < grid) grid = DMB_OPT(9);   // development: few workgroups walk many items
-  const int run = DMB_OPT(16) > 0 ? DMB_OPT(16) : ZY_RUN;
-  ZYArgs a{x, wp, res, y, ws, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8, run, DMB_OPT(20) ? 1 : ZY_PARTS, DMB_OPT(12)};
-  if (DMB_OPT(20)) a.run = (int)ntiles;   // development: ONE class-major list over the whole layer (the round-3 order)
+  if (4 * ntiles >= (1LL << 27)) return -1;   // (ticket field of the published draw; 33 M tiles: far beyond any volume here)
+  int lrun = DMB_OPT(16) > 0 ? DMB_OPT(16) - 1 : ZY_RUN_LOG2;   // (development option 16 = log2(tiles per group) + 1)
+  int nparts = ZY_PARTS;
+  if (DMB_OPT(20)) {   // development: ONE class-major list over the whole layer (the round-3 order)
+    nparts = 1;
+    lrun = 0;
+    while ((1LL << lrun) < ntiles) ++lrun;
+  }
+  ZYArgs a{x, wp, res, y, ws, Ci, D, H, W, ntx, nty, ntz, (int)ntiles, relu & 0xff, relu >> 8, Wout, lrun, nparts,
+           (int)(ntiles / nparts), (int)(ntiles % nparts), DMB_OPT(12)};
   hipLaunchKernelGGL((deconv3d_zy_kernel<C>), dim3((unsigned)grid), dim3(256), lds, st, a, scale, shift);
   return launch_status("deconv3d (z/y-parity items) launch failed");
 }
@@ -476,15 +517,16 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
 // 64 output channels real, whole 16-channel chunks and at least two of them, 16 input channels of one batch item and one batch item of the output
 // below 2 GiB (32-bit buffer offsets).
 int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                    int B, int Ci, int Co, int D, int H, int W, int relu, int* ws, hipStream_t st) {
+                    int B, int Ci, int Co, int D, int H, int W, int Wout, int relu, int* ws, hipStream_t st) {
   if (DMB_OPT(4) == 1 || !ws) return -1;   // (development option 4 = 1: deconv3d_kernel)
   if ((((uintptr_t)ws) & 3) != 0) return fail(DMB_EINVAL, "deconv3d: misaligned workspace");
-  if (!(Co == 32 || Co == 64) || Ci % 16 != 0 || Ci < 32 || W % 4 != 0) return -1;   // (>= 2 chunks in every class)
+  if (!(Co == 32 || Co == 64) || Ci % 16 != 0 || Ci < 32 || W % 4 != 0 || Wout % 4 != 0) return -1;   // (>= 2 chunks in every class)
   if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) != 0) return -1;
   if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;
-  if (cdiv(W, 28) * 32 < cdiv(W, 60) * 64) return -1;   // narrow images: deconv3d_kernel's 2 x 28 tiles compute fewer positions
-  if (Co == 32) return launch_zy<ZYCfg<32>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, ws, st);
-  return launch_zy<ZYCfg<64>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, relu, ws, st);
+  // narrow images: deconv3d_kernel's 2 x 28 tiles compute fewer positions (it has no padded-row form, though)
+  if (Wout == 2 * W && cdiv(W, 28) * 32 < cdiv(W, 60) * 64) return -1;
+  if (Co == 32) return launch_zy<ZYCfg<32>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
+  return launch_zy<ZYCfg<64>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
 }
 
 }  // namespace dmb

@@ -113,6 +113,6 @@ __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >>
 // csrc/deconv3d_zy.hip: the (tile, z parity, y parity) form of the transposed convolution; -1 = does not apply.
 // `workspace`: DMB_DECONV3D_WORKSPACE_BYTES of device memory holding zeros (see include/dmb_hip.h); the launch leaves it zeroed.
 int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
-                    int B, int Ci, int Co, int D, int H, int W, int relu, int* workspace, hipStream_t st);
+                    int B, int Ci, int Co, int D, int H, int W, int Wout, int relu, int* workspace, hipStream_t st);
 
 }  // namespace dmb

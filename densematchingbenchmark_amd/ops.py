@@ -347,6 +347,24 @@ def copy_window(src, Wd, xs):
     return dst
 
 
+def zero_columns_(t, x0):
+    """t[..., x0:] = 0 in place: the padding columns of a row-padded tensor (see deconv3d_k3s2, ``out_width``)."""
+    lib = _lib.load()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.DmbLibraryError("zero_columns_: contiguous float32 tensor expected")
+    pitch = t.shape[-1]
+    check(lib.dmb_zero_columns_f32(dev_ptr(t), t.numel() // pitch, pitch, int(x0), stream_ptr(t.device)), "dmb_zero_columns_f32")
+    return t
+
+
+def padded_rows_applicable(x, Co):
+    """Whether a [B, Ci, D, H, W] tensor whose rows are NOT a 16-byte multiple (W % 4 != 0) can go through a stride-1 unit and a
+    transposed unit with its rows padded to the next multiple of 4 (zero padding columns): the transposed kernel's padded-row
+    form needs an even W with 2 W % 4 == 0 ... i.e. W % 4 == 2, Co in (32, 64), whole 16-channel chunks."""
+    W, Ci = x.shape[-1], x.shape[1]
+    return x.is_cuda and W % 4 == 2 and Co in (32, 64) and Ci % 16 == 0 and Ci >= 32
+
+
 CATCONV_CH = 128   # channel count of the per-dz map tensors: 3 * Co used (Co <= 32), the rest are zero-weight rows
 
 
@@ -530,13 +548,15 @@ def deconv3d_workspace(device):
     return ws
 
 
-def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=False, workspace="auto", out=None):
+def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=False, workspace="auto", out=None, out_width=None):
     """``workspace``: "auto" = the per-stream workspace above; None = the kernel form without counters; or an int32 tensor of
-    DECONV3D_WORKSPACE_BYTES holding zeros."""
+    DECONV3D_WORKSPACE_BYTES holding zeros.  ``out_width``: for an input whose rows are zero-padded on the right to a multiple
+    of 4 columns, the real output width (2 x the unpadded input width); default 2 W."""
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Ci, D, H, W = x.shape
-    y = _out_tensor(out, (B, Co, 2 * D, 2 * H, 2 * W), x.device, "deconv3d_k3s2")
+    Wout = 2 * W if out_width is None else int(out_width)
+    y = _out_tensor(out, (B, Co, 2 * D, 2 * H, Wout), x.device, "deconv3d_k3s2")
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise _lib.DmbLibraryError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
     _affine_ok(scale, shift, Co, "deconv3d_k3s2")
@@ -551,7 +571,7 @@ def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=Fals
                                    % (_lib.DECONV3D_WORKSPACE_BYTES, x.device))
     check(lib.dmb_deconv3d_k3s2_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                     dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
-                                    B, Ci, Co, D, H, W, _relu_mode(relu),
+                                    B, Ci, Co, D, H, W, Wout, _relu_mode(relu),
                                     None if workspace is None else ctypes.c_void_p(workspace.data_ptr()), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
     return y
 

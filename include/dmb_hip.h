@@ -134,6 +134,9 @@ int dmb_gwc_fms_f32(const float* L, const float* R, float* out, int B, int C, in
  * dmb_catconv_combine_f32: out[b, co, z, y, x] = act(scale[co] * (f + g) + shift[co]) -> [B, Co, D, H, W], one pass
  *   (planes 0 and D-1 are summed from FA / HC on the fly).  D % 4 == 0, W >= D + 8, Wc = D + 4. */
 int dmb_copy_window_f32(const float* src, float* dst, long long rows, int W, int Wd, int xs, void* stream);
+/* t[r, x0 .. pitch) = 0 for rows r of `pitch` floats: re-zeroes the padding columns of a row-padded tensor after a convolution has
+ * run over it as if they were image columns (see dmb_deconv3d_k3s2_f32, `Wout`). */
+int dmb_zero_columns_f32(float* t, long long rows, int pitch, int x0, void* stream);
 int dmb_catconv_finalize_f32(const float* FA, const float* FB, const float* HC, const float* HD, float* FM, float* BAND,
                              float* GM, float* GB, int B, int Co, int CA, int CB, int D, int H, int W, int Wc, void* stream);
 int dmb_catconv_combine_f32(const float* FA, const float* HC, const float* FM, const float* BAND, const float* GM,
@@ -196,16 +199,21 @@ int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float
                          int B, int Ci, int D, int H, int W, void* stream);
 
 /* ConvTranspose3d kernel 3, stride 2, padding 1, output_padding 1 (hourglass.py:52-60):
- * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, 2W];  y[o] += x[i] * w[k] with o = 2i - 1 + k.  Co = 64 or any Co <= 32
+ * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, Wout];  y[o] += x[i] * w[k] with o = 2i - 1 + k.  Co = 64 or any Co <= 32
  * (fewer than 32: zero-padded weight rows, e.g. GC-Net's 1-channel output layer, aggregators/GCNet.py:63-67).
+ * Wout: the output (and residual) row length: 2W -- or, for an input whose rows are ZERO-PADDED on the right to a 16-byte multiple
+ * (an image of Wi columns stored with W = Wi rounded up to a multiple of 4: the hourglass's deepest level at the KITTI shape is
+ * 78 columns wide), Wout = 2 Wi < 2W with Wout % 4 == 0: only output columns below Wout exist.  Such a padded input must
+ * hold zeros in its padding columns (dmb_copy_window_f32 / dmb_zero_columns_f32); it keeps the layer on the 16-byte paths.
+ * Wout < 2W needs the workspace form (Co = 32 or 64, Ci % 16 == 0, aligned operands), otherwise DMB_EUNSUPPORTED.
  * workspace: DMB_DECONV3D_WORKSPACE_BYTES of device memory, 4-byte aligned, holding ZEROS (the caller zeroes it once, e.g.
  * at allocation); the launch uses it for its work-item counters and leaves it zeroed again, so the same workspace serves
  * every later call on that stream, eager or replayed from a captured graph.  Launches that may be in flight at the same
  * time (different streams) need different workspaces.  NULL selects the kernel form without counters (static tile walk:
  * same results bit for bit, slower). */
-#define DMB_DECONV3D_WORKSPACE_BYTES 64
+#define DMB_DECONV3D_WORKSPACE_BYTES 2048
 int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
-                          const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
+                          const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W, int Wout,
                           int relu, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -52,6 +52,21 @@ def conv_case(Ci, Co, stride, d, h, w, name, res=False):
     lib.dmb_dev_set_option(6, 0)
 
 
+def padded_case(d, h, w, name):
+    """conv4 + conv5 of the hourglass as the module runs them when the rows are not a 16-byte multiple (W % 4 == 2): rows padded
+    with zero columns (Hourglass.forward, ops.padded_rows_applicable)."""
+    wpad = (w + 3) // 4 * 4
+    x = torch.randn(B, 64, d, h, w, device=dev)
+    wp4 = ops.pack_conv3d_weights(torch.randn(64, 64, 3, 3, 3, device=dev) * 0.03)
+    wp5 = ops.pack_deconv3d_weights(torch.randn(64, 64, 3, 3, 3, device=dev) * 0.03)
+    sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    r = torch.randn(B, 64, 2 * d, 2 * h, 2 * w, device=dev)
+    fl = 2.0 * 27 * 64 * 64 * B * d * h * w
+    xp = ops.copy_window(x, wpad, 0)
+    report(name + ": pad copy + conv4 + clear", timeit(lambda: ops.zero_columns_(ops.conv3d_k3(ops.copy_window(x, wpad, 0), wp4, 64, sc, sh, None, 1, True), w)), fl)
+    report(name + ": conv5 +res (Wout = %d)" % (2 * w), timeit(lambda: ops.deconv3d_k3s2(xp, wp5, 64, sc, sh, r, True, out_width=2 * w)), fl)
+
+
 def deconv_case(Ci, Co, d, h, w, name, res=False):
     x = torch.randn(B, Ci, d, h, w, device=dev)
     wt = torch.randn(Ci, Co, 3, 3, 3, device=dev) * 0.03
@@ -92,6 +107,8 @@ for _rep in range(1 if diag else 2):
   conv_case(64, 64, 2, D // 2, H // 2, W // 2, "conv3 s2 64->64 half->quarter")
   conv_case(64, 64, 1, D // 4, H // 4, W // 4, "conv4 s1 64->64 quarter")
   deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv 64->64 quarter->half", res=True)
+  if (W // 4) % 4 == 2:
+    padded_case(D // 4, H // 4, W // 4, "quarter level, rows padded to %d" % ((W // 4 + 3) // 4 * 4))
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv 64->32 half->full", res=False)
   deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv 64->32 half->full", res=True)
   lib.dmb_dev_set_option(13, 1)   # A/B: quarter-resolution stride-1 layer on 4 x 4 x 60 boxes (216 workgroups) instead of 64-voxel runs (768)
@@ -101,8 +118,9 @@ for _rep in range(1 if diag else 2):
   conv_case(32, 64, 2, D, H, W, "conv1 s2 32->64 (4-wave workgroups)")
   conv_case(64, 64, 2, D // 2, H // 2, W // 2, "conv3 s2 64->64 (4-wave workgroups)")
   lib.dmb_dev_set_option(10, 0)
-  for run in (1, 4, 16):           # A/B: zy item order in groups of `run` tiles (default: deconv3d_zy.hip ZY_RUN)
-    lib.dmb_dev_set_option(16, run)
+  for run in (1, 4, 16):           # (option 16 = log2(run) + 1)
+              # A/B: zy item order in groups of `run` tiles (default: deconv3d_zy.hip ZY_RUN)
+    lib.dmb_dev_set_option(16, run.bit_length())
     deconv_case(64, 64, D // 4, H // 4, W // 4, "conv5 deconv (zy groups of %d tiles)" % run, res=True)
     deconv_case(64, 32, D // 2, H // 2, W // 2, "conv6 deconv (zy groups of %d tiles)" % run, res=True)
   lib.dmb_dev_set_option(16, 0)

@@ -6,10 +6,14 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from densematchingbenchmark_amd import ops
+from densematchingbenchmark_amd import _lib, ops
 
 dev = torch.device("cuda:0")
-B, D, H, W = 4, 48, 136, 240
+B = int(os.environ.get("KB_B", "4"))
+D, H, W = [int(v) for v in os.environ.get("KB_SHAPE", "48,136,240").split(",")]   # full-resolution volume (48,96,312 = KITTI)
+# KC_OPTS="16=1,20=0": development options (needs DMB_LIB=dev: the development build of the library)
+for kv in filter(None, os.environ.get("KC_OPTS", "").split(",")):
+    _lib.load().dmb_dev_set_option(*[int(v) for v in kv.split("=")])
 name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 g = lambda *s: torch.randn(*s, device=dev)

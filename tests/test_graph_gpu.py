@@ -10,6 +10,11 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+def _lib_ws_ints():
+    from densematchingbenchmark_amd import _lib
+    return _lib.DECONV3D_WORKSPACE_BYTES // 4
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -64,7 +69,7 @@ def test_deconv3d_replays_from_a_graph_many_times(dev):
     w = (torch.randn((64, 32, 3, 3, 3), generator=g) * 0.05).to(dev)
     res = torch.randn((2, 32, 12, 34, 120), generator=g).to(dev)
     wp = ops.pack_deconv3d_weights(w)
-    ws = torch.zeros(16, dtype=torch.int32, device=dev)
+    ws = torch.zeros(_lib_ws_ints(), dtype=torch.int32, device=dev)
     want = ops.deconv3d_k3s2(x, wp, 32, None, None, res, True, workspace=None)      # the form without counters
     out = torch.empty_like(want)
     torch.cuda.synchronize()

@@ -15,6 +15,11 @@ from tests._util import golden, maxdiff, sha
 pytestmark = pytest.mark.gpu
 
 
+def _lib_ws_ints():
+    from densematchingbenchmark_amd import _lib
+    return _lib.DECONV3D_WORKSPACE_BYTES // 4
+
+
 def _ops():
     from densematchingbenchmark_amd import ops
 
@@ -986,7 +991,7 @@ def test_deconv3d_parity_class_items_match_the_two_parity_form(dev, Ci, Co, shap
     x, w = xc.to(dev), wc.to(dev)
     wp = ops.pack_deconv3d_weights(w)
     res = _rand((B, Co, 2 * D, 2 * H, 2 * W), 614).to(dev)
-    ws = torch.zeros(16, dtype=torch.int32, device=dev)
+    ws = torch.zeros(_lib_ws_ints(), dtype=torch.int32, device=dev)
     ref = F.conv_transpose3d(xc, wc, None, stride=2, padding=1, output_padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
     for r, relu in ((None, False), (None, True), (res, True), (res, False), (res, "pre")):
         new = ops.deconv3d_k3s2(x, wp, Co, sc.to(dev), sh.to(dev), r, relu, workspace=ws)
@@ -1067,3 +1072,36 @@ def test_conv3d_linear_runs_for_narrow_planes(dev, Ci, shape):
     ref = F.conv3d(xc, wc, None, padding=1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
     got = ops.conv3d_k3(x, wp, 64, sc.to(dev), sh.to(dev), None, 1, False).cpu()
     assert (got - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("Co,shape", [(64, (2, 3, 5, 78)), (32, (1, 4, 6, 130)), (64, (1, 2, 24, 78))])
+def test_row_padded_hourglass_level_matches_the_unpadded_one(dev, Co, shape):
+    """Rows that are not a 16-byte multiple (W % 4 == 2: the KITTI hourglass's deepest level is 78 columns wide) padded with
+    zero columns to the next multiple of 4 -- the stride-1 unit over the padded tensor, its padding columns cleared again
+    (dmb_zero_columns_f32), and the transposed unit writing only the real 2 W output columns (``Wout``) -- against the same two
+    units on the unpadded tensor (dword kernels): the same fma chain per output, so BIT-identical."""
+    ops = _ops()
+    B, D, H, W = shape
+    Wp = (W + 3) // 4 * 4
+    xc = _rand((B, 64, D, H, W), 701)
+    x = xc.to(dev)
+    w4 = _rand((64, 64, 3, 3, 3), 702, 1.0 / math.sqrt(64 * 27)).to(dev)
+    w5 = _rand((64, Co, 3, 3, 3), 703, 0.05).to(dev)
+    sc4, sh4 = _affine(64, 704)
+    sc5, sh5 = _affine(Co, 705)
+    res = _rand((B, Co, 2 * D, 2 * H, 2 * W), 706).to(dev)
+    wp4, wp5 = ops.pack_conv3d_weights(w4), ops.pack_deconv3d_weights(w5)
+    assert ops.padded_rows_applicable(x, Co)
+    mid = ops.conv3d_k3(x, wp4, 64, sc4.to(dev), sh4.to(dev), None, 1, True)
+    want = ops.deconv3d_k3s2(mid, wp5, Co, sc5.to(dev), sh5.to(dev), res, True)
+    xp = ops.copy_window(x, Wp, 0)
+    assert tuple(xp.shape) == (B, 64, D, H, Wp) and torch.equal(xp[..., :W], x) and float(xp[..., W:].abs().max()) == 0.0
+    midp = ops.conv3d_k3(xp, wp4, 64, sc4.to(dev), sh4.to(dev), None, 1, True)
+    ops.zero_columns_(midp, W)
+    assert torch.equal(midp[..., :W], mid) and float(midp[..., W:].abs().max()) == 0.0
+    got = ops.deconv3d_k3s2(midp, wp5, Co, sc5.to(dev), sh5.to(dev), res, True, out_width=2 * W)
+    assert tuple(got.shape) == tuple(want.shape) and torch.equal(got, want)
+    # the padded-row form exists only with the workspace kernels: anything else says so
+    from densematchingbenchmark_amd._lib import DmbLibraryError
+    with pytest.raises(DmbLibraryError):
+        ops.deconv3d_k3s2(midp, wp5, Co, sc5.to(dev), sh5.to(dev), res, True, out_width=2 * W, workspace=None)
