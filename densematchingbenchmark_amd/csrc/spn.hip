@@ -18,7 +18,7 @@
 
 namespace dmb {
 
-constexpr int SPN_MAXT = 2048;   // longest transverse line: two positions per thread
+constexpr int SPN_MAXT = 2046;   // longest transverse line: two positions per thread, and the backward's 8 LDS rows of T + 2 floats within 64 KiB -- ONE limit for both directions, so that a forward that succeeds under autograd can always run its backward
 
 #pragma clang fp contract(off)
 template <int TPT>
@@ -138,7 +138,7 @@ static int spn_dims(int N, int C, int H, int W, int horizontal, int& S, int& T, 
   T = horizontal ? H : W;
   ss = horizontal ? 1 : W;
   ts = horizontal ? W : 1;
-  if (T > SPN_MAXT) return fail(DMB_EUNSUPPORTED, "spn: the line across the scan direction is limited to 2048 positions");
+  if (T > SPN_MAXT) return fail(DMB_EUNSUPPORTED, "spn: the line across the scan direction is limited to 2046 positions");
   if ((long long)N * C > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "spn: too many planes");
   return DMB_OK;
 }

@@ -181,12 +181,19 @@ class DifFmsFn(torch.autograd.Function):
         return dL, dR, None
 
 
+FAST_FMS_BWD_MAX_W = 1024   # dmb_fast_fms_bwd_f32: 2 * 8 channels * W * 4 bytes of LDS <= 64 KiB
+
+
 class FastFmsFn(torch.autograd.Function):
     """fast_cat_fms / fast_dif_fms (normalize=False) under autograd: gradients for the two feature maps (the sampler's adjoint,
     csrc/warp_volume.hip); the disparity samples are treated as constants."""
 
     @staticmethod
     def forward(ctx, left, right, disp_sample, dif):
+        if left.shape[-1] > FAST_FMS_BWD_MAX_W:   # refuse here, not inside backward(): the adjoint keeps 2 x 8 rows of W floats in LDS
+            raise NotImplementedError("fast_cat_fms / fast_dif_fms under autograd: feature maps wider than %d columns have no "
+                                      "backward on the HIP path (the forward alone has no such limit: run it under torch.no_grad())"
+                                      % FAST_FMS_BWD_MAX_W)
         ctx.save_for_backward(left, right, disp_sample)
         ctx.dif = bool(dif)
         return ops.fast_dif_fms(left, right, disp_sample) if dif else ops.fast_cat_fms(left, right, disp_sample)

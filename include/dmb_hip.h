@@ -91,7 +91,8 @@ int dmb_fast_dif_fms_f32(const float* L, const float* R, const float* disp_sampl
  *   partial: workspace of B * C * H * 2 * W floats (per output row the gradient rows of its two source rows).
  *   dL = sum_k dvol_ref * (T > 0);  dR = the sampler's adjoint of dvol_tgt (cat) or of -dvol (dif).
  * Sums along x go through LDS atomics (their order is the hardware's, as in the reference's own GPU backward); no gradient
- * with respect to disp_sample.  Same D, H, W >= 2 rule as the forward. */
+ * with respect to disp_sample.  Same D, H, W >= 2 rule as the forward; W <= 1024 (two groups of 8 channel rows in 64 KiB of
+ * LDS: DMB_EUNSUPPORTED beyond -- the forward has no such limit, the host layer refuses wider maps under autograd up front). */
 int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol, float* dL, float* dR,
                          float* partial, int B, int C, int D, int H, int W, int per_pixel, int dif, void* stream);
 
@@ -100,7 +101,7 @@ int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sampl
  * scanned line there, ONE launch here).  X, G1, G2, G3, H: [N, C, H, W].
  *   H[s, t] = (1 - g1 - g2 - g3) * X[s, t] + g1 * H[s', t - 1] + g2 * H[s', t] + g3 * H[s', t + 1],   g_k = G_k[s, t] where
  *   the neighbour lies inside the image, else 0; s along the columns if horizontal else along the rows, s' = s - 1 (s + 1 if
- *   reverse).  The line across the scan direction may hold at most 2048 positions.
+ *   reverse).  The line across the scan direction may hold at most 2046 positions (forward and backward alike).
  * Backward: dH = gradient of the output; writes dX, dG1, dG2, dG3 (zero where a link leaves the image).  Unlike the reference
  * (kernel.cu:317) it does not overwrite dH.  Parity UNPINNED: the reference op cannot be built here (CUDA). */
 int dmb_spn_gaterecurrent2d_f32(const float* X, const float* G1, const float* G2, const float* G3, float* H_out, int N, int C,

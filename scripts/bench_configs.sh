@@ -3,6 +3,9 @@
 R=$GRAFT_REPO_ROOT
 cd $R
 python bench.py --steps 20 --warmup 5 --no-extras 2>/dev/null | tail -1
+# the reference's published operating point for PSMNet / AcfNet: KITTI, 384x1248 (configs/PSMNet/kitti_2015.py:113, ResultOfPSMNet.md:15-19)
+python bench.py --config $R/configs/PSMNet/kitti_2015.py --steps 20 --warmup 5 --no-extras 2>/dev/null | tail -1
+python bench.py --config $R/configs/AcfNet/kitti_2015_adaptive.py --steps 10 --warmup 3 --no-extras 2>/dev/null | tail -1
 python bench.py --config $R/configs/GwcNet/scene_flow.py --steps 20 --warmup 5 --no-extras 2>/dev/null | tail -1
 python bench.py --config $R/configs/AcfNet/scene_flow_adaptive.py --steps 10 --warmup 3 --no-extras 2>/dev/null | tail -1
 python bench.py --config $R/configs/AcfNet/scene_flow_uniform.py --steps 10 --warmup 3 --no-extras 2>/dev/null | tail -1

@@ -10,7 +10,7 @@ NB = 2 * int(os.environ.get("KB_B", "4"))
 H, W = 544, 960
 
 
-def timeit(fn, n=5, warm=2):
+def timeit(fn, n=20, warm=5):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -31,7 +31,7 @@ def case(name, Ci, Co, k, stride, dil, h, w, count):
     ms = timeit(lambda: ops.conv2d(x, wp, Co, k, stride, dil, sc, sh, None, True))
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     fl = 2.0 * k * k * Ci * Co * NB * ho * wo
-    print("%-34s x%-2d %7.3f ms  %7.2f TFLOP/s  total %7.3f ms" % (name, count, ms, fl / ms / 1e9, ms * count), flush=True)
+    print("%-34s x%-2d %7.3f ms  %7.2f TFLOP/s  (%4.1f%% of 157.3)  total %7.3f ms" % (name, count, ms, fl / ms / 1e9, fl / ms / 1e9 / 1.573, ms * count), flush=True)
     return ms * count, fl * count
 
 

@@ -13,6 +13,10 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# the dominant kernel's instantiation and its launch shape: the 48 x 4 row pairs at 544x960, the 32 x 4 row pairs at 384x1248 (KITTI)
+DOM = os.environ.get("DOM_PREFIX", "conv3d_s1_kernel<S1Cfg<0, 32, 4, 48")
+DOM_SHAPE = [int(v) for v in os.environ.get("DOM_SHAPE", "4,32,48,136,240").split(",")]
+WHAT = os.environ.get("PROF_CONFIG", "")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 DST = os.path.join(ROOT, "profiles")
@@ -26,7 +30,7 @@ def short(name):
 
 rows = list(csv.DictReader(open(os.path.join(SRC, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(DST, tag + "_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2  (MI355X, batch 4; scripts/profile.sh)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras %s--steps 5 --warmup 2  (MI355X, batch 4; scripts/profile.sh)\n" % ("--config %s " % WHAT if WHAT else ""))
     f.write("kernel,calls,total_ms,avg_us,percent,min_us,max_us\n")
     for r in rows:
         if float(r["Percentage"]) < 0.05:
@@ -46,7 +50,7 @@ if os.path.exists(tr):
     with open(os.path.join(DST, tag + "_kernel_stats.csv"), "a") as f:
         f.write("# split of the shared stride-1 kernel by launch duration (short = Ci 32, long = Ci 64)\n")
         for k, v in d.items():
-            if not k.startswith("conv3d_s1_kernel<S1Cfg<0, 32, 4, 48"):
+            if not k.startswith(DOM):
                 continue
             lo = min(v)
             for name, sel in (("Ci=32", [t for t in v if t < 1.5 * lo]), ("Ci=64", [t for t in v if t >= 1.5 * lo])):
@@ -76,7 +80,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_gwc", "pmc_write_gwc", 
         k, us = meta[did]
         if d.endswith("_gwc") and not k.startswith("gwc"):
             continue
-        if k.startswith("conv3d_s1_kernel<S1Cfg<0, 32, 4, 48") and us >= 1.5 * shortest[k]:
+        if k.startswith(DOM) and us >= 1.5 * shortest[k]:
             k += " [Ci=64]"
         for c, v in cs.items():
             pmc[k][c].append(v)
@@ -101,15 +105,15 @@ with open(os.path.join(DST, tag + "_pmc.csv"), "w") as f:
                                                    m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / 1e9,
                                                    sum(dur[k]) / len(dur[k]) if dur[k] else float("nan")))
 # pmc_dominant.json is a VIEW of the dominant kernel's row of <tag>_pmc.csv (same launches, same means): bench.py reads it
-dom = [k for k in pmc if k.startswith("conv3d_s1_kernel<S1Cfg<0, 32, 4, 48") and not k.endswith("[Ci=64]")]
+dom = [k for k in pmc if k.startswith(DOM) and not k.endswith("[Ci=64]")]
 dom.sort(key=lambda k: -sum(pmc[k].get("GRBM_GUI_ACTIVE", [0])))
 if dom:
     v = pmc[dom[0]]
     fetch, write = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
-    json.dump({"kernel": dom[0], "round": tag, "derived_from": "profiles/%s_pmc.csv" % tag, "launches": len(v["FETCH_SIZE"]),
+    json.dump({"kernel": dom[0], "round": tag, "derived_from": "profiles/%s_pmc.csv" % tag, "launches": len(v["FETCH_SIZE"]), "shape": DOM_SHAPE,
                "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
                "note": "gfx950: FETCH_SIZE counts half of the fetched bytes (calibrated on soft_argmin_kernel); WRITE_SIZE exact"},
-              open(os.path.join(DST, "pmc_dominant.json"), "w"), indent=1)
+              open(os.path.join(DST, "pmc_dominant.json" if not WHAT else "pmc_dominant_%s.json" % tag), "w"), indent=1)
 print(open(os.path.join(DST, tag + "_kernel_stats.csv")).read())
 print(open(os.path.join(DST, tag + "_pmc.csv")).read()[:3000])

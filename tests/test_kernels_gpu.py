@@ -1013,10 +1013,11 @@ def test_spn_gaterecurrent2d(dev, horizontal, reverse, shape):
     """GateRecurrent2dnoind (dmb/ops/spn, the reference's only native op; ONE launch per scan here instead of one per scanned
     line) against the oracle's restatement of the recurrence (UNPINNED: the CUDA reference cannot run here), forward and --
     through torch.autograd -- backward against the oracle's own autograd with an FP64 evaluation as yardstick.  Lines across
-    the scan longer than 1024 positions take two positions per thread; longer than 2048 are refused."""
+    the scan longer than 1024 positions take two positions per thread; longer than 2046 are refused (by the forward already: the
+    backward's limit)."""
     from densematchingbenchmark_amd.ops import GateRecurrent2dnoind
     N, C, H, W = shape
-    if (H if horizontal else W) > 2048:
+    if (H if horizontal else W) > 2046:
         pytest.skip("line too long")
     g = torch.Generator().manual_seed(41)
     X = torch.randn(shape, generator=g)
