@@ -16,7 +16,7 @@ def rnd(shape, scale=1.0):
 
 
 for it in range(N):
-    kind = rng.choice(["s1", "s1", "s2", "deconv", "c2d", "c2d", "x6", "c1", "gwc", "gwc", "catfirst"])
+    kind = rng.choice(["s1", "s1", "s2", "deconv", "c2d", "c2d", "x6", "c1", "gwc", "gwc", "catfirst", "padlevel"])
     B = rng.choice([1, 1, 2])
     try:
         if kind in ("s1", "s2", "deconv", "x6"):
@@ -53,6 +53,17 @@ for it in range(N):
             else:
                 got = ops.conv3d_k3(x.to(dev), ops.pack_conv3d_weights(w.to(dev)), Co, *args, 2 if kind == "s2" else 1, relu)
             desc = (kind, B, Ci, Co, D, H, W, relu, use_res)
+        elif kind == "padlevel":   # the hourglass's deepest level on rows padded to a 16-byte multiple (W % 4 == 2), Hourglass.forward
+            Co = rng.choice([32, 64])
+            D, H, W = rng.randint(1, 7), rng.randint(1, 12), 4 * rng.randint(2, 40) + 2
+            x = rnd((B, 64, D, H, W))
+            w4, w5 = rnd((64, 64, 3, 3, 3), 1.0 / math.sqrt(64 * 27)), rnd((64, Co, 3, 3, 3), 1.0 / math.sqrt(64 * 27 / 8))
+            res = rnd((B, Co, 2 * D, 2 * H, 2 * W))
+            y = F.relu(F.conv_transpose3d(F.relu(F.conv3d(x, w4, None, padding=1)), w5, None, stride=2, padding=1, output_padding=1) + res)
+            mid = ops.conv3d_k3(ops.copy_window(x.to(dev), (W + 3) // 4 * 4, 0), ops.pack_conv3d_weights(w4.to(dev)), 64, None, None, None, 1, True)
+            ops.zero_columns_(mid, W)
+            got = ops.deconv3d_k3s2(mid, ops.pack_deconv3d_weights(w5.to(dev)), Co, None, None, res.to(dev), True, out_width=2 * W)
+            desc = (kind, B, Co, D, H, W)
         elif kind == "c1":       # 32 -> 1 head: the 16-byte form (W % 4 == 0) and the dword form
             D, H = rng.randint(1, 19), rng.randint(1, 19)
             W = rng.choice([rng.randint(1, 130), 60, 64, 120, 124, 240])
