@@ -533,12 +533,15 @@ def conv3d_k3_c1(x, w, bias=0.0, residual=None):
 
 # Work-item counters of the transposed convolution (include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES): the library allocates
 # nothing, so the host layer keeps ONE zeroed workspace per (device, stream) -- launches on one stream run one after the other
-# and each leaves the workspace zeroed; launches on different streams may overlap and get different workspaces.  Allocated
-# during a graph capture it comes from the graph's pool, zero fill included.
+# and each leaves the workspace zeroed; launches on different streams may overlap and get different workspaces.  During a graph
+# capture nothing is cached: a workspace allocated there comes from the graph's pool and its zero fill is a captured node -- it
+# only holds zeros once THAT graph has been replayed, so every call inside a capture gets its own (one 3 us fill per call).
 _deconv_ws = {}
 
 
 def deconv3d_workspace(device):
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros((_lib.DECONV3D_WORKSPACE_BYTES // 4,), dtype=torch.int32, device=device)
     st = torch.cuda.current_stream(device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), st.cuda_stream)
     ws = _deconv_ws.get(key)

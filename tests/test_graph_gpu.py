@@ -121,3 +121,27 @@ def test_deconv3d_from_two_host_threads_on_two_streams(dev):
     assert not errors, errors[:5]
     # the two streams got two workspaces
     assert len({ws.data_ptr() for ws in ops._deconv_ws.values()}) == len(ops._deconv_ws) >= 2
+
+
+def test_two_graphs_captured_before_either_is_replayed(dev):
+    """The host layer's per-stream workspace cache must not hand a graph a workspace whose zero fill is a node of ANOTHER graph
+    that has not run yet: capture A, capture B on the same capture stream, replay only B (then A)."""
+    from densematchingbenchmark_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((1, 64, 4, 9, 60), generator=g).to(dev)
+    w = (torch.randn((64, 64, 3, 3, 3), generator=g) * 0.05).to(dev)
+    wp = ops.pack_deconv3d_weights(w)
+    want = ops.deconv3d_k3s2(x, wp, 64, None, None, None, True, workspace=None)
+    outs = [torch.zeros_like(want) for _ in range(2)]
+    graphs = []
+    torch.cuda.synchronize()
+    for k in range(2):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            ops.deconv3d_k3s2(x, wp, 64, None, None, None, True, out=outs[k])      # workspace="auto"
+        graphs.append(gr)
+    for k in (1, 0, 1):
+        outs[k].zero_()
+        graphs[k].replay()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[k], want), k
