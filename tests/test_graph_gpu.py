@@ -61,6 +61,55 @@ def test_psmnet_step_captured_in_a_hip_graph_replays_bit_identically(dev):
         del eager, want, got
 
 
+@pytest.mark.parametrize("cfg_rel,shape", [("AcfNet/kitti_2015_adaptive.py", (96, 312)), ("StereoNet/scene_flow_8x_2stage.py", (48, 156)),
+                                           ("GwcNet/scene_flow.py", (136, 240))])
+def test_other_configurations_capture_too(dev, cfg_rel, shape):
+    """AcfNet with its confidence network at the KITTI shape (learned up-sampling, composed confidence heads, the row-padded
+    deepest level), the StereoNet cost path and the GwcNet-style volume: one captured step replayed on fresh inputs equals the
+    eager evaluation bit for bit -- no entry point on these paths synchronises, allocates device memory behind the caller's
+    back or reads a result back to the host after the first (warm-up) call."""
+    from densematchingbenchmark_amd import synthetic
+    model = _model(dev, cfg_rel)
+    fh, fw = shape
+    gwc = cfg_rel.startswith("GwcNet")
+
+    def features(first):
+        if gwc:
+            lg, rg = synthetic.feature_batch(first, 1, 1, 320, fh, fw, dev)
+            lc, rc = synthetic.feature_batch(first + 100000, 1, 1, 12, fh, fw, dev)
+            return [lg, lc, rg, rc]
+        return list(synthetic.feature_batch(first, 1, 1, 32, fh, fw, dev))
+
+    def run(ts):
+        batch = dict(leftFeature=(ts[0], ts[1]), rightFeature=(ts[2], ts[3])) if gwc else dict(leftFeature=ts[0], rightFeature=ts[1])
+        res, _ = model(batch)
+        return list(res["disps"]) + list(res["costs"]) + list(res.get("confs", []))
+
+    static = features(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(2):
+            run(static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        captured = run(static)
+    for rep in range(2):
+        fresh = features(20 + rep)
+        for a, b in zip(static, fresh):
+            a.copy_(b)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in captured]
+        with torch.no_grad():
+            want = run(fresh)
+        assert len(got) == len(want)
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (cfg_rel, rep, k, (a - b).abs().max().item())
+
+
 def test_deconv3d_replays_from_a_graph_many_times(dev):
     """The transposed convolution alone, 50 replays: every replay finds the workspace zeroed by the previous one."""
     from densematchingbenchmark_amd import ops
