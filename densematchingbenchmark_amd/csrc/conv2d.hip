@@ -516,7 +516,7 @@ static int launch_conv2d_auto(const float* x, const float* wp, const float* scal
   const long long slots = 2LL * num_cus();
   const long long t4 = (long long)B * cdiv(W, C4::TX) * cdiv(H, C4::TY), t2 = (long long)B * cdiv(W, C2::TX) * cdiv(H, C2::TY);
   const long long cost4 = ((t4 + slots - 1) / slots) * C4::RY, cost2 = ((t2 + slots - 1) / slots) * C2::RY;
-  if (cost2 < cost4 && !DMB_OPT(18))   // (development option 18: always the default height)
+  if ((cost2 < cost4 && !DMB_OPT(18)) || DMB_OPT(18) == 2)   // (development option 18: 1 = always the default height, 2 = always 2 rows per wave)
     return launch_conv2d<C2>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
   return launch_conv2d<C4>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
 }

@@ -4,6 +4,7 @@ batch."""
 import torch
 import torch.nn as nn
 
+from .... import ops
 from ..layers import train_fn
 from ..layers.basic_layers_2d import BasicBlock, conv_bn_relu
 from .StereoNet import _HipConv2d
@@ -25,6 +26,5 @@ class GCNetBackbone(nn.Module):
         if train_fn.wants_grad(self, l_img, r_img):
             # one view after the other, as the reference does (backbones/GCNet.py:47-51): BatchNorm statistics per call
             return self.backbone(l_img), self.backbone(r_img)
-        B = l_img.shape[0]
-        f = self.backbone(torch.cat((l_img, r_img), 0))   # shared weights: one batch of 2B images
-        return f[:B], f[B:]
+        # shared weights, per-image results: two chains on two streams, or one batch of 2B images (ops.two_view_forward)
+        return ops.two_view_forward(self.backbone, l_img, r_img)

@@ -87,11 +87,9 @@ class PSMNetBackbone(nn.Module):
             # one view after the other, as the reference does (PSMNet.py:127-131): in training mode the BatchNorm statistics
             # are those of each call, and the running buffers are updated twice
             return self._forward_train(l_img), self._forward_train(r_img)
-        # shared weights (PSMNet.py:127-131): both views go through as one batch of 2B images -- per-image results are
-        # unchanged, the launches are half as many and twice as wide
-        B = l_img.shape[0]
-        f = self._forward(torch.cat((l_img, r_img), 0))
-        return f[:B], f[B:]
+        # shared weights (PSMNet.py:127-131), per-image results: the two views as two chains on two streams (or, with
+        # ops.set_view_streams(False), as one batch of 2B images) -- see ops.two_view_forward
+        return ops.two_view_forward(self._forward, l_img, r_img)
 
 
 class _BareConv1x1(nn.Conv2d):

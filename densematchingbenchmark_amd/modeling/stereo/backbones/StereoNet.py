@@ -70,6 +70,8 @@ class StereoNetBackbone(nn.Module):
         if train_fn.wants_grad(self, l_img, r_img):
             # one view after the other, as the reference does (backbones/StereoNet.py:95-99): BatchNorm statistics per call
             return self._forward(l_img), self._forward(r_img)
+        # shared weights: one batch of 2B images (this backbone is a millisecond of small launches: two chains on two streams,
+        # ops.two_view_forward, measured 1.05 -> 1.14 ms at 8 pairs of 384x1248 -- they pay for the PSMNet and GC-Net backbones)
         B = l_img.shape[0]
-        f = self._forward(torch.cat((l_img, r_img), 0))   # shared weights: one batch of 2B images
+        f = self._forward(torch.cat((l_img, r_img), 0))
         return f[:B], f[B:]

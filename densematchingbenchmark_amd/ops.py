@@ -319,6 +319,44 @@ def side_stream(device, which=0):
     return _side_streams[key]
 
 
+# The two views of a stereo pair go through a shared-weight backbone independently.  As ONE batch of 2B images a layer's tiles
+# rarely divide over the persistent grid (8 images of 136 x 240 at 64 channels: 1360 tiles on 512 slots = 2.66 rounds, 5.3 tiles
+# per CU however they are dealt); as two chains of B images on two streams the partial rounds of one chain are filled by the
+# other's.  Measured on the PSMNet backbone (scripts/backbone_streams_probe.py): 16.15 -> 14.67 ms at B = 4, 5.60 -> 5.14 at
+# B = 1, 30.4 -> 28.6 at B = 8; four or eight chains are slower than one batch.  Same launches per image: identical results.
+_view_streams = True
+
+
+def set_view_streams(flag):
+    global _view_streams
+    _view_streams = bool(flag)
+
+
+def view_streams():
+    return _view_streams
+
+
+def two_view_forward(fn, left, right):
+    """``(fn(left), fn(right))`` for a per-image function (an eval-mode backbone): the right view on a side stream of the device,
+    forked from and joined back into the caller's stream with events; ``ops.set_view_streams(False)``: one batch of both views."""
+    if not (_view_streams and left.is_cuda):
+        B = left.shape[0]
+        f = fn(torch.cat((left, right), 0))
+        return f[:B], f[B:]
+    main = torch.cuda.current_stream(left.device)
+    side = side_stream(left.device, 2)
+    fork = main.record_event()
+    with torch.cuda.stream(side):
+        side.wait_event(fork)
+        fr = fn(right)
+        fr.record_stream(main)          # allocated on the side stream, consumed on the caller's
+        right.record_stream(side)       # ... and the caller's input is read there
+        done = side.record_event()
+    fl = fn(left)
+    main.wait_event(done)
+    return fl, fr
+
+
 _first_layer_mode = "merged"
 
 

@@ -1,0 +1,32 @@
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from densematchingbenchmark_amd import ops, synthetic
+from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone, StereoNetBackbone
+from densematchingbenchmark_amd.modeling.stereo.backbones.GCNet import GCNetBackbone
+dev = torch.device("cuda:0")
+from densematchingbenchmark_amd import _lib
+for kv in filter(None, os.environ.get("KC_OPTS", "").split(",")):   # development options (DMB_LIB=dev)
+    _lib.load().dmb_dev_set_option(*[int(v) for v in kv.split("=")])
+def run(fn, n):
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+for name, mk, B, H, W in (("PSMNet", lambda: PSMNetBackbone(3, True), 4, 544, 960), ("StereoNet", lambda: StereoNetBackbone(3, True, 3, 6), 8, 384, 1248),
+                          ("StereoNet", lambda: StereoNetBackbone(3, True, 3, 6), 16, 384, 1248), ("GCNet", lambda: GCNetBackbone(3, True), 1, 544, 960)):
+    bb = mk().eval(); synthetic.init_params_(bb, seed=8, classif_gain=1.0); bb = bb.to(dev)
+    g = torch.Generator().manual_seed(7)
+    l, r = (torch.randn((B, 3, H, W), generator=g).to(dev) for _ in range(2))
+    with torch.no_grad():
+        res = {}
+        for flag in (True, False):
+            ops.set_view_streams(flag)
+            out = bb(l, r); torch.cuda.synchronize()
+            run(lambda: bb(l, r), 3)
+            res[flag] = (min(run(lambda: bb(l, r), 8) for _ in range(3)), out)
+        ops.set_view_streams(True)
+    same = all(torch.equal(a, b) for a, b in zip(res[True][1], res[False][1]))
+    print("%-10s B=%2d %dx%d: one batch %.3f ms, two streams %.3f ms, identical %s" % (name, B, H, W, res[False][0], res[True][0], same), flush=True)

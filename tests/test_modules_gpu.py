@@ -558,3 +558,27 @@ def test_combined_loss_evaluator_vs_oracle(dev):
         want_l = wl * 2.0 * float(O.disp_smooth_l1_loss(disps[i], gt, 32))
         assert abs(float(got["stereo_focal_loss_lvl%d" % i]) - want_f) <= 2e-5 * abs(want_f)
         assert abs(float(got["l1_loss_lvl%d" % i]) - want_l) <= 2e-6
+
+
+def test_backbone_views_on_two_streams_equal_one_batch(dev):
+    """ops.two_view_forward: the two views of a pair through the PSMNet / GC-Net backbones as two chains on two HIP streams (the
+    default: the partial tile rounds of one chain are filled by the other's) against one batch of both views -- the same launches
+    per image, so bit-identical; and the caller's stream is joined (the features are usable right away on it)."""
+    from densematchingbenchmark_amd import ops, synthetic
+    from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone
+    from densematchingbenchmark_amd.modeling.stereo.backbones.GCNet import GCNetBackbone
+    for mk, shape in ((lambda: PSMNetBackbone(3, True), (2, 3, 256, 512)), (lambda: GCNetBackbone(3, True), (1, 3, 64, 128))):
+        bb = mk().eval()
+        synthetic.init_params_(bb, seed=8, classif_gain=1.0)
+        bb = bb.to(dev)
+        l, r = rand(shape, 441).to(dev), rand(shape, 442).to(dev)
+        assert ops.view_streams()
+        with torch.no_grad():
+            fl, fr = bb(l, r)
+            s = (fl.sum() + fr.sum()).item()             # consumed on the caller's stream without any explicit synchronisation
+            ops.set_view_streams(False)
+            try:
+                gl, gr = bb(l, r)
+            finally:
+                ops.set_view_streams(True)
+        assert torch.equal(fl, gl) and torch.equal(fr, gr) and s == (gl.sum() + gr.sum()).item()
