@@ -14,8 +14,16 @@
 
 #include "dmb_common.h"
 
+// Workgroups per CU the kernel is built for (build-time experiment knob, build.py DMB_BUILD_DEFS): LDS budget per workgroup,
+// register cap and persistent grid follow it.
+#ifndef DMB_C2_WPE
+#define DMB_C2_WPE 2
+#endif
+
 namespace dmb {
 
+constexpr int C2_WPE = DMB_C2_WPE;
+constexpr int C2_LDS_BUDGET = 160 * 1024 / C2_WPE;
 constexpr int C2_CK = 8;  // packed weight streams are zero-padded to a multiple of this many input channels
 
 // wp[((kp * KK + tap) * NTT + nt) * 64 + lane] = w[co = nt*32 + (lane & 31)][ci = 2*kp + (lane >> 5)][tap]; zero padded
@@ -73,13 +81,15 @@ struct C2Cfg {
   // input channels per chunk: the largest of 8 / 4 / 2 whose double-buffered chunk (input rows + weight fragments)
   // lets two workgroups share one CU's 160 KB of LDS
   static constexpr int lds_bytes(int ck) { return 2 * ((ck * CH_STRIDE + 3) / 4 * 4 + (ck / 2) * KK * NTT * 64) * 4; }
-  static constexpr int CK = lds_bytes(8) <= 80 * 1024 ? 8 : (lds_bytes(4) <= 80 * 1024 ? 4 : 2);
+  static constexpr int CK = lds_bytes(8) <= C2_LDS_BUDGET ? 8 : (lds_bytes(4) <= C2_LDS_BUDGET ? 4 : 2);
   static constexpr int NK = (CK / 2) * KK;  // k-steps per chunk
   static constexpr int IN_FLOATS = (CK * CH_STRIDE + 3) / 4 * 4;
   static constexpr int W_FLOATS = NK * NTT * 64;
-  static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int TR_PITCH = 36;                        // transposition scratch: [32 channels][32 pixels + 4]
   static constexpr int TR_FLOATS = 4 * 32 * TR_PITCH;        // one accumulator tile per wave
+  // (a chunk buffer a few floats short of the scratch is rounded up to it: cheaper than a third region behind the two buffers)
+  static constexpr int BUF_RAW = IN_FLOATS + W_FLOATS;
+  static constexpr int BUF_FLOATS = (V16_ && BUF_RAW < TR_FLOATS && TR_FLOATS - BUF_RAW <= 256) ? TR_FLOATS : BUF_RAW;
   // the scratch lives in the chunk buffer that was consumed last (free until the next copy lands in it) when that
   // buffer is large enough, else (1x1 layers) behind the two buffers
   static constexpr bool TR_OWN = V16 && BUF_FLOATS < TR_FLOATS;
@@ -89,7 +99,7 @@ struct C2Cfg {
   static constexpr int VUNITS = CK * UPC;
   static_assert(C2_CK % CK == 0, "chunks tile the padded channel count");
   static_assert(W_FLOATS % 16 == 0, "weights are copied with 16-byte words, evenly over 4 waves");
-  static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+  static_assert(LDS_FLOATS * 4 <= C2_LDS_BUDGET, "C2_WPE workgroups per CU");
 };
 
 template <class F>
@@ -115,7 +125,7 @@ struct C2Jobs {
 };
 
 template <class C, bool MULTI = false>
-__global__ __launch_bounds__(256, 2) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, C2_WPE) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ res, float* __restrict__ y, int Ci,
                                                         int Co, int H, int W, int relu, int in_ctot, int out_ctot,
@@ -499,7 +509,7 @@ static int launch_conv2d(const float* x, const float* wp, const float* scale, co
   if (ntiles > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv2d: grid too large");
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   DMB_ENSURE_LDS((&conv2d_kernel<C>), (size_t)(lds));
-  const long long slots = 2LL * num_cus();   // two workgroups per CU, a multiple of the 8 XCDs
+  const long long slots = (long long)C2_WPE * num_cus();   // C2_WPE workgroups per CU, a multiple of the 8 XCDs
   const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
   hipLaunchKernelGGL((conv2d_kernel<C>), dim3(grid), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, Co, H, W, relu,
                      in_ctot, out_ctot, res_ctot, ntx, nty, (int)ntiles, C2Jobs{});
@@ -513,7 +523,7 @@ static int launch_conv2d_auto(const float* x, const float* wp, const float* scal
                               int res_ctot, hipStream_t st) {
   using C4 = C2Cfg<N, K, DL, 1, V16, false, 0>;
   using C2 = C2Cfg<N, K, DL, 1, V16, false, 2>;
-  const long long slots = 2LL * num_cus();
+  const long long slots = (long long)C2_WPE * num_cus();
   const long long t4 = (long long)B * cdiv(W, C4::TX) * cdiv(H, C4::TY), t2 = (long long)B * cdiv(W, C2::TX) * cdiv(H, C2::TY);
   const long long cost4 = ((t4 + slots - 1) / slots) * C4::RY, cost2 = ((t2 + slots - 1) / slots) * C2::RY;
   if ((cost2 < cost4 && !DMB_OPT(18)) || DMB_OPT(18) == 2)   // (development option 18: 1 = always the default height, 2 = always 2 rows per wave)
@@ -536,7 +546,7 @@ static int launch_conv2d_multi(const C2Jobs& jobs_in, int B, int Ci, int Co, int
   }
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   DMB_ENSURE_LDS((&conv2d_kernel<C, true>), (size_t)(lds));
-  const long long slots = 2LL * num_cus();
+  const long long slots = (long long)C2_WPE * num_cus();
   const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
   hipLaunchKernelGGL((conv2d_kernel<C, true>), dim3(grid), dim3(256), lds, st, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, Ci, Co, H, 0, 0, Ci,
