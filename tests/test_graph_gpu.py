@@ -194,3 +194,35 @@ def test_two_graphs_captured_before_either_is_replayed(dev):
         graphs[k].replay()
         torch.cuda.synchronize()
         assert torch.equal(outs[k], want), k
+
+
+def test_backbone_with_its_two_view_streams_captures(dev):
+    """The PSMNet backbone runs the two views on two streams (ops.two_view_forward: fork / join by events) -- a capture on the
+    caller's stream has to pick the side stream up through those events and replay both chains."""
+    from densematchingbenchmark_amd import ops, synthetic
+    from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone
+    bb = PSMNetBackbone(3, True).eval()
+    synthetic.init_params_(bb, seed=8, classif_gain=1.0)
+    bb = bb.to(dev)
+    g = torch.Generator().manual_seed(3)
+    l, r = (torch.randn((1, 3, 256, 512), generator=g).to(dev) for _ in range(2))
+    assert ops.view_streams()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        bb(l, r)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        fl, fr = bb(l, r)
+    for rep in range(2):
+        l2, r2 = (torch.randn((1, 3, 256, 512), generator=g).to(dev) for _ in range(2))
+        l.copy_(l2)
+        r.copy_(r2)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (fl.clone(), fr.clone())
+        with torch.no_grad():
+            want = bb(l2, r2)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), rep
