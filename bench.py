@@ -446,11 +446,14 @@ def main():
             disps = step()
         acc.acc.zero_()
         counter[0] = 0
-        timer = ops.KernelTimer([DOMINANT])
+        # live HIP-event timing of the dominant kernel's launches inside the timed region: every launch of every step for short
+        # runs, of every 4th step from 16 steps on (>= 24 timed launches either way; each bracketed launch costs its stream ~10 us)
+        timer = ops.KernelTimer([DOMINANT], every=4 if args.steps >= 16 else 1)
         ops.set_kernel_timer(timer)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            timer.begin_step()
             disps = step()
         acc.all_reduce()
         fence()
@@ -506,6 +509,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_source,
                          "launch_ms": round(kms, 4), "launches_timed": timer.count(DOMINANT),
+                         "timed_every_nth_step": timer.every,
                          "flop_per_launch": flop},
             "epe_accumulator": metrics[0],
             "per_rank_ms": [round(t, 3) for t in per_rank_ms],
