@@ -1,8 +1,10 @@
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
-from densematchingbenchmark_amd import ops
+from densematchingbenchmark_amd import _lib, ops
 dev = torch.device("cuda:0")
+for kv in filter(None, os.environ.get("KC_OPTS", "").split(",")):   # development options (DMB_LIB=dev...)
+    _lib.load().dmb_dev_set_option(*[int(v) for v in kv.split("=")])
 def timeit(fn, n=40, warm=10):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
