@@ -267,9 +267,18 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
       float af[2][3], bf[2][2][C::MT];   // af[buf][kx], bf[buf][ox][mt]
       auto load_frag = [&](int u, float (&fa)[3], float (&fb)[2][C::MT]) {
         const int cp = u / K::NA, ta = u % K::NA, az = ta / K::NAY, ay = ta % K::NAY;
+        // (volatile: one ds_read_b32 per fragment with an immediate offset from ONE base register.  Left to itself the compiler
+        // pairs the reads into ds_read2_b32, whose 8-bit offsets need a fresh base -- a v_add -- per pair: 16 vector instructions
+        // per 48 MFMAs in a loop where vector time adds to matrix time)
+#ifdef DMB_ZY_PLAIN_READS   // (build-time A/B knob: the compiler's paired reads)
+        typedef const __attribute__((address_space(3))) float* lds_cvf;
+#else
+        typedef const volatile __attribute__((address_space(3))) float* lds_cvf;   // (LDS address space, kept explicit under volatile)
+#endif
+        lds_cvf av = (lds_cvf)abase;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) fa[k] = abase[(u * 3 + k) * C::NTT * 64];
-        const float* bp = bbase + 2 * cp * K::CH_STRIDE + az * K::PLANE + ay * C::P;
+        for (int k = 0; k < 3; ++k) fa[k] = av[(u * 3 + k) * C::NTT * 64];
+        lds_cvf bp = (lds_cvf)(bbase + 2 * cp * K::CH_STRIDE + az * K::PLANE + ay * C::P);
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
