@@ -177,25 +177,40 @@ __global__ __launch_bounds__(256, C2_WPE) void conv2d_kernel(const float* __rest
 
   constexpr int WPW = C::W_FLOATS / 16;      // 16-byte weight words per wave
   constexpr int WI = (WPW + 63) / 64;
-  auto stage = [&](const Tile& tl, int c0, float* buf) {
+  // Vector path: the per-lane source offsets of a chunk's copies depend on the TILE only (the chunk's channels are selected by the
+  // resource base), so they are computed once per tile, not once per chunk: the unit -> (channel, row, 16-byte column) decode, the
+  // bounds tests and the row multiplies were 50 - 70 vector instructions per chunk (five of them quarter-rate multiplies) next to
+  // 108 - 216 MFMAs, in a loop where vector time adds to matrix time.
+  constexpr int IPW = C::V16 ? (C::VUNITS + 255) / 256 : 1;   // copy instructions per wave and chunk
+  auto tile_offsets = [&](const Tile& tl, unsigned (&off)[IPW]) {
+    if constexpr (C::V16) {
+      const int W = W_of(tl);
+      const unsigned HW = (unsigned)H * W;
+      const int gxb = tl.x0 * C::S - C::LP, gyb = tl.y0 * C::S - C::HALO;
+#pragma unroll
+      for (int q = 0; q < IPW; ++q) {
+        // unit u = 4 consecutive floats of the staged chunk, linear in LDS: u -> (channel, tile row, 16-byte column)
+        const int u = (wave * IPW + q) * 64 + lane;
+        const int cl = u / C::UPC, rr = u - cl * C::UPC, yy = rr / C::UPR, sg = rr - yy * C::UPR;
+        const int gy = gyb + yy, gx = gxb + sg * 4;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        off[q] = ok ? ((unsigned)cl * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB;
+      }
+    }
+  };
+  auto stage = [&](const Tile& tl, int c0, float* buf, const unsigned (&off)[IPW]) {
     const int W = W_of(tl);   // (shadows the launch's W: everything below is per tile)
     const unsigned HW = (unsigned)H * W;
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp_of(tl), (unsigned)((C::DOT ? res_ctot : 1) * (Cipad / 2) * C::KK * C::NTT * 64) * 4u);
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x_of(tl) + (size_t)tl.b * in_ctot * HW, (unsigned)Ci * HW * 4u);
     if constexpr (C::V16) {
-      // unit u = 4 consecutive floats of the staged chunk, linear in LDS: u -> (channel, tile row, 16-byte column)
-      constexpr int IPW = (C::VUNITS + 255) / 256;   // instructions per wave
-      const int gxb = tl.x0 * C::S - C::LP, gyb = tl.y0 * C::S - C::HALO;
+      // the chunk's first channel is one uniform add per copy; a channel past Ci lies beyond the resource and reads zeros, and an
+      // out-of-image unit (DMA_OOB) stays out of range (c0 * HW * 4 < 2^31: checked on the host)
+      const unsigned cbase = (unsigned)c0 * HW * 4u;
 #pragma unroll
-      for (int q = 0; q < IPW; ++q) {
-        const int u = (wave * IPW + q) * 64 + lane;
-        const int cl = u / C::UPC, rr = u - cl * C::UPC, yy = rr / C::UPR, sg = rr - yy * C::UPR;
-        const int gy = gyb + yy, gx = gxb + sg * 4;
-        const bool ok = c0 + cl < Ci && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        if (u < C::VUNITS)   // inactive lanes write nothing: the words behind the last unit belong to the weight fragments
-          dma16(xrs, ok ? ((unsigned)(c0 + cl) * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB, 0u,
-                buf + (wave * IPW + q) * 256);
-      }
+      for (int q = 0; q < IPW; ++q)
+        if ((wave * IPW + q) * 64 + lane < C::VUNITS)   // inactive lanes write nothing: the words behind the last unit belong to the weight fragments
+          dma16(xrs, off[q] + cbase, 0u, buf + (wave * IPW + q) * 256);
     } else {
       constexpr int RPW = (C::UNITS + 3) / 4;    // row segments per wave per chunk
       const int gx0 = tl.x0 * C::S - C::HALO + lane;
@@ -367,13 +382,20 @@ __global__ __launch_bounds__(256, C2_WPE) void conv2d_kernel(const float* __rest
 
   const int NC = Cipad / C::CK;
   Tile cur_t = tile_at(0);
-  stage(cur_t, 0, lds);
+  unsigned coff[IPW], noff[IPW];   // copy offsets of the current / the next tile
+  tile_offsets(cur_t, coff);
+#pragma unroll
+  for (int q = 0; q < IPW; ++q) noff[q] = coff[q];
+  stage(cur_t, 0, lds, coff);
   __syncthreads();
   int g = 0;  // chunks consumed by this workgroup so far: selects the LDS buffer
   for (int it = 0; it < my_tiles; ++it) {
     const bool has_next = it + 1 < my_tiles;
     Tile next_t = cur_t;
-    if (has_next) next_t = tile_at(it + 1);
+    if (has_next) {
+      next_t = tile_at(it + 1);
+      tile_offsets(next_t, noff);
+    }
     clear();
     for (int ci = 0; ci < NC; ++ci, ++g) {
       // The copy into `nxt` must stay in flight while `cur` is multiplied.  The compiler orders an LDS read after every
@@ -390,7 +412,10 @@ __global__ __launch_bounds__(256, C2_WPE) void conv2d_kernel(const float* __rest
           st_t.y0 = same ? cur_t.y0 : next_t.y0;
           st_t.p = same ? cur_t.p : next_t.p;
           st_t.job = same ? cur_t.job : next_t.job;
-          if (same || has_next) stage(st_t, same ? (ci + 1) * C::CK : 0, nxt);
+          unsigned st_off[IPW];
+#pragma unroll
+          for (int q = 0; q < IPW; ++q) st_off[q] = same ? coff[q] : noff[q];
+          if (same || has_next) stage(st_t, same ? (ci + 1) * C::CK : 0, nxt, st_off);
         }
         const float* abase = cur + C::IN_FLOATS + wn * 64 + lane;
         const float* bbase = cur + h * C::CH_STRIDE + ((wy * C::RY + (j >> 4)) * C::P + (j & 15)) * C::S + (C::LP - C::HALO);
@@ -428,6 +453,8 @@ __global__ __launch_bounds__(256, C2_WPE) void conv2d_kernel(const float* __rest
     }
     if constexpr ((C::V16 && !C::TR_OWN) || C::DOT) __syncthreads();
     cur_t = next_t;
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) coff[q] = noff[q];
   }
 }
 
