@@ -8,7 +8,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from densematchingbenchmark_amd import ops, synthetic
+RESERVE_KB = int(os.environ.get("TAIL_RESERVE_KB", "0"))   # needs DMB_LIB=dev
+from densematchingbenchmark_amd import _lib, ops, synthetic
 from densematchingbenchmark_amd.config import Config
 from densematchingbenchmark_amd.modeling import build_model
 
@@ -50,7 +51,11 @@ def tail_overlapped():
                     t.record_stream(main)
                 hid.record_stream(side)
                 done = side.record_event()
+            if RESERVE_KB:   # development build: pad the convolution's LDS request so that only two of its workgroups fit a CU
+                _lib.load().dmb_dev_set_option(17, RESERVE_KB)
             hid = nxt_cl[0](out_next)          # the matrix-bound convolution of the next level, on the caller's stream
+            if RESERVE_KB:
+                _lib.load().dmb_dev_set_option(17, 0)
             main.wait_event(done)
         else:
             cost = cl[1](hid, residual=prev)
