@@ -391,3 +391,10 @@ def test_dmb_ops_namespace():
     from densematchingbenchmark_amd.ops import GateRecurrent2dnoind
     from densematchingbenchmark_amd.spn import GateRecurrent2dnoind as G2
     assert GateRecurrent2dnoind is G2 and GateRecurrent2dnoind(True, False).horizontal is True
+
+
+def test_binding_constants_match_the_header():
+    import re
+    text = open(_lib.HEADER_PATH).read()
+    assert int(re.search(r"#define DMB_DECONV3D_WORKSPACE_BYTES (\d+)", text).group(1)) == _lib.DECONV3D_WORKSPACE_BYTES
+    assert "ABI version" in text and "(4:" in text and _lib.ABI_VERSION == 4
