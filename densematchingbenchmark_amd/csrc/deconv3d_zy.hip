@@ -53,13 +53,16 @@
 
 namespace dmb {
 
-template <int COUT_>
+// MT_: 32-column MFMA tiles per input row of a work item: 2 (60 real positions + the halo column of the odd outputs in 64 staged
+// columns) or 1 (28 real positions in 32) -- the narrower tile computes fewer discarded columns where the image width is
+// awkward for 60 (80 columns: 3 x 32 computed instead of 2 x 64); deconv3d_zy_try picks per launch.
+template <int COUT_, int MT_ = 2>
 struct ZYCfg {
   static constexpr int COUT = COUT_;
   static constexpr int NTT = COUT / 32;       // 32-channel row tiles
   static constexpr int WN = NTT;              // waves along the output channels: one row tile per wave
   static constexpr int WZ = 4 / WN, TZ = WZ;  // waves (= input planes) along z
-  static constexpr int TX = 60, P = 64, MT = 2;   // one input row: 60 real positions in two 32-column MFMA tiles
+  static constexpr int MT = MT_, P = 32 * MT_, TX = P - 4;   // one input row: P staged columns, TX real positions, MT 32-column MFMA tiles
   static constexpr int RUN = 3 * NTT * 64;    // weight floats of one (channel pair, kz, ky): its three kx taps
   static constexpr int SCR_PITCH = 68, PCH = 8;   // epilogue scratch: 8 channels x 64 output columns per pass and wave
   static constexpr int AFF_FLOATS = 2 * COUT;     // scale / shift table
@@ -203,7 +206,8 @@ __device__ __forceinline__ int zy_body(float* lds, int* slot, const ZYArgs& a, i
 #pragma unroll
     for (int q = 0; q < K::IPC; ++q) {
       const int u = q * 64 + lane;
-      const int zz = u / (K::ROWS * 16), rr = u - zz * (K::ROWS * 16), yy = rr / 16, sg = rr - yy * 16;
+      constexpr int UPR = C::P / 4;   // 16-byte units per staged row
+      const int zz = u / (K::ROWS * UPR), rr = u - zz * (K::ROWS * UPR), yy = rr / UPR, sg = rr - yy * UPR;
       const int gz = tl.z0 + zz, gy = tl.y0 + yy, gx = tl.x0 + sg * 4;
       o[q] = (u < K::UPC && gz < D && gy < H && gx < W) ? ((unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB;
     }
@@ -532,10 +536,13 @@ int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const f
   if (!(Co == 32 || Co == 64) || Ci % 16 != 0 || Ci < 32 || W % 4 != 0 || Wout % 4 != 0) return -1;   // (>= 2 chunks in every class)
   if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) != 0) return -1;
   if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;
-  // narrow images: deconv3d_kernel's 2 x 28 tiles compute fewer positions (it has no padded-row form, though)
-  if (Wout == 2 * W && cdiv(W, 28) * 32 < cdiv(W, 60) * 64) return -1;
-  if (Co == 32) return launch_zy<ZYCfg<32>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
-  return launch_zy<ZYCfg<64>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
+  // 28-column tiles where they compute fewer columns than 60-column ones (80 input columns: 96 against 128)
+  const bool narrow = cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
+  if (Co == 32)
+    return narrow ? launch_zy<ZYCfg<32, 1>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st)
+                  : launch_zy<ZYCfg<32, 2>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
+  return narrow ? launch_zy<ZYCfg<64, 1>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st)
+                : launch_zy<ZYCfg<64, 2>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
 }
 
 }  // namespace dmb
