@@ -23,7 +23,7 @@ _P = _c_void_p  # device pointer
 _HI = ctypes.POINTER(ctypes.c_int)  # host int array
 _HF = ctypes.POINTER(ctypes.c_float)  # host float array
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes)
 SIGNATURES = {
@@ -34,7 +34,7 @@ SIGNATURES = {
     "dmb_gwc_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
     "dmb_fast_cat_fms_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 6 + [_P]),
     "dmb_fast_dif_fms_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 7 + [_c_float, _P]),
-    "dmb_fast_fms_bwd_f32": (_c_int, [_P] * 7 + [_c_int] * 7 + [_P]),
+    "dmb_fast_fms_bwd_f32": (_c_int, [_P] * 9 + [_c_int] * 7 + [_c_float, _P]),
     "dmb_spn_gaterecurrent2d_f32": (_c_int, [_P] * 5 + [_c_int] * 6 + [_P]),
     "dmb_spn_gaterecurrent2d_bwd_f32": (_c_int, [_P] * 10 + [_c_int] * 6 + [_P]),
     "dmb_conv2d_k3_multi_f32": (_c_int, [_c_int, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),

@@ -33,6 +33,7 @@ int num_cus() {
 //   14  start-up stagger unit of the stride-1 kernels                   16  zy item order: tiles per class run (0 = default)
 //   17  extra KB of LDS per stride-1 workgroup (occupancy)              18  = 1: default tile height for the 64-channel conv2d layers
 //   19  stride-1 tile override (see dmb_conv3d_k3_f32)                   20  = 1: zy items from ONE counter instead of one per XCD
+//   21  = 32 / 64: options 16 and 20 for that output width only         22  up-sampling: 1 = row form, 2 = flat form
 namespace dmb {
 int g_dev_opts[32] = {0};
 }
@@ -41,5 +42,5 @@ extern "C" void dmb_dev_set_option(int key, int value) {
 }
 #endif
 
-extern "C" int dmb_abi_version(void) { return 4; }
+extern "C" int dmb_abi_version(void) { return 5; }
 extern "C" const char* dmb_last_error(void) { return dmb::g_last_error; }

@@ -512,9 +512,10 @@ static int launch_zy(const float* x, const float* wp, const float* scale, const 
   long long grid = 4 * ntiles < slots ? 4 * ntiles : slots;
   if (DMB_OPT(9) > 0 && DMB_OPT(9) < grid) grid = DMB_OPT(9);   // development: few workgroups walk many items
   if (4 * ntiles >= (1LL << 27)) return -1;   // (ticket field of the published draw; 33 M tiles: far beyond any volume here)
-  int lrun = DMB_OPT(16) > 0 ? DMB_OPT(16) - 1 : ZY_RUN_LOG2;   // (development option 16 = log2(tiles per group) + 1)
+  const bool sel = DMB_OPT(21) == 0 || DMB_OPT(21) == C::COUT;   // (development option 21: options 16 / 20 for one width only)
+  int lrun = sel && DMB_OPT(16) > 0 ? DMB_OPT(16) - 1 : ZY_RUN_LOG2;   // (development option 16 = log2(tiles per group) + 1)
   int nparts = ZY_PARTS;
-  if (DMB_OPT(20)) {   // development: ONE class-major list over the whole layer (the round-3 order)
+  if (sel && DMB_OPT(20)) {   // development: ONE class-major list over the whole layer (the round-3 order)
     nparts = 1;
     lrun = 0;
     while ((1LL << lrun) < ntiles) ++lrun;

@@ -634,6 +634,15 @@ extern "C" int dmb_local_soft_argmin_f32(const float* cost, float* disp, long lo
   return launch_status("local_soft_argmin launch failed");
 }
 
+// Row form or flat form of trilinear_zcol_kernel (see the kernel): flat wherever rows are 16-byte multiples.  Measured inside
+// the PSMNet step, forms alternated in one process (scripts/ab_step.py, development option 22): 544 x 960 (240 of a row block's 256
+// lanes busy) 27.05 ms with the row form against 26.94 flat; 384 x 1248 (312 of 512) 26.60 against 26.24.
+static int trilinear_flat(int Ho, int Wo) {
+  if ((Wo & 3) != 0 || (long long)Ho * (Wo / 4) >= 0x7fffff00LL) return 0;
+  if (DMB_OPT(22)) return DMB_OPT(22) == 2;   // (development option 22: 1 = row form, 2 = flat form)
+  return 1;
+}
+
 extern "C" int dmb_trilinear_ac_f32(const float* x, float* y, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                                     void* stream) {
   if (!x || !y || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0)
@@ -642,7 +651,7 @@ extern "C" int dmb_trilinear_ac_f32(const float* x, float* y, int B, int Di, int
     return fail(DMB_EUNSUPPORTED, "trilinear: grid too large");
   hipStream_t st = (hipStream_t)stream;
   if (Ho <= 65535 && B <= 65535) {
-    const int flat = (Wo & 3) == 0 && (long long)Ho * cdiv(Wo, 4) < 0x7fffff00LL;
+    const int flat = trilinear_flat(Ho, Wo);
     const long long nxb = flat ? ((long long)Ho * (Wo / 4) + 255) / 256 : cdiv(cdiv(Wo, 4), 256);
     // split the plane walk only when the (row, column-block) grid alone cannot fill the chip
     const long long nblk0 = nxb * (flat ? 1 : Ho) * B;
@@ -667,7 +676,7 @@ extern "C" int dmb_trilinear_ac_soft_argmin_f32(const float* x, float* y, float*
   if (Ho > 65535 || B > 65535) return fail(DMB_EUNSUPPORTED, "trilinear_ac_soft_argmin: grid too large");
   DispVal dv;
   if (int e = fill_samples(disp_sample_host, Do, dv)) return e;
-  const int flat = (Wo & 3) == 0 && (long long)Ho * cdiv(Wo, 4) < 0x7fffff00LL;
+  const int flat = trilinear_flat(Ho, Wo);
   const long long nxb = flat ? ((long long)Ho * (Wo / 4) + 255) / 256 : cdiv(cdiv(Wo, 4), 256);
   hipLaunchKernelGGL(trilinear_zcol_kernel<true>, dim3((unsigned)nxb, flat ? 1 : Ho, B), dim3(256), 0, (hipStream_t)stream, x, y,
                      Di, Hi, Wi, Do, Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), 1, disp, alpha, dv, flat);

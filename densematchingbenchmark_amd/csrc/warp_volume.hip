@@ -142,15 +142,45 @@ static int launch_warp(const float* L, const float* R, const float* disp, float*
 // columns and scatters into two LDS rows (north / south source row) with LDS atomics -- the order of the adds is the
 // hardware's, as in the reference's own GPU backward (atomicAdd) -- and leaves them as partial rows; kernel B adds, per
 // source row, the two or three partial rows that point at it in ascending y.  dL needs no scatter: one register per column.
-// The gradient with respect to the disparity samples themselves is not provided (the builders raise for it).
+//     normalised dif (dif_fms.py:82-84):  out = || L * (T > 0) - T ||_p over the channels;  with v_c the channel's difference,
+//     d out / d v_c = sgn(v_c) |v_c|^(p-1) / out^(p-1)  (0 where v_c == 0 or out == 0, torch's norm backward), then as dif.
+// Per-pixel samples get a gradient too (AnyNet.py:60-73 and DeepPruner.py:192 build them from predicted disparities): the
+// sampler's derivative with respect to the column coordinate,
+//     d T_c / d ix = sum over the taps inside the volume of  (+1 east | -1 west) * w_row * w_plane * R_c[tap],
+// times d ix / d sample = -(W / 2) * (2 / (W - 1))  (grid_sample's un-normalisation, inverse_warp_3d.py:41's normalisation and
+// cat_fms.py:74's sign), summed over the channels: kernel C, one thread per sample, no scatter.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int WB_CG = 8;   // channels per workgroup (two per wave)
+
+// d ||v||_p / d v_c times the upstream gradient g (FunctionsManual.cpp's norm_backward: sgn(0) = 0, zero norm -> 0)
+__device__ inline float norm_grad(float v, float nrm, float g, float p) {
+  if (v == 0.f || nrm == 0.f) return 0.f;
+  if (p == 1.f) return v > 0.f ? g : -g;
+  if (p == 2.f) return g * (v / nrm);
+  const float a = powf(fabsf(v), p - 1.f) * (g / powf(nrm, p - 1.f));
+  return v > 0.f ? a : -a;
+}
+
+// upstream gradients of one voxel's channel c: g_ref (reference half) and g_tgt (the warped target T)
+template <int MODE>
+__device__ inline void warp_upstream(const float* __restrict__ G, const float* __restrict__ nrm, size_t vox, size_t o, int c, int C,
+                                     size_t DHW, float lv, float tv, float p, float& g_ref, float& g_tgt) {
+  if (MODE == WARP_DIF_NORM) {
+    const float v = (tv > 0.f ? lv : 0.f) - tv;
+    g_ref = norm_grad(v, nrm[vox], G[vox], p);
+    g_tgt = -g_ref;
+  } else {
+    g_ref = G[o + (size_t)c * DHW];
+    g_tgt = MODE == WARP_CAT ? G[o + (size_t)(C + c) * DHW] : -g_ref;
+  }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256) void warp_volume_bwd_kernel(const float* __restrict__ L, const float* __restrict__ R,
                                                               const float* __restrict__ disp, const float* __restrict__ G,
-                                                              float* __restrict__ dL, float* __restrict__ part, int C, int D,
-                                                              int H, int W, int per_pixel) {
+                                                              const float* __restrict__ nrm, float* __restrict__ dL,
+                                                              float* __restrict__ part, int C, int D, int H, int W,
+                                                              int per_pixel, float p) {
   extern __shared__ float rows[];   // [2][WB_CG][W]
   const int y = blockIdx.x, c0 = blockIdx.y * WB_CG, b = blockIdx.z;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -175,8 +205,10 @@ __global__ __launch_bounds__(256) void warp_volume_bwd_kernel(const float* __res
         if (c >= C) continue;
         const float tv = warp_blend(t, Rb + (size_t)c * HW);
         const size_t o = ((size_t)b * OC * D + k) * HW + (size_t)y * W + x;
-        const float g_ref = G[o + (size_t)c * DHW];
-        const float g_tgt = MODE == WARP_CAT ? G[o + (size_t)(C + c) * DHW] : -g_ref;
+        const size_t vox = ((size_t)b * D + k) * HW + (size_t)y * W + x;
+        float g_ref, g_tgt;
+        warp_upstream<MODE>(G, nrm, vox, o, c, C, DHW, MODE == WARP_DIF_NORM ? L[((size_t)b * C + c) * HW + (size_t)y * W + x] : 0.f,
+                            tv, p, g_ref, g_tgt);
         if (tv > 0.f) dl[cc] += g_ref;
         float* r0 = rows + (size_t)cl * W;                 // north source row
         float* r1 = rows + (size_t)(WB_CG + cl) * W;       // south source row
@@ -219,24 +251,79 @@ __global__ __launch_bounds__(256) void warp_volume_bwd_rows_kernel(const float* 
   dR[(size_t)bc * H * W + i] = acc;
 }
 
+// Kernel C: dS[b, k, y, x] for per-pixel samples.  The taps' x weights are (x1 - ix) west and (ix - x0) east, so the derivative
+// of a tap's weight with respect to ix is -/+ (row weight * plane weight); the planes share the image, so both plane taps of
+// an image point use the same feature value.  Accumulated over the channels in the order grid_sample's backward does.
+template <int MODE>
+__global__ __launch_bounds__(256) void warp_volume_bwd_samples_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                                      const float* __restrict__ disp, const float* __restrict__ G,
+                                                                      const float* __restrict__ nrm, float* __restrict__ dS,
+                                                                      int C, int D, int H, int W, float p) {
+  const int HW = H * W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y, b = blockIdx.z;
+  if (i >= HW) return;
+  const int y = i / W, x = i - y * W;
+  const size_t vox = ((size_t)b * D + k) * HW + i;
+  const WarpTaps t = warp_taps(-disp[vox], k, y, x, D, H, W);
+  // d w_tap / d ix, plane taps of one image point added up; w = wx * wy * wz, so the quotient is taken from the factors again
+  const float gd = ((((float)k / (float)(D - 1)) * 2.f) - 1.f), gh = ((((float)y / (float)(H - 1)) * 2.f) - 1.f);
+  const float iy = ((((gh + 1.f) * (float)H) - 1.f) / 2.f), iz = ((((gd + 1.f) * (float)D) - 1.f) / 2.f);
+  const float wy1 = iy - floorf(iy), wy0 = (floorf(iy) + 1.f) - iy, wz1 = iz - floorf(iz), wz0 = (floorf(iz) + 1.f) - iz;
+  const float wyq[4] = {wy0, wy0, wy1, wy1};
+  float dq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float wz = ((t.valid >> q & 1u) ? wz0 : 0.f) + ((t.valid >> (q + 4) & 1u) ? wz1 : 0.f);
+    dq[q] = (q & 1 ? wyq[q] : -wyq[q]) * wz;
+  }
+  const int OC = MODE == WARP_CAT ? 2 * C : C;
+  const size_t DHW = (size_t)D * HW;
+  const size_t o = ((size_t)b * OC * D + k) * HW + i;
+  const float* Rb = R + (size_t)b * C * HW;
+  const unsigned any = t.valid | (t.valid >> 4);
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* plane = Rb + (size_t)c * HW;
+    float gx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (any >> q & 1u) gx += plane[t.off[q]] * dq[q];
+    float g_ref, g_tgt;
+    const float tv = MODE == WARP_DIF_NORM ? warp_blend(t, plane) : 0.f;
+    warp_upstream<MODE>(G, nrm, vox, o, c, C, DHW, MODE == WARP_DIF_NORM ? L[((size_t)b * C + c) * HW + i] : 0.f, tv, p, g_ref, g_tgt);
+    acc += g_tgt * gx;
+  }
+  dS[vox] = -((acc * (0.5f * (float)W)) * 2.f / (float)(W - 1));
+}
+
 }  // namespace dmb
 
 using namespace dmb;
 
-extern "C" int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol, float* dL,
-                                    float* dR, float* partial, int B, int C, int D, int H, int W, int per_pixel, int dif,
-                                    void* stream) {
-  if (!L || !R || !disp_sample || !dvol || !dL || !dR || !partial || B <= 0 || C <= 0 || D < 2 || H < 2 || W < 2)
+extern "C" int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol,
+                                    const float* norm_out, float* dL, float* dR, float* d_samples, float* partial, int B, int C,
+                                    int D, int H, int W, int per_pixel, int mode, float p, void* stream) {
+  if (!L || !R || !disp_sample || !dvol || !dL || !dR || !partial || B <= 0 || C <= 0 || D < 2 || H < 2 || W < 2 || mode < 0 ||
+      mode > 2 || (mode == WARP_DIF_NORM && (!norm_out || !(p > 0.f))) || (d_samples && !per_pixel))
     return fail(DMB_EINVAL, "fast_fms_bwd: bad argument");
-  if ((long long)C * H * W >= 0x7fffffffLL || H > 65535 || B > 65535 || (size_t)2 * WB_CG * W * 4 > 64 * 1024)
+  if ((long long)C * H * W >= 0x7fffffffLL || H > 65535 || D > 65535 || B > 65535 || (size_t)2 * WB_CG * W * 4 > 64 * 1024)
     return fail(DMB_EUNSUPPORTED, "fast_fms_bwd: feature map too large");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)2 * WB_CG * W * sizeof(float);
-  const dim3 grid(H, cdiv(C, WB_CG), B);
-  if (dif)
-    hipLaunchKernelGGL((warp_volume_bwd_kernel<WARP_DIF>), grid, dim3(256), lds, st, L, R, disp_sample, dvol, dL, partial, C, D, H, W, per_pixel);
-  else
-    hipLaunchKernelGGL((warp_volume_bwd_kernel<WARP_CAT>), grid, dim3(256), lds, st, L, R, disp_sample, dvol, dL, partial, C, D, H, W, per_pixel);
+  const dim3 grid(H, cdiv(C, WB_CG), B), sgrid(cdiv(H * W, 256), D, B);
+#define DMB_WARP_BWD(MODE)                                                                                                        \
+  do {                                                                                                                            \
+    hipLaunchKernelGGL((warp_volume_bwd_kernel<MODE>), grid, dim3(256), lds, st, L, R, disp_sample, dvol, norm_out, dL, partial,  \
+                       C, D, H, W, per_pixel, p);                                                                                 \
+    if (d_samples)                                                                                                                \
+      hipLaunchKernelGGL((warp_volume_bwd_samples_kernel<MODE>), sgrid, dim3(256), 0, st, L, R, disp_sample, dvol, norm_out,      \
+                         d_samples, C, D, H, W, p);                                                                               \
+  } while (0)
+  if (mode == WARP_CAT) DMB_WARP_BWD(WARP_CAT);
+  else if (mode == WARP_DIF) DMB_WARP_BWD(WARP_DIF);
+  else DMB_WARP_BWD(WARP_DIF_NORM);
+#undef DMB_WARP_BWD
   hipLaunchKernelGGL(warp_volume_bwd_rows_kernel, dim3(cdiv(H * W, 256), B * C), dim3(256), 0, st, partial, dR, C, H, W);
   return launch_status("fast_fms_bwd launch failed");
 }

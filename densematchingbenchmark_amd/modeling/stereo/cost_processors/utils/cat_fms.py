@@ -40,15 +40,14 @@ def fast_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1
     linspace(start, end, D) samples the builder generates itself -- and the reference features masked where the warped
     target is not positive.  Not equivalent to cat_fms: the reference samples a (size - 1)-normalised grid with
     F.grid_sample's align_corners=False default; csrc/warp_volume.hip reproduces that blend bit for bit.
-    Under autograd the two feature maps get their gradients from the sampler's adjoint (``ops.fast_fms_bwd``); the samples
-    themselves are constants here: a ``disp_sample`` that requires grad is refused."""
-    if disp_sample is not None and torch.is_grad_enabled() and disp_sample.requires_grad:
-        raise NotImplementedError("fast_cat_fms: no gradient with respect to disp_sample on the HIP path (detach it)")
+    Under autograd the two feature maps get their gradients from the sampler's adjoint and per-pixel samples that require one
+    get theirs from the sampler's column derivative (``ops.fast_fms_bwd``), as the reference's do from F.grid_sample."""
+    wrt_samples = disp_sample is not None and disp_sample.requires_grad
     if disp_sample is None:
         disp_sample = ops.fast_disp_samples(max_disp, start_disp, dilation)
-    if torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad):
+    if torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad or wrt_samples):
         return train_fn.FastFmsFn.apply(reference_fm.float().contiguous(), target_fm.float().contiguous(),
-                                        disp_sample.detach().float().to(reference_fm.device).contiguous(), False)
+                                        train_fn.fast_samples_for_autograd(disp_sample, reference_fm), False)
     return ops.fast_cat_fms(reference_fm.float(), target_fm.float(), disp_sample)
 
 

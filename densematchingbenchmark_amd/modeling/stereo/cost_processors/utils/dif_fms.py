@@ -19,17 +19,15 @@ def fast_dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1
     """dif_fms.py:49-86: reference features (masked where the warped target is not positive) minus the target features
     warped by ``disp_sample`` ([B, D, H, W]) or by the builder's own linspace samples; ``normalize`` reduces the channels
     with a p-norm ([B, D, H, W]).  Same sampling convention as fast_cat_fms (csrc/warp_volume.hip).  Under autograd the two
-    feature maps get their gradients from the sampler's adjoint (not with ``normalize``, not for ``disp_sample``)."""
-    needs_grad = torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad)
-    if disp_sample is not None and torch.is_grad_enabled() and disp_sample.requires_grad:
-        raise NotImplementedError("fast_dif_fms: no gradient with respect to disp_sample on the HIP path (detach it)")
-    if needs_grad and normalize:
-        raise NotImplementedError("fast_dif_fms(normalize=True) has no backward on the HIP path")
+    feature maps get their gradients from the sampler's adjoint and per-pixel samples theirs from its column derivative (what
+    the reference gets from F.grid_sample's backward), with or without ``normalize``."""
+    wrt_samples = disp_sample is not None and disp_sample.requires_grad
+    needs_grad = torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad or wrt_samples)
     if disp_sample is None:
         disp_sample = ops.fast_disp_samples(max_disp, start_disp, dilation)
     if needs_grad:
         return train_fn.FastFmsFn.apply(reference_fm.float().contiguous(), target_fm.float().contiguous(),
-                                        disp_sample.detach().float().to(reference_fm.device).contiguous(), True)
+                                        train_fn.fast_samples_for_autograd(disp_sample, reference_fm), True, bool(normalize), p)
     return ops.fast_dif_fms(reference_fm.float(), target_fm.float(), disp_sample, normalize, p)
 
 

@@ -184,25 +184,38 @@ class DifFmsFn(torch.autograd.Function):
 FAST_FMS_BWD_MAX_W = 1024   # dmb_fast_fms_bwd_f32: 2 * 8 channels * W * 4 bytes of LDS <= 64 KiB
 
 
+def fast_samples_for_autograd(disp_sample, like):
+    """The samples as FastFmsFn takes them (FP32, contiguous, on the features' device) without cutting their autograd history."""
+    if disp_sample.requires_grad and torch.is_grad_enabled() and disp_sample.dim() != 4:
+        raise NotImplementedError("fast_cat_fms / fast_dif_fms: a gradient for the samples needs per-pixel samples [B, D, H, W]")
+    return disp_sample.float().to(like.device).contiguous()
+
+
 class FastFmsFn(torch.autograd.Function):
-    """fast_cat_fms / fast_dif_fms (normalize=False) under autograd: gradients for the two feature maps (the sampler's adjoint,
-    csrc/warp_volume.hip); the disparity samples are treated as constants."""
+    """fast_cat_fms / fast_dif_fms under autograd (csrc/warp_volume.hip): gradients for the two feature maps (the sampler's
+    adjoint) and, when they require one, for per-pixel disparity samples (the sampler's column derivative: the route AnyNet's
+    and DeepPruner's predicted disparities take, AnyNet.py:60-73, DeepPruner.py:192).  ``normalize`` = fast_dif_fms's p-norm
+    over the channels (dif_fms.py:82-84)."""
 
     @staticmethod
-    def forward(ctx, left, right, disp_sample, dif):
+    def forward(ctx, left, right, disp_sample, dif, normalize=False, p=1.0):
         if left.shape[-1] > FAST_FMS_BWD_MAX_W:   # refuse here, not inside backward(): the adjoint keeps 2 x 8 rows of W floats in LDS
             raise NotImplementedError("fast_cat_fms / fast_dif_fms under autograd: feature maps wider than %d columns have no "
                                       "backward on the HIP path (the forward alone has no such limit: run it under torch.no_grad())"
                                       % FAST_FMS_BWD_MAX_W)
-        ctx.save_for_backward(left, right, disp_sample)
-        ctx.dif = bool(dif)
-        return ops.fast_dif_fms(left, right, disp_sample) if dif else ops.fast_cat_fms(left, right, disp_sample)
+        if normalize and not dif:
+            raise ValueError("normalize belongs to fast_dif_fms")
+        ctx.dif, ctx.p = bool(dif), float(p)
+        out = ops.fast_dif_fms(left, right, disp_sample, normalize, p) if dif else ops.fast_cat_fms(left, right, disp_sample)
+        ctx.save_for_backward(left, right, disp_sample, out if normalize else None)
+        return out
 
     @staticmethod
     def backward(ctx, dvol):
-        left, right, disp_sample = ctx.saved_tensors
-        dL, dR = ops.fast_fms_bwd(left, right, disp_sample, dvol.contiguous(), ctx.dif)
-        return dL, dR, None, None
+        left, right, disp_sample, norm_out = ctx.saved_tensors
+        dL, dR, dS = ops.fast_fms_bwd(left, right, disp_sample, dvol.contiguous(), ctx.dif, norm_out, ctx.p,
+                                      wrt_samples=ctx.needs_input_grad[2])
+        return dL, dR, dS, None, None, None
 
 
 class UpsampleRegressFn(torch.autograd.Function):

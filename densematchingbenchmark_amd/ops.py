@@ -168,21 +168,32 @@ def fast_dif_fms(left, right, disp_sample, normalize=False, p=1.0):
     return out
 
 
-def fast_fms_bwd(left, right, disp_sample, dvol, dif=False):
-    """Backward of fast_cat_fms / fast_dif_fms (normalize=False): (d left, d right), each [B, C, H, W]."""
+def fast_fms_bwd(left, right, disp_sample, dvol, dif=False, norm_out=None, p=1.0, wrt_samples=False):
+    """Backward of fast_cat_fms / fast_dif_fms: (d left, d right, d disp_sample); the first two [B, C, H, W], the third
+    [B, D, H, W] with ``wrt_samples`` (per-pixel samples only) and None otherwise.  ``norm_out`` = the forward's output of
+    fast_dif_fms(normalize=True, p) selects the normalised form (grad_output [B, D, H, W])."""
     lib = _lib.load()
     left, right = _feature_pair(left, right, "fast_fms_bwd")
     ds, D, per_pixel = _fast_samples(left, disp_sample)
     dvol = _f32c(dvol, "grad_output")
     B, C, H, W = left.shape
-    want = (B, C if dif else 2 * C, D, H, W)
+    mode = 2 if norm_out is not None else (1 if dif else 0)
+    want = (B, D, H, W) if mode == 2 else (B, C if dif else 2 * C, D, H, W)
     if tuple(dvol.shape) != want:
         raise _lib.DmbLibraryError("fast_fms_bwd: grad_output is %s, expected %s" % (tuple(dvol.shape), want))
+    if mode == 2:
+        norm_out = _f32c(norm_out, "norm_out")
+        if tuple(norm_out.shape) != want:
+            raise _lib.DmbLibraryError("fast_fms_bwd: norm_out is %s, expected %s" % (tuple(norm_out.shape), want))
+    if wrt_samples and not per_pixel:
+        raise _lib.DmbLibraryError("fast_fms_bwd: a gradient for the samples needs per-pixel samples [B, D, H, W]")
     dl, dr = torch.empty_like(left), torch.empty_like(right)
+    dsamp = torch.empty((B, D, H, W), dtype=torch.float32, device=left.device) if wrt_samples else None
     part = torch.empty((B, C, H, 2, W), dtype=torch.float32, device=left.device)
-    check(lib.dmb_fast_fms_bwd_f32(dev_ptr(left), dev_ptr(right), dev_ptr(ds), dev_ptr(dvol), dev_ptr(dl), dev_ptr(dr), dev_ptr(part),
-                                   B, C, D, H, W, per_pixel, 1 if dif else 0, stream_ptr(left.device)), "dmb_fast_fms_bwd_f32")
-    return dl, dr
+    check(lib.dmb_fast_fms_bwd_f32(dev_ptr(left), dev_ptr(right), dev_ptr(ds), dev_ptr(dvol), dev_ptr(norm_out, "norm_out", True), dev_ptr(dl),
+                                   dev_ptr(dr), dev_ptr(dsamp, "d_samples", True), dev_ptr(part), B, C, D, H, W, per_pixel, mode, float(p),
+                                   stream_ptr(left.device)), "dmb_fast_fms_bwd_f32")
+    return dl, dr, dsamp
 
 
 def gwc_fms(left, right, disp_idx, num_groups, out=None, out_ch_offset=0):

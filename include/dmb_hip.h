@@ -44,8 +44,9 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes (4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads
- * entry points of version 3 removed). */
+/* ABI version: bumped whenever a signature below changes (5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
+ * optional gradient buffer for per-pixel samples; 4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads entry
+ * points of version 3 removed). */
 int dmb_abi_version(void);
 /* Static string describing the last DMB_E* code returned on this thread ("" if none). */
 const char* dmb_last_error(void);
@@ -85,16 +86,23 @@ int dmb_fast_cat_fms_f32(const float* L, const float* R, const float* disp_sampl
 int dmb_fast_dif_fms_f32(const float* L, const float* R, const float* disp_sample, float* out, int B, int C, int D, int H,
                          int W, int per_pixel, int normalize, float p, void* stream);
 
-/* Backward of fast_cat_fms (dif == 0) / fast_dif_fms without normalisation (dif != 0): what the reference obtains from
- * torch.autograd through F.grid_sample and the expand of inverse_warp_3d.py:19-20 (cat_fms.py:51-82, dif_fms.py:49-86).
- *   dvol: gradient of the builder's output ([B, 2C, D, H, W] / [B, C, D, H, W]);  dL, dR: [B, C, H, W];
+/* Backward of fast_cat_fms (mode 0), fast_dif_fms (mode 1) and fast_dif_fms(normalize=True) (mode 2): what the reference
+ * obtains from torch.autograd through F.grid_sample, the expand of inverse_warp_3d.py:19-20 and torch.norm (cat_fms.py:51-82,
+ * dif_fms.py:49-86).
+ *   dvol: gradient of the builder's output ([B, 2C, D, H, W] / [B, C, D, H, W] / [B, D, H, W]);  dL, dR: [B, C, H, W];
+ *   norm_out: mode 2 only (else NULL): the forward's output [B, D, H, W], with its p;
+ *   d_samples: NULL, or [B, D, H, W] = the gradient with respect to per-pixel samples (per_pixel != 0 only: the sampler's
+ *     column derivative times -(W / 2) * 2 / (W - 1), summed over the channels -- the path AnyNet.py:60-73 and
+ *     DeepPruner.py:192 train through);
  *   partial: workspace of B * C * H * 2 * W floats (per output row the gradient rows of its two source rows).
- *   dL = sum_k dvol_ref * (T > 0);  dR = the sampler's adjoint of dvol_tgt (cat) or of -dvol (dif).
- * Sums along x go through LDS atomics (their order is the hardware's, as in the reference's own GPU backward); no gradient
- * with respect to disp_sample.  Same D, H, W >= 2 rule as the forward; W <= 1024 (two groups of 8 channel rows in 64 KiB of
- * LDS: DMB_EUNSUPPORTED beyond -- the forward has no such limit, the host layer refuses wider maps under autograd up front). */
-int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol, float* dL, float* dR,
-                         float* partial, int B, int C, int D, int H, int W, int per_pixel, int dif, void* stream);
+ *   dL = sum_k dvol_ref * (T > 0);  dR = the sampler's adjoint of dvol_tgt (cat) or of -dvol (dif); the mask (T > 0) is a
+ *   constant, as in the reference (cat_fms.py:77).
+ * Sums along x go through LDS atomics (their order is the hardware's, as in the reference's own GPU backward).  Same
+ * D, H, W >= 2 rule as the forward; W <= 1024 (two groups of 8 channel rows in 64 KiB of LDS: DMB_EUNSUPPORTED beyond -- the
+ * forward has no such limit, the host layer refuses wider maps under autograd up front). */
+int dmb_fast_fms_bwd_f32(const float* L, const float* R, const float* disp_sample, const float* dvol, const float* norm_out,
+                         float* dL, float* dR, float* d_samples, float* partial, int B, int C, int D, int H, int W,
+                         int per_pixel, int mode, float p, void* stream);
 
 /* Spatial propagation scan: dmb/ops/spn (GateRecurrent2dnoind: functions/gaterecurrent2dnoind.py:10-44 on
  * src/gaterecurrent2dnoind_kernel.cu:10-166,288-345,535-552), the reference's only native op (CUDA; one kernel launch per

@@ -170,15 +170,18 @@ def fast_dif_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1
 
 
 def fast_volume_grads(reference_fm, target_fm, grad_out, max_disp=192, start_disp=0, dilation=1, disp_sample=None, kind="cat",
-                      dtype=torch.float32):
-    """Gradients of fast_cat_fms / fast_dif_fms (``kind``) with respect to the two feature maps for an upstream gradient
+                      dtype=torch.float32, normalize=False, p=1.0, wrt_samples=False):
+    """Gradients of fast_cat_fms / fast_dif_fms (``kind``) with respect to the two feature maps -- and, with ``wrt_samples``, the
+    per-pixel samples (third return value) -- for an upstream gradient
     ``grad_out``, the way the reference gets them: torch.autograd through the sampler of layers/inverse_warp_3d.py:19-50 (the
     image expanded over the D planes, a (size - 1)-normalised grid, F.grid_sample with its align_corners=False default).  The
     mask ``(warped > 0)`` is a constant (cat_fms.py:77 builds it with ``.type_as``: no gradient path).  Pinned by
     tests/golden/fast_volumes_grad.npz (the reference's own functions under autograd).  ``dtype=torch.float64`` = yardstick."""
     L = reference_fm.detach().to(dtype).requires_grad_()
     R = target_fm.detach().to(dtype).requires_grad_()
-    ds = _fast_samples(reference_fm, max_disp, start_disp, dilation, disp_sample).to(dtype)
+    ds = _fast_samples(reference_fm, max_disp, start_disp, dilation, disp_sample).detach().to(dtype)
+    if wrt_samples:
+        ds = ds.clone().requires_grad_()
     B, D, H, W = ds.shape
     C = R.shape[1]
     img = R.unsqueeze(2).expand(B, C, D, H, W)
@@ -189,8 +192,10 @@ def fast_volume_grads(reference_fm, target_fm, grad_out, max_disp=192, start_dis
     tgt = F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
     ref = L.unsqueeze(2) * (tgt > 0).to(dtype)
     vol = torch.cat((ref, tgt), dim=1) if kind == "cat" else ref - tgt
+    if normalize:                                                     # dif_fms.py:82-84
+        vol = torch.norm(vol, p=p, dim=1, keepdim=False)
     vol.backward(grad_out.to(dtype))
-    return L.grad, R.grad
+    return (L.grad, R.grad, ds.grad) if wrt_samples else (L.grad, R.grad)
 
 
 def correlation1d_cost(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, disp_sample=None):

@@ -2,7 +2,8 @@
 (cost_processors/utils/cat_fms.py:51-82) and fast_dif_fms (dif_fms.py:49-86), imported from the reference tree -- obtained the
 way the reference obtains them: torch.autograd through F.grid_sample and the expand of inverse_warp_3d.py, on CPU, for a
 seeded upstream gradient.  Stored: d reference_fm, d target_fm for per-pixel samples and for the builders' own linspace
-samples.  Fixtures are data.
+samples; and (round 4) d disp_sample for per-pixel samples that require a gradient, for the plain builders and for
+fast_dif_fms(normalize=True, p in {0.5, 1, 2, 3}).  Fixtures are data.
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fast_grad.py
 """
@@ -41,6 +42,22 @@ def main():
                 vol.backward(up)
                 out["%s_%s_dL_%d" % (name, mode, i)] = G.npy(a.grad)
                 out["%s_%s_dR_%d" % (name, mode, i)] = G.npy(b.grad)
+        # round 4: the samples themselves carry a gradient (AnyNet.py:60-73 / DeepPruner.py:192 build them from predicted
+        # disparities), with and without fast_dif_fms's p-norm over the channels (dif_fms.py:82-84)
+        for name, fn, kw in (("cat", fast_cat_fms, {}), ("dif", fast_dif_fms, {}), ("difn1", fast_dif_fms, dict(normalize=True, p=1.0)),
+                             ("difn2", fast_dif_fms, dict(normalize=True, p=2.0)), ("difn3", fast_dif_fms, dict(normalize=True, p=3.0)),
+                             ("difnh", fast_dif_fms, dict(normalize=True, p=0.5))):
+            a = G.rand(sh, seed).requires_grad_()
+            b = G.rand(sh, seed + 1000).requires_grad_()
+            s = ds.clone().requires_grad_()
+            vol = fn(a, b, disp_sample=s, **kw)
+            up = G.rand(tuple(vol.shape), seed + 3000 + (0 if name == "cat" else 1))
+            vol.backward(up)
+            out["%s_samples_dL_%d" % (name, i)] = G.npy(a.grad)
+            out["%s_samples_dR_%d" % (name, i)] = G.npy(b.grad)
+            out["%s_samples_dS_%d" % (name, i)] = G.npy(s.grad)
+            if kw:
+                out["%s_samples_out_%d" % (name, i)] = G.npy(vol)
     path = os.path.join(G.OUT, "fast_volumes_grad.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")

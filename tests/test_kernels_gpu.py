@@ -146,11 +146,12 @@ def test_fast_mode_argument_errors(dev):
     with pytest.raises(_lib.DmbLibraryError):
         ops.fast_cat_fms(a, a, torch.zeros(1, device=dev))               # D = 1: the reference divides by D - 1
     from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import fast_cat_fms
-    with pytest.raises(NotImplementedError):   # the samples are constants on the HIP path: a sample tensor that wants a gradient is refused
-        fast_cat_fms(a, a, 4, disp_sample=torch.zeros(1, 3, 4, 6, device=dev).requires_grad_())
-    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.dif_fms import fast_dif_fms
-    with pytest.raises(NotImplementedError):
-        fast_dif_fms(a.clone().requires_grad_(), a, 4, normalize=True)
+    with pytest.raises(NotImplementedError):   # a gradient for the samples exists for per-pixel samples only
+        fast_cat_fms(a, a, 4, disp_sample=torch.zeros(3, device=dev).requires_grad_())
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.fast_fms_bwd(a, a, torch.zeros(3, device=dev), torch.zeros(1, 4, 3, 4, 6, device=dev), wrt_samples=True)
+    with pytest.raises(_lib.DmbLibraryError):  # the normalised form's grad_output is [B, D, H, W]
+        ops.fast_fms_bwd(a, a, torch.zeros(3, device=dev), torch.zeros(1, 2, 3, 4, 6, device=dev), True, norm_out=torch.zeros(1, 3, 4, 6, device=dev))
 
 
 def test_fast_volume_builders_backward(dev):
@@ -184,6 +185,45 @@ def test_fast_volume_builders_backward(dev):
                     e_got = (got.cpu().double() - truth).abs().max().item()
                     e_ref = (ref.double() - truth).abs().max().item()
                     assert e_got <= max(4 * e_ref, 1e-6 * scale), (kind, mode, name, i, e_got, e_ref)
+
+
+def test_fast_volume_builders_backward_through_the_samples(dev):
+    """Per-pixel samples that require a gradient (what AnyNet.py:60-73 and DeepPruner.py:192 feed the builders): d disp_sample,
+    d reference_fm and d target_fm of the module-level builders under torch.autograd -- the plain builders and fast_dif_fms's
+    p-norm over the channels (p = 0.5, 1, 2, 3) -- against the REFERENCE's builders under its own autograd
+    (tests/golden/fast_volumes_grad.npz) and against an FP64 evaluation of the oracle (error <= 4x the FP32 reference's own)."""
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import fast_cat_fms
+    from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.dif_fms import fast_dif_fms
+    g = golden("fast_volumes_grad.npz")
+    forms = [("cat", "cat", {}), ("dif", "dif", {}), ("difn1", "dif", dict(normalize=True, p=1.0)), ("difn2", "dif", dict(normalize=True, p=2.0)),
+             ("difn3", "dif", dict(normalize=True, p=3.0)), ("difnh", "dif", dict(normalize=True, p=0.5))]
+    for i, row in enumerate(g["cases"]):
+        sh, D, seed = tuple(int(v) for v in row[:4]), int(row[4]), int(row[5])
+        a, b = _rand(sh, seed), _rand(sh, seed + 1000)
+        gen = torch.Generator().manual_seed(seed + 2000)
+        ds = torch.rand((sh[0], D, sh[2], sh[3]), generator=gen) * sh[3] * 0.6 - 2.0
+        for name, kind, kw in forms:
+            shape = (sh[0], D, sh[2], sh[3]) if kw else (sh[0], (2 if kind == "cat" else 1) * sh[1], D, sh[2], sh[3])
+            up = _rand(shape, seed + 3000 + (0 if name == "cat" else 1))
+            L, R, S = a.to(dev).requires_grad_(), b.to(dev).requires_grad_(), ds.to(dev).requires_grad_()
+            vol = (fast_cat_fms if kind == "cat" else fast_dif_fms)(L, R, disp_sample=S, **kw)
+            vol.backward(up.to(dev))
+            t64 = O.fast_volume_grads(a, b, up, kind=kind, disp_sample=ds, dtype=torch.float64, wrt_samples=True, **kw)
+            if kw:
+                want = torch.as_tensor(g["%s_samples_out_%d" % (name, i)])     # (p = 0.5 sums square roots: values of 20 - 30)
+                assert (vol.detach().cpu() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+            for got, key, truth in ((L.grad, "dL", t64[0]), (R.grad, "dR", t64[1]), (S.grad, "dS", t64[2])):
+                ref = torch.as_tensor(g["%s_samples_%s_%d" % (name, key, i)])
+                scale = max(1.0, ref.abs().max().item())
+                assert got.shape == ref.shape
+                assert (got.cpu() - ref).abs().max().item() <= 2e-5 * scale, (name, key, i)
+                e_got = (got.cpu().double() - truth).abs().max().item()
+                e_ref = (ref.double() - truth).abs().max().item()
+                assert e_got <= max(4 * e_ref, 1e-6 * scale), (name, key, i, e_got, e_ref)
+    # only the samples want a gradient (the features detached, DeepPruner's refinement of the range predictors)
+    S = ds.to(dev).requires_grad_()
+    fast_cat_fms(a.to(dev), b.to(dev), disp_sample=S).backward(_rand((sh[0], 2 * sh[1], D, sh[2], sh[3]), seed + 3000).to(dev))
+    assert (S.grad.cpu() - torch.as_tensor(g["cat_samples_dS_%d" % i])).abs().max().item() <= 2e-5 * max(1.0, float(np.abs(g["cat_samples_dS_%d" % i]).max()))
 
 
 @pytest.mark.parametrize("C,G", [(16, 2), (32, 8), (12, 12), (320, 40)])

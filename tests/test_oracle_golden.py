@@ -547,6 +547,32 @@ def test_oracle_fast_volume_gradients_match_the_reference_autograd():
                 assert maxdiff(dR, g["%s_%s_dR_%d" % (kind, mode, i)]) <= 1e-5
 
 
+FAST_SAMPLE_GRAD_FORMS = [("cat", "cat", {}), ("dif", "dif", {}), ("difn1", "dif", dict(normalize=True, p=1.0)),
+                          ("difn2", "dif", dict(normalize=True, p=2.0)), ("difn3", "dif", dict(normalize=True, p=3.0)),
+                          ("difnh", "dif", dict(normalize=True, p=0.5))]
+
+
+def test_oracle_fast_volume_sample_gradients_match_the_reference_autograd():
+    """Per-pixel samples that require a gradient (AnyNet.py:60-73, DeepPruner.py:192): d disp_sample, d reference_fm, d target_fm
+    of the REFERENCE's builders under torch.autograd, with and without fast_dif_fms's p-norm (dif_fms.py:82-84)."""
+    g = golden("fast_volumes_grad.npz")
+    for i, row in enumerate(g["cases"]):
+        sh, D, seed = tuple(int(v) for v in row[:4]), int(row[4]), int(row[5])
+        a, b = rand(sh, seed), rand(sh, seed + 1000)
+        gen = torch.Generator().manual_seed(seed + 2000)
+        ds = torch.rand((sh[0], D, sh[2], sh[3]), generator=gen) * sh[3] * 0.6 - 2.0
+        for name, kind, kw in FAST_SAMPLE_GRAD_FORMS:
+            shape = (sh[0], D, sh[2], sh[3]) if kw else (sh[0], (2 if kind == "cat" else 1) * sh[1], D, sh[2], sh[3])
+            up = rand(shape, seed + 3000 + (0 if name == "cat" else 1))
+            dL, dR, dS = O.fast_volume_grads(a, b, up, kind=kind, disp_sample=ds, wrt_samples=True, **kw)
+            assert dS.shape == ds.shape
+            for got, key in ((dL, "dL"), (dR, "dR"), (dS, "dS")):
+                want = g["%s_samples_%s_%d" % (name, key, i)]
+                assert maxdiff(got, want) <= 1e-5 * max(1.0, float(np.abs(want).max())), (name, key, i)
+            if kw:
+                assert maxdiff(O.fast_dif_fms(a, b, disp_sample=ds, **kw), g["%s_samples_out_%d" % (name, i)]) <= 1e-5
+
+
 def test_oracle_gwc_has_two_witnesses():
     """Second witness for the UNPINNED group-wise correlation volume: two statements that share no code pin
     each other, and one of them is pinned to the reference.
