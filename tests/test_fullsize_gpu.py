@@ -152,7 +152,7 @@ def _f64(p, device="cpu"):
 def _truth(fn, dev):
     """The FP64 yardstick: ``fn(device)`` evaluates the oracle in double precision.  It runs on the GPU through torch's OWN
     double-precision kernels (test infrastructure: nothing of libdmb_hip.so) -- 0.3 s per pair against 28 s on 32 host threads,
-    equal to the host evaluation to 6e-15 (scripts/fp64_gpu_probe.py) -- and on the host if the GPU evaluation is unavailable."""
+    equal to the host evaluation to 6e-15 (tests/fp64_gpu_probe.py) -- and on the host if the GPU evaluation is unavailable."""
     try:
         with torch.no_grad():
             return [c.cpu() for c in fn(dev)]
@@ -402,3 +402,26 @@ def test_fullsize_psmnet_full_map_vs_reference(dev):
     d = maxdiff(results["disps"][0], g["disp3"])
     print("psmnet full map: max |disp - reference| over %d pixels = %.3g" % (g["disp3"].size, d))
     assert d <= DISP_MAX_FULL and _meandiff(results["disps"][0], g["disp3"]) <= DISP_MEAN_FULL
+
+
+@pytest.mark.parametrize("hw", [(64, 128), (80, 240), (120, 160), (128, 256), (92, 308)])
+def test_fp64_yardstick_psmnet_other_shapes(dev, hw):
+    """The same contract away from the two operating points the kernels were tuned on (feature maps of 256x512 = BASELINE
+    configs[0], 320x960, 480x640, 512x1024 and 368x1232 images; the last one leaves the deepest hourglass level with 77 columns,
+    which no 16-byte kernel form takes): the tile choice is a cost estimate over shapes, so every shape has to land on kernels
+    that compute the same thing.  One pair each, max_disp 192."""
+    from densematchingbenchmark_amd import synthetic
+    cfg, model = _built("PSMNet/scene_flow.py", 0)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    h, w = hw
+    lf, rf = synthetic.feature_pair(5, 32, h, w)
+    results, _ = model(dict(leftFeature=lf.to(dev), rightFeature=rf.to(dev)))
+    assert [tuple(d.shape) for d in results["disps"]] == [(1, 1, 4 * h, 4 * w)] * 3
+    gpu = [d.cpu() for d in results["disps"]]
+    del results
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref32, _ = O.psmnet_path(lf, rf, p, 192)
+        c64 = _truth(lambda d: O.psm_aggregator(O.cat_fms(lf, rf, 48, 0, 1).double().to(d), _f64(p, d), 192, "cost_processor.aggregator."), dev)
+        _assert_yardstick("psmnet %dx%d" % (4 * h, 4 * w), gpu, ref32, c64)
