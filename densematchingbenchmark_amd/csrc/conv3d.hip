@@ -21,6 +21,11 @@
 
 #include "dmb_common.h"
 
+// Build-time experiment knob (build.py DMB_BUILD_DEFS): 0 = natural row pairs (r, r + 1) in the stride-1 kernel (see S1Cfg::GSTR).
+#ifndef DMB_S1_GSTR
+#define DMB_S1_GSTR 1
+#endif
+
 #ifndef DMB_EPI_LD
 #define DMB_EPI_LD 0   // buffer cache policy of the transposed kernel's epilogue: bit 1 = nt (streaming)
 #endif
@@ -103,11 +108,22 @@ struct S1Cfg {
   //    row r, 16-31 = row r + 1) or row quads of 8: every computed voxel is a real output.  Used when W % TX == 0.
   static constexpr int XS = ROWPAIR ? TX / (G_ ? G_ : 1) : 1;
   static constexpr int MT = LIN ? 2 : (ROWPAIR ? (TY / GR) * XS : (TY * P + 31) / 32);  // 32-voxel column tiles per wave
-  __device__ static constexpr int lane_off(int j) { return ROWPAIR ? (j / (G_ ? G_ : 1)) * P + (j % (G_ ? G_ : 1)) : j; }
-  __device__ static constexpr int tile_off(int mt) { return ROWPAIR ? GR * (mt / XS) * P + (mt % XS) * G_ : mt * 32; }
+  // Which rows a row PAIR takes.  A B-fragment read (ds_read_b32) is served 32 lanes at a time, bank = dword address mod 32: lanes
+  // 0-15 cover 16 banks of one row, lanes 16-31 the same columns of the pair's other row, GSTR * P floats on.  With the natural
+  // pair (rows r, r + 1) and P = 56 (48-column tiles) or 40 (32-column tiles) the second row starts 24 / 8 banks on: eight lanes
+  // collide and every such read takes two LDS cycles (counters of the dominant layer: 45 % of its LDS cycles were conflicts).
+  // Pairing rows (r, r + 2) of a four-row tile instead -- tile q of a column = rows q and q + 2 -- puts the second row
+  // 2 P = 16 (mod 32) banks on: conflict-free.  Same MFMAs on the same operands; only which accumulator holds which row changes
+  // (bit-identical: scripts/kbench_s1_ab.py prints a checksum).  What it buys is LDS cycles, not time: 2.389 / 2.396 against
+  // 2.386 / 2.391 ms at [4, 32, 48, 136, 240] (noise), 2.236 / 2.240 against 2.244 / 2.243 ms at [4, 32, 48, 96, 312] (-0.3 %) --
+  // the LDS pipe is a quarter busy either way and the fragment reads run a k-step ahead of their MFMAs.
+  static constexpr int GSTR = (G_ == 16 && TY_ == 4 && !LIN_ && (2 * P) % 32 == 16 && P % 32 != 16 && DMB_S1_GSTR) ? 2 : 1;
+  __device__ static constexpr int row_base(int q) { return GSTR == 2 ? q : GR * q; }   // first row of the q-th group of a column
+  __device__ static constexpr int lane_off(int j) { return ROWPAIR ? (j / (G_ ? G_ : 1)) * GSTR * P + (j % (G_ ? G_ : 1)) : j; }
+  __device__ static constexpr int tile_off(int mt) { return ROWPAIR ? row_base(mt / XS) * P + (mt % XS) * G_ : mt * 32; }
   __device__ static void decode(int mt, int j, int& ly, int& lx, bool& valid) {
     if (ROWPAIR) {
-      ly = GR * (mt / XS) + j / (G_ ? G_ : 1);
+      ly = row_base(mt / XS) + GSTR * (j / (G_ ? G_ : 1));
       lx = (mt % XS) * G_ + j % (G_ ? G_ : 1);
       valid = true;
     } else {
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
         const unsigned pos = (unsigned)(p0 + mt * 32 + px);
         return (gz < D && pos < HW) ? ((unsigned)(wn * 32 + (lane >> 3)) * DHW + (unsigned)gz * HW + pos) * 4u : DMA_OOB;
       }
-      const int gy = y0 + C::GR * (mt / C::XS) + px / C::G, gxo = x0 + (mt % C::XS) * C::G + px % C::G;
+      const int gy = y0 + C::row_base(mt / C::XS) + C::GSTR * (px / C::G), gxo = x0 + (mt % C::XS) * C::G + px % C::G;
       const bool inb = gz < D && gy < H && gxo < W;
       return inb ? ((unsigned)(wn * 32 + (lane >> 3)) * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gxo) * 4u : DMA_OOB;
     };
