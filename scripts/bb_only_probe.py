@@ -32,3 +32,10 @@ if os.environ.get("BB_NOSPP"):
     ops.bilinear_ac = lambda x, size, out=None, out_ch_offset=0: out   # no up-sampling (those channels stay uninitialised)
     print("backbone without the pooling branches %.3f ms" % timeit())
     ops.avgpool2d, ops.bilinear_ac = real
+if os.environ.get("BB_OPT18"):
+    from densematchingbenchmark_amd import _lib
+    lib = _lib.load()
+    for v in (0, 1, 2, 0):
+        lib.dmb_dev_set_option(18, v)
+        print("option 18 = %d (0 = by rounds x rows, 1 = always 4 rows per wave, 2 = always 2): backbone %.3f ms" % (v, timeit()))
+    lib.dmb_dev_set_option(18, 0)
