@@ -267,7 +267,7 @@ def training_leg(cfg, dev, steps):
     Adam step -- at the reference's training shape (256 x 512 crops, configs/PSMNet/scene_flow.py), batch 4."""
     from densematchingbenchmark_amd.dist_utils import FlatGradients
     B, H, W = 4, 256, 512
-    model = build_model(cfg).to(dev)
+    model = build_model(cfg, backbone=None).to(dev)
     synthetic.init_params_(model, seed=0)
     model.train()
     flat = FlatGradients(model)
@@ -383,7 +383,7 @@ def main():
     B = args.batch
 
     ops.set_conv3d_mode(args.conv3d_mode)
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     synthetic.init_params_(model, seed=0, classif_gain=10.0)
     model = model.to(dev)
     n_ids = len(cfg.get("eval_disparity_id", [0]))

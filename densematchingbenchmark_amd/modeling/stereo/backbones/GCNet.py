@@ -27,4 +27,4 @@ class GCNetBackbone(nn.Module):
             # one view after the other, as the reference does (backbones/GCNet.py:47-51): BatchNorm statistics per call
             return self.backbone(l_img), self.backbone(r_img)
         # shared weights, per-image results: two chains on two streams, or one batch of 2B images (ops.two_view_forward)
-        return ops.two_view_forward(self.backbone, l_img, r_img)
+        return ops.two_view_forward(self.backbone, l_img, r_img, module=self)

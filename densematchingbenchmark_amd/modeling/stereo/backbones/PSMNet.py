@@ -89,7 +89,7 @@ class PSMNetBackbone(nn.Module):
             return self._forward_train(l_img), self._forward_train(r_img)
         # shared weights (PSMNet.py:127-131), per-image results: the two views as two chains on two streams (or, with
         # ops.set_view_streams(False), as one batch of 2B images) -- see ops.two_view_forward
-        return ops.two_view_forward(self._forward, l_img, r_img)
+        return ops.two_view_forward(self._forward, l_img, r_img, module=self)
 
 
 class _BareConv1x1(nn.Conv2d):
@@ -99,11 +99,14 @@ class _BareConv1x1(nn.Conv2d):
         super().__init__(in_planes, out_planes, kernel_size=1, padding=0, stride=1, dilation=1, bias=False)
         self._key, self._wp = None, None
 
-    def forward(self, x):
+    def _prepacked(self):
         from ..layers.basic_layers import _versions
-        if train_fn.wants_grad(self, x):
-            return train_fn.BareConv1x1Fn.apply(x, self.weight)
         key = _versions(self.weight)
         if key != self._key:
             self._key, self._wp = key, ops.pack_conv2d_weights(self.weight.detach())
-        return ops.conv2d(x, self._wp, self.out_channels, 1, 1, 1, None, None, None, False)
+        return self._wp
+
+    def forward(self, x):
+        if train_fn.wants_grad(self, x):
+            return train_fn.BareConv1x1Fn.apply(x, self.weight)
+        return ops.conv2d(x, self._prepacked(), self.out_channels, 1, 1, 1, None, None, None, False)

@@ -19,14 +19,17 @@ class _HipConv2d(nn.Conv2d):
             raise NotImplementedError("HIP conv2d: 'same' padding only")
         self._key, self._cache = None, None
 
-    def forward(self, x):
-        if train_fn.wants_grad(self, x):
-            return train_fn.BareConv2dFn.apply(x, self.weight, self.bias, None, False)
+    def _prepacked(self):
         key = _versions(self.weight, self.bias)
         if key != self._key:
             self._key = key
             self._cache = (ops.pack_conv2d_weights(self.weight.detach()), self.bias.detach().float().contiguous())
-        wp, bias = self._cache
+        return self._cache
+
+    def forward(self, x):
+        if train_fn.wants_grad(self, x):
+            return train_fn.BareConv2dFn.apply(x, self.weight, self.bias, None, False)
+        wp, bias = self._prepacked()
         return ops.conv2d(x, wp, self.out_channels, self.kernel_size[0], self.stride[0], 1, None, bias, None, False)
 
 

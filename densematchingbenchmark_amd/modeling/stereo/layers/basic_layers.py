@@ -39,7 +39,7 @@ def _versions(*tensors):
     """Cache key of folded / packed parameters.  BatchNorm's ``num_batches_tracked`` is part of every key that covers running
     statistics: the training-mode kernel rewrites ``running_mean`` / ``running_var`` through raw device pointers (their
     ``_version`` does not move), but every such forward bumps ``num_batches_tracked`` in place."""
-    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+    return tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None)
 
 
 class FusedConv3d(nn.Sequential):

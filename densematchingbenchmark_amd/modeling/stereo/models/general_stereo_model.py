@@ -1,10 +1,13 @@
 """The caller of the hot path: models/general_stereo_model.py:14-92 (eval-mode contract; training mode = the same cost path
 under autograd on the HIP kernels + the configured disparity losses).
 
-The hot path starts at the feature maps: feed pre-computed features with ``batch['leftFeature'] /
-batch['rightFeature']``, pass any ``nn.Module`` with the reference's ``backbone(left, right) -> (ref_fms, tgt_fms)``
-contract, or ``backbone="hip"`` for this package's HIP backbone.  A ``disp_refinement`` entry in the
-config attaches the HIP refinement stage exactly where the reference runs it."""
+``build_model(cfg)`` means what it means in the reference (dmb/modeling/__init__.py:10, general_stereo_model.py:24): the
+backbone ``cfg.model.backbone`` names is built with the model (this package's HIP backbone), so a reference
+checkpoint loads with ``strict=True``.  The hot path itself starts at the feature maps: a model WITH a backbone still takes
+pre-computed features through ``batch['leftFeature'] / batch['rightFeature']``; ``backbone=None`` builds the path alone (the
+benchmarks' and kernel tests' configuration) and any ``nn.Module`` with the reference's ``backbone(left, right) -> (ref_fms,
+tgt_fms)`` contract may be passed instead.  A ``disp_refinement`` entry in the config attaches the HIP refinement stage
+ exactly where the reference runs it."""
 import torch
 import torch.nn as nn
 
@@ -14,13 +17,20 @@ from ..disp_predictors import build_disp_predictor
 
 
 class GeneralizedStereoModel(nn.Module):
-    def __init__(self, cfg, backbone=None):
+    def __init__(self, cfg, backbone="auto"):
         super().__init__()
         self.cfg = cfg.copy()
         self.max_disp = cfg.model.max_disp
-        if backbone == "hip":   # the HIP backbone of this package (PSMNet only so far)
-            from ..backbones import build_backbone
-            backbone = build_backbone(cfg)
+        if isinstance(backbone, str):
+            # "auto" (default) = the reference's behaviour: build what cfg.model.backbone names (general_stereo_model.py:24);
+            # a config without that entry builds the path alone.  "hip" insists on the entry.
+            if backbone not in ("auto", "hip"):
+                raise ValueError("backbone must be 'auto', 'hip', None or an nn.Module, got %r" % (backbone,))
+            if backbone == "hip" or 'backbone' in cfg.model:
+                from ..backbones import build_backbone
+                backbone = build_backbone(cfg)
+            else:
+                backbone = None
         self.backbone = backbone
         self.cost_processor = build_cost_processor(cfg)
         self.cmn = build_cmn(cfg) if 'cmn' in cfg.model else None

@@ -354,13 +354,29 @@ def view_streams():
     return _view_streams
 
 
-def two_view_forward(fn, left, right):
+def warm_packed_parameters(module):
+    """Fill (on the CURRENT stream) every lazily packed / folded parameter cache below ``module``: each fused unit keeps its packed
+    weights and folded BatchNorm affine keyed by the parameters' versions (``_prepacked()``) and refills them inside its first
+    forward after a change -- pack kernels and torch ops on whatever stream that forward runs on."""
+    for m in module.modules():
+        pre = getattr(m, "_prepacked", None)
+        if pre is not None:
+            pre()
+
+
+def two_view_forward(fn, left, right, module=None):
     """``(fn(left), fn(right))`` for a per-image function (an eval-mode backbone): the right view on a side stream of the device,
-    forked from and joined back into the caller's stream with events; ``ops.set_view_streams(False)``: one batch of both views."""
+    forked from and joined back into the caller's stream with events; ``ops.set_view_streams(False)``: one batch of both views.
+    ``module``: the nn.Module ``fn`` evaluates.  Its packed-weight caches are filled on the CALLER's stream before the fork:
+    filled lazily inside ``fn(right)`` they would be written by pack kernels on the side stream while ``fn(left)`` -- which finds
+    the host-side cache entry already present -- reads them on the caller's stream with nothing ordering the two (cold caches:
+    the first forward, after load_state_dict, after a training step)."""
     if not (_view_streams and left.is_cuda):
         B = left.shape[0]
         f = fn(torch.cat((left, right), 0))
         return f[:B], f[B:]
+    if module is not None:
+        warm_packed_parameters(module)
     main = torch.cuda.current_stream(left.device)
     side = side_stream(left.device, 2)
     fork = main.record_event()

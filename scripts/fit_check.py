@@ -8,7 +8,7 @@ from densematchingbenchmark_amd import synthetic
 dev = torch.device("cuda:0")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
-model = build_model(cfg).to(dev)
+model = build_model(cfg, backbone=None).to(dev)
 synthetic.init_params_(model, seed=0, classif_gain=1.0)
 model.train()
 flat = FlatGradients(model)

@@ -8,7 +8,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 dev = torch.device("cuda:0")
 for cfgrel, B, C, fh, fw in (("StereoNet/scene_flow_8x_2stage.py", 8, 32, 48, 156), ("AcfNet/scene_flow_adaptive.py", 4, 32, 136, 240)):
     cfg = Config.fromfile(os.path.join(ROOT, "configs", cfgrel))
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     synthetic.init_params_(model, seed=0, classif_gain=10.0)
     model = model.to(dev)
     left, right = synthetic.feature_batch(0, 1, B, C, fh, fw, dev)

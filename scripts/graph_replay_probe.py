@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 for rel, B, (fh, fw) in (("StereoNet/scene_flow_8x_2stage.py", 8, (48, 156)), ("PSMNet/scene_flow.py", 4, (136, 240)),
                          ("PSMNet/scene_flow.py", 1, (136, 240))):
     cfg = Config.fromfile(os.path.join(ROOT, "configs", rel))
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     synthetic.init_params_(model, seed=0, classif_gain=10.0)
     model = model.to(dev)
     left, right = synthetic.feature_batch(0, 1, B, 32, fh, fw, dev)

@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 cfg_rel = sys.argv[1] if len(sys.argv) > 1 else "PSMNet/scene_flow.py"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = Config.fromfile(os.path.join(ROOT, "configs", cfg_rel))
-model = build_model(cfg).eval()
+model = build_model(cfg, backbone=None).eval()
 synthetic.init_params_(model, seed=0, classif_gain=10.0)
 model = model.to(dev)
 left, right = synthetic.feature_batch(0, 1, 4, 32, 136, 240, dev)

@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 B = int(os.environ.get("SWEEP_B", "4"))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = Config.fromfile(os.path.join(ROOT, "configs", "PSMNet", "scene_flow.py"))
-model = build_model(cfg).eval()
+model = build_model(cfg, backbone=None).eval()
 synthetic.init_params_(model, seed=0, classif_gain=10.0)
 model = model.to(dev)
 SHAPES = [(544, 960), (384, 1248), (256, 512), (320, 960), (368, 1232), (480, 640), (512, 1024), (576, 1024), (720, 1280), (1088, 1920)]

@@ -15,7 +15,7 @@ cfg.model.max_disp = md
 cfg.model.cost_processor.cost_computation.max_disp = md // 4
 cfg.model.cost_processor.cost_aggregator.max_disp = md
 cfg.model.disp_predictor.max_disp = md
-model = build_model(cfg).eval()
+model = build_model(cfg, backbone=None).eval()
 synthetic.init_params_(model, seed=0, classif_gain=gain)
 p = {k: v.clone() for k, v in model.state_dict().items()}
 lf, rf = synthetic.feature_pair(0, 32, fh, fw)

@@ -235,7 +235,7 @@ def test_deconv3d_wgrad(dev, Ci, Co, shape):
 
 
 def test_psmnet_training_step(dev):
-    """One training iteration of the PSMNet cost path through build_model(cfg) in train() mode: losses, the gradient of
+    """One training iteration of the PSMNet cost path through build_model(cfg, backbone=None) in train() mode: losses, the gradient of
     every parameter and of both feature maps, and the BatchNorm running buffers against the oracle's autograd.
 
     Tolerances are written at the asserts (losses 1e-4 relative; gradients see the comment there)."""
@@ -251,7 +251,7 @@ def test_psmnet_training_step(dev):
     cfg.model.disp_predictor.max_disp = md
     cfg.model.losses.l1_loss.max_disp = md
     p = O.random_params_psm(seed=7, classif_gain=4.0)
-    model = build_model(cfg)
+    model = build_model(cfg, backbone=None)
     sd = {"cost_processor.aggregator." + k: v for k, v in p.items()}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected
@@ -379,7 +379,7 @@ def test_acfnet_uniform_training_step(dev):
     cfg.model.losses.l1_loss.max_disp = md
     cfg.model.losses.focal_loss.max_disp = md
     p = O.with_prefix(O.random_params_psm(seed=3, classif_gain=4.0, acf=True), "cost_processor.aggregator.")
-    model = build_model(cfg)
+    model = build_model(cfg, backbone=None)
     missing, unexpected = model.load_state_dict(p, strict=False)
     assert not unexpected
     model = model.to(dev).train()
@@ -475,7 +475,7 @@ def test_acfnet_adaptive_training_step(dev):
         p[pre + "0.1.running_mean"] = torch.zeros(Cm)
         p[pre + "0.1.running_var"] = torch.ones(Cm)
         p[pre + "1.weight"] = (torch.rand((1, Cm, 1, 1), generator=g) * 2 - 1) / Cm ** 0.5
-    model = build_model(cfg)
+    model = build_model(cfg, backbone=None)
     missing, unexpected = model.load_state_dict(p, strict=False)
     assert not unexpected
     model = model.to(dev).train()

@@ -23,7 +23,7 @@ def _model(dev, cfg_rel="PSMNet/scene_flow.py"):
     from densematchingbenchmark_amd.config import Config
     from densematchingbenchmark_amd.modeling import build_model
     cfg = Config.fromfile(os.path.join(ROOT, "configs", cfg_rel))
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     synthetic.init_params_(model, seed=0, classif_gain=10.0)
     return model.to(dev)
 

@@ -126,7 +126,7 @@ def test_state_dict_keys_match_reference(tag, rel):
     want = set(str(s) for s in golden("state_dict_keys.npz")[tag])
     cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", rel)
     cfg = Config.fromfile(cfg_path)
-    model = build_model(cfg)
+    model = build_model(cfg, backbone=None)
     got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items())
     assert got == want, (sorted(got - want)[:5], sorted(want - got)[:5])
     n = {"psmnet": 154, "acfnet": 185, "stereonet": 31}[tag]
@@ -148,7 +148,7 @@ def test_bn_fold_matches_batch_norm():
 
 def test_modules_refuse_cpu_tensors():
     from densematchingbenchmark_amd.modeling import build_model
-    m = build_model(_cfg())
+    m = build_model(_cfg(), backbone=None)
     feats = dict(leftFeature=torch.zeros(1, 32, 16, 16), rightFeature=torch.zeros(1, 32, 16, 16))
     with pytest.raises(_lib.DmbLibraryError):    # training mode runs the same HIP kernels under autograd: no CPU path either
         m.train()(feats)
@@ -376,14 +376,51 @@ def test_every_in_scope_reference_config_loads_unchanged():
                 continue
             cfg = Config.fromfile(os.path.join(d, f))
             if fam in IN_SCOPE:
-                model = build_model(cfg)
+                model = build_model(cfg, backbone=None)
                 assert sum(p.numel() for p in model.parameters()) > 0
                 assert list(cfg.data.eval.input_shape) in ([544, 960], [384, 1248]), (fam, f)
                 seen += 1
             else:
                 with pytest.raises(NotImplementedError):
-                    build_model(cfg)
+                    build_model(cfg, backbone=None)
     assert seen >= 10
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_CONFIGS), reason="the reference tree is only present in the build container")
+def test_reference_state_dicts_load_strictly_into_default_build_model():
+    """``build_model(cfg)`` is the reference's ``build_model(cfg)`` (dmb/modeling/__init__.py:10): for every in-scope file of the
+    reference's own configs/ tree the REFERENCE model's state_dict loads ``strict=True`` into this package's default build --
+    backbone included (dmb/apis/inference.py:61-85).  Runs oracle/check_strict_load.py in a child process (it imports the
+    reference with stubbed third-party modules, which must not leak into this interpreter)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "check_strict_load.py")], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(res) >= 10
+    bad = {k: v for k, v in res.items() if v[1] is not None}
+    assert not bad, bad
+    assert res["configs/PSMNet/scene_flow.py"][0] == 517 and res["configs/AcfNet/scene_flow_adaptive.py"][0] == 548
+
+
+def test_build_model_backbone_argument():
+    """Default = the backbone the config names; ``None`` = the cost path alone; a config without the entry builds none."""
+    from densematchingbenchmark_amd.modeling import build_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    assert build_model(cfg).backbone is not None and build_model(cfg, backbone=None).backbone is None
+    assert any(k.startswith("backbone.") for k in build_model(cfg).state_dict())
+    assert build_model(_cfg()).backbone is None                  # no cfg.model.backbone entry: nothing to build
+    with pytest.raises(AttributeError):
+        build_model(_cfg(), backbone="hip")                      # "hip" insists on the entry
+    gwc = Config.fromfile(os.path.join(root, "configs", "GwcNet", "scene_flow.py"))
+    assert "backbone" not in gwc.model and build_model(gwc).backbone is None
+    with pytest.raises(ValueError):
+        build_model(cfg, backbone="torch")
 
 
 def test_dmb_ops_namespace():

@@ -82,7 +82,7 @@ def test_stereonet_aggregator(dev):
 
 
 def test_psmnet_path_cfg1_through_builders(dev):
-    """BASELINE configs[0]: PSMNet cat volume + soft-argmin, 256x512, max_disp=64, via build_model(cfg)."""
+    """BASELINE configs[0]: PSMNet cat volume + soft-argmin, 256x512, max_disp=64, via build_model(cfg, backbone=None)."""
     from densematchingbenchmark_amd.config import Config
     from densematchingbenchmark_amd.modeling import build_model
     g = golden("psmnet_path_cfg1.npz")
@@ -92,7 +92,7 @@ def test_psmnet_path_cfg1_through_builders(dev):
     cfg.model.cost_processor.cost_computation.max_disp = md // 4
     cfg.model.cost_processor.cost_aggregator.max_disp = md
     cfg.model.disp_predictor.max_disp = md
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     assert sorted(k for k in model.cost_processor.state_dict()) == [str(s) for s in g["cp_keys"]]
     assert sorted(k for k in model.disp_predictor.state_dict()) == [str(s) for s in g["disp_keys"]]
     _load(model, O.random_params_psm(seed=2, classif_gain=10.0), "cost_processor.aggregator.")
@@ -282,7 +282,7 @@ def _built(cfg_rel, seed, tweak=None):
     cfg = Config.fromfile(os.path.join(ROOT, "configs", cfg_rel))
     if tweak:
         tweak(cfg)
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     synthetic.init_params_(model, seed=seed, classif_gain=10.0)
     return cfg, model
 
@@ -413,7 +413,7 @@ def test_stereonet_model_with_refinement_vs_oracle(dev):
     from densematchingbenchmark_amd.modeling import build_model
     cfg = Config.fromfile(os.path.join(ROOT, "configs", "StereoNet", "scene_flow_8x_2stage.py"))
     cfg.model.disp_refinement = dict(type="StereoNet", in_planes=4, num=1)
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     synthetic.init_params_(model, seed=11, classif_gain=10.0)
     p = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)

@@ -166,7 +166,7 @@ def _model_params(cfg_rel, seed, tweak=None):
     cfg = Config.fromfile(os.path.join(root, "configs", cfg_rel))
     if tweak:
         tweak(cfg)
-    model = build_model(cfg).eval()
+    model = build_model(cfg, backbone=None).eval()
     synthetic.init_params_(model, seed=seed, classif_gain=10.0)
     return cfg, model
 
@@ -262,7 +262,7 @@ def test_stereonet_refinement_vs_reference():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = Config.fromfile(os.path.join(root, "configs", "StereoNet", "scene_flow_8x_2stage.py"))
     cfg.model.disp_refinement = dict(type="StereoNet", in_planes=4, num=1)
-    model = build_model(cfg)
+    model = build_model(cfg, backbone=None)
     want = set(str(s) for s in golden("state_dict_keys.npz")["stereonet_refinement"])
     got = set("%s %s" % (k, tuple(v.shape)) for k, v in model.state_dict().items() if k.startswith("disp_refinement"))
     assert got == want and len(got) == 81
@@ -433,7 +433,7 @@ def test_backbone_training_matches_reference_autograd():
 
 
 def test_stereonet_training_matches_reference_autograd():
-    """oracle.stereonet_e2e_train_step against one training iteration of the reference's WHOLE StereoNet model (build_model(cfg)
+    """oracle.stereonet_e2e_train_step against one training iteration of the reference's WHOLE StereoNet model (build_model(cfg, backbone=None)
     .train(), its own loss evaluator and autograd; gen_golden.py section 4h)."""
     from densematchingbenchmark_amd import synthetic
     from densematchingbenchmark_amd.config import Config
@@ -464,7 +464,7 @@ def _fullsize_model(cfg_rel, seed):
     from densematchingbenchmark_amd.config import Config
     from densematchingbenchmark_amd.modeling import build_model
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    model = build_model(Config.fromfile(os.path.join(root, "configs", cfg_rel))).eval()   # parameter container only
+    model = build_model(Config.fromfile(os.path.join(root, "configs", cfg_rel)), backbone=None).eval()   # parameter container only
     synthetic.init_params_(model, seed=seed, classif_gain=10.0)
     return {k: v.clone() for k, v in model.state_dict().items()}
 
