@@ -23,6 +23,6 @@ model = dict(
     ),
     eval=_c['evaluation'](max_disp),
 )
-data = dict(sparse=True, eval=dict(input_shape=[384, 1248], original_shape=[375, 1242]))
+data = dict(sparse=True, eval=dict(input_shape=[384, 1248], original_shape=[375, 1242], mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]))
 eval_disparity_id = [0, 1, 2]
 dist_params = dict(backend='nccl')

@@ -17,6 +17,6 @@ model = dict(
     losses=dict(l1_loss=dict(max_disp=max_disp, weights=(1.0,), weight=1.0)),
     eval=_c['evaluation'](max_disp),
 )
-data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960]))
+data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960], mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]))
 eval_disparity_id = [0]
 dist_params = dict(backend='nccl')

@@ -16,6 +16,6 @@ model = dict(
     disp_predictor=_c['predictor']('FASTER', max_disp),
     eval=_c['evaluation'](max_disp),
 )
-data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960]))
+data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960], mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]))
 eval_disparity_id = [0, 1, 2]
 dist_params = dict(backend='nccl')

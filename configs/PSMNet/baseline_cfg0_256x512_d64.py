@@ -1,8 +1,9 @@
-# PSMNet, SceneFlow 540x960 padded to 544x960, max_disp 192 (BASELINE.json configs[1]).
+# BASELINE.json configs[0]: PSMNet cat-cost-volume + soft-argmin, ONE 256x512 pair, max_disp=64 (the reference's own
+# CPU-runnable case; the five max_disp fields are changed consistently).
 import os, runpy
 _c = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "_common.py"))
 task = 'stereo'
-max_disp = 192
+max_disp = 64
 model = dict(
     meta_architecture="GeneralizedStereoModel",
     max_disp=max_disp,
@@ -17,6 +18,6 @@ model = dict(
     losses=dict(l1_loss=dict(max_disp=max_disp, weights=(1.0, 0.7, 0.5), weight=1.0)),
     eval=_c['evaluation'](max_disp),
 )
-data = dict(sparse=False, eval=dict(input_shape=[544, 960], original_shape=[540, 960], mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]))
+data = dict(sparse=False, eval=dict(input_shape=[256, 512], original_shape=[256, 512], mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]))
 eval_disparity_id = [0, 1, 2]
 dist_params = dict(backend='nccl')

@@ -18,6 +18,6 @@ model = dict(
     losses=dict(l1_loss=dict(max_disp=max_disp, weights=(1.0, 0.7, 0.5), weight=1.0)),
     eval=_c['evaluation'](max_disp),
 )
-data = dict(sparse=True, eval=dict(input_shape=[384, 1248], original_shape=[375, 1242]))
+data = dict(sparse=True, eval=dict(input_shape=[384, 1248], original_shape=[375, 1242], mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]))
 eval_disparity_id = [0, 1, 2]
 dist_params = dict(backend='nccl')

@@ -23,7 +23,7 @@ _P = _c_void_p  # device pointer
 _HI = ctypes.POINTER(ctypes.c_int)  # host int array
 _HF = ctypes.POINTER(ctypes.c_float)  # host float array
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes)
 SIGNATURES = {
@@ -102,6 +102,8 @@ SIGNATURES = {
     "dmb_stereo_focal_loss_bwd_f32": (_c_int, [_P, _P, _P, _c_float, _HF, _P, _P, _P, _c_float, _P, _P] + [_c_int] * 4
                                       + [_c_float] * 5 + [_P]),
     "dmb_map_loss_fwd_f32": (_c_int, [_P, _P, _P, _P, _c_ll, _c_float, _c_float, _c_int, _P]),
+    "dmb_stereo_pad_normalize_f32": (_c_int, [_P, _P] + [_c_int] * 11 + [_HF, _HF, _P]),
+    "dmb_stereo_pad_normalize_u8": (_c_int, [_P, _P] + [_c_int] * 11 + [_HF, _HF, _P]),
     "dmb_map_loss_bwd_f32": (_c_int, [_P, _P, _P, _P, _c_float, _P, _c_ll, _c_float, _c_float, _c_int, _P]),
 }
 

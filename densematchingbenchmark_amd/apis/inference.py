@@ -1,0 +1,152 @@
+"""The reference's serving entry point, one stereo pair per call: drop-in for ``dmb/apis/inference.py`` (``init_model`` :60-85,
+``inference_stereo`` :88-148, ``_prepare_data`` :151-188, ``_inference_single`` :191-225) -- the caller of the hot path in the
+batch-1 regime the reference publishes its timings in (configs/PSMNet/ResultOfPSMNet.md:15-19).
+
+Same arguments, same steps, same ``result.pkl``; what differs is WHERE the steps run.  Images are decoded on the host
+(``data.imread``) and go to the GPU as bytes; crop / pad / normalise is one HIP launch per image (csrc/preprocess.hip); the
+model is ``build_model(cfg)`` of this package (HIP backbone + cost path); its eval-mode forward is, by default, captured once per
+input shape in a HIP graph and replayed (``graph="auto"``: graph_runner.wants_graph -- at batch 1 the ~190 launches of a step
+cost the host more than the device, see graph_runner.py); the result is cropped with ``remove_padding`` and written by
+``result_io.save_result`` in the reference's layout.  ``scale_factor`` other than 1 goes through the library's half-pixel
+bilinear kernel (``ops.bilinear_scale``) and is supported where the resampled size is integral (otherwise torch's two
+scale conventions differ and this raises instead of guessing)."""
+import os.path as osp
+
+import numpy as np
+import torch
+
+from .. import ops, result_io
+from ..config import Config, ConfigDict
+from ..data import CenterCrop, Compose, Normalize, StereoPad, ToTensor, imread
+from ..disp_io import load_scene_flow_disp
+from ..evaluation.stereo import remove_padding
+from ..graph_runner import GraphedForward, wants_graph
+from ..modeling import build_model
+
+IMG_EXTENSIONS = ['.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP']
+
+
+def is_image_file(filename):
+    return any(filename.endswith(extension) for extension in IMG_EXTENSIONS)
+
+
+def is_pfm_file(filename):
+    return filename.endswith('.pfm')
+
+
+def load_disp(item, filename, disp_div_factor=1.0):
+    """inference.py:36-46: a disparity map from an image file (KITTI: 16-bit PNG / 256) or a SceneFlow .pfm."""
+    Disp = None
+    if filename in item.keys() and item[filename] is not None:
+        if is_image_file(item[filename]):
+            Disp = imread(item[filename]).squeeze().astype(np.float32) / disp_div_factor
+        elif is_pfm_file(item[filename]):
+            Disp = load_scene_flow_disp(item[filename]).astype(np.float32) / disp_div_factor
+        else:
+            raise NotImplementedError
+    return Disp
+
+
+def init_model(config, checkpoint=None, device='cuda:0'):
+    """inference.py:60-85: config file (or object) -> eval-mode model on ``device``, optionally with a checkpoint
+    (``{'state_dict': ...}`` as mmcv writes it, or a bare state dict) loaded STRICTLY -- the reference's own keys."""
+    if isinstance(config, str):
+        config = Config.fromfile(config)
+    elif not isinstance(config, ConfigDict):
+        raise TypeError('config must be a filename or Config object, but got {}'.format(type(config)))
+    model = build_model(config)
+    if checkpoint is not None:
+        ckpt = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, str) else checkpoint
+        state = ckpt.get("state_dict", ckpt)
+        state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}   # (mmcv strips DataParallel's prefix)
+        model.load_state_dict(state, strict=True)
+    model.cfg = config
+    model.to(device)
+    model.eval()
+    return model
+
+
+def _resample(t, scale_factor, mult=1.0):
+    """F.interpolate(t * mult, scale_factor=scale_factor, mode='bilinear', align_corners=False) where the output size is integral."""
+    H, W = t.shape[-2:]
+    Ho, Wo = H * scale_factor, W * scale_factor
+    if abs(Ho - round(Ho)) > 1e-9 or abs(Wo - round(Wo)) > 1e-9:
+        raise NotImplementedError("scale_factor %r does not map %dx%d to an integral size" % (scale_factor, H, W))
+    return ops.bilinear_scale(t.contiguous(), (int(round(Ho)), int(round(Wo))), mult)
+
+
+def prepare_data(item, img_transform, cfg, device):
+    """inference.py:151-188: (processed sample on ``device``, original arrays as read)."""
+    oriLeftImage = imread(item['left_image_path'])[:, :, :3]
+    oriRightImage = imread(item['right_image_path'])[:, :, :3]
+    oriLeftDisp = load_disp(item, 'left_disp_map_path', cfg.disp_div_factor)
+    oriRightDisp = load_disp(item, 'right_disp_map_path', cfg.disp_div_factor)
+    oriSample = {'leftImage': oriLeftImage.astype(np.float32), 'rightImage': oriRightImage.astype(np.float32),
+                 'leftDisp': oriLeftDisp, 'rightDisp': oriRightDisp}
+    h, w = oriLeftImage.shape[0], oriLeftImage.shape[1]
+    procSample = {'leftImage': np.ascontiguousarray(oriLeftImage), 'rightImage': np.ascontiguousarray(oriRightImage),   # uint8 [H, W, 3]
+                  'leftDisp': None if oriLeftDisp is None else oriLeftDisp.copy()[np.newaxis, ...],
+                  'rightDisp': None if oriRightDisp is None else oriRightDisp.copy()[np.newaxis, ...],
+                  'original_size': (h, w)}
+    procSample = img_transform(procSample)
+    scale_factor = cfg.scale_factor
+    for k, v in procSample.items():
+        if torch.is_tensor(v):
+            v = v.unsqueeze(0)
+            if scale_factor != 1.0:
+                v = _resample(v, scale_factor, scale_factor if 'Disp' in k else 1.0)
+            procSample[k] = v.to(device)
+    return procSample, oriSample
+
+
+def _forward(model, procData, graph):
+    batch = {k: v for k, v in procData.items() if torch.is_tensor(v)}
+    if graph == "auto":
+        graph = wants_graph(batch)
+    if not graph:
+        with torch.no_grad():
+            return model(batch)
+    runner = getattr(model, "_dmb_graphed_forward", None)
+    if runner is None:
+        runner = GraphedForward(model)
+        model._dmb_graphed_forward = runner
+    return runner(batch)
+
+
+def _inference_single(model, batchDict, img_transform, device, graph="auto", save=True):
+    cfg = model.cfg.copy()
+    procData, oriData = prepare_data(batchDict, img_transform, cfg, device)
+    result, _ = _forward(model, procData, graph)
+    assert isinstance(result, dict)
+    ori_size = procData['original_size'] if cfg.pad_to_shape is not None else None
+    name = batchDict['left_image_path'].split('/')[-1].split('.')[0]
+    save_root = osp.join(cfg.log_dir, name)
+    if not save:
+        return {'Result': result_io.crop_result(result, ori_size, cfg.scale_factor), 'OriginalData': oriData}
+    path = result_io.save_result(result, oriData, save_root, ori_size, cfg.scale_factor)
+    print('Result of {} will be saved to {}!'.format(batchDict['left_image_path'].split('/')[-1], path))
+    return result_io.load_result(path)
+
+
+def inference_stereo(model, batchesDict, log_dir, pad_to_shape=None, crop_shape=None, scale_factor=1.0, disp_div_factor=1.0,
+                     device='cuda:0', graph="auto", save=True):
+    """inference.py:88-148.  ``batchesDict``: list of dicts with left_image_path, right_image_path and optionally
+    left_disp_map_path, right_disp_map_path.  Returns the list of logged dicts ({'Result', 'OriginalData'}) -- the reference
+    returns None and only writes the files.  ``graph``: "auto" (default) | True | False, see the module docstring."""
+    device = next(model.parameters()).device   # model device (inference.py:146)
+    img_transform = [ToTensor(device)]
+    if pad_to_shape is not None:
+        assert crop_shape is None
+        img_transform.append(StereoPad(pad_to_shape))
+    if crop_shape is not None:
+        assert pad_to_shape is None
+        img_transform.append(CenterCrop(crop_shape))
+    img_transform.append(Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD))
+    img_transform = Compose(img_transform)
+    model.cfg.update({'log_dir': log_dir, 'pad_to_shape': pad_to_shape, 'crop_shape': crop_shape, 'scale_factor': scale_factor,
+                      'disp_div_factor': disp_div_factor})
+    out = []
+    with torch.cuda.device(device):
+        for batchDict in batchesDict:
+            out.append(_inference_single(model, batchDict, img_transform, device, graph, save))
+    return out

@@ -14,7 +14,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmb_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip", "path_bwd.hip", "catconv.hip", "warp_volume.hip", "deconv3d_zy.hip", "spn.hip"]
+SOURCES = ["core.cpp", "volume.hip", "regression.hip", "conv3d.hip", "confhead.hip", "gwc_mfma.hip", "conv2d.hip", "losses.hip", "conv3d_x6.hip", "wgrad.hip", "norm.hip", "path_bwd.hip", "catconv.hip", "warp_volume.hip", "deconv3d_zy.hip", "spn.hip", "preprocess.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # warp_volume.hip restates the reference's FP32 sampler arithmetic operation by operation: no fused multiply-adds there

@@ -42,5 +42,5 @@ extern "C" void dmb_dev_set_option(int key, int value) {
 }
 #endif
 
-extern "C" int dmb_abi_version(void) { return 5; }
+extern "C" int dmb_abi_version(void) { return 6; }
 extern "C" const char* dmb_last_error(void) { return dmb::g_last_error; }

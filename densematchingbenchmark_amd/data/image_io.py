@@ -1,0 +1,18 @@
+"""Image files -> the array the reference's loaders hand to their transforms: ``imageio.imread`` of a PNG / JPEG, uint8
+[H, W, C] (dmb/data/datasets/stereo/scene_flow/base.py:17-23, dmb/apis/inference.py:153-154).  Host code (decoding is not on the
+hot path); PIL is the decoder in this image -- PNG decoding is lossless, so the bytes equal imageio's."""
+import numpy as np
+
+
+def imread(path):
+    try:
+        from PIL import Image
+    except ImportError as e:   # loud: no silent alternative decoder
+        raise ImportError("densematchingbenchmark_amd.data.imread needs PIL (Pillow) to decode %s" % path) from e
+    with Image.open(path) as im:
+        if im.mode not in ("RGB", "RGBA", "L"):
+            im = im.convert("RGB")
+        arr = np.asarray(im)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    return np.ascontiguousarray(arr)

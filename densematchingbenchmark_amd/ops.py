@@ -1374,6 +1374,45 @@ def bilinear_scale(x, out_hw, mult=1.0, out=None, out_ch_offset=0):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- data-side conventions
+IMAGENET_MEAN = (123.675, 116.28, 103.53)     # dmb/apis/inference.py:120-121, configs/PSMNet/scene_flow.py:94 (0..255 scale)
+IMAGENET_STD = (58.395, 57.12, 57.375)
+
+
+def stereo_pad_normalize(src, size=None, mean=None, std=None, window=None, channels=None, out=None):
+    """CenterCrop window -> StereoPad (zeros on the top and on the right) -> Normalize, one launch (csrc/preprocess.hip;
+    dmb/data/transforms/stereo_trans.py:20-44,78-119 in the order of dmb/data/datasets/stereo/builder.py:22-28).
+    ``src``: float32 [B, Cs, sh, sw], or the decoder's uint8 [B, sh, sw, Cs] (the first ``channels`` are taken, default
+    min(Cs, 3)); ``window`` = (y0, x0, h, w) of the source kept (default: all of it); ``size`` = (th, tw) >= window (default:
+    the window's); ``mean`` / ``std``: per-channel sequences (both or neither).  Returns float32 [B, C, th, tw]."""
+    lib = _lib.load()
+    if not isinstance(src, torch.Tensor) or not src.is_cuda:
+        raise _lib.DmbLibraryError("stereo_pad_normalize: the source must be a GPU tensor (no CPU fallback), got %s"
+                                   % (getattr(src, "device", type(src)),))
+    if src.dim() != 4 or src.dtype not in (torch.float32, torch.uint8):
+        raise _lib.DmbLibraryError("stereo_pad_normalize: float32 [B, C, H, W] or uint8 [B, H, W, C] expected, got %s %s"
+                                   % (src.dtype, tuple(src.shape)))
+    src = src.contiguous()
+    u8 = src.dtype == torch.uint8
+    if u8:
+        B, sh, sw, Cs = src.shape
+        C = min(Cs, 3) if channels is None else int(channels)
+    else:
+        B, Cs, sh, sw = src.shape
+        C = Cs if channels is None else int(channels)
+    y0, x0, h, w = (0, 0, sh, sw) if window is None else [int(v) for v in window]
+    th, tw = (h, w) if size is None else [int(v) for v in size]
+    if (mean is None) != (std is None) or (mean is not None and (len(mean) != C or len(std) != C)):
+        raise _lib.DmbLibraryError("stereo_pad_normalize: mean and std must both hold %d values" % C)
+    y = _out_tensor(out, (B, C, th, tw), src.device, "stereo_pad_normalize")
+    stream_ptr(src.device)     # (validates the device)
+    fn = lib.dmb_stereo_pad_normalize_u8 if u8 else lib.dmb_stereo_pad_normalize_f32
+    check(fn(ctypes.c_void_p(src.data_ptr()), dev_ptr(y), B, C, Cs, sh, sw, y0, x0, h, w, th, tw,
+             host_floats(mean) if mean is not None else None, host_floats(std) if std is not None else None,
+             stream_ptr(src.device)), "dmb_stereo_pad_normalize")
+    return y
+
+
 # ---------------------------------------------------------------------------------------------- training-side losses
 def _loss_workspace(n, device):
     lib = _lib.load()

@@ -23,11 +23,10 @@ def to_cpu(obj):
     return obj
 
 
-def save_result(results, original_data, save_root, original_size=None, scale_factor=1.0):
-    """Write ``<save_root>/result.pkl`` in the reference's layout (inference.py:197-223); returns the path.
-    Every tensor of every list (``disps``, ``costs`` and, for AcfNet, ``confs``) is brought back to the input scale
-    (``scale_factor``: the test-time resampling of inference.py:183-189, undone at :205-206) and cropped to
-    ``original_size`` (top / right padding removed); pickle protocol 2 = what ``mmcv.dump`` writes for a .pkl path."""
+def crop_result(results, original_size=None, scale_factor=1.0):
+    """inference.py:197-211: every tensor of every list of the result dict on the host, brought back to the input scale
+    (``scale_factor``: the test-time resampling of inference.py:183-189, undone at :205-206) and cropped to ``original_size``
+    (top / right padding removed)."""
     result = to_cpu(results)
     for k, v in result.items():
         if not isinstance(v, (list, tuple)):
@@ -42,7 +41,14 @@ def save_result(results, original_data, save_root, original_size=None, scale_fac
                     t = remove_padding(t, original_size).contiguous()
             out.append(t)
         result[k] = out
-    log_data = {"Result": result, "OriginalData": to_cpu(original_data)}
+    return result
+
+
+def save_result(results, original_data, save_root, original_size=None, scale_factor=1.0):
+    """Write ``<save_root>/result.pkl`` in the reference's layout (inference.py:197-223); returns the path.
+    Every tensor of every list (``disps``, ``costs`` and, for AcfNet, ``confs``) goes through ``crop_result``; pickle
+    protocol 2 = what ``mmcv.dump`` writes for a .pkl path."""
+    log_data = {"Result": crop_result(results, original_size, scale_factor), "OriginalData": to_cpu(original_data)}
     os.makedirs(save_root, exist_ok=True)
     path = os.path.join(save_root, "result.pkl")
     with open(path, "wb") as fp:

@@ -44,7 +44,7 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes (5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
+/* ABI version: bumped whenever a signature below changes (6: dmb_stereo_pad_normalize_f32 / _u8 added; 5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
  * optional gradient buffer for per-pixel samples; 4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads entry
  * points of version 3 removed). */
 int dmb_abi_version(void);
@@ -334,6 +334,21 @@ int dmb_epe_accum_f64(const float* est, const float* gt, double* acc, double* wo
  * Per estimate the arithmetic is dmb_epe_accum_f64's. */
 int dmb_epe_accum_multi_f64(int nmaps, const float* const* est, const float* gt, double* acc, double* workspace, int B,
                             int Hp, int Wp, int H0, int W0, float lb, float ub, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-side conventions in front of the path: dmb/data/transforms/stereo_trans.py:20-44 (CenterCrop), :92-119 (StereoPad),
+ * :78-90 (Normalize), composed in the order of dmb/data/datasets/stereo/builder.py:22-28 and dmb/apis/inference.py:120-129
+ * (pad BEFORE normalise: a padded pixel holds (0 - mean[c]) / std[c]).  One pass:
+ *   dst[b, c, y, x] = n(src[b, c, y - (th - h) + y0, x + x0])   for y >= th - h and x < w,   n(0) elsewhere;
+ *   n(v) = (v - mean[c]) / std[c]  (FP32 subtract, correctly rounded FP32 divide -- torchvision's sub_().div_()), or v when
+ *   mean_host / std_host are NULL (pad / crop only).
+ * src: planar FP32 [B, Cs, sh, sw] (_f32) or the decoder's interleaved bytes [B, sh, sw, Cs] (_u8; imread's layout, the first
+ * C <= Cs channels are taken as stereo/scene_flow/base.py:17-23 does); (y0, x0, h, w) = the window of the source that is kept
+ * (the whole image: 0, 0, sh, sw); dst [B, C, th, tw] with th >= h, tw >= w, tw % 4 == 0, C <= 4. */
+int dmb_stereo_pad_normalize_f32(const float* src, float* dst, int B, int C, int Cs, int sh, int sw, int y0, int x0, int h, int w,
+                                 int th, int tw, const float* mean_host, const float* std_host, void* stream);
+int dmb_stereo_pad_normalize_u8(const unsigned char* src_hwc, float* dst, int B, int C, int Cs, int sh, int sw, int y0, int x0,
+                                int h, int w, int th, int tw, const float* mean_host, const float* std_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * "Next" rows: the 2-D networks either side of the path.

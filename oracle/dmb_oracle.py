@@ -525,6 +525,64 @@ def dataset_metrics(est_list, gt_list, original_size, lb, ub):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# data-side conventions in front of the path: data/transforms/stereo_trans.py (ToTensor :9-18, CenterCrop :20-44, Normalize :78-90,
+# StereoPad :92-119) in the order of data/datasets/stereo/builder.py:22-28 and apis/inference.py:120-129,151-188
+# (pinned by tests/golden/demo_sceneflow.npz: the reference's own inference_stereo on its demo pair, oracle/gen_golden_demo.py)
+# ------------------------------------------------------------------------------------------------------------
+IMAGENET_MEAN = (123.675, 116.28, 103.53)    # apis/inference.py:120-121
+IMAGENET_STD = (58.395, 57.12, 57.375)
+
+
+def image_to_chw(img_hwc_u8):
+    """apis/inference.py:153-165 (and stereo/scene_flow/base.py:17-23): imread's uint8 [H, W, C] -> float32 [3, H, W], values 0..255."""
+    return torch.from_numpy(np.ascontiguousarray(img_hwc_u8[:, :, :3].astype(np.float32).transpose(2, 0, 1)))
+
+
+def stereo_pad(img, size):
+    """stereo_trans.py:92-119: zeros on the TOP (th - h rows) and on the RIGHT (tw - w columns) of a [C, H, W] image."""
+    h, w = img.shape[-2:]
+    th, tw = size
+    if (h, w) == (th, tw):
+        return img
+    return F.pad(img, [0, tw - w, th - h, 0], mode="constant", value=0)
+
+
+def center_crop(img, size):
+    """stereo_trans.py:20-44."""
+    h, w = img.shape[-2:]
+    th, tw = size
+    if (h, w) == (th, tw):
+        return img
+    x1, y1 = (w - tw) // 2, (h - th) // 2
+    return img[:, y1:y1 + th, x1:x1 + tw]
+
+
+def normalize(img, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """stereo_trans.py:78-90 -> torchvision's normalize: (x - mean[c]) / std[c], a subtraction then a division in the tensor's
+    dtype (so that a padded pixel, normalised AFTER the padding, holds -mean[c] / std[c])."""
+    m = torch.as_tensor(mean, dtype=img.dtype).view(-1, 1, 1)
+    s = torch.as_tensor(std, dtype=img.dtype).view(-1, 1, 1)
+    return img.clone().sub_(m).div_(s)
+
+
+def prepare_image(img_hwc_u8, pad_to_shape=None, crop_shape=None):
+    """The image side of apis/inference.py:_prepare_data: -> [1, 3, th, tw] float32."""
+    x = image_to_chw(img_hwc_u8)
+    if pad_to_shape is not None:
+        x = stereo_pad(x, pad_to_shape)
+    if crop_shape is not None:
+        x = center_crop(x, crop_shape)
+    return normalize(x).unsqueeze(0)
+
+
+def psmnet_model(left_img, right_img, p, max_disp):
+    """GeneralizedStereoModel.forward in eval mode for PSMNet (models/general_stereo_model.py:42-90): images [B, 3, H, W] ->
+    ([disp3, disp2, disp1], [cost3, cost2, cost1])."""
+    lf, rf = psmnet_backbone(left_img, p), psmnet_backbone(right_img, p)
+    return psmnet_path(lf, rf, p, max_disp)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # whole path (what bench.py's cpu_baseline times): SURVEY 8-a1/a13
 # ------------------------------------------------------------------------------------------------------------
 def psmnet_path(ref_fms, tgt_fms, p, max_disp, scale=4, alpha=1.0, prefix="cost_processor.aggregator."):

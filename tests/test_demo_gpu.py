@@ -1,0 +1,126 @@
+"""One REAL stereo pair at the headline size, end to end through the reference's own data conventions and serving API:
+PNG / PFM bytes (the reference's tools/demo_data pair 0, carried by tests/golden/demo_sceneflow.npz) -> data.imread / disp_io ->
+ToTensor -> StereoPad -> Normalize (csrc/preprocess.hip) -> build_model(cfg) (HIP backbone + cost path, by default replayed from a
+HIP graph at batch 1) -> remove_padding -> calc_error -> result.pkl; against what the reference's inference_stereo produced on the
+same files (oracle/gen_golden_demo.py) and against its FP64 evaluation (the parity contract of bench.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dmb_oracle as O
+from tests._util import golden, maxdiff
+from tests.test_oracle_golden import _demo_files
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DISP_MAX_FULL = 1.6e-4       # tests/test_fullsize_gpu.py: max |disparity - reference| over a whole 544x960 map
+KEYS = ("epe", "1px", "2px", "3px", "5px")
+
+
+def _model(dev):
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.apis import init_model
+    model = init_model(os.path.join(ROOT, "configs", "PSMNet", "scene_flow.py"), None, "cpu")
+    synthetic.init_params_(model, seed=21, classif_gain=10.0)      # the generator's weights (oracle/gen_golden_demo.py)
+    return model.to(dev).eval()
+
+
+def test_transforms_equal_the_reference_bit_for_bit(dev, tmp_path):
+    """uint8 [H, W, 3] bytes -> padded, normalised [3, 544, 960] in ONE launch, as three separate transforms, and from a float
+    [3, H, W] sample: every variant equals the tensor the reference's ToTensor / StereoPad / Normalize fed its model (sampled rows
+    + FP64 checksums); a centre crop equals the oracle's."""
+    from densematchingbenchmark_amd import ops
+    from densematchingbenchmark_amd.data import CenterCrop, Compose, Normalize, StereoPad, ToTensor, imread
+    g = golden("demo_sceneflow.npz")
+    paths = _demo_files(g, tmp_path)
+    raw = {k: imread(paths[k + "_image_path"]) for k in ("left", "right")}
+    assert raw["left"].dtype == np.uint8 and raw["left"].shape == (540, 960, 3)
+    fused = Compose([ToTensor(dev), StereoPad((544, 960)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])
+    apart = [ToTensor(dev), StereoPad((544, 960)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)]
+    s1 = fused(dict(leftImage=raw["left"], rightImage=raw["right"], leftDisp=None))
+    s2 = dict(leftImage=raw["left"], rightImage=raw["right"])
+    for t in apart:
+        s2 = t(s2)
+    s3 = fused(dict(leftImage=raw["left"].astype(np.float32).transpose(2, 0, 1), rightImage=raw["right"].astype(np.float32).transpose(2, 0, 1)))
+    for s in (s1, s2, s3):
+        li, ri = s["leftImage"], s["rightImage"]
+        assert tuple(li.shape) == (3, 544, 960) and li.dtype == torch.float32
+        assert np.array_equal(li[None][:, :, ::17, :].cpu().numpy(), g["left_rows"])
+        assert np.array_equal(ri[None][:, :, 3::31, :].cpu().numpy(), g["right_rows"])
+        assert li.double().sum().item() == g["left_sum_f64"][0] and li.double().abs().sum().item() == g["left_sum_f64"][1]
+        assert ri.double().sum().item() == g["right_sum_f64"][0] and ri.double().abs().sum().item() == g["right_sum_f64"][1]
+    want = O.normalize(O.center_crop(O.image_to_chw(raw["left"]), (256, 512)))
+    got = Compose([ToTensor(dev), CenterCrop((256, 512)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])(
+        dict(leftImage=raw["left"], rightImage=raw["right"], leftDisp=np.zeros((1, 540, 960), np.float32)))
+    assert torch.equal(got["leftImage"].cpu(), want) and tuple(got["leftDisp"].shape) == (1, 256, 512)
+    with pytest.raises(Exception):
+        StereoPad((544, 960))(dict(leftImage=torch.zeros(3, 540, 960), rightImage=torch.zeros(3, 540, 960)))   # host tensors: no CPU path
+
+
+def test_inference_stereo_on_the_reference_demo_pair(dev, tmp_path):
+    from densematchingbenchmark_amd import result_io
+    from densematchingbenchmark_amd.apis import inference_stereo
+    from densematchingbenchmark_amd.evaluation import calc_error
+    g = golden("demo_sceneflow.npz")
+    paths = _demo_files(g, tmp_path)
+    model = _model(dev)
+    assert model.backbone is not None
+    logs = {}
+    for mode in (False, "auto"):          # eager, then the default (a HIP graph at this size)
+        out_dir = tmp_path / ("log_%s" % mode)
+        logged = inference_stereo(model, [paths], str(out_dir), pad_to_shape=(544, 960), graph=mode)
+        assert len(logged) == 1
+        saved = result_io.load_result(os.path.join(str(out_dir), "left", "result.pkl"))
+        assert set(saved) == {"Result", "OriginalData"} and set(saved["Result"]) == {"disps", "costs"}
+        assert set(saved["OriginalData"]) == {"leftImage", "rightImage", "leftDisp", "rightDisp"}
+        assert saved["OriginalData"]["leftImage"].shape == (540, 960, 3) and saved["OriginalData"]["rightDisp"] is None
+        assert float(saved["OriginalData"]["leftImage"].astype(np.float64).sum()) == g["ori_left_image_sum"][0]
+        logs[mode] = saved["Result"]
+    assert hasattr(model, "_dmb_graphed_forward") and len(model._dmb_graphed_forward._graphs) == 1
+    for a, b in zip(logs[False]["disps"] + logs[False]["costs"], logs["auto"]["disps"] + logs["auto"]["costs"]):
+        assert torch.equal(a, b)                     # the replayed graph is the eager forward, bit for bit
+    res = logs["auto"]
+    gt = torch.from_numpy(np.ascontiguousarray(saved["OriginalData"]["leftDisp"]))[None, None]
+    assert np.array_equal(gt[0, 0, ::45].numpy(), g["ori_left_disp_rows"])
+    worst = []
+    for i, (d, c) in enumerate(zip(res["disps"], res["costs"])):
+        assert tuple(d.shape) == tuple(g["cropped_shape"]) == (1, 1, 540, 960) and tuple(c.shape) == tuple(g["cost_shape"])
+        ref, truth = torch.from_numpy(g["disp%d_s4" % i]).double(), torch.from_numpy(g["truth%d_s4" % i])
+        e_hip, e_ref = (d[:, :, ::4, ::4].double() - truth).abs(), (ref - truth).abs()
+        # bench.py's PARITY_CONTRACT against the reference's FP64 evaluation of the same images
+        assert e_hip.max().item() <= max(1e-4, 1.25 * e_ref.max().item()), (i, e_hip.max().item(), e_ref.max().item())
+        assert e_hip.mean().item() <= e_ref.mean().item(), (i, e_hip.mean().item(), e_ref.mean().item())
+        assert maxdiff(d[:, :, ::4, ::4], g["disp%d_s4" % i]) <= DISP_MAX_FULL
+        assert maxdiff(c[:, ::24, 5::107, :], g["cost%d_rows" % i]) <= 5e-5
+        worst.append((maxdiff(d[:, :, ::4, ::4], g["disp%d_s4" % i]), e_hip.max().item(), e_ref.max().item()))
+        err = calc_error(d.to(dev), gt.to(dev), 0, 192)
+        want = dict(zip(KEYS, g["err%d" % i]))
+        assert abs(err["epe"] - want["epe"]) <= 1e-5 * max(1.0, want["epe"]), (err, want)
+        assert all(abs(err[k] - want[k]) <= 1e-3 for k in KEYS[1:]), (err, want)
+    assert maxdiff(res["disps"][0], g["disp0_full"]) <= DISP_MAX_FULL
+    print("demo pair: per level (max |disp - reference|, max |hip - fp64|, max |reference - fp64|) =", [tuple("%.3g" % v for v in w) for w in worst])
+
+
+def test_accumulator_on_the_padded_maps_equals_calc_error_on_the_cropped_ones(dev, tmp_path):
+    """The evaluation harness's form of the same numbers: padded estimates against the top-padded ground truth with
+    original_size = (540, 960) -> the error dict of the cropped maps."""
+    from densematchingbenchmark_amd.data import Compose, Normalize, StereoPad, ToTensor, imread
+    from densematchingbenchmark_amd import ops
+    from densematchingbenchmark_amd.disp_io import load_scene_flow_disp
+    from densematchingbenchmark_amd.evaluation import EpeAccumulator
+    g = golden("demo_sceneflow.npz")
+    paths = _demo_files(g, tmp_path)
+    model = _model(dev)
+    sample = Compose([ToTensor(dev), StereoPad((544, 960)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])(
+        dict(leftImage=imread(paths["left_image_path"]), rightImage=imread(paths["right_image_path"])))
+    with torch.no_grad():
+        results, _ = model(dict(leftImage=sample["leftImage"][None], rightImage=sample["rightImage"][None]))
+    gt = torch.from_numpy(np.ascontiguousarray(load_scene_flow_disp(paths["left_disp_map_path"]))).to(dev)[None, None]
+    gt_padded = ops.stereo_pad_normalize(gt, (544, 960))            # ground truth padded like the images (zeros: masked by lower_bound 0)
+    acc = EpeAccumulator(dev, 3, 0, 192)
+    acc.update(results["disps"], gt_padded, (540, 960))
+    for i, got in enumerate(acc.summary()):
+        want = dict(zip(KEYS, g["err%d" % i]))
+        assert abs(got["epe"] - want["epe"]) <= 1e-5 * max(1.0, want["epe"]) and all(abs(got[k] - want[k]) <= 1e-3 for k in KEYS[1:])

@@ -425,3 +425,64 @@ def test_fp64_yardstick_psmnet_other_shapes(dev, hw):
         ref32, _ = O.psmnet_path(lf, rf, p, 192)
         c64 = _truth(lambda d: O.psm_aggregator(O.cat_fms(lf, rf, 48, 0, 1).double().to(d), _f64(p, d), 192, "cost_processor.aggregator."), dev)
         _assert_yardstick("psmnet %dx%d" % (4 * h, 4 * w), gpu, ref32, c64)
+
+
+# ------------------------------------------------------------------------------------------------- BASELINE configs[3] / [4] at their bench batches
+def _batch_vs_single(model, left, right, dev, keys=("disps", "costs", "confs")):
+    """Every pair of a batch against its own single-pair evaluation.  A batch changes tile counts, XCD ranges and the multi-job
+    launches, never the arithmetic of a pixel: the outputs must be BIT-IDENTICAL."""
+    with torch.no_grad():
+        whole, _ = model(dict(leftFeature=left, rightFeature=right))
+        B = left.shape[0]
+        for i in range(B):
+            single, _ = model(dict(leftFeature=left[i:i + 1].contiguous(), rightFeature=right[i:i + 1].contiguous()))
+            for k in keys:
+                if k not in whole:
+                    continue
+                for lvl, (a, b) in enumerate(zip(whole[k], single[k])):
+                    assert torch.equal(a[i:i + 1], b), (k, lvl, i, (a[i:i + 1] - b).abs().max().item())
+            del single
+    return whole
+
+
+def test_fullsize_acfnet_bench_batch_equals_single_pairs(dev):
+    """BASELINE configs[3] as bench.py runs it per GPU: AcfNet (adaptive) 544x960, max_disp 192, batch 4 -- each pair bit-identical
+    to its single-pair evaluation (disparities, full-resolution costs, confidences), pair 0 against the reference's outputs."""
+    from densematchingbenchmark_amd import synthetic
+    g = golden("fullsize_acfnet.npz")
+    cfg, model = _built("AcfNet/scene_flow_adaptive.py", 5)
+    model = model.to(dev)
+    left, right = synthetic.feature_batch(0, 1, 4, 32, 136, 240, dev)
+    whole = _batch_vs_single(model, left, right, dev)
+    for lvl in range(3):
+        k = 3 - lvl
+        assert maxdiff(whole["disps"][lvl][0:1][SUB], g["disp%d" % k]) <= DISP_MAX_FULL
+        assert maxdiff(whole["confs"][lvl][0:1][SUB], g["conf%d" % k]) <= 2e-5
+        assert maxdiff(whole["costs"][lvl][0:1][CROWS], g["cost%d_rows" % k]) <= COST_TOL
+
+
+def test_fullsize_stereonet_bench_batch_equals_single_pairs(dev):
+    """BASELINE configs[4] as bench.py runs it per GPU: StereoNet-8x cost path at 384x1248, batch 8."""
+    from densematchingbenchmark_amd import synthetic
+    g = golden("fullsize_stereonet.npz")
+    cfg, model = _built("StereoNet/scene_flow_8x_2stage.py", 6)
+    model = model.to(dev)
+    left, right = synthetic.feature_batch(0, 1, 8, 32, 48, 156, dev)
+    whole = _batch_vs_single(model, left, right, dev)
+    assert maxdiff(whole["disps"][0][0:1], g["disp"]) <= 1e-4
+    assert maxdiff(whole["costs"][0][0:1][:, :, 1::2, :], g["cost"]) <= 2e-5
+
+
+def test_psmnet_batch_one_equals_batch_four(dev):
+    """The batch-1 (latency) regime selects other tiles than the bench batch (the tile cost model sees a quarter of the voxels): the
+    same pairs through batch 4 and one at a time, bit-identical, at 544x960 and at BASELINE configs[0]'s 256x512 / max_disp 64."""
+    from densematchingbenchmark_amd import synthetic
+    cfg, model = _built("PSMNet/scene_flow.py", 0)
+    model = model.to(dev)
+    left, right = synthetic.feature_batch(0, 1, 4, 32, 136, 240, dev)
+    _batch_vs_single(model, left, right, dev)
+    cfg0, model0 = _built("PSMNet/baseline_cfg0_256x512_d64.py", 2)
+    model0 = model0.to(dev)
+    left, right = synthetic.feature_batch(40, 1, 4, 32, 64, 128, dev)
+    whole = _batch_vs_single(model0, left, right, dev)
+    assert [tuple(d.shape) for d in whole["disps"]] == [(4, 1, 256, 512)] * 3
