@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--conv3d-mode", default="exact", choices=["exact", "bf16x6"],
                     help="opt-in EXPERIMENT: 32-channel stride-1 layers on 3-way bf16 splits (FP32-equivalent accuracy, not "
                          "bit-identical); the headline is always measured with 'exact'")
+    ap.add_argument("--latency", action="store_true", help="add the batch-1 latency legs (implied by --batch 1)")
+    ap.add_argument("--no-latency", action="store_true", help="no latency legs even at --batch 1 (profiling runs)")
     ap.add_argument("--fused-regression", action="store_true",
                     help="opt-in fast path: fused up-sampling + soft-argmin, full-resolution costs not materialised")
     return ap.parse_args()
@@ -185,36 +187,109 @@ def _single_thread_layer(cores):
     return out
 
 
-def end_to_end(model, dev, B, Hp, Wp, steps):
-    """Secondary figure (not the headline metric): images -> PSMNet backbone (HIP conv2d) -> the path."""
-    from densematchingbenchmark_amd.modeling.stereo.backbones import PSMNetBackbone
-    bb = PSMNetBackbone(3, True).eval()
-    synthetic.init_params_(bb, seed=8, classif_gain=1.0)
-    bb = bb.to(dev)
-    g = torch.Generator().manual_seed(77)
-    li, ri = (torch.randn((B, 3, Hp, Wp), generator=g).to(dev) for _ in range(2))
-    def timed(fn):
-        """``steps`` back-to-back evaluations between two synchronisations (as the headline loop is timed: the launch queues stay
-        full, nothing waits on the host in between)"""
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
+def _full_model(cfg, model, dev, seed=8):
+    """``build_model(cfg)`` as the reference means it (backbone included), carrying the path model's weights; the backbone gets
+    seeded ones.  None for configurations whose file names no backbone."""
+    full = build_model(cfg).eval()
+    if full.backbone is None:
+        return None
+    synthetic.init_params_(full.backbone, seed=seed, classif_gain=1.0)
+    full.load_state_dict(model.state_dict(), strict=False)
+    return full.to(dev)
 
-    def whole():
-        lf, rf = bb(li, ri)
-        model(dict(leftFeature=lf, rightFeature=rf))
 
+def _image_inputs(first, world, B, H0, W0, Hp, Wp, dev, mean, std):
+    """Synthetic image pairs as decoder bytes [B, H0, W0, 3], padded + normalised on the device the way the
+    reference's transforms do it (StereoPad -> Normalize, csrc/preprocess.hip): [B, 3, Hp, Wp] x 2, resident in HBM."""
+    lu8, ru8 = synthetic.image_batch(first, world, B, H0, W0, dev)
+    return ops.stereo_pad_normalize(lu8, (Hp, Wp), mean, std), ops.stereo_pad_normalize(ru8, (Hp, Wp), mean, std)
+
+
+def _timed(fn, steps, sync_each=False):
+    """``steps`` evaluations between two synchronisations (back to back: the launch queues stay full), or -- ``sync_each`` -- each
+    one followed by a synchronisation (what one caller of a serving API waits for)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+        if sync_each:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def end_to_end(cfg, model, dev, B, H0, W0, Hp, Wp, steps, check=True):
+    """Secondary figure (not the headline metric): images -> PSMNet backbone (HIP conv2d) -> the path, on SYNTHETIC
+    IMAGE pairs (textured left view, right view = left warped by the ground-truth field) that went through the data-side kernel;
+    ``max_abs_disp``: pair 0 against the oracle's whole model (backbone + path) on the host."""
+    full = _full_model(cfg, model, dev)
+    if full is None:
+        return None
+    mean, std = cfg.data.eval.get("mean", ops.IMAGENET_MEAN), cfg.data.eval.get("std", ops.IMAGENET_STD)
+    li, ri = _image_inputs(0, 1, B, H0, W0, Hp, Wp, dev, mean, std)
+    batch = dict(leftImage=li, rightImage=ri)
     with torch.no_grad():
-        whole()                              # first pass packs the weights
-        t_bb = timed(lambda: bb(li, ri))
-        t_all = timed(whole)
-    return {"pairs_per_s": round(B * steps / t_all, 2), "ms_per_step": round(t_all / steps * 1e3, 3),
-            "backbone_ms": round(t_bb / steps * 1e3, 3), "steps": steps,
-            "note": "left/right images [%d,3,%d,%d] resident in HBM; the backbone runs the two views as two chains on two HIP streams "
-                    "(ops.two_view_forward); %d back-to-back steps between two synchronisations" % (B, Hp, Wp, steps)}
+        res, _ = full(batch)                              # first pass packs the weights
+        t_bb = _timed(lambda: full.backbone(li, ri), steps)
+        t_all = _timed(lambda: full(batch), steps)
+    out = {"pairs_per_s": round(B * 1e3 / t_all, 2), "ms_per_step": round(t_all, 3), "backbone_ms": round(t_bb, 3), "steps": steps,
+           "note": "synthetic left/right IMAGES (uint8 [%d,%d,%d,3]) padded + normalised on the device (StereoPad -> Normalize, one launch per "
+                   "view) to [%d,3,%d,%d], resident in HBM; build_model(cfg) with the HIP backbone (two views on two streams); %d "
+                   "back-to-back steps between two synchronisations" % (B, H0, W0, B, Hp, Wp, steps)}
+    if check and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and cfg.model.cost_processor.type == "Concatenation":
+        from oracle import dmb_oracle as O   # checker only
+        p = {k: v.detach().cpu() for k, v in full.state_dict().items()}
+        with torch.no_grad():
+            ref, _ = O.psmnet_model(li[0:1].cpu(), ri[0:1].cpu(), p, cfg.model.max_disp)
+        out["max_abs_disp"] = [round((a[0:1].cpu() - b).abs().max().item(), 7) for a, b in zip(res["disps"], ref)]
+        out["mean_abs_disp"] = [round((a[0:1].cpu() - b).abs().mean().item(), 8) for a, b in zip(res["disps"], ref)]
+    del full
+    torch.cuda.empty_cache()
+    return out
+
+
+def latency_leg(cfg, model, dev, first_batch, H0, W0, Hp, Wp, steps):
+    """The batch-1 regime the reference publishes and serves in (configs/PSMNet/ResultOfPSMNet.md:15-19: 384x1248, B = 1;
+    dmb/apis/inference.py:191-225: one pair per call): ONE pair through (a) the path alone (features -> disparities) and (b)
+    build_model(cfg) whole (padded, normalised images -> disparities), each eagerly and replayed from a HIP graph
+    (graph_runner.GraphedForward, the serving API's default at this size) -- as milliseconds one caller waits per pair (every
+    call followed by a synchronisation) and as back-to-back pairs/s."""
+    from densematchingbenchmark_amd.graph_runner import GraphedForward
+    feats = {k: (tuple(t[0:1].contiguous() for t in v) if isinstance(v, tuple) else v[0:1].contiguous()) for k, v in first_batch.items()}
+    n = max(5, steps)
+    out = {"batch": 1, "calls_timed": n}
+
+    def legs(fn_eager, batch, tag):
+        with torch.no_grad():
+            for _ in range(2):
+                fn_eager(batch)
+            e_sync, e_b2b = _timed(lambda: fn_eager(batch), n, True), _timed(lambda: fn_eager(batch), n)
+        out[tag] = {"eager_ms_per_pair": round(e_sync, 3), "eager_back_to_back_ms": round(e_b2b, 3)}
+        try:
+            graphed = GraphedForward(fn_eager)
+            for _ in range(2):
+                graphed(batch)
+            g_sync, g_b2b = _timed(lambda: graphed(batch), n, True), _timed(lambda: graphed(batch), n)
+            with torch.no_grad():
+                same = all(torch.equal(a, b) for a, b in zip(graphed(batch)[0]["disps"], fn_eager(batch)[0]["disps"]))
+            out[tag].update({"graph_ms_per_pair": round(g_sync, 3), "graph_back_to_back_ms": round(g_b2b, 3),
+                             "pairs_per_s_best": round(1e3 / min(e_b2b, g_b2b), 2), "graph_identical_to_eager": bool(same)})
+            graphed.reset()
+        except Exception as e:  # noqa: BLE001  (a capture failure must not lose the eager figures)
+            out[tag]["graph_error"] = repr(e)[:300]
+
+    legs(model, feats, "path")
+    full = _full_model(cfg, model, dev)
+    if full is not None:
+        mean, std = cfg.data.eval.get("mean", ops.IMAGENET_MEAN), cfg.data.eval.get("std", ops.IMAGENET_STD)
+        li, ri = _image_inputs(0, 1, 1, H0, W0, Hp, Wp, dev, mean, std)
+        legs(full, dict(leftImage=li, rightImage=ri), "images_to_disparity")
+        del full
+    torch.cuda.empty_cache()
+    out["note"] = ("ms_per_pair = mean wall time of one call followed by a synchronisation (inputs resident in HBM); graph = the "
+                   "eval-mode forward captured once in a HIP graph and replayed (identical outputs); images_to_disparity = "
+                   "build_model(cfg) with the HIP backbone on padded, normalised synthetic images")
+    return out
 
 
 def split_mode_leg(step, exact_disps, B, steps):
@@ -259,6 +334,25 @@ def overlap_leg(step, exact_disps, B, steps):
     same = all(torch.equal(a, b) for a, b in zip(disps, exact_disps))
     return {"pairs_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
             "identical_to_sequential": bool(same)}
+
+
+def fused_leg(step_fused, exact_disps, B, steps):
+    """Secondary figure, NOT the headline ("report both modes"): the same step with the up-sampling and the
+    soft-argmin fused (dmb_trilinear_soft_argmin_f32) -- the three full-resolution cost volumes (3 x 1.6 GB at batch 4) are never
+    written, so ``results['costs']`` does not exist in this mode; the disparity maps are the materialised mode's up to the
+    regression's rounding."""
+    with torch.no_grad():
+        for _ in range(2):
+            disps = step_fused()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            disps = step_fused()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    diff = [round((a - b).abs().max().item(), 7) for a, b in zip(disps, exact_disps)]
+    return {"pairs_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "costs_materialised": False, "max_abs_disp_vs_materialised_mode": diff}
 
 
 def training_leg(cfg, dev, steps):
@@ -414,7 +508,7 @@ def main():
 
     last_results = {}
 
-    def step(k=None):
+    def step(k=None, fused=fused):
         if k is None:
             k = counter[0]
             counter[0] += 1
@@ -427,7 +521,11 @@ def main():
             last_results.update({k: v for k, v in results.items() if k == "confs"})
         else:
             agg = model.cost_processor.aggregator
-            raw = model.cost_processor.vol_func(left, right, **model.cost_processor.default_args)
+            if ops.cat_fusion() and ptype == "Concatenation":   # the volume-free first layer, as the default mode runs it
+                from densematchingbenchmark_amd.modeling.stereo.cost_processors.utils.cat_fms import LazyCatVolume
+                raw = LazyCatVolume(left, right, kind="cat", **model.cost_processor.default_args)
+            else:
+                raw = model.cost_processor.vol_func(left, right, **model.cost_processor.default_args)
             c1, c2, c3 = agg.trunk(raw)
             vals = model.disp_predictor._sample_values()
             disps = [ops.trilinear_soft_argmin(c.squeeze(1), (md, Hp, Wp), vals, model.disp_predictor.alpha)
@@ -480,15 +578,17 @@ def main():
         # `traffic` is NOT measured by this run: it is the PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same
         # command, scripts/profile.sh) of the tracked profile summary, valid for the workload that summary was taken on
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
-        if os.path.exists(pmc):
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_dominant*.json")), reverse=True):   # one summary per profiled workload
             try:
                 rec = json.load(open(pmc))
-                if tuple(rec.get("shape", [4, 32, 48, 136, 240])) == (B, 32, d4, h4, w4):
+                if tuple(rec.get("shape", [])) == (B, 32, d4, h4, w4):
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/pmc_dominant.json (rocprofv3 PMC passes of an earlier run of this command: %s)" % rec.get("derived_from", "see the file")
-            except Exception:
-                traffic = None
+                    traffic_source = "profiles/%s (rocprofv3 PMC passes of an earlier run of this command: %s)" % (
+                        os.path.basename(pmc), rec.get("derived_from", "see the file"))
+                    break
+            except Exception:  # noqa: BLE001
+                continue
         out = {
             "metric": "stereo pairs/s (%dx%d, max_disp=%d)" % (H0, W0, md), "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "pairs": pairs,
@@ -500,7 +600,7 @@ def main():
                                                                         ", fused up-sample+regression" if fused else ""),
                        "pairs_per_step_per_gpu": B, "sharding": "pair i -> rank i mod world; 1 all-reduce of the EPE accumulator",
                        "costs_materialised": not fused, "conv3d_mode": args.conv3d_mode},
-            "first_layer": ("3-D convolution on the materialised volume" if (fused or not ops.cat_fusion()) else
+            "first_layer": ("3-D convolution on the materialised volume" if not ops.cat_fusion() else
                             {"Concatenation": "2-D maps, volume not materialised (csrc/catconv.hip)",
                              "Difference": "2-D maps, volume not materialised (csrc/catconv.hip)",
                              "Correlation": "correlation channels 3-D, concat channels as 2-D maps (csrc/catconv.hip)"}.get(ptype, "3-D convolution")),
@@ -522,13 +622,15 @@ def main():
                 out["rccl_version"] = None
         if ptype == "Concatenation" and cfg.model.cost_processor.cost_aggregator.type == "PSMNet" and (Hp, Wp, md) in PATH_FIGURES:
             gf_ref, gf_exec, gb = PATH_FIGURES[(Hp, Wp, md)]
-            if fused or not ops.cat_fusion():
+            if not ops.cat_fusion():
                 gf_exec = gf_ref
             # arithmetic of the REFERENCE's formulation per second (1015.84 GFLOP per pair at 544x960, 932.18 at
             # 384x1248); the path itself executes less (dres0[0] in its 2-D form: 2/3 of that layer's multiplications do not exist)
             out["path_gflop_per_pair"] = {"reference_formulation": gf_ref, "executed": round(gf_exec, 2)}
             out["path_tflops_reference_formulation"] = round(value * gf_ref / 1e3, 2)
-            out["path_frac_fp32_peak_reference_formulation"] = round(value * gf_ref / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4)
+            # NOT a roofline fraction: the reference's formulation counts 173 GFLOP per pair that the volume-free first layer never
+            # executes -- this is the speed-up over executing that formulation at the matrix peak
+            out["path_speed_vs_reference_formulation_at_fp32_peak"] = round(value * gf_ref / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4)
             # ... and the arithmetic the path really EXECUTES: the achieved fraction of the matrix peak
             out["path_tflops_executed"] = round(value * gf_exec / 1e3, 2)
             out["path_frac_fp32_peak_executed"] = round(value * gf_exec / 1e3 / world / PEAK_FP32_MFMA_TFLOPS, 4)
@@ -563,12 +665,18 @@ def main():
                 # arithmetic sits 1.2 .. 2.5e-4 from the exact value, so the contract the tests enforce is a
                 # RELAXATION of north_star, stated here with both distances from an FP64 evaluation of the same network:
                 truth = _fp64_truth(model, cfg, (first, first_r), ptype, agg_type, dev)
+                out["parity_vs_cpu"]["north_star_bound"] = 1e-4
+                out["parity_vs_cpu"]["north_star_met"] = bool(max(out["parity_vs_cpu"]["max_abs_disp"]) <= 1e-4)
+                if truth is None:    # (only PSMNet / AcfNet concatenation configurations have an FP64 evaluation; or it failed: stderr)
+                    out["parity_vs_cpu"]["fp64_yardstick"] = "unavailable"
                 if truth is not None:
                     e_hip = [(a.double() - t).abs() for a, t in zip(d_gpu, truth)]
                     e_ref = [(b.double() - t).abs() for b, t in zip(ref[0], truth)]
                     out["parity_vs_cpu"].update({
-                        "north_star_bound": 1e-4, "north_star_met": bool(max(out["parity_vs_cpu"]["max_abs_disp"]) <= 1e-4),
+                        "fp64_yardstick": "torch FP64 kernels on the GPU, oracle's aggregator",
                         "parity_contract": PARITY_CONTRACT,
+                        "parity_contract_proof": "tests/test_oracle_golden.py::test_reference_faster_soft_argmin_is_an_fp32_fma_chain_bit_for_bit, "
+                                                 "::test_reproducing_the_reference_order_cannot_meet_1e4_without_bit_identical_costs",
                         "max_abs_disp_vs_fp64": [round(e.max().item(), 7) for e in e_hip],
                         "reference_arithmetic_max_abs_disp_vs_fp64": [round(e.max().item(), 7) for e in e_ref],
                         "mean_abs_disp_vs_fp64": [round(e.mean().item(), 8) for e in e_hip],
@@ -578,10 +686,14 @@ def main():
                 if len(ref) > 2 and "confs" in last_results:
                     out["parity_vs_cpu"]["max_abs_conf"] = [round((a[0:1].cpu() - b).abs().max().item(), 7)
                                                             for a, b in zip(last_results["confs"], ref[2])]
+        if world == 1 and (B == 1 or args.latency) and not args.no_latency and not fused and args.conv3d_mode == "exact":
+            # the batch-1 / serving regime (dmb/apis/inference.py:191-225): ms per pair, eager and replayed from a HIP graph
+            out["latency"] = latency_leg(cfg, model, dev, batches[0][0], H0, W0, Hp, Wp, min(args.steps, 20))
         if world == 1 and ptype == "Concatenation" and agg_type == "PSMNet" and not fused and not args.no_extras:
-            out["end_to_end_with_backbone"] = end_to_end(model, dev, B, Hp, Wp, min(args.steps, 5))
+            out["end_to_end_with_backbone"] = end_to_end(cfg, model, dev, B, H0, W0, Hp, Wp, min(args.steps, 5), check=not args.no_cpu_baseline)
             if args.conv3d_mode == "exact":
                 out["opt_in_branch_overlap"] = overlap_leg(lambda: step(0), disps, B, min(args.steps, 10))
+                out["opt_in_fused_regression"] = fused_leg(lambda: step(0, fused=True), disps, B, min(args.steps, 10))
                 out["opt_in_bf16x6"] = split_mode_leg(lambda: step(0), disps, B, min(args.steps, 5))
                 if "losses" in cfg.model:
                     out["training_step"] = training_leg(cfg, dev, min(args.steps, 5))

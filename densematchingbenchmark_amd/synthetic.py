@@ -88,6 +88,33 @@ def gt_batch(first_pair_index, stride, batch, height, width, pad_top=0, device="
     return torch.cat([gt_disparity(first_pair_index + j * stride, 1, height, width, pad_top) for j in range(batch)]).to(device)
 
 
+def image_pair(global_pair_index, height, width):
+    """SURVEY.md 8-d's synthetic IMAGE pair, as the decoder would hand it over: uint8 [H, W, 3] left / right views.  Left =
+    low-pass-filtered uniform texture in [0, 255); right = the left view resampled along x by the pair's smooth ground-truth
+    field (``gt_disparity``), R(x) = L(x + d(x)) with linear interpolation -- so the evaluation mask and the two views belong
+    together.  Host-side input generation (torch CPU), not part of the path."""
+    g = torch.Generator().manual_seed(2468 + int(global_pair_index))
+    tex = torch.rand((1, 3, height // 4 + 2, width // 4 + 2), generator=g)
+    fine = torch.rand((1, 3, height, width), generator=g)
+    left = torch.nn.functional.interpolate(tex, (height, width), mode="bicubic", align_corners=True).clamp(0, 1) * 0.75 + fine * 0.25
+    d = gt_disparity(global_pair_index, 1, height, width)[0, 0]                      # [H, W]
+    xs = torch.arange(width, dtype=torch.float32).view(1, width) + d
+    x0 = xs.floor().clamp(0, width - 1)
+    x1 = (x0 + 1).clamp(max=width - 1)
+    lam = (xs.clamp(0, width - 1) - x0).clamp(0, 1)
+    rows = left[0]                                                                   # [3, H, W]
+    gather = lambda ix: torch.gather(rows, 2, ix.long().unsqueeze(0).expand(3, -1, -1))   # noqa: E731
+    right = gather(x0) * (1 - lam) + gather(x1) * lam
+    to_u8 = lambda t: (t.clamp(0, 1) * 255.0).floor().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous()   # noqa: E731
+    return to_u8(left[0]), to_u8(right)
+
+
+def image_batch(first_pair_index, stride, batch, height, width, device="cpu"):
+    """uint8 [B, H, W, 3] x 2 of pairs ``first, first + stride, ...`` (the decoder's layout: what ops.stereo_pad_normalize takes)."""
+    pairs = [image_pair(first_pair_index + j * stride, height, width) for j in range(batch)]
+    return torch.stack([p[0] for p in pairs]).to(device), torch.stack([p[1] for p in pairs]).to(device)
+
+
 def peaked_cost_volume(seed, planes, height, width):
     """A quarter-resolution cost volume [1, planes, height, width] with ground-truth-like peaks: the peak plane
     follows a smooth field that sits near plane 1.25 (full-resolution disparity 5) on the left quarter of the image, near plane

@@ -11,3 +11,4 @@ python bench.py --config $R/configs/AcfNet/scene_flow_adaptive.py --steps 10 --w
 python bench.py --config $R/configs/AcfNet/scene_flow_uniform.py --steps 10 --warmup 3 --no-extras 2>/dev/null | tail -1
 python bench.py --config $R/configs/StereoNet/scene_flow_8x_2stage.py --batch 8 --steps 300 --warmup 50 --no-extras 2>/dev/null | tail -1
 python bench.py --config $R/configs/GCNet/scene_flow.py --batch 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | tail -1
+bash $R/scripts/bench_b1.sh
