@@ -1545,11 +1545,13 @@ struct S1Tile {
 static double s1_cost(const S1Tile& t, int B, int D, int H, int W) {
   const long long n = t.lin ? (long long)B * cdiv(D, t.tz) * cdiv(H * W, 64)
                             : (long long)B * cdiv(D, t.tz) * cdiv(H, t.ty) * cdiv(W, t.tx);
-  const long long slots = (long long)t.wpe * num_cus();
-  // a round of `wpe` co-resident workgroups shares the CU's matrix cores; + 0.1: set-up and epilogue of a workgroup in units of
-  // one column tile's arithmetic (launches here are 1 .. 15 rounds deep, so the last, partly filled round matters).  Checked
-  // against profiles/r04_kbench_hg*.log: the estimate ranks the candidates as measured on 240 / 120 / 60 and 312 / 156 columns.
-  return (double)cdiv_ll(n, slots) * t.wpe * (t.mt + 0.1) / t.eff;
+  // What a CU holds is ceil(n / CUs) workgroups, each with one wave per SIMD running `mt` column tiles -- serial chains of
+  // 27 Ci / 2 MFMAs -- one after the other; + 0.1: set-up and epilogue of a workgroup in units of one column tile's arithmetic.
+  // (Round 4 counted rounds of `wpe` co-resident workgroups instead: the same ranking on full grids, but a step function at
+  // n = wpe x CUs that misjudged launches around one round -- batch 1, small images.)  Checked against every candidate measured
+  // so far: profiles/r04_kbench_hg*.log (batch 4: 240 / 120 / 60 and 312 / 156 columns) and profiles/r05_kbench_small.log (batch 1
+  // at 256x512 / D 64, 544x960 and 384x1248) -- the estimate ranks them as measured.
+  return (double)cdiv_ll(n, num_cus()) * (t.mt + 0.1) / t.eff;
 }
 // index of the cheapest candidate (ties: the earlier one); DMB_OPT(19) = k > 0 forces candidate k - 1 (development build)
 static int s1_pick(const S1Tile* cand, const bool* ok, int n, int B, int D, int H, int W) {
@@ -1610,13 +1612,17 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
         // 64-voxel runs of the plane in memory order for rows of up to 64 voxels (planes no box tiling fills the chip with: the
         // deepest hourglass level), row quads of 40 / 24 / 32 columns x 4 rows otherwise; two z-slices x two channel tiles per
         // workgroup.  A launch here is only a few rounds of workgroups deep, so the estimate decides per launch.
-        static const S1Tile cand[4] = {{64, 3, 2, 2, 3, true, 1.0}, {40, 4, 2, 5, 3, false, 1.0}, {24, 4, 2, 3, 3, false, 1.0}, {32, 4, 2, 4, 3, false, 1.0}};
-        const bool ok[4] = {W >= 32 && W <= 64 && (H * W) % 4 == 0 && DMB_OPT(13) == 0, true, true, true};
-        switch (s1_pick(cand, ok, 4, B, D, H, W)) {
+        // (round 5) + row pairs of 16 columns x 2 rows: ONE column tile per wave, for launches that do not fill the chip (batch 1,
+        // small images: 62 -> 37 us at [1, 64, 8, 32, 64], 59 -> 33 us at [1, 64, 4, 16, 32]); twice the halo per output of the quads
+        static const S1Tile cand[5] = {{64, 3, 2, 2, 3, true, 1.0}, {40, 4, 2, 5, 3, false, 1.0}, {24, 4, 2, 3, 3, false, 1.0}, {32, 4, 2, 4, 3, false, 1.0},
+                                       {16, 2, 2, 1, 3, false, 0.95}};
+        const bool ok[5] = {W >= 32 && W <= 64 && (H * W) % 4 == 0 && DMB_OPT(13) == 0, true, true, true, true};
+        switch (s1_pick(cand, ok, 5, B, D, H, W)) {
           case 0: return launch_s1<S1Cfg<0, 64, 3, 64, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
           case 1: return DMB_S1(64, 4, 40, 2, 8, 56);
           case 2: return DMB_S1(64, 4, 24, 2, 8, 40);
-          default: return DMB_S1(64, 4, 32, 2, 8, 40);
+          case 3: return DMB_S1(64, 4, 32, 2, 8, 40);
+          default: return DMB_S1(64, 2, 16, 2, 16, 0);
         }
       }
       return tx == 52 ? DMB_S1(64, 4, 52, 2, 0, 0) : DMB_S1(64, 4, 60, 2, 0, 0);
@@ -1628,16 +1634,35 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     if (Co == 64 && v16) {
       // output positions computed per tile row: 32 with 30-column tiles, 24 with 22-column ones; the narrower tile wins at
       // the training-crop widths (Wo = 64: 3 x 96 against 3 x 128 positions per 4 rows, Wo = 32: 2 x 96 against 2 x 128)
-      const int Wo = (W - 1) / 2 + 1;
-      if (cdiv(Wo, 22) * 96 < cdiv(Wo, 30) * 128)
+      const int Wo = (W - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Do = (D - 1) / 2 + 1;
+      // 8-byte epilogue: W % 4 == 0 makes Wo even; the output (and skip operand) base must be 8-byte aligned and one batch item
+      // of the output addressable with 32-bit byte offsets
+      const bool pair_ok = ((((uintptr_t)y | (uintptr_t)residual) & 7) == 0) && (long long)Co * Do * Ho * Wo * 4 < 0x7fffffffLL;
+      const bool narrow = cdiv(Wo, 22) * 96 < cdiv(Wo, 30) * 128;
+      // (round 5) A launch of at most ONE workgroup per CU (batch 1, small images: 108 four-row workgroups at 544x960 / batch 1,
+      // 16 at 256x512) takes as long as the column tiles ONE SIMD runs for a workgroup, one after the other -- 4 with the 4 x 30
+      // eight-wave tiles, 3 with 4 x 22: two-row (2 per SIMD) or one-row tiles (1) shorten that chain at the price of more halo
+      // rows per output, which a launch that leaves CUs idle does not feel (112 -> 59 us at [1, 64, 24, 68, 120]).
+      const long long nz = (long long)B * cdiv(Do, 2);
+      const long long n_old = nz * (narrow ? cdiv(Wo, 22) : cdiv(Wo, 30)) * cdiv(Ho, 4);
+      if (pair_ok && n_old <= num_cus() && DMB_OPT(10) == 0) {
+        const int ncu = num_cus();
+        const double c_old = (double)cdiv_ll(n_old, ncu) * (narrow ? 3.1 : 4.1);
+        const double c_two = (double)cdiv_ll(nz * cdiv(Wo, 30) * cdiv(Ho, 2), ncu) * 2.1 / 0.9;
+        const double c_one = (double)cdiv_ll(nz * cdiv(Wo, 30) * Ho, ncu) * 1.1 / 0.8;
+        if (c_one < c_two && c_one < c_old)
+          return launch_s2<S2Cfg<0, 64, 1, 30, 2, 2, true, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+        if (c_two < c_old)
+          return launch_s2<S2Cfg<0, 64, 2, 30, 2, 2, true, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      }
+      // output positions computed per tile row: 32 with 30-column tiles, 24 with 22-column ones; the narrower tile wins at
+      // the training-crop widths (Wo = 64: 3 x 96 against 3 x 128 positions per 4 rows, Wo = 32: 2 x 96 against 2 x 128)
+      if (narrow)
         return launch_s2<S2Cfg<0, 64, 4, 22, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
 #ifdef DMB_DEV
       if (DMB_OPT(10) == 1)   // A/B: four-wave workgroups
         return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
 #endif
-      // 8-byte epilogue: W % 4 == 0 makes Wo even; the output (and skip operand) base must be 8-byte aligned and one batch item
-      // of the output addressable with 32-bit byte offsets
-      const bool pair_ok = ((((uintptr_t)y | (uintptr_t)residual) & 7) == 0) && (long long)Co * ((D - 1) / 2 + 1) * ((H - 1) / 2 + 1) * Wo * 4 < 0x7fffffffLL;
       if (pair_ok && DMB_OPT(10) != 2)   // (A/B: 10 = 2 keeps the dword epilogue)
         return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
       return launch_s2<S2Cfg<0, 64, 4, 30, 2, 2, true, 2>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);

@@ -82,7 +82,7 @@ class PSMAggregator(nn.Module):
 
     def forward(self, raw_cost):
         B, C, D, H, W = raw_cost.shape
-        if ops.branch_overlap() and raw_cost.device.type == "cuda" and not train_fn.wants_grad(self, raw_cost):
+        if ops.branch_overlap(raw_cost) and raw_cost.device.type == "cuda" and not train_fn.wants_grad(self, raw_cost):
             return self._forward_overlapped(raw_cost)
         cost1, cost2, cost3 = self.trunk(raw_cost)
         size = (self.max_disp, H * 4, W * 4)                             # PSMNet.py:75-88, align_corners=True

@@ -314,19 +314,31 @@ def cat_fusion():
 # the chip.  With the switch on, the aggregators issue the branch on a second HIP stream (fork / join with events):
 # same kernels, same operands, identical results; 27.28 -> 27.03 ms per BASELINE step (scripts/overlap_probe.py).  The
 # opposite arrangement -- the dependent chain on a high-priority stream, the branches on the caller's -- gains half as much.
-# Off by default: under concurrency the per-kernel durations that the roofline accounting rests on (HIP events in bench.py,
-# rocprofv3 --stats) no longer describe one kernel alone; bench.py reports the overlapped step as a secondary leg.
-_branch_overlap = False
+# Default "auto" (round 5): on for launches of at most AUTO_OVERLAP_MAX_VOXELS quarter-resolution voxels -- ONE pair of up to
+# 544x960 / max_disp 192, the serving regime (dmb/apis/inference.py: one pair per call), where no layer fills the chip and the
+# branch's kernels run in the gaps of the dependent chain: 1.72 -> 1.62 ms at 256x512 / D 64, 7.48 -> 7.30 ms at 384x1248, 7.71 ->
+# 7.65 ms at 544x960 (profiles/r05_cosched_probe.log) -- and off for anything larger.  Under concurrency the per-kernel durations
+# that the roofline accounting rests on (HIP events in bench.py, rocprofv3 --stats) no longer describe one kernel alone, so bench.py's
+# timed loop switches it OFF explicitly and reports the overlapped batch-4 step as a secondary leg.
+_branch_overlap = "auto"
+AUTO_OVERLAP_MAX_VOXELS = 48 * 136 * 240
 _side_streams = {}
 
 
 def set_branch_overlap(flag):
+    """True / False, or "auto" (default): on for one small pair, off for batches (see above)."""
     global _branch_overlap
-    _branch_overlap = bool(flag)
+    _branch_overlap = "auto" if flag == "auto" else bool(flag)
 
 
-def branch_overlap():
-    return _branch_overlap
+def branch_overlap(raw_cost=None):
+    """The switch's value for a launch on the volume ``raw_cost`` ([B, C, D, H, W] tensor or description)."""
+    if _branch_overlap != "auto":
+        return _branch_overlap
+    if raw_cost is None:
+        return False
+    B, _, D, H, W = raw_cost.shape
+    return B * D * H * W <= AUTO_OVERLAP_MAX_VOXELS
 
 
 def side_stream(device, which=0):
