@@ -29,6 +29,7 @@ ABI_VERSION = 6
 SIGNATURES = {
     "dmb_abi_version": (_c_int, []),
     "dmb_last_error": (ctypes.c_char_p, []),
+    "dmb_build_id": (ctypes.c_char_p, []),
     "dmb_cat_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
     "dmb_dif_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
     "dmb_gwc_fms_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
@@ -139,6 +140,13 @@ def load():
     if lib.dmb_abi_version() != ABI_VERSION:
         raise DmbLibraryError("%s reports ABI version %d, this binding is written for %d: rebuild it (python -m "
                               "densematchingbenchmark_amd.build)" % (LIB_PATH, lib.dmb_abi_version(), ABI_VERSION))
+    tagged = DEV_BUILD and os.environ["DMB_LIB"] != "dev"     # (a build-time experiment: its defines are not known here)
+    if not tagged:
+        from . import build
+        want, got = build.sources_digest(dev=DEV_BUILD), (lib.dmb_build_id() or b"").decode()
+        if want != got:
+            raise DmbLibraryError("%s was built from other sources than the ones next to it (build id %s..., sources %s...): "
+                                  "rebuild it (python -m densematchingbenchmark_amd.build)" % (LIB_PATH, got[:12], want[:12]))
     if DEV_BUILD:
         lib.dmb_dev_set_option.restype = None
         lib.dmb_dev_set_option.argtypes = [_c_int, _c_int]

@@ -610,8 +610,10 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
   if (stride != 1 && stride != 2) return fail(DMB_EUNSUPPORTED, "conv2d: stride must be 1 or 2");
   if (in_channels_total < Ci || out_channels_total < Co || (residual && res_channels_total < Co))
     return fail(DMB_EINVAL, "conv2d: channel window");
+  // (+ 8: the staging adds the chunk's first channel, < Ci rounded up to the chunk size, to per-lane offsets of which DMA_OOB =
+  // 2^31 marks "outside the image": the sum must not wrap past 2^32 back into the tensor)
   if ((long long)in_channels_total * H * W * 4 >= 0x7fffffffLL || (long long)out_channels_total * H * W * 4 >= 0x7fffffffLL ||
-      (long long)res_channels_total * H * W * 4 >= 0x7fffffffLL)
+      (long long)res_channels_total * H * W * 4 >= 0x7fffffffLL || (long long)(Ci + 8) * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "conv2d: one batch item must stay below 2 GiB");
   const int NTT = cdiv(Co, 32);
   hipStream_t st = (hipStream_t)stream;

@@ -397,71 +397,116 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __
 
 // ------------------------------------------------------------------------------------------------------------------
 // One output channel (the classifier heads, nn.Conv3d(C, 1, 3, 1, 1)): dw[ci, tap] = sum_u x[ci, u] * dy[u - tap + 1].
-// 27 x C x voxels multiply-adds is nothing for the vector ALUs; the kernel is one coalesced pass over x with the 27 dy
-// neighbours from the cache hierarchy (dy is one channel), private sums per lane, one block reduction at the end, partials
-// per voxel chunk added in a fixed order.
+// Round 5: on the matrix cores.  It is a GEMM with M = 32 input channels, N = 27 taps (one 32 x 32 tile) and K = the voxels:
+// A[ci][u] = x[ci][u], B[u][tap] = dy[u - tap + 1] -- the 27 shifted views of ONE small dy neighbourhood.  A workgroup walks
+// tiles of 4 rows x 64 columns of one (b, z) plane, one row per wave: the x tile (32 channels x 4 x 64, read coalesced, 256 B per
+// channel row) and the dy neighbourhood (3 planes x 6 rows x 66 columns) are fetched into registers one tile AHEAD, committed to
+// LDS between two barriers, and a wave then issues 32 MFMAs (two voxels per k-step) whose A / B operands are single LDS dwords
+// (x pitch 65: conflict-free; taps 27 .. 31 read a zero row).  The round-1 form -- a VALU kernel, 27 address computations and
+// cached loads per voxel and channel group -- ran at 0.11 of the HBM rate (0.30 ms per head at the training shape; rocprofv3,
+// profiles/r05_train_pmc.csv): 10x the time of its one pass over x.  Partials per workgroup ([ci][tap], the four waves added in
+// a fixed order) go to the workspace and are added in a fixed order in FP64 by the reduce kernel: bit-reproducible, no atomics.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int C1_CHUNKS = 256, C1_CG = 4;   // voxel chunks; channels per thread
-// A thread owns voxels (coalesced along x) and C1_CG channels: the 27 dy neighbours of a voxel are loaded once for all of
-// them (27 loads against 8 x 27 multiply-adds), the 8 x 27 sums live in registers until one block reduction at the end.
-__global__ __launch_bounds__(256, 2) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 float* __restrict__ ws, int B, int Ci, int D, int H, int W) {
-  __shared__ float red[4][C1_CG * 27];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c0 = blockIdx.y * C1_CG;
-  // 32-bit index arithmetic throughout (the launcher checks B * D * H * W < 2^31): 64-bit divisions per voxel cost more than
-  // the 27 loads and the multiply-adds together
-  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
-  const unsigned vox = (unsigned)B * DHW;
-  const unsigned per = ((vox + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
-  const unsigned v0 = blockIdx.x * per, v1 = v0 + per < vox ? v0 + per : vox;
-  float acc[C1_CG][27];
+constexpr int C1M_XT = 64, C1M_ROWS = 4, C1M_XP = C1M_XT + 1;        // tile columns, rows (= waves), LDS pitch of an x row
+constexpr int C1M_DYP = 68, C1M_DYROWS = 3 * (C1M_ROWS + 2) + 1;     // dy neighbourhood: pitch, rows (+ 1 zero row)
+constexpr int C1M_XS = C1M_ROWS * 32 * C1M_XP, C1M_DYS = C1M_DYROWS * C1M_DYP;
+constexpr int C1M_XPT = C1M_ROWS * 32 * C1M_XT / 256;                // x words per thread and tile (32)
+constexpr int C1M_DYN = 3 * (C1M_ROWS + 2) * (C1M_XT + 2);           // dy words per tile (1188)
+constexpr int C1M_DPT = (C1M_DYN + 255) / 256;                       // ... per thread (5)
+static_assert(C1M_XS >= 4 * 32 * 33, "the wave reduction reuses the x tile");
+
+__global__ __launch_bounds__(256, 4) void conv3d_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ ws, int B, int Ci, int D, int H, int W,
+                                                                 int ntx, int nty, int ntiles) {
+  __shared__ float xs[C1M_XS];
+  __shared__ float dys[C1M_DYS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c0 = blockIdx.y * 32;
+  const long long HW = (long long)H * W, DHW = (long long)D * HW;
+  for (int i = tid; i < C1M_DYP; i += 256) dys[(C1M_DYROWS - 1) * C1M_DYP + i] = 0.f;   // the zero row (never overwritten)
+
+  float xr[C1M_XPT], dr[C1M_DPT];
+  auto fetch = [&](int t) {
+    const int tx = t % ntx;
+    int r = t / ntx;
+    const int ty = r % nty;
+    r /= nty;
+    const int z = r % D, b = r / D;
+    const int x0 = tx * C1M_XT, y0 = ty * C1M_ROWS;
+    const float* xb = x + ((long long)b * Ci + c0) * DHW + (long long)z * HW;
 #pragma unroll
-  for (int c = 0; c < C1_CG; ++c)
-#pragma unroll
-    for (int t = 0; t < 27; ++t) acc[c][t] = 0.f;
-  for (unsigned v = v0 + threadIdx.x; v < v1; v += 256) {
-    const unsigned b = v / DHW, r = v - b * DHW;
-    const unsigned zu = r / HW, r2 = r - zu * HW, yu = r2 / W;
-    const int z = (int)zu, y = (int)yu, xx = (int)(r2 - yu * W);
-    const float* db = dy + (size_t)b * DHW;
-    float dn[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      const int zz = z - t / 9 + 1, yy = y - (t / 3) % 3 + 1, xn = xx - t % 3 + 1;
-      const bool ok = zz >= 0 && zz < D && yy >= 0 && yy < H && xn >= 0 && xn < W;
-      dn[t] = ok ? db[(unsigned)zz * HW + (unsigned)yy * W + (unsigned)xn] : 0.f;
+    for (int q = 0; q < C1M_XPT; ++q) {
+      const int idx = q * 256 + tid;                  // (row, channel, column): 64 consecutive lanes = one 256-byte run
+      const int xx = idx & 63, ci = (idx >> 6) & 31, rr = idx >> 11;
+      const int gy = y0 + rr, gx = x0 + xx;
+      xr[q] = (c0 + ci < Ci && gy < H && gx < W) ? xb[(long long)ci * DHW + (long long)gy * W + gx] : 0.f;
     }
-    const float* xp = x + ((size_t)b * Ci + c0) * DHW + r;
+    const float* db = dy + (long long)b * DHW;
 #pragma unroll
-    for (int c = 0; c < C1_CG; ++c) {
-      const float xv = c0 + c < Ci ? xp[(size_t)c * DHW] : 0.f;
-#pragma unroll
-      for (int t = 0; t < 27; ++t) acc[c][t] = fmaf(xv, dn[t], acc[c][t]);
+    for (int q = 0; q < C1M_DPT; ++q) {
+      const int idx = q * 256 + tid;
+      const int cc = idx % (C1M_XT + 2), r2 = idx / (C1M_XT + 2), rr = r2 % (C1M_ROWS + 2), zz = r2 / (C1M_ROWS + 2);
+      const int gz = z - 1 + zz, gy = y0 - 1 + rr, gx = x0 - 1 + cc;
+      dr[q] = (idx < C1M_DYN && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) ? db[(long long)gz * HW + (long long)gy * W + gx] : 0.f;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < C1M_XPT; ++q) {
+      const int idx = q * 256 + tid;
+      xs[(idx >> 6) * C1M_XP + (idx & 63)] = xr[q];   // row index (rr * 32 + ci) = idx >> 6
+    }
+#pragma unroll
+    for (int q = 0; q < C1M_DPT; ++q) {
+      const int idx = q * 256 + tid;
+      if (idx < C1M_DYN) dys[(idx / (C1M_XT + 2)) * C1M_DYP + idx % (C1M_XT + 2)] = dr[q];
+    }
+  };
+
+  // operand addresses of this lane: A = x[channel i][voxel 2 s + k] of the wave's row, B = dy[voxel 2 s + k - tap j + 1]
+  const int i = lane & 31, k = lane >> 5;
+  const int tz = i / 9, tyy = (i / 3) % 3, txx = i % 3;
+  const float* ap = xs + (wave * 32 + i) * C1M_XP + k;
+  const float* bp = (i < 27) ? dys + ((2 - tz) * (C1M_ROWS + 2) + wave + 2 - tyy) * C1M_DYP + 2 - txx + k
+                             : dys + (C1M_DYROWS - 1) * C1M_DYP + k;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  int t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+    __syncthreads();          // every wave is done with the previous tile
+    commit();
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);   // lands while this tile is multiplied
+#pragma unroll 8
+    for (int s = 0; s < C1M_XT / 2; ++s) acc = DMB_MFMA(ap[2 * s], bp[2 * s], acc);
   }
-#pragma unroll
-  for (int c = 0; c < C1_CG; ++c)
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      float vsum = acc[c][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
-      if (lane == 0) red[wave][c * 27 + t] = vsum;
-    }
+  // the four waves' tiles, added in a fixed order (the x tile's LDS is free now)
   __syncthreads();
-  for (int i = threadIdx.x; i < C1_CG * 27; i += 256) {
-    const int c = i / 27, t = i - c * 27;
-    if (c0 + c < Ci) ws[((size_t)blockIdx.x * Ci + c0 + c) * 27 + t] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  float* red = xs;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 32 + cd_row(r, k)) * 33 + i] = acc[r];
+  __syncthreads();
+  for (int e = tid; e < 32 * 27; e += 256) {
+    const int ci = e / 27, tp = e - ci * 27;
+    if (c0 + ci < Ci)
+      ws[((size_t)blockIdx.x * Ci + c0 + ci) * 27 + tp] =
+          (red[ci * 33 + tp] + red[(32 + ci) * 33 + tp]) + (red[(64 + ci) * 33 + tp] + red[(96 + ci) * 33 + tp]);
   }
 }
 
-__global__ void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Ci, int nchunk) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per (channel, tap): the lanes walk the workgroups' partials 64 apart (independent loads; one thread walking all of
+// them alone was a chain of 256 .. 1024 dependent-latency loads, 63 us for 864 numbers), each in FP64, then a fixed butterfly.
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Ci, int nchunk) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= Ci * 27) return;
   double s = 0.0;
-  for (int c = 0; c < nchunk; ++c) s += (double)ws[(size_t)c * Ci * 27 + i];
-  dw[i] = (float)s;
+  for (int c = lane; c < nchunk; c += 64) s += (double)ws[(size_t)c * Ci * 27 + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) dw[i] = (float)s;
 }
 
 // dw[co][ci][tap] = sum over slots (fixed order, FP32 pairwise by halves of the slot range would not be more accurate than
@@ -529,9 +574,18 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
     return fail(DMB_EINVAL, "conv3d_wgrad: bad argument");
   if ((long long)32 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_wgrad: 32 channels of one batch item must stay below 2 GiB");
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 1 && (long long)B * D * H * W < 0x7fffffffLL) {   // classifier heads: the dedicated single-channel kernel
-    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(C1_CHUNKS, cdiv(Ci, C1_CG)), dim3(256), 0, st, x, dc, workspace, B, Ci, D, H, W);
-    hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(cdiv(Ci * 27, 256)), dim3(256), 0, st, workspace, dw, Ci, C1_CHUNKS);
+  if (Co == 1) {   // classifier heads: the single-output-channel form (M = channels, N = taps, K = voxels on the matrix cores)
+    const int ntx = cdiv(W, C1M_XT), nty = cdiv(H, C1M_ROWS);
+    const long long nt = (long long)B * D * ntx * nty;
+    if (nt > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_wgrad (1 channel): too many tiles");
+    // persistent grid: four workgroups per CU, bounded by the tiles and by the caller's workspace ([workgroup][Ci][27] partials)
+    long long g = 4LL * wgrad_slots();
+    const long long cap = dmb_conv3d_wgrad_workspace_floats(Co, Ci) / ((long long)Ci * 27);
+    if (g > nt) g = nt;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3((unsigned)g, cdiv(Ci, 32)), dim3(256), 0, st, x, dc, workspace, B, Ci, D, H, W, ntx, nty, (int)nt);
+    hipLaunchKernelGGL(conv3d_c1_wgrad_reduce_kernel, dim3(cdiv(Ci * 27, 4)), dim3(256), 0, st, workspace, dw, Ci, (int)g);
     return launch_status("conv3d_wgrad (1 channel) launch failed");
   }
   const int nblk = cdiv(Co, 32) * cdiv(Ci, 32);

@@ -41,7 +41,9 @@ def fast_cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1
     target is not positive.  Not equivalent to cat_fms: the reference samples a (size - 1)-normalised grid with
     F.grid_sample's align_corners=False default; csrc/warp_volume.hip reproduces that blend bit for bit.
     Under autograd the two feature maps get their gradients from the sampler's adjoint and per-pixel samples that require one
-    get theirs from the sampler's column derivative (``ops.fast_fms_bwd``), as the reference's do from F.grid_sample."""
+    get theirs from the sampler's column derivative (``ops.fast_fms_bwd``), as the reference's do from F.grid_sample.
+    Limit: when a gradient is requested the feature maps may be at most 1024 columns wide (train_fn.FAST_FMS_BWD_MAX_W: the
+    adjoint keeps two 8-channel rows in LDS); wider inputs raise NotImplementedError in the forward already."""
     wrt_samples = disp_sample is not None and disp_sample.requires_grad
     if disp_sample is None:
         disp_sample = ops.fast_disp_samples(max_disp, start_disp, dilation)

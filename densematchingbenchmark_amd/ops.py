@@ -446,7 +446,14 @@ def padded_rows_applicable(x, Co):
     transposed unit with its rows padded to the next multiple of 4 (zero padding columns): the transposed kernel's padded-row
     form needs an even W with 2 W % 4 == 0 ... i.e. W % 4 == 2, Co in (32, 64), whole 16-channel chunks."""
     W, Ci = x.shape[-1], x.shape[1]
-    return x.is_cuda and W % 4 == 2 and Co in (32, 64) and Ci % 16 == 0 and Ci >= 32
+    if not (x.is_cuda and W % 4 == 2 and Co in (32, 64) and Ci % 16 == 0 and Ci >= 32):
+        return False
+    # ... and what csrc/deconv3d_zy.hip::deconv3d_zy_try checks besides (it is the only form that takes a row-padded input: if it
+    # declined, dmb_deconv3d_k3s2_f32 would fail with DMB_EUNSUPPORTED where the unpadded path has a fallback): 16 input channels of
+    # one batch item and one batch item of the output below 2 GiB; 16-byte alignment holds for every tensor the allocator hands out
+    D, H = x.shape[2], x.shape[3]
+    Wp = (W + 3) // 4 * 4
+    return 16 * D * H * Wp * 4 < 2 ** 31 - 1 and Co * 8 * D * H * Wp * 4 < 2 ** 31 - 1 and x.data_ptr() % 16 == 0
 
 
 CATCONV_CH = 128   # channel count of the per-dz map tensors: 3 * Co used (Co <= 32), the rest are zero-weight rows

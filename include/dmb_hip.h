@@ -50,6 +50,11 @@ extern "C" {
 int dmb_abi_version(void);
 /* Static string describing the last DMB_E* code returned on this thread ("" if none). */
 const char* dmb_last_error(void);
+/* sha256 (hex) of the sources this binary was built from: every translation unit, the shared headers, this file and the
+ * compiler flags (densematchingbenchmark_amd/build.py::sources_digest).  The Python binding refuses a library whose id does
+ * not match the sources next to it -- a prebuilt library that travels with a snapshot is then PROVEN to be built from that
+ * snapshot's sources, not merely assumed to be. */
+const char* dmb_build_id(void);
 
 /* ------------------------------------------------------------------------------------------
  * Cost-volume builders

@@ -124,3 +124,68 @@ def test_accumulator_on_the_padded_maps_equals_calc_error_on_the_cropped_ones(de
     for i, got in enumerate(acc.summary()):
         want = dict(zip(KEYS, g["err%d" % i]))
         assert abs(got["epe"] - want["epe"]) <= 1e-5 * max(1.0, want["epe"]) and all(abs(got[k] - want[k]) <= 1e-3 for k in KEYS[1:])
+
+
+def test_resampling_and_crop_of_the_serving_api(dev, tmp_path):
+    """inference.py's other two pre-processing branches: ``crop_shape`` (CenterCrop of images AND disparities, then Normalize) and
+    ``scale_factor`` (F.interpolate(bilinear, align_corners=False) of the processed sample, disparities multiplied by the factor)
+    against the oracle / torch CPU on the demo pair; a scale that does not give an integral size refuses."""
+    import torch.nn.functional as F
+    from densematchingbenchmark_amd import ops
+    from densematchingbenchmark_amd.apis.inference import _resample, prepare_data
+    from densematchingbenchmark_amd.config import ConfigDict
+    from densematchingbenchmark_amd.data import CenterCrop, Compose, Normalize, ToTensor
+    g = golden("demo_sceneflow.npz")
+    paths = _demo_files(g, tmp_path)
+    tf = Compose([ToTensor(dev), CenterCrop((512, 896)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])
+    for scale in (1.0, 0.5):
+        proc, ori = prepare_data(paths, tf, ConfigDict(scale_factor=scale, disp_div_factor=1.0), dev)
+        from densematchingbenchmark_amd.data import imread
+        want_img = O.normalize(O.center_crop(O.image_to_chw(imread(paths["left_image_path"])), (512, 896))).unsqueeze(0)
+        want_disp = O.center_crop(torch.from_numpy(np.ascontiguousarray(ori["leftDisp"]))[None], (512, 896)).unsqueeze(0)
+        if scale != 1.0:
+            want_img = F.interpolate(want_img, scale_factor=scale, mode="bilinear", align_corners=False)
+            want_disp = F.interpolate(want_disp * scale, scale_factor=scale, mode="bilinear", align_corners=False)
+        assert tuple(proc["leftImage"].shape) == tuple(want_img.shape) and proc["rightDisp"] is None
+        assert maxdiff(proc["leftImage"], want_img) <= (0.0 if scale == 1.0 else 2e-6)
+        assert maxdiff(proc["leftDisp"], want_disp) <= (0.0 if scale == 1.0 else 2e-5)
+    with pytest.raises(NotImplementedError):
+        _resample(torch.zeros(1, 1, 15, 20, device=dev), 0.3)
+
+
+def test_graphed_forward_tracks_shapes_and_parameters(dev):
+    """graph_runner.GraphedForward: one graph per input signature (oldest evicted), replays equal the eager forward bit for bit on
+    fresh inputs, and an in-place parameter change re-captures (the captured launches hold the packed weights of their moment)."""
+    from densematchingbenchmark_amd import synthetic
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.graph_runner import GraphedForward, wants_graph
+    from densematchingbenchmark_amd.modeling import build_model
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "PSMNet", "baseline_cfg0_256x512_d64.py"))
+    model = build_model(cfg).eval()                      # backbone included: two view streams inside the capture
+    synthetic.init_params_(model, seed=3, classif_gain=10.0)
+    model = model.to(dev)
+    runner = GraphedForward(model, max_graphs=2)
+
+    def images(seed, h, w):
+        gen = torch.Generator().manual_seed(seed)
+        return dict(leftImage=torch.randn((1, 3, h, w), generator=gen).to(dev), rightImage=torch.randn((1, 3, h, w), generator=gen).to(dev))
+
+    def same(batch):
+        got = [t.clone() for t in runner(batch)[0]["disps"]]
+        with torch.no_grad():
+            want = model(batch)[0]["disps"]
+        return all(torch.equal(a, b) for a, b in zip(got, want))
+
+    # (the PSMNet backbone pools 64 x 64 windows at quarter resolution: 256 rows / columns is its smallest input)
+    assert wants_graph(images(0, 256, 512)) and not wants_graph(dict(leftImage=torch.zeros(1, 3, 8, 8)))
+    assert same(images(1, 256, 512)) and same(images(2, 256, 512)) and len(runner._graphs) == 1
+    assert same(images(3, 256, 256)) and len(runner._graphs) == 2
+    assert same(images(4, 320, 256)) and len(runner._graphs) == 2            # the 256x512 graph was evicted
+    with torch.no_grad():
+        model.cost_processor.aggregator.classif3[1].weight.mul_(1.5)         # in place: version bump, same storage
+    before = runner._graphs
+    assert same(images(5, 320, 256))
+    assert len(runner._graphs) == 1 and runner._graphs is before             # reset + one fresh capture
+    model.train()
+    with pytest.raises(RuntimeError):
+        GraphedForward(model)(images(6, 256, 256))

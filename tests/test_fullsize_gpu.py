@@ -196,6 +196,33 @@ def test_fp64_yardstick_psmnet_all_four_pairs(dev):
             del c64
 
 
+def test_fp64_yardstick_psmnet_in_the_opt_in_bf16x6_mode(dev):
+    """The opt-in split arithmetic (csrc/conv3d_x6.hip: every FP32 operand of the stride-1 layers as three bf16 pieces, six
+    products, FP32 accumulate) under the SAME full-path contract as the exact mode, on two pairs of the bench batch: it stays a
+    secondary leg of bench.py (dtype of the headline is f32), but what it reports is gated by the path-level test, not only by
+    the per-layer one (tests/test_kernels_gpu.py::test_conv3d_bf16x6_is_as_accurate_as_fp32)."""
+    from densematchingbenchmark_amd import ops, synthetic
+    cfg, model = _built("PSMNet/scene_flow.py", 0)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    left, right = synthetic.feature_batch(0, 1, 2, 32, 136, 240, dev)
+    ops.set_conv3d_mode("bf16x6")
+    try:
+        results, _ = model(dict(leftFeature=left, rightFeature=right))
+    finally:
+        ops.set_conv3d_mode("exact")
+    gpu = [d.cpu() for d in results["disps"]]
+    del results
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    with torch.no_grad():
+        for i in range(2):
+            lf, rf = synthetic.feature_pair(i, 32, 136, 240)
+            ref32, _ = O.psmnet_path(lf, rf, p, 192)
+            c64 = _truth(lambda d: O.psm_aggregator(O.cat_fms(lf, rf, 48, 0, 1).double().to(d), _f64(p, d), 192, "cost_processor.aggregator."), dev)
+            _assert_yardstick("psmnet pair %d, bf16x6" % i, [d[i:i + 1] for d in gpu], ref32, c64)
+            del c64
+
+
 def test_fp64_yardstick_acfnet(dev):
     """BASELINE configs[3]: the learned k8/s4 up-sampling instead of the trilinear one."""
     from densematchingbenchmark_amd import synthetic

@@ -435,3 +435,41 @@ def test_binding_constants_match_the_header():
     text = open(_lib.HEADER_PATH).read()
     assert int(re.search(r"#define DMB_DECONV3D_WORKSPACE_BYTES (\d+)", text).group(1)) == _lib.DECONV3D_WORKSPACE_BYTES
     assert "ABI version" in text and "(6:" in text and _lib.ABI_VERSION == 6
+
+
+def test_data_side_and_serving_api_refuse_host_tensors():
+    """The data-side transforms and the graph policy have no CPU path either: host tensors raise, and the auto policy never asks
+    for a graph on them."""
+    from densematchingbenchmark_amd.data import Compose, Normalize, StereoPad
+    from densematchingbenchmark_amd.graph_runner import wants_graph
+    sample = dict(leftImage=torch.zeros(3, 8, 12), rightImage=torch.zeros(3, 8, 12))
+    with pytest.raises(_lib.DmbLibraryError):
+        Compose([StereoPad((8, 16)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])(dict(sample))
+    with pytest.raises(_lib.DmbLibraryError):
+        ops.stereo_pad_normalize(torch.zeros(1, 3, 8, 12), (8, 16))
+    assert not wants_graph(sample) and not wants_graph({})
+    from densematchingbenchmark_amd.apis import init_model, is_image_file, is_pfm_file
+    assert is_image_file("a/b.png") and is_pfm_file("x.pfm") and not is_image_file("x.pfm")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = init_model(os.path.join(root, "configs", "PSMNet", "scene_flow.py"), None, "cpu")
+    assert m.backbone is not None and not m.training and m.cfg.model.max_disp == 192
+    sd = {"module." + k: v for k, v in m.state_dict().items()}          # a DataParallel checkpoint as mmcv writes it
+    m2 = init_model(os.path.join(root, "configs", "PSMNet", "scene_flow.py"), {"state_dict": sd}, "cpu")
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_branch_overlap_auto_policy():
+    """Default "auto": on for ONE pair of up to 544x960 / max_disp 192 at quarter resolution, off for batches; explicit values win."""
+    class V:
+        def __init__(self, *shape):
+            self.shape = shape
+    try:
+        ops.set_branch_overlap("auto")
+        assert ops.branch_overlap(V(1, 64, 48, 136, 240)) and ops.branch_overlap(V(1, 64, 16, 64, 128))
+        assert not ops.branch_overlap(V(4, 64, 48, 136, 240)) and not ops.branch_overlap(V(2, 64, 48, 96, 312)) and not ops.branch_overlap()
+        ops.set_branch_overlap(True)
+        assert ops.branch_overlap(V(4, 64, 48, 136, 240)) is True
+        ops.set_branch_overlap(False)
+        assert ops.branch_overlap(V(1, 64, 16, 64, 128)) is False
+    finally:
+        ops.set_branch_overlap("auto")
