@@ -388,8 +388,14 @@ def training_leg(cfg, dev, steps):
         one()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # arithmetic of one iteration = forward + data gradients + weight gradients = 3 x the forward's (SURVEY 8-d figure of the
+    # reference's formulation, scaled by the crop's area: in training the first layer runs on the materialised volume);
+    # rocprofv3 counts 3048 GFLOP of matrix instructions per step at this shape (profiles/r05_train_pmc.csv) against 3060 here
+    gflop = 3.0 * PATH_GFLOP_PER_PAIR * (H * W) / (544.0 * 960.0) * B
     out = {"pairs_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "workload": "PSMNet cost path, training mode, batch %d x %dx%d crops, max_disp=192, Adam" % (B, H, W),
+           "gflop_per_step": round(gflop, 1), "frac_fp32_peak": round(gflop / (dt / steps) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+           "per_kernel_roofline": "profiles/r05_train_pmc.csv",
            "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
     del model, flat, opt, batch
     torch.cuda.empty_cache()

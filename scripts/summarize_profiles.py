@@ -16,7 +16,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 # the dominant kernel's instantiation and its launch shape: the 48 x 4 row pairs at 544x960, the 32 x 4 row pairs at 384x1248 (KITTI)
 DOM = os.environ.get("DOM_PREFIX", "conv3d_s1_kernel<S1Cfg<0, 32, 4, 48")
 DOM_SHAPE = [int(v) for v in os.environ.get("DOM_SHAPE", "4,32,48,136,240").split(",")]
-WHAT = os.environ.get("PROF_CONFIG", "")
+WHAT = " ".join(([("--config " + os.environ["PROF_CONFIG"])] if os.environ.get("PROF_CONFIG") else []) +
+                ([("--batch " + os.environ["PROF_BATCH"])] if os.environ.get("PROF_BATCH") else []))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 DST = os.path.join(ROOT, "profiles")
@@ -45,7 +46,7 @@ for k, v in d.items():
 total = sum(sum(keep) for _, keep, _ in stats)
 stats.sort(key=lambda e: -sum(e[1]))
 with open(os.path.join(DST, tag + "_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras %s--steps 5 --warmup 2  (MI355X, batch 4; scripts/profile.sh)\n" % ("--config %s " % WHAT if WHAT else ""))
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras %s--steps 5 --warmup 2  (MI355X; scripts/profile.sh)\n" % (WHAT + " " if WHAT else ""))
     f.write("# from the per-dispatch trace; a launch stretched to more than 4x its kernel's median by the profiler is left out and listed in the last column (scripts/summarize_profiles.py)\n")
     f.write("kernel,calls,total_ms,avg_us,percent,min_us,max_us,left_out\n")
     for k, keep, out in stats:
