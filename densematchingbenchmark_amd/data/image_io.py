@@ -12,7 +12,7 @@ def imread(path):
     with Image.open(path) as im:
         if im.mode not in ("RGB", "RGBA", "L"):
             im = im.convert("RGB")
-        arr = np.asarray(im)
+        arr = np.array(im)          # (a writable copy: the sample dict is handed to torch.from_numpy)
     if arr.ndim == 2:
         arr = arr[:, :, None]
     return np.ascontiguousarray(arr)

@@ -55,6 +55,12 @@ def test_transforms_equal_the_reference_bit_for_bit(dev, tmp_path):
     got = Compose([ToTensor(dev), CenterCrop((256, 512)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])(
         dict(leftImage=raw["left"], rightImage=raw["right"], leftDisp=np.zeros((1, 540, 960), np.float32)))
     assert torch.equal(got["leftImage"].cpu(), want) and tuple(got["leftDisp"].shape) == (1, 256, 512)
+    from densematchingbenchmark_amd.disp_io import load_scene_flow_disp
+    disp = np.ascontiguousarray(load_scene_flow_disp(paths["left_disp_map_path"]))[None]
+    got = Compose([ToTensor(dev), CenterCrop((512, 896)), Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])(
+        dict(leftImage=raw["left"], rightImage=raw["right"], leftDisp=disp))                     # ... and the reference's own crop
+    assert np.array_equal(got["leftImage"][:, ::37, :].cpu().numpy(), g["crop_left_rows"])
+    assert np.array_equal(got["leftDisp"][:, ::37, :].cpu().numpy(), g["crop_disp_rows"])
     with pytest.raises(Exception):
         StereoPad((544, 960))(dict(leftImage=torch.zeros(3, 540, 960), rightImage=torch.zeros(3, 540, 960)))   # host tensors: no CPU path
 

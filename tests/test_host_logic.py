@@ -473,3 +473,36 @@ def test_branch_overlap_auto_policy():
         assert ops.branch_overlap(V(1, 64, 16, 64, 128)) is False
     finally:
         ops.set_branch_overlap("auto")
+
+
+def test_library_refuses_a_binary_built_from_other_sources(monkeypatch):
+    """The library carries the sha256 of the sources it was linked from (dmb_build_id); the binding recomputes it from the sources
+    next to the library and refuses a mismatch -- here simulated by a digest function that sees 'other' sources."""
+    from densematchingbenchmark_amd import build
+    lib = _lib.load()
+    assert lib.dmb_build_id().decode() == build.sources_digest(dev=_lib.DEV_BUILD) and len(lib.dmb_build_id()) == 64
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "sources_digest", lambda dev=False, defs="": "0" * 64)
+    with pytest.raises(_lib.DmbLibraryError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
+
+
+def test_graph_runner_flattens_nested_batches():
+    from densematchingbenchmark_amd.graph_runner import _flatten, _rebuild
+    a, b, c = torch.zeros(1), torch.ones(2), torch.full((3,), 2.0)
+    batch = dict(leftFeature=(a, b), rightFeature=c, original_size=(540, 960), name="x")
+    flat = _flatten(batch)
+    assert [p for p, _ in flat] == ["/leftFeature/0", "/leftFeature/1", "/rightFeature"]
+    again = _rebuild(batch, {p: t + 1 for p, t in flat})
+    assert isinstance(again["leftFeature"], tuple) and torch.equal(again["leftFeature"][1], b + 1) and again["original_size"] == (540, 960)
+
+
+def test_baseline_cfg0_config_builds():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "baseline_cfg0_256x512_d64.py"))
+    assert cfg.model.max_disp == 64 and cfg.model.cost_processor.cost_computation.max_disp == 16 and list(cfg.data.eval.input_shape) == [256, 512]
+    from densematchingbenchmark_amd.modeling import build_model
+    m = build_model(cfg)
+    assert m.backbone is not None and m.disp_predictor.max_disp == 64

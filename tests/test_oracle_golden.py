@@ -768,6 +768,10 @@ def test_oracle_data_conventions_and_whole_model_on_the_reference_demo_pair(tmp_
     assert maxdiff(li[0, :, 0, 0], pad) <= 1e-6 and maxdiff(li[0, :, 3, 959], pad) <= 1e-6      # padded BEFORE normalisation
     gt = torch.from_numpy(np.ascontiguousarray(load_scene_flow_disp(paths["left_disp_map_path"])))
     assert np.array_equal(gt[::45].numpy(), g["ori_left_disp_rows"])
+    # the crop branch (the reference's CenterCrop + Normalize on the same files): images and disparity
+    crop = O.normalize(O.center_crop(O.image_to_chw(imread(paths["left_image_path"])), (512, 896)))
+    assert tuple(crop.shape) == tuple(g["crop_shape"]) and np.array_equal(crop[:, ::37, :].numpy(), g["crop_left_rows"])
+    assert np.array_equal(O.center_crop(gt[None], (512, 896))[:, ::37, :].numpy(), g["crop_disp_rows"])
     p = _demo_model_params()
     with torch.no_grad():
         disps, costs = O.psmnet_model(li, ri, p, 192)
