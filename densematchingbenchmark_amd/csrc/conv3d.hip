@@ -1639,17 +1639,22 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       // of the output addressable with 32-bit byte offsets
       const bool pair_ok = ((((uintptr_t)y | (uintptr_t)residual) & 7) == 0) && (long long)Co * Do * Ho * Wo * 4 < 0x7fffffffLL;
       const bool narrow = cdiv(Wo, 22) * 96 < cdiv(Wo, 30) * 128;
-      // (round 5) A launch of at most ONE workgroup per CU (batch 1, small images: 108 four-row workgroups at 544x960 / batch 1,
-      // 16 at 256x512) takes as long as the column tiles ONE SIMD runs for a workgroup, one after the other -- 4 with the 4 x 30
-      // eight-wave tiles, 3 with 4 x 22: two-row (2 per SIMD) or one-row tiles (1) shorten that chain at the price of more halo
-      // rows per output, which a launch that leaves CUs idle does not feel (112 -> 59 us at [1, 64, 24, 68, 120]).
+      // (round 5) Tile height by estimate.  What a CU holds is ceil(workgroups / CUs) workgroups, and one SIMD runs a workgroup's
+      // column tiles one after the other -- 4 with the 4 x 30 eight-wave tiles, 3 with 4 x 22, 2 with two-row tiles, 1 with one-row
+      // tiles -- so finer tiles shorten the chain of a launch that leaves CUs idle (batch 1, small images: 112 -> 59 us at
+      // [1, 64, 24, 68, 120]) and even out a grid that does not divide over the chip (432 four-row workgroups on 256 CUs: the
+      // 64 -> 64 layer at batch 4, 201 -> 188 us on 1632 one-row ones), at the price of more halo rows per output: efficiencies
+      // fitted to profiles/r05_s2_tile_probe.log and r05_kbench_small.log (same results bit for bit whatever the tile).
       const long long nz = (long long)B * cdiv(Do, 2);
-      const long long n_old = nz * (narrow ? cdiv(Wo, 22) : cdiv(Wo, 30)) * cdiv(Ho, 4);
-      if (pair_ok && n_old <= num_cus() && DMB_OPT(10) == 0) {
-        const int ncu = num_cus();
-        const double c_old = (double)cdiv_ll(n_old, ncu) * (narrow ? 3.1 : 4.1);
-        const double c_two = (double)cdiv_ll(nz * cdiv(Wo, 30) * cdiv(Ho, 2), ncu) * 2.1 / 0.9;
-        const double c_one = (double)cdiv_ll(nz * cdiv(Wo, 30) * Ho, ncu) * 1.1 / 0.8;
+      const int ncu = num_cus();
+      const double c_old = (double)cdiv_ll(nz * (narrow ? cdiv(Wo, 22) : cdiv(Wo, 30)) * cdiv(Ho, 4), ncu) * (narrow ? 3.0 / 0.85 : 4.0);
+      const double c_two = (double)cdiv_ll(nz * cdiv(Wo, 30) * cdiv(Ho, 2), ncu) * 2.0 / 0.97;
+      const double c_one = (double)cdiv_ll(nz * cdiv(Wo, 30) * Ho, ncu) * 1.0 / 0.94;
+#ifdef DMB_DEV
+      if (pair_ok && DMB_OPT(10) == 3) return launch_s2<S2Cfg<0, 64, 1, 30, 2, 2, true, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      if (pair_ok && DMB_OPT(10) == 4) return launch_s2<S2Cfg<0, 64, 2, 30, 2, 2, true, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+#endif
+      if (pair_ok && DMB_OPT(10) == 0) {
         if (c_one < c_two && c_one < c_old)
           return launch_s2<S2Cfg<0, 64, 1, 30, 2, 2, true, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
         if (c_two < c_old)

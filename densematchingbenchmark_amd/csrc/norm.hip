@@ -94,13 +94,20 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ c, const doub
                                          float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean_out,
                                          float* __restrict__ invstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
                                          int B, int C, long long S, int nsplit) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= C) return;
+  // one wave per channel: the lanes walk the slices 64 apart (independent loads) and a fixed butterfly adds them -- one thread
+  // walking up to 128 slices alone was a chain of dependent-latency loads, 10 us for a kernel that does nothing else
+  const int ch = blockIdx.x, lane = threadIdx.x;
   double sum = 0.0, sq = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
+  for (int s = lane; s < nsplit; s += 64) {
     sum += ws[((long long)ch * nsplit + s) * 2];
     sq += ws[((long long)ch * nsplit + s) * 2 + 1];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_down(sum, o, 64);
+    sq += __shfl_down(sq, o, 64);
+  }
+  if (lane != 0) return;
   const double n = (double)B * (double)S;
   const double dm = sum / n;                      // mean - pivot
   double var = sq / n - dm * dm;
@@ -200,13 +207,18 @@ __global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const float* __restri
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                        int nsplit) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= C) return;
+  const int ch = blockIdx.x, lane = threadIdx.x;   // one wave per channel (see bn_stats_finalize_kernel)
   double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
+  for (int s = lane; s < nsplit; s += 64) {
     s1 += ws[((long long)ch * nsplit + s) * 2];
     s2 += ws[((long long)ch * nsplit + s) * 2 + 1];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_down(s1, o, 64);
+    s2 += __shfl_down(s2, o, 64);
+  }
+  if (lane != 0) return;
   dbeta[ch] = (float)s1;
   dgamma[ch] = (float)s2;
 }
@@ -326,7 +338,7 @@ extern "C" int dmb_bn_train_stats_f32(const float* c, const float* gamma, const 
   const int nsplit = bn_nsplit(C, S);
   const int vec = S % 4 == 0 && ((uintptr_t)c & 15) == 0;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NB), 0, st, c, workspace, B, C, S, nsplit, vec);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, c, workspace, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, c, workspace, gamma, beta, running_mean,
                      running_var, momentum, eps, mean_out, invstd_out, scale_out, shift_out, B, C, S, nsplit);
   return launch_status("bn_train_stats launch failed");
 }
@@ -353,7 +365,7 @@ extern "C" int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* 
   const int vec = S % 4 == 0 && (((uintptr_t)dy | (uintptr_t)c | (uintptr_t)y | (uintptr_t)dc | (uintptr_t)dres) & 15) == 0;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nsplit, C), dim3(NB), 0, st, dy, c, y, scale, shift, mean, invstd, workspace, B, C, S,
                      nsplit, relu, vec);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, workspace, dgamma, dbeta, C, nsplit);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, dgamma, dbeta, C, nsplit);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(total, vec ? 8 : 2)), dim3(NB), 0, st, dy, c, y, scale, shift, mean,
                      invstd, dgamma, dbeta, dc, dres, C, S, total, (float)(1.0 / ((double)B * (double)S)), relu, training, vec);
   return launch_status("bn_act_bwd launch failed");
