@@ -121,11 +121,11 @@ def _inference_single(model, batchDict, img_transform, device, graph="auto", sav
     ori_size = procData['original_size'] if cfg.pad_to_shape is not None else None
     name = batchDict['left_image_path'].split('/')[-1].split('.')[0]
     save_root = osp.join(cfg.log_dir, name)
-    if not save:
-        return {'Result': result_io.crop_result(result, ori_size, cfg.scale_factor), 'OriginalData': oriData}
-    path = result_io.save_result(result, oriData, save_root, ori_size, cfg.scale_factor)
-    print('Result of {} will be saved to {}!'.format(batchDict['left_image_path'].split('/')[-1], path))
-    return result_io.load_result(path)
+    logData = {'Result': result_io.crop_result(result, ori_size, cfg.scale_factor), 'OriginalData': result_io.to_cpu(oriData)}
+    if save:
+        path = result_io.dump_log(logData, save_root)
+        print('Result of {} will be saved to {}!'.format(batchDict['left_image_path'].split('/')[-1], path))
+    return logData
 
 
 def inference_stereo(model, batchesDict, log_dir, pad_to_shape=None, crop_shape=None, scale_factor=1.0, disp_div_factor=1.0,

@@ -10,8 +10,8 @@ def imread(path):
     except ImportError as e:   # loud: no silent alternative decoder
         raise ImportError("densematchingbenchmark_amd.data.imread needs PIL (Pillow) to decode %s" % path) from e
     with Image.open(path) as im:
-        if im.mode not in ("RGB", "RGBA", "L"):
-            im = im.convert("RGB")
+        if im.mode in ("P", "PA", "LA", "CMYK", "YCbCr", "1"):   # palette / exotic colour models: what imageio hands back is RGB
+            im = im.convert("RGB")                                 # (8-bit grey, 16-bit "I;16" -- KITTI disparities -- and "I" / "F" stay as they are)
         arr = np.array(im)          # (a writable copy: the sample dict is handed to torch.from_numpy)
     if arr.ndim == 2:
         arr = arr[:, :, None]

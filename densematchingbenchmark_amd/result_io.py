@@ -44,16 +44,19 @@ def crop_result(results, original_size=None, scale_factor=1.0):
     return result
 
 
-def save_result(results, original_data, save_root, original_size=None, scale_factor=1.0):
-    """Write ``<save_root>/result.pkl`` in the reference's layout (inference.py:197-223); returns the path.
-    Every tensor of every list (``disps``, ``costs`` and, for AcfNet, ``confs``) goes through ``crop_result``; pickle
-    protocol 2 = what ``mmcv.dump`` writes for a .pkl path."""
-    log_data = {"Result": crop_result(results, original_size, scale_factor), "OriginalData": to_cpu(original_data)}
+def dump_log(log_data, save_root):
+    """``mmcv.dump(logData, <save_root>/result.pkl)`` (inference.py:213-223): pickle protocol 2 = what mmcv writes for a .pkl path."""
     os.makedirs(save_root, exist_ok=True)
     path = os.path.join(save_root, "result.pkl")
     with open(path, "wb") as fp:
         pickle.dump(log_data, fp, protocol=2)
     return path
+
+
+def save_result(results, original_data, save_root, original_size=None, scale_factor=1.0):
+    """Write ``<save_root>/result.pkl`` in the reference's layout (inference.py:197-223); returns the path.
+    Every tensor of every list (``disps``, ``costs`` and, for AcfNet, ``confs``) goes through ``crop_result``."""
+    return dump_log({"Result": crop_result(results, original_size, scale_factor), "OriginalData": to_cpu(original_data)}, save_root)
 
 
 def load_result(path):

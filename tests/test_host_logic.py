@@ -506,3 +506,20 @@ def test_baseline_cfg0_config_builds():
     from densematchingbenchmark_amd.modeling import build_model
     m = build_model(cfg)
     assert m.backbone is not None and m.disp_predictor.max_disp == 64
+
+
+def test_imread_keeps_16_bit_disparity_pngs(tmp_path):
+    """KITTI ground truth is a 16-bit PNG (disparity * 256, apis/inference.py:36-46 divides by disp_div_factor): the decoder
+    wrapper must hand back the 16-bit values, as imageio does, not an 8-bit conversion."""
+    from PIL import Image
+    from densematchingbenchmark_amd.apis import load_disp
+    from densematchingbenchmark_amd.data import imread
+    a = (np.arange(12, dtype=np.uint16).reshape(3, 4) * 5000)
+    Image.fromarray(a).save(str(tmp_path / "k.png"))
+    got = imread(str(tmp_path / "k.png"))
+    assert got.dtype == np.uint16 and np.array_equal(got.squeeze(), a)
+    d = load_disp({"left_disp_map_path": str(tmp_path / "k.png")}, "left_disp_map_path", 256.0)
+    assert d.dtype == np.float32 and d.shape == (3, 4) and np.allclose(d, a.astype(np.float32) / 256.0)
+    rgb = (np.arange(36, dtype=np.uint8).reshape(3, 4, 3))
+    Image.fromarray(rgb).save(str(tmp_path / "c.png"))
+    assert np.array_equal(imread(str(tmp_path / "c.png")), rgb)
