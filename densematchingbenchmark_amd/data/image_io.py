@@ -13,6 +13,4 @@ def imread(path):
         if im.mode in ("P", "PA", "LA", "CMYK", "YCbCr", "1"):   # palette / exotic colour models: what imageio hands back is RGB
             im = im.convert("RGB")                                 # (8-bit grey, 16-bit "I;16" -- KITTI disparities -- and "I" / "F" stay as they are)
         arr = np.array(im)          # (a writable copy: the sample dict is handed to torch.from_numpy)
-    if arr.ndim == 2:
-        arr = arr[:, :, None]
-    return np.ascontiguousarray(arr)
+    return np.ascontiguousarray(arr)      # [H, W, C], or [H, W] for a single-channel file -- as imageio returns it

@@ -517,7 +517,7 @@ def test_imread_keeps_16_bit_disparity_pngs(tmp_path):
     a = (np.arange(12, dtype=np.uint16).reshape(3, 4) * 5000)
     Image.fromarray(a).save(str(tmp_path / "k.png"))
     got = imread(str(tmp_path / "k.png"))
-    assert got.dtype == np.uint16 and np.array_equal(got.squeeze(), a)
+    assert got.dtype == np.uint16 and got.shape == (3, 4) and np.array_equal(got, a)
     d = load_disp({"left_disp_map_path": str(tmp_path / "k.png")}, "left_disp_map_path", 256.0)
     assert d.dtype == np.float32 and d.shape == (3, 4) and np.allclose(d, a.astype(np.float32) / 256.0)
     rgb = (np.arange(36, dtype=np.uint8).reshape(3, 4, 3))
