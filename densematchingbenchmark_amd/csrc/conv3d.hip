@@ -1303,7 +1303,10 @@ __device__ __forceinline__ float dpp_row_shl1(float v) {   // lane i <- lane i +
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
 
-__global__ __launch_bounds__(256, 2) void conv3d_c1v_kernel(const float* __restrict__ x, const float* __restrict__ w,
+#ifndef DMB_C1V_WPE
+#define DMB_C1V_WPE 2   // workgroups per CU the register allocation is held to (build-time experiment knob)
+#endif
+__global__ __launch_bounds__(256, DMB_C1V_WPE) void conv3d_c1v_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float bias, const float* __restrict__ res,
                                                             float* __restrict__ y, int Ci, int D, int H, int W, int ntx,
                                                             int nty, int ntz) {
