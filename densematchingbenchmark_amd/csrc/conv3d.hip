@@ -1540,6 +1540,7 @@ extern "C" int dmb_conv3d_pack_dgrad_weights_f32(const float* w, float* wpack, i
 // table of image widths: e.g. 240 columns -> 48-column row pairs (5 tiles, nothing discarded), 312 columns (KITTI, 1248 / 4) ->
 // 24-column row quads of 8 rows (13 tiles, nothing discarded), 156 -> 40-column row quads (4 tiles, 2.5 % discarded).
 // Without 16-byte rows: the flattened mapping (dword staging) with the TX (60 or 52) that wastes fewer columns.
+constexpr double S1_EFF_32x2 = 1.0;    // 32 x 2 row pairs (two column tiles per wave): measured rate relative to the estimate, profiles/r05_kbench_small_32.log
 struct S1Tile {
   int tx, ty, tz, mt, wpe;   // tile extent, 32-voxel column tiles per wave, workgroups per CU
   bool lin;                  // 64-voxel runs of the (y, x) plane instead of boxes
@@ -1600,12 +1601,14 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
         // row pairs (16 columns x 2 rows per 32-voxel column tile) of 48 or 32 columns x 4 rows, row quads (8 x 4) of 24 columns x 8
         // rows; one z-slice per wave, three workgroups per CU each
         // (8-row quads stage a quarter more halo rows per byte of output and store 32-byte instead of 64-byte runs: 0.972)
-        static const S1Tile cand[3] = {{48, 4, 4, 6, 3, false, 1.0}, {24, 8, 4, 6, 3, false, 0.972}, {32, 4, 4, 4, 3, false, 1.0}};
-        const bool ok[3] = {true, true, true};
-        switch (s1_pick(cand, ok, 3, B, D, H, W)) {
+        static const S1Tile cand[4] = {{48, 4, 4, 6, 3, false, 1.0}, {24, 8, 4, 6, 3, false, 0.972}, {32, 4, 4, 4, 3, false, 1.0},
+                                       {32, 2, 4, 2, 3, false, S1_EFF_32x2}};
+        const bool ok[4] = {true, true, true, true};
+        switch (s1_pick(cand, ok, 4, B, D, H, W)) {
           case 0: return DMB_S1(32, 4, 48, 1, 16, 0);
           case 1: return DMB_S1(32, 8, 24, 1, 8, 40);
-          default: return DMB_S1(32, 4, 32, 1, 16, 0);
+          case 2: return DMB_S1(32, 4, 32, 1, 16, 0);
+          default: return DMB_S1(32, 2, 32, 1, 16, 0);
         }
       }
       return tx == 52 ? DMB_S1(32, 4, 52, 1, 0, 0) : DMB_S1(32, 4, 60, 1, 0, 0);

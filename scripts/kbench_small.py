@@ -54,6 +54,10 @@ for D, H, W in ((16, 64, 128), (48, 136, 240), (48, 96, 312)):
     print("B = %d, quarter-resolution volume %d x %d x %d" % (B, D, H, W))
     f, fl = conv(32, 32, 1, D, H, W)
     line("32->32 full (library's pick)", timeit(f), fl)
+    for cand, what in ((1, "48 x 4 pairs"), (2, "24 x 8 quads"), (3, "32 x 4 pairs"), (4, "32 x 2 pairs")):
+        lib.dmb_dev_set_option(19, cand)
+        line("32->32 full on " + what, timeit(f), fl)
+    lib.dmb_dev_set_option(19, 0)
     for name, (Ci, Co, s, sc) in (("conv1 s2 32->64 full->half", (32, 64, 2, 1)), ("conv3 s2 64->64 half->quarter", (64, 64, 2, 2))):
         f, fl = conv(Ci, Co, s, D // sc, H // sc, W // sc)
         line(name + " (library's pick)", timeit(f), fl)
