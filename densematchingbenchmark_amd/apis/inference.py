@@ -23,11 +23,11 @@ from ..evaluation.stereo import remove_padding
 from ..graph_runner import GraphedForward, wants_graph
 from ..modeling import build_model
 
-IMG_EXTENSIONS = ['.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP']
+IMG_EXTENSIONS = ('.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP')   # inference.py:22-25
 
 
 def is_image_file(filename):
-    return any(filename.endswith(extension) for extension in IMG_EXTENSIONS)
+    return filename.endswith(IMG_EXTENSIONS)
 
 
 def is_pfm_file(filename):
@@ -35,16 +35,18 @@ def is_pfm_file(filename):
 
 
 def load_disp(item, filename, disp_div_factor=1.0):
-    """inference.py:36-46: a disparity map from an image file (KITTI: 16-bit PNG / 256) or a SceneFlow .pfm."""
-    Disp = None
-    if filename in item.keys() and item[filename] is not None:
-        if is_image_file(item[filename]):
-            Disp = imread(item[filename]).squeeze().astype(np.float32) / disp_div_factor
-        elif is_pfm_file(item[filename]):
-            Disp = load_scene_flow_disp(item[filename]).astype(np.float32) / disp_div_factor
-        else:
-            raise NotImplementedError
-    return Disp
+    """inference.py:36-46: the disparity map named by ``item[filename]`` -- an image file (KITTI: 16-bit PNG, disparity * 256) or
+    a SceneFlow .pfm -- as float32 divided by ``disp_div_factor``; None when the item has no such entry."""
+    path = item.get(filename)
+    if path is None:
+        return None
+    if is_image_file(path):
+        raw = imread(path).squeeze()
+    elif is_pfm_file(path):
+        raw = load_scene_flow_disp(path)
+    else:
+        raise NotImplementedError
+    return raw.astype(np.float32) / disp_div_factor
 
 
 def init_model(config, checkpoint=None, device='cuda:0'):
@@ -77,26 +79,25 @@ def _resample(t, scale_factor, mult=1.0):
 
 def prepare_data(item, img_transform, cfg, device):
     """inference.py:151-188: (processed sample on ``device``, original arrays as read)."""
-    oriLeftImage = imread(item['left_image_path'])[:, :, :3]
-    oriRightImage = imread(item['right_image_path'])[:, :, :3]
-    oriLeftDisp = load_disp(item, 'left_disp_map_path', cfg.disp_div_factor)
-    oriRightDisp = load_disp(item, 'right_disp_map_path', cfg.disp_div_factor)
-    oriSample = {'leftImage': oriLeftImage.astype(np.float32), 'rightImage': oriRightImage.astype(np.float32),
-                 'leftDisp': oriLeftDisp, 'rightDisp': oriRightDisp}
-    h, w = oriLeftImage.shape[0], oriLeftImage.shape[1]
-    procSample = {'leftImage': np.ascontiguousarray(oriLeftImage), 'rightImage': np.ascontiguousarray(oriRightImage),   # uint8 [H, W, 3]
-                  'leftDisp': None if oriLeftDisp is None else oriLeftDisp.copy()[np.newaxis, ...],
-                  'rightDisp': None if oriRightDisp is None else oriRightDisp.copy()[np.newaxis, ...],
-                  'original_size': (h, w)}
-    procSample = img_transform(procSample)
-    scale_factor = cfg.scale_factor
-    for k, v in procSample.items():
-        if torch.is_tensor(v):
-            v = v.unsqueeze(0)
-            if scale_factor != 1.0:
-                v = _resample(v, scale_factor, scale_factor if 'Disp' in k else 1.0)
-            procSample[k] = v.to(device)
-    return procSample, oriSample
+    views = {side: imread(item['%s_image_path' % side])[:, :, :3] for side in ('left', 'right')}       # uint8 [H, W, 3]
+    disps = {side: load_disp(item, '%s_disp_map_path' % side, cfg.disp_div_factor) for side in ('left', 'right')}
+    oriSample = {'leftImage': views['left'].astype(np.float32), 'rightImage': views['right'].astype(np.float32),
+                 'leftDisp': disps['left'], 'rightDisp': disps['right']}
+    sample = {'leftImage': np.ascontiguousarray(views['left']), 'rightImage': np.ascontiguousarray(views['right']),
+              'leftDisp': None if disps['left'] is None else disps['left'][np.newaxis].copy(),
+              'rightDisp': None if disps['right'] is None else disps['right'][np.newaxis].copy(),
+              'original_size': views['left'].shape[:2]}
+    sample = img_transform(sample)
+    factor = cfg.scale_factor
+    for key in list(sample):
+        t = sample[key]
+        if not torch.is_tensor(t):
+            continue
+        t = t.unsqueeze(0)
+        if factor != 1.0:      # inference.py:183-187: disparities scale with the image
+            t = _resample(t, factor, factor if 'Disp' in key else 1.0)
+        sample[key] = t.to(device)
+    return sample, oriSample
 
 
 def _forward(model, procData, graph):
@@ -134,15 +135,9 @@ def inference_stereo(model, batchesDict, log_dir, pad_to_shape=None, crop_shape=
     left_disp_map_path, right_disp_map_path.  Returns the list of logged dicts ({'Result', 'OriginalData'}) -- the reference
     returns None and only writes the files.  ``graph``: "auto" (default) | True | False, see the module docstring."""
     device = next(model.parameters()).device   # model device (inference.py:146)
-    img_transform = [ToTensor(device)]
-    if pad_to_shape is not None:
-        assert crop_shape is None
-        img_transform.append(StereoPad(pad_to_shape))
-    if crop_shape is not None:
-        assert pad_to_shape is None
-        img_transform.append(CenterCrop(crop_shape))
-    img_transform.append(Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD))
-    img_transform = Compose(img_transform)
+    assert pad_to_shape is None or crop_shape is None      # inference.py:124,127: one geometric transform at most
+    geometry = [StereoPad(pad_to_shape)] if pad_to_shape is not None else ([CenterCrop(crop_shape)] if crop_shape is not None else [])
+    img_transform = Compose([ToTensor(device)] + geometry + [Normalize(ops.IMAGENET_MEAN, ops.IMAGENET_STD)])
     model.cfg.update({'log_dir': log_dir, 'pad_to_shape': pad_to_shape, 'crop_shape': crop_shape, 'scale_factor': scale_factor,
                       'disp_div_factor': disp_div_factor})
     out = []
