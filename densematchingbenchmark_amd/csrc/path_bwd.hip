@@ -102,11 +102,18 @@ __global__ __launch_bounds__(256) void upsample_regress_bwd_z_kernel(const float
     return lerp2(h0, lz.w0, h1, lz.w1) * alpha;
   };
   Lerp lz;
+  // (round 5) running maximum and normaliser in ONE walk over the planes (the walk -- a lerp set-up and a blend per plane -- is
+  // what this kernel's time goes into, not memory): the sum is rescaled when the maximum moves, which it does a few times per pixel
   float m = -INFINITY;
-  for (int zo = 0; zo < Do; ++zo) m = fmaxf(m, logit(zo, lz));
-  cz0 = cz1 = -1;
   double s = 0.0;
-  for (int zo = 0; zo < Do; ++zo) s += (double)__expf(logit(zo, lz) - m);
+  for (int zo = 0; zo < Do; ++zo) {
+    const float v = logit(zo, lz);
+    if (v > m) {
+      s *= (m == -INFINITY) ? 0.0 : (double)__expf(m - v);
+      m = v;
+    }
+    s += (double)__expf(v - m);
+  }
   cz0 = cz1 = -1;
   const float inv = (float)(1.0 / s);
   const size_t pix = ((size_t)b * Ho + yo) * Wo + xo;
@@ -193,6 +200,36 @@ __global__ __launch_bounds__(256) void upsample_regress_bwd_hw_kernel(const floa
   range(xl, sw, Wo, xlo, xhi);
   const float* tb = t + ((size_t)b * Di + zi) * Ho * Wo;
   float acc = 0.f;
+  // (round 5) The column weights of this thread's window do not depend on the row: they are computed ONCE (the window of a 4x
+  // up-sampling is 9 .. 12 columns wide) instead of once per (row, column) -- the kernel spent its time in ~100 lerp set-ups per
+  // output, not in its 100 loads (0.137 -> see profiles/r05_train_pmc.csv).  Wider windows (other scale factors) take the old loop.
+  constexpr int KMAX = 16;
+  if (xhi - xlo < KMAX) {
+    float wxs[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int xo = xlo + k;
+      float wv = 0.f;
+      if (xo <= xhi) {
+        const Lerp lx = lerp_setup(xo, Wi, sw);
+        wv = (lx.i0 == xl ? lx.w0 : 0.f) + (lx.i1 == xl ? lx.w1 : 0.f);
+      }
+      wxs[k] = wv;
+    }
+    for (int yo = ylo; yo <= yhi; ++yo) {
+      const Lerp ly = lerp_setup(yo, Hi, sh);
+      const float wy = (ly.i0 == yl ? ly.w0 : 0.f) + (ly.i1 == yl ? ly.w1 : 0.f);
+      if (wy == 0.f) continue;
+      const float* tr = tb + (size_t)yo * Wo + xlo;
+      float row = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (wxs[k] != 0.f) row = fmaf(tr[k], wxs[k], row);     // same terms, same ascending order as the loop below
+      acc = fmaf(row, wy, acc);
+    }
+    dx[(((size_t)b * Di + zi) * Hi + yl) * Wi + xl] = acc;
+    return;
+  }
   for (int yo = ylo; yo <= yhi; ++yo) {
     const Lerp ly = lerp_setup(yo, Hi, sh);
     const float wy = (ly.i0 == yl ? ly.w0 : 0.f) + (ly.i1 == yl ? ly.w1 : 0.f);
