@@ -16,6 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 DEV_BUILD = os.environ.get("DMB_LIB", "").startswith("dev")    # "dev" or "dev_<tag>" (a build-time experiment, build.py)
 LIB_PATH = os.path.join(_PKG, "lib", "libdmb_hip_%s.so" % os.environ["DMB_LIB"] if DEV_BUILD else "libdmb_hip.so")
 DECONV3D_WORKSPACE_BYTES = 2048   # include/dmb_hip.h: DMB_DECONV3D_WORKSPACE_BYTES
+CONV_SINGLE_CHAIN = 0x100         # include/dmb_hip.h: DMB_CONV_SINGLE_CHAIN
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dmb_hip.h")
 
 _c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
@@ -23,7 +24,7 @@ _P = _c_void_p  # device pointer
 _HI = ctypes.POINTER(ctypes.c_int)  # host int array
 _HF = ctypes.POINTER(ctypes.c_float)  # host float array
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes)
 SIGNATURES = {
@@ -49,7 +50,7 @@ SIGNATURES = {
     "dmb_conv3d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_deconv3d_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _P]),
     "dmb_conv3d_k3_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 8 + [_P]),
-    "dmb_conv3d_k3_c1_f32": (_c_int, [_P, _P, _c_float, _P, _P] + [_c_int] * 5 + [_P]),
+    "dmb_conv3d_k3_c1_f32": (_c_int, [_P, _P, _c_float, _P, _P] + [_c_int] * 6 + [_P]),
     "dmb_deconv3d_k3s2_f32": (_c_int, [_P, _P, _P, _P, _P, _P] + [_c_int] * 8 + [_P, _P]),
     "dmb_zero_columns_f32": (_c_int, [_P, _c_ll, _c_int, _c_int, _P]),
     "dmb_trilinear_ac_f32": (_c_int, [_P, _P] + [_c_int] * 7 + [_P]),

@@ -1434,6 +1434,161 @@ __global__ __launch_bounds__(256, DMB_C1V_WPE) void conv3d_c1v_kernel(const floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same layer for launches that do not fill the chip (round 6: one small pair -- [1, 32, 16, 64, 128] is 48 tiles of
+// conv3d_c1v_kernel, each walking its 32 channels one after the other behind two barriers: 32 x (a memory round trip) = 60 us for
+// 17 MB).  Here a tile is 2 z x 8 y x 60 x and the FOUR WAVES of a workgroup split the input channels: wave w stages and multiplies
+// channels [w Ci / 4, (w + 1) Ci / 4) in its own LDS tile (no workgroup barrier in the channel loop, the fetches of the next two
+// channels in flight), then the four partial sums of an output are added in ascending wave order (fixed order: reproducible run to
+// run; not the single ascending chain of the kernels above, so the last bits differ from them).  Thread mapping, row reads and the
+// packed-fma arithmetic are conv3d_c1v_kernel's.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int C1S_TZ = 2, C1S_ZS = C1S_TZ + 2;
+constexpr int C1S_UNITS = C1S_ZS * C1V_ROWS * C1V_RW;      // 680 words per channel
+constexpr int C1S_UPT = (C1S_UNITS + 63) / 64;              // 11 per lane
+constexpr int C1S_TILE = C1S_ZS * C1V_ROWS * C1V_P;         // floats of one wave's tile
+
+__global__ __launch_bounds__(256, 1) void conv3d_c1s_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
+                                                            const float* __restrict__ res, float* __restrict__ y, int Ci, int D,
+                                                            int H, int W, int ntx, int nty, int ntz) {
+  __shared__ __attribute__((aligned(16))) float tiles[4 * C1S_TILE];
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int tz = t % ntz;
+  const int b = t / ntz;
+  const int x0 = tx * C1V_TX, y0 = ty * C1V_TY, z0 = tz * C1S_TZ;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const float* xb = x + (size_t)b * Ci * DHW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lq = lane & 15, lyp = lane >> 4;
+  float* tile = tiles + wave * C1S_TILE;
+  const int CW = (Ci + 3) / 4, cb = wave * CW, ce = min(Ci, cb + CW);
+
+  unsigned soff[C1S_UPT];
+#pragma unroll
+  for (int q = 0; q < C1S_UPT; ++q) {
+    const int u = q * 64 + lane;
+    const int zz = u / (C1V_ROWS * C1V_RW), rr = u - zz * (C1V_ROWS * C1V_RW), yy = rr / C1V_RW, sg = rr - yy * C1V_RW;
+    const int gz = z0 - 1 + zz, gy = y0 - 1 + yy, gx = x0 - 4 + sg * 4;
+    const bool ok = u < C1S_UNITS && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    soff[q] = ok ? ((unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB;
+  }
+  // LDS float offset of word q * 64 + lane = doff0 + what q adds: 64 = 3 x 17 + 13 words on -> 3 rows and 13 words, one more row when
+  // the word index wraps past 17 (recomputed per commit: eleven registers fewer than a table)
+  const int rw0 = lane / C1V_RW, sg0 = lane - rw0 * C1V_RW;
+  auto fetch = [&](u32x4 (&stg)[C1S_UPT], int c) {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xb + (size_t)c * DHW, DHW * 4u);
+#pragma unroll
+    for (int q = 0; q < C1S_UPT; ++q) stg[q] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)soff[q], 0, 0);
+  };
+  auto commit = [&](const u32x4 (&stg)[C1S_UPT]) {
+#pragma unroll
+    for (int q = 0; q < C1S_UPT; ++q) {
+      const int sg = sg0 + (q * 64) % C1V_RW, wrap = sg >= C1V_RW ? 1 : 0;
+      const int rw = rw0 + (q * 64) / C1V_RW + wrap;
+      if (q * 64 + lane < C1S_UNITS) *reinterpret_cast<u32x4*>(tile + rw * C1V_P + (sg - wrap * C1V_RW) * 4) = stg[q];
+    }
+  };
+  f32x2 acc[2][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int o = 0; o < 2; ++o) acc[a][c2][o] = f32x2{0.f, 0.f};
+  auto multiply = [&](int c) {
+    const float* wc = w + (size_t)c * 27;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {   // input plane z0 - 1 + p
+      f32x2 ev[4][3], od[4][2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // input row y0 - 1 + 2 lyp + r
+        const float* row = tile + (p * C1V_ROWS + 2 * lyp + r) * C1V_P;
+        const float4 m = *reinterpret_cast<const float4*>(row + lq * 4);
+        const float v0 = dpp_row_shr1(m.w);
+        float v5 = dpp_row_shl1(m.x);
+        if (lq == 15) v5 = row[64];
+        ev[r][0] = f32x2{v0, m.x};
+        ev[r][1] = f32x2{m.y, m.z};
+        ev[r][2] = f32x2{m.w, v5};
+        od[r][0] = f32x2{m.x, m.y};
+        od[r][1] = f32x2{m.z, m.w};
+      }
+#pragma unroll
+      for (int oz = 0; oz < 2; ++oz) {
+        const int dz = p - oz;
+        if (dz < 0 || dz > 2) continue;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float wv = wc[dz * 9 + dy * 3 + dx];
+            const f32x2 w2 = f32x2{wv, wv};
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+              for (int o = 0; o < 2; ++o) {
+                const f32x2 in = dx == 0 ? ev[oy + dy][o] : (dx == 1 ? od[oy + dy][o] : ev[oy + dy][o + 1]);
+                acc[oz][oy][o] = __builtin_elementwise_fma(in, w2, acc[oz][oy][o]);
+              }
+          }
+      }
+    }
+  };
+  // the wave's channels, two fetches in flight; the tile is this wave's own: ordering inside a wave is program order (the fences
+  // only keep the compiler from moving LDS accesses across the lane-crossing hand-over)
+  u32x4 sa[C1S_UPT], sb[C1S_UPT];
+  if (cb < ce) fetch(sa, cb);
+  if (cb + 1 < ce) fetch(sb, cb + 1);
+  for (int c = cb; c < ce; c += 2) {
+    commit(sa);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (c + 2 < ce) fetch(sa, c + 2);
+    multiply(c);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (c + 1 < ce) {
+      commit(sb);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (c + 3 < ce) fetch(sb, c + 3);
+      multiply(c + 1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  // partial sums [wave][16 values][64 lanes] into the wave's own (now dead) tile, then thread (lane, q) adds the four partials of
+  // output row q = (oz, oy) of its lane in ascending wave order
+#pragma unroll
+  for (int oz = 0; oz < 2; ++oz)
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        tile[((oz * 2 + oy) * 4 + o * 2) * 64 + lane] = acc[oz][oy][o].x;
+        tile[((oz * 2 + oy) * 4 + o * 2 + 1) * 64 + lane] = acc[oz][oy][o].y;
+      }
+  __syncthreads();
+  const int q = wave, oz = q >> 1, oy = q & 1;
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = tiles[(q * 4 + i) * 64 + lane];
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) s += tiles[ww * C1S_TILE + (q * 4 + i) * 64 + lane];
+    v[i] = s + bias;
+  }
+  const int gx = x0 - 4 + lq * 4, gz = z0 + oz, gy = y0 + 2 * lyp + oy;
+  if (lq == 0 || gx >= W || gz >= D || gy >= H) return;
+  const size_t o = (size_t)b * DHW + (size_t)gz * HW + (size_t)gy * W + gx;
+  float4 r4 = make_float4(v[0], v[1], v[2], v[3]);
+  if (res) {
+    const float4 r = *reinterpret_cast<const float4*>(res + o);
+    r4.x += r.x; r4.y += r.y; r4.z += r.z; r4.w += r.w;
+  }
+  *reinterpret_cast<float4*>(y + o) = r4;
+}
+
 // The accumulation order above is (dz, dy) outer, dx inner PER channel, i.e. tap-ascending within a channel and
 // channels ascending -- identical to the MFMA kernels' k order up to their channel pairing.
 
@@ -1577,6 +1732,24 @@ static int flat_tx(int W) {
   return e52 > e60 ? 52 : 60;
 }
 
+// ---- Which launches take the split-K form (csrc/conv3d_sk.hip): 0 = none, else its variant --------------------------------
+// A full-grid kernel gives one wave the whole chain of 27 Ci / 2 MFMAs of a tile, in chunks of two channels behind a barrier each:
+// with fewer tile chains than SIMDs a launch costs ~1 us per chunk whatever its arithmetic (31-35 us for 64 channels).  Split-K
+// puts eight waves on a tile.  Units: 32-voxel column tiles (16 x 2 row pairs) x 32-channel row tiles.
+static int sk_variant(int B, int Ci, int Co, int D, int H, int W, int stride) {
+  const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long tiles = (long long)B * Do * cdiv(Ho, 2) * cdiv(Wo, 16);
+  const int ntt = Co / 32, ncu = num_cus();
+  // measured (profiles/r06_sk_probe.log, one MI355X): [1, 64, 4, 16, 32] 64 -> 64: stride 1 32.4 -> 12.8 us, stride 2 (from
+  // [1, 64, 8, 32, 64]) 33.8 -> 14.9 us with one row tile per workgroup (128 workgroups); [1, 32, 16, 64, 128] -> 64 channels at
+  // stride 2: 31.6 -> 22.0 us with 32 x 2 voxels x both row tiles (256 workgroups; 32 input channels = 2 pairs per wave keep the
+  // A fragments of both row tiles in registers).  At 1500 tile chains and more the full-grid kernels win (each split-K workgroup
+  // re-reads its share of the weights from L2: 0.45 of the matrix peak at best).
+  if (tiles * ntt <= ncu + ncu / 2) return 1;
+  if (stride == 2 && Ci == 32 && Co == 64 && tiles * ntt <= 4LL * ncu) return 3;
+  return 0;
+}
+
 extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                  const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int stride, int relu, void* stream) {
@@ -1585,10 +1758,22 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
     return fail(DMB_EUNSUPPORTED, "conv3d: 8 channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   const bool out_small = (long long)Co * D * H * W * 4 < 0x7fffffffLL;   // the vector epilogue addresses the whole output item
   hipStream_t st = (hipStream_t)stream;
+  const bool single_chain = (relu & DMB_CONV_SINGLE_CHAIN) != 0;
   relu &= 0xff;
   relu |= (DMB_OPT(6) & 0xff) << 8;                    // (development build: diagnostics, see the kernels)
   const int relu_s1 = relu | (DMB_OPT(14) << 16);      // (development build: start-up stagger unit of the stride-1 kernels)
 #define DMB_S1(CO, TY, TX, WN, G, PM) launch_s1<S1Cfg<0, CO, TY, TX, 2, WN, 1, G, PM>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st)
+  if ((stride == 1 || stride == 2) && (Co == 32 || Co == 64)) {
+    // (round 6) launches that leave most of the chip idle: the K chain of a tile split over the eight waves of a workgroup
+    // (csrc/conv3d_sk.hip).  DMB_OPT(23) (development build): 1 = never, k >= 2 = force variant k - 1.
+    int v = single_chain ? 0 : sk_variant(B, Ci, Co, D, H, W, stride);
+    if (DMB_OPT(23) == 1) v = 0;
+    if (DMB_OPT(23) >= 2) v = DMB_OPT(23) - 1;
+    if (v > 0) {
+      const int rc = conv3d_sk_try(v, x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, stride, relu & 0xff, st);
+      if (rc != -1) return rc;
+    }
+  }
   if (stride == 1) {
     // the vector path: 16-byte rows for staging, skip operand and stores
     const bool vec = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 && out_small && DMB_OPT(2) == 0;
@@ -1623,6 +1808,11 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
         static const S1Tile cand[5] = {{64, 3, 2, 2, 3, true, 1.0}, {40, 4, 2, 5, 3, false, 1.0}, {24, 4, 2, 3, 3, false, 1.0}, {32, 4, 2, 4, 3, false, 1.0},
                                        {16, 2, 2, 1, 3, false, 0.95}};
         const bool ok[5] = {W >= 32 && W <= 64 && (H * W) % 4 == 0 && DMB_OPT(13) == 0, true, true, true, true};
+#ifdef DMB_DEV
+        // (round 6 experiment) the 16 x 2 tile with chunks of 4 / 8 input channels: fewer, longer chunks per barrier
+        if (DMB_OPT(19) == 6) return launch_s1<S1Cfg<0, 64, 2, 16, 4, 2, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
+        if (DMB_OPT(19) == 7) return launch_s1<S1Cfg<0, 64, 2, 16, 8, 2, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
+#endif
         switch (s1_pick(cand, ok, 5, B, D, H, W)) {
           case 0: return launch_s1<S1Cfg<0, 64, 3, 64, 2, 2, 1, 16, 0, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
           case 1: return DMB_S1(64, 4, 40, 2, 8, 56);
@@ -1659,6 +1849,9 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
 #ifdef DMB_DEV
       if (pair_ok && DMB_OPT(10) == 3) return launch_s2<S2Cfg<0, 64, 1, 30, 2, 2, true, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
       if (pair_ok && DMB_OPT(10) == 4) return launch_s2<S2Cfg<0, 64, 2, 30, 2, 2, true, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      // (round 6 experiment) chunks of 4 input channels
+      if (pair_ok && DMB_OPT(10) == 5) return launch_s2<S2Cfg<0, 64, 1, 30, 4, 2, true, 1, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
+      if (pair_ok && DMB_OPT(10) == 6) return launch_s2<S2Cfg<0, 64, 2, 30, 4, 2, true, 2, true>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu, st);
 #endif
       if (pair_ok && DMB_OPT(10) == 0) {
         if (c_one < c_two && c_one < c_old)
@@ -1686,6 +1879,18 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
   return fail(DMB_EUNSUPPORTED, "conv3d: output channels must be 32 or 64 (or 1: dmb_conv3d_k3_c1_f32), stride 1 or 2");
 }
 
+// Split-K form of the transposed convolution (csrc/conv3d_sk.hip): 0 = no, else its variant.  Units: input-resolution tiles.
+static int dsk_variant(int B, int Ci, int Co, int D, int H, int W) {
+  const long long tiles = (long long)B * D * cdiv(H, 2) * cdiv(W, 16);
+  const int ncu = num_cus();
+  // measured: [1, 64, 4, 16, 32] -> 64 channels 37.3 -> 14.1 us (variant 1: 512 workgroups of eight waves, 3 - 12 MFMAs per channel
+  // pair); [1, 64, 8, 32, 64] -> 32 channels 50.3 -> 41.3 us (variant 4: 32 x 2 positions, four waves); from 6000 tiles on the
+  // work-queue kernel (deconv3d_zy.hip) wins by 2x
+  if (tiles * cdiv(Co, 32) <= ncu / 2) return 1;
+  if (Ci % 8 == 0 && Ci <= 64 && tiles * cdiv(Co, 32) <= 2LL * ncu) return 4;
+  return 0;
+}
+
 extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                                      const float* residual, float* y, int B, int Ci, int Co, int D, int H, int W, int Wout,
                                      int relu, void* workspace, void* stream) {
@@ -1694,8 +1899,20 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
   if ((long long)8 * D * H * W * 4 >= 0x7fffffffLL)
     return fail(DMB_EUNSUPPORTED, "deconv3d: 8 input channels of one batch item must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t st = (hipStream_t)stream;
+  const bool single_chain = (relu & DMB_CONV_SINGLE_CHAIN) != 0;
   relu &= 0xff;
   relu |= DMB_OPT(6) << 8;   // (development build: diagnostics)
+  {
+    // (round 6) launches that leave most of the chip idle: split-K over the waves of a workgroup (csrc/conv3d_sk.hip).
+    // DMB_OPT(25) (development build): 1 = never, k >= 2 = force variant k - 1.
+    int v = single_chain ? 0 : dsk_variant(B, Ci, Co, D, H, W);
+    if (DMB_OPT(25) == 1) v = 0;
+    if (DMB_OPT(25) >= 2) v = DMB_OPT(25) - 1;
+    if (v > 0) {
+      const int rc = deconv3d_sk_try(v, x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, Wout, relu & 0xff, st);
+      if (rc != -1) return rc;
+    }
+  }
   if (workspace && !DMB_OPT(3) && !DMB_OPT(7)) {   // three workgroups per CU where the shape admits it (csrc/deconv3d_zy.hip)
     const int rc = deconv3d_zy_try(x, wpack, scale, shift, residual, y, B, Ci, Co, D, H, W, Wout, relu, static_cast<int*>(workspace), st);
     if (rc != -1) return rc;
@@ -1719,7 +1936,7 @@ extern "C" int dmb_deconv3d_k3s2_f32(const float* x, const float* wpack, const f
 }
 
 extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float* residual, float* y,
-                                    int B, int Ci, int D, int H, int W, void* stream) {
+                                    int B, int Ci, int D, int H, int W, int flags, void* stream) {
   if (!x || !w || !y || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d_c1: bad argument");
   const int ntx = cdiv(W, C1_TX), nty = cdiv(H, C1_TY), ntz = cdiv(D, C1_TZ);
   const long long nblk = (long long)B * ntx * nty * ntz;
@@ -1729,6 +1946,15 @@ extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, 
   if ((long long)2 * D * H * W * 4 >= 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d_c1: tensor too large for 32-bit offsets");
   if (W % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) && !DMB_OPT(3)) {   // 16-byte rows
     const int vx = cdiv(W, C1V_TX), vy = cdiv(H, C1V_TY), vz = cdiv(D, C1V_TZ);
+    // (round 6) fewer tiles than one round of two workgroups per CU: the channels split over the waves of a workgroup
+    // (conv3d_c1s_kernel).  DMB_OPT(24) (development build): 1 = never, 2 = always.
+    const bool small = !(flags & DMB_CONV_SINGLE_CHAIN) && (long long)B * vx * vy * vz <= num_cus() / 2;   // ([1, 32, 16, 64, 128]: 48 tiles, 52 -> 18 us; 408 tiles: 70 against 107 us)
+    if ((small && DMB_OPT(24) != 1) || DMB_OPT(24) == 2) {
+      const int sz = cdiv(D, C1S_TZ);
+      hipLaunchKernelGGL(conv3d_c1s_kernel, dim3((unsigned)((long long)B * vx * vy * sz)), dim3(256), 0, (hipStream_t)stream, x, w,
+                         bias, residual, y, Ci, D, H, W, vx, vy, sz);
+      return launch_status("conv3d_c1 launch failed");
+    }
     hipLaunchKernelGGL(conv3d_c1v_kernel, dim3((unsigned)((long long)B * vx * vy * vz)), dim3(256), 0, (hipStream_t)stream, x, w,
                        bias, residual, y, Ci, D, H, W, vx, vy, vz);
     return launch_status("conv3d_c1 launch failed");

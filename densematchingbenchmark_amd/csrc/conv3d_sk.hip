@@ -1,0 +1,454 @@
+// 3x3x3 convolution (stride 1 or 2) for launches that do NOT fill the chip: the K chain of a tile split over the waves of a
+// workgroup (split-K), round 6.
+//
+// Why.  conv3d_s1_kernel / conv3d_s2_kernel (conv3d.hip) give one wave the whole chain of 27 Ci / 2 MFMAs of its 32 x 32 tiles and
+// walk the input channels in chunks of two behind a workgroup barrier each.  On a full grid that is the fastest form (0.9 of the
+// FP32 matrix peak); on the deepest levels of the hourglass for ONE small pair (BASELINE configs[0]: [1, 64, 4, 16, 32] = 128 tiles
+// for 1024 SIMDs; hourglass.py:62-86 called as apis/inference.py:191-225 does, one pair per call) a launch takes 31-35 us whatever
+// its arithmetic (2.9 us at the matrix peak): 32 chunks x (one LDS-DMA round trip + a barrier) with nothing else resident on the
+// CU to hide them, on an eighth of the chip.
+//
+// Here a workgroup of NW (8) waves owns ONE output tile -- MT column tiles of 16 x  x  2 y voxels of one z-slice, NT 32-channel row
+// tiles -- and wave w multiplies input channels [w Ci / NW, (w + 1) Ci / NW) only:
+//   * every wave stages the haloed input tile of ITS channels with one burst of 16-byte LDS-DMA copies into its own LDS region
+//     (whole K range resident: 64 channels x 3 x 4 x 24 floats = 74 KB for a stride-1 tile): ONE memory round trip, one barrier;
+//   * no wave shares weights with another one, so the A fragments (prepacked, one 256-byte line per k-step and row tile) come
+//     straight from L2 into registers -- all of the wave's (at most 4 channel pairs x 27 taps), requested next to the copies;
+//   * the NW partial tiles are summed in LDS in ascending wave order (a fixed order: results are reproducible run to run), then
+//     the shared epilogue (BatchNorm affine, skip operand, ReLU in the reference's order: layers/basic_layers.py:68-100) stores
+//     16-byte words.
+// The sum of a voxel is therefore NW partial fma chains added in order, not one chain: results differ from the full-grid kernels
+// in the last bits (and with them batch 1 from batch 4 where this form is picked) -- both are FP32 evaluations of the same
+// convolution; the tests bound them against the FP64 yardstick instead of against each other.
+//
+// Which launches take this form is a cost estimate in dmb_conv3d_k3_f32 (conv3d.hip); conv3d_sk_try returns -1 where the shape
+// does not qualify.
+#include "dmb_common.h"
+
+namespace dmb {
+
+template <int S_, int NW_, int NT_, int XS_, int YS_, int NPR_>
+struct SKCfg {
+  static constexpr int S = S_, NW = NW_, NT = NT_, XS = XS_, YS = YS_;
+  static constexpr int NPR = NPR_;   // channel pairs per wave whose A fragments are resident in registers (Ci <= 2 NW NPR)
+  static constexpr int NTHREADS = 64 * NW;
+  static constexpr int TXO = 16 * XS, TYO = 2 * YS, MT = XS * YS;   // output tile; 32-voxel column tiles = row pairs of 16 columns
+  static constexpr int ROWS = S == 1 ? TYO + 2 : 2 * TYO + 1;      // staged input rows
+  static constexpr int P = S == 1 ? TXO + 8 : 2 * TXO + 4;         // staged row: from the 16-byte aligned column S x0 - 4
+  static constexpr int ZS = 3;
+  static constexpr int PLANE = ROWS * P, CHS = ZS * PLANE;         // one channel of the tile (a whole number of 16-byte units)
+  static constexpr int UPR = P / 4, UPC = ZS * ROWS * UPR;         // 16-byte units per row / per channel
+  static constexpr int PP = MT * 32 + 4;                           // pitch of a partial tile's rows
+  static constexpr int PART = NT * 32 * PP;                        // floats of one wave's partial sums
+  static_assert(P % 4 == 0 && CHS % 4 == 0, "16-byte units");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ res, float* __restrict__ y, int Ci, int D,
+                                                                int H, int W, int Do, int Ho, int Wo, int ntx, int nty, int NTT,
+                                                                int relu) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int NTS = NTT / C::NT;
+  const int nt0 = (t % NTS) * C::NT;   // first 32-channel row tile of this workgroup (innermost: the row tiles of a voxel tile share its input in L2)
+  t /= NTS;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int z0 = t % Do, b = t / Do;
+  const int x0 = tx * C::TXO, y0 = ty * C::TYO;   // output coordinates
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const int CW = Ci / C::NW;           // input channels of this wave (even: checked on the host)
+  const int c0 = wave * CW;
+  float* region = lds + c0 * C::CHS;   // the wave's own part of the staged tile
+
+  // ---- staging: one burst; unit u = 4 consecutive floats of a staged row, the units of the wave's channels are linear in LDS
+  {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)b * Ci + c0) * DHW, (unsigned)CW * DHW * 4u);
+    const int NU = CW * C::UPC;
+    for (int u0 = 0; u0 < NU; u0 += 64) {
+      const int u = u0 + lane;
+      const int cl = u / C::UPC, r0 = u - cl * C::UPC;
+      const int zz = r0 / (C::ROWS * C::UPR), r1 = r0 - zz * (C::ROWS * C::UPR), yy = r1 / C::UPR, sg = r1 - yy * C::UPR;
+      const int gz = C::S * z0 - 1 + zz, gy = C::S * y0 - 1 + yy, gx = C::S * x0 - 4 + sg * 4;
+      const bool ok = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      if (u < NU)
+        dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB, 0u, region + u0 * 4);
+    }
+  }
+
+  // ---- A fragments: ALL of the wave's channel pairs (27 taps x NT row tiles each) are requested before the barrier, next to the
+  // copies: one memory round trip for the launch's whole operand set.  (Requested a pair ahead of their MFMAs they arrived late:
+  // a pair's 27 MFMAs last 0.7 us, an L2 round trip under load longer -- 16 us instead of 10 for the [1, 64, 4, 16, 32] layer.)
+  const int NP = CW / 2;   // <= NPR (checked on the host)
+  const float* wbase = wp + ((size_t)(c0 / 2) * 27 * NTT + nt0) * 64 + lane;
+  float a[C::NPR][27][C::NT];
+#pragma unroll
+  for (int p = 0; p < C::NPR; ++p)
+    if (p < NP) {
+      const float* wq = wbase + (size_t)p * 27 * NTT * 64;
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) a[p][tap][nt] = wq[(tap * NTT + nt) * 64];
+    }
+
+  f32x16 acc[C::MT][C::NT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  __syncthreads();   // (the compiler drains the copies -- vmcnt(0) -- here)
+
+  // B fragment of (pair p, tap, column tile): lane (j, h) reads channel 2 p + h at the tap's input voxel of output (j / 16, j % 16)
+  const float* bb = region + h * C::CHS + C::S * (j >> 4) * C::P + C::S * (j & 15) + 3;
+#pragma unroll
+  for (int p = 0; p < C::NPR; ++p)
+    if (p < NP) {
+      const float* bp = bb + 2 * p * C::CHS;
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        float bf[C::MT];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+          bf[mt] = bp[dz * C::PLANE + (dy + C::S * 2 * (mt / C::XS)) * C::P + dx + C::S * 16 * (mt % C::XS)];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(a[p][tap][nt], bf[mt], acc[mt][nt]);
+      }
+    }
+
+  // ---- partial tiles -> LDS (the staged tile is dead once every wave has left the loop), summed in ascending wave order
+  __syncthreads();
+  {
+    float* part = lds + wave * C::PART;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(nt * 32 + cd_row(r, h)) * C::PP + mt * 32 + j] = acc[mt][nt][r];
+  }
+  __syncthreads();
+  const unsigned HWo = (unsigned)Ho * Wo, DHWo = (unsigned)Do * HWo;
+  const int Co = NTT * 32;
+  float* yb = y + (size_t)b * Co * DHWo;
+  const float* rb = res ? res + (size_t)b * Co * DHWo : nullptr;
+  const bool vec = (Wo & 3) == 0;
+  constexpr int NE4 = C::NT * 32 * C::MT * 8;   // 16-byte words of the workgroup's output tile
+  for (int e = threadIdx.x; e < NE4; e += C::NTHREADS) {
+    const int row = e / (C::MT * 8), c4 = e - row * (C::MT * 8), mt = c4 >> 3, jj = (c4 & 7) * 4;
+    const float* pp = lds + row * C::PP + mt * 32 + jj;
+    float4 s = *reinterpret_cast<const float4*>(pp);
+#pragma unroll
+    for (int w = 1; w < C::NW; ++w) {
+      const float4 q = *reinterpret_cast<const float4*>(pp + w * C::PART);
+      s.x += q.x;
+      s.y += q.y;
+      s.z += q.z;
+      s.w += q.w;
+    }
+    const int co = nt0 * 32 + row;
+    const int gy = y0 + 2 * (mt / C::XS) + (jj >> 4), gx = x0 + 16 * (mt % C::XS) + (jj & 15);
+    if (gy >= Ho || gx >= Wo) continue;
+    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+    float v[4] = {fmaf(s.x, sc, sh), fmaf(s.y, sc, sh), fmaf(s.z, sc, sh), fmaf(s.w, sc, sh)};
+    const size_t o = (size_t)co * DHWo + (size_t)z0 * HWo + (size_t)gy * Wo + gx;
+    if (vec) {
+      if (relu == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      if (rb) {
+        const float4 r4 = *reinterpret_cast<const float4*>(rb + o);
+        v[0] += r4.x;
+        v[1] += r4.y;
+        v[2] += r4.z;
+        v[3] += r4.w;
+      }
+      if (relu == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (gx + i >= Wo) break;
+        float q = v[i];
+        if (relu == 2) q = fmaxf(q, 0.f);
+        if (rb) q += rb[o + i];
+        if (relu == 1) q = fmaxf(q, 0.f);
+        yb[o + i] = q;
+      }
+    }
+  }
+}
+
+template <class C>
+static int launch_sk(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
+                     int Ci, int Co, int D, int H, int W, int relu, hipStream_t st) {
+  const int Do = (D - 1) / C::S + 1, Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
+  const int ntx = cdiv(Wo, C::TXO), nty = cdiv(Ho, C::TYO), NTT = Co / 32;
+  const long long nblk = (long long)B * Do * nty * ntx * (NTT / C::NT);
+  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
+  const size_t in_floats = (size_t)Ci * C::CHS, part_floats = (size_t)C::NW * C::PART;
+  const size_t lds = (in_floats > part_floats ? in_floats : part_floats) * sizeof(float);
+  DMB_ENSURE_LDS((&conv3d_sk_kernel<C>), (size_t)(160 * 1024));
+  hipLaunchKernelGGL((conv3d_sk_kernel<C>), dim3((unsigned)nblk), dim3(C::NTHREADS), lds, st, x, wp, scale, shift, res, y, Ci, D, H, W,
+                     Do, Ho, Wo, ntx, nty, NTT, relu);
+  return launch_status("conv3d split-K launch failed");
+}
+
+// LDS bytes a variant needs for Ci input channels (the whole K range of a tile is resident)
+template <class C>
+static constexpr long long sk_lds_bytes(int Ci) {
+  const long long a = (long long)Ci * C::CHS, b = (long long)C::NW * C::PART;
+  return (a > b ? a : b) * 4;
+}
+
+// variant: 1 = 16 x 2 voxel tile, one 32-channel row tile per workgroup; 2 = 32 x 2 voxels, one row tile; 3 = 32 x 2 voxels, both row
+// tiles of a 64-channel layer (32 input channels only: the A fragments of a wave must fit its registers).  -1: the shape does not qualify.
+int conv3d_sk_try(int variant, const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                  int B, int Ci, int Co, int D, int H, int W, int stride, int relu, hipStream_t st) {
+  constexpr int NW = 8;
+  if (Ci % (2 * NW) != 0 || (Co != 32 && Co != 64) || W % 4 != 0 || (((uintptr_t)x) & 15) != 0) return -1;
+  const int Wo = (W - 1) / stride + 1;
+  if (Wo % 4 == 0 && ((((uintptr_t)y) | ((uintptr_t)res)) & 15) != 0) return -1;
+  if ((long long)(Ci / NW) * D * H * W * 4 >= 0x7fffffffLL) return -1;   // 32-bit offsets inside a wave's channels
+  const int NP = Ci / (2 * NW);
+#define DMB_SK(S, NT, XS, YS, NPR)                                                                             \
+  do {                                                                                                         \
+    using C = SKCfg<S, NW, NT, XS, YS, NPR>;                                                                   \
+    if (NP > NPR || sk_lds_bytes<C>(Ci) > 160 * 1024) return -1;                                               \
+    return launch_sk<C>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, relu, st);                            \
+  } while (0)
+  if (stride == 1) {
+    if (variant == 1) DMB_SK(1, 1, 1, 1, 4);
+    if (variant == 2) DMB_SK(1, 1, 2, 1, 4);
+    if (variant == 3 && Co == 64) DMB_SK(1, 2, 2, 1, 2);
+  } else if (stride == 2) {
+    if (variant == 1) DMB_SK(2, 1, 1, 1, 4);
+    if (variant == 2) DMB_SK(2, 1, 2, 1, 4);
+    if (variant == 3 && Co == 64) DMB_SK(2, 2, 2, 1, 2);
+  }
+#undef DMB_SK
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Transposed convolution k3 s2 p1 op1 (hourglass conv5 / conv6: utils/hourglass.py:53-60,84-86), the same split-K idea.
+//   y[2 i - 1 + k] += x[i] w[k] per axis: an even output 2 m sees k = 1 from input m; an odd output 2 m + 1 sees k = 2 from input m
+//   and k = 0 from input m + 1.
+// A workgroup owns (input-resolution tile of XS x 16 x  x  2 y positions of one z-slice, output z parity, output y parity, one
+// 32-channel row tile): both x parities are accumulated side by side so that a thread of the epilogue owns four consecutive
+// output columns.  Wave w multiplies its Ci / NW input channels -- the tile's (1 + pz) x (2 + py) x (16 XS + 1) haloed inputs in
+// its own LDS region, its (1 + pz)(1 + py) x 3 taps of every channel pair in registers -- then the partial tiles are added in
+// ascending wave order.  The four parity classes carry 3 / 6 / 6 / 12 MFMAs per channel pair and column tile.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NW_, int XS_, int NPR_>
+struct DSKCfg {
+  static constexpr int NW = NW_, XS = XS_, NPR = NPR_, NTHREADS = 64 * NW_;
+  static constexpr int TXI = 16 * XS, TYI = 2, MT = XS;
+  static constexpr int P = TXI + 4;                   // staged row: columns x0 .. x0 + TXI (+ padding to 16 bytes)
+  static constexpr int UPR = P / 4;
+  static constexpr int PP = MT * 64 + 4;              // pitch of a partial tile's rows: 2 x 32 output columns per column tile
+  static constexpr int PART = 32 * PP;
+  static constexpr int IN_MAX = 2 * 3 * P;            // floats per channel of the largest class
+};
+
+template <class C, int PZ, int PY>
+__device__ __forceinline__ void deconv_sk_body(float* lds, const float* __restrict__ x, const float* __restrict__ wp,
+                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                               const float* __restrict__ res, float* __restrict__ y, int Ci, int D, int H, int W,
+                                               int Wout, int NTT, int cvalid, int relu, int b, int z0, int y0, int x0, int nt0) {
+  constexpr int ZS = 1 + PZ, ROWS = 2 + PY, PLANE = ROWS * C::P, CHS = ZS * PLANE, UPC = ZS * ROWS * C::UPR;
+  constexpr int NA = (1 + PZ) * (1 + PY);   // (kz, ky) pairs an output of the class sees
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
+  const int CW = Ci / C::NW, c0 = wave * CW;
+  float* region = lds + c0 * CHS;
+  {
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)b * Ci + c0) * DHW, (unsigned)CW * DHW * 4u);
+    const int NU = CW * UPC;
+    for (int u0 = 0; u0 < NU; u0 += 64) {
+      const int u = u0 + lane;
+      const int cl = u / UPC, r0 = u - cl * UPC;
+      const int zz = r0 / (ROWS * C::UPR), r1 = r0 - zz * (ROWS * C::UPR), yy = r1 / C::UPR, sg = r1 - yy * C::UPR;
+      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + sg * 4;
+      const bool ok = gz < D && gy < H && gx < W;
+      if (u < NU)
+        dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB, 0u, region + u0 * 4);
+    }
+  }
+  const int NP = CW / 2;
+  const float* wbase = wp + ((size_t)(c0 / 2) * 27 * NTT + nt0) * 64 + lane;
+  float a[C::NPR][NA][3];
+#pragma unroll
+  for (int p = 0; p < C::NPR; ++p)
+    if (p < NP) {
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int az = q / (1 + PY), ay = q % (1 + PY);
+        const int kz = PZ ? (az ? 0 : 2) : 1, ky = PY ? (ay ? 0 : 2) : 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) a[p][q][kx] = wbase[((size_t)(p * 27 + kz * 9 + ky * 3 + kx) * NTT) * 64];
+      }
+    }
+  f32x16 acc[2][C::MT];   // [x parity][column tile]
+#pragma unroll
+  for (int px = 0; px < 2; ++px)
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[px][mt][r] = 0.f;
+  __syncthreads();
+  const float* bb = region + h * CHS + (j >> 4) * C::P + (j & 15);
+#pragma unroll
+  for (int p = 0; p < C::NPR; ++p)
+    if (p < NP) {
+      const float* bp = bb + 2 * p * CHS;
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int az = q / (1 + PY), ay = q % (1 + PY);
+        float b0[C::MT], b1[C::MT];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          b0[mt] = bp[az * PLANE + ay * C::P + 16 * mt];
+          b1[mt] = bp[az * PLANE + ay * C::P + 16 * mt + 1];
+        }
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          acc[0][mt] = DMB_MFMA(a[p][q][1], b0[mt], acc[0][mt]);   // even x: kx = 1 from input m
+          acc[1][mt] = DMB_MFMA(a[p][q][2], b0[mt], acc[1][mt]);   // odd x: kx = 2 from input m ...
+          acc[1][mt] = DMB_MFMA(a[p][q][0], b1[mt], acc[1][mt]);   // ... and kx = 0 from input m + 1
+        }
+      }
+    }
+  __syncthreads();
+  {
+    float* part = lds + wave * C::PART;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float2*>(part + cd_row(r, h) * C::PP + mt * 64 + (j >> 4) * 32 + 2 * (j & 15)) = make_float2(acc[0][mt][r], acc[1][mt][r]);
+  }
+  __syncthreads();
+  const int Do = 2 * D, Ho = 2 * H;
+  const unsigned HWo = (unsigned)Ho * Wout, DHWo = (unsigned)Do * HWo;
+  const int Co = cvalid;
+  float* yb = y + (size_t)b * Co * DHWo;
+  const float* rb = res ? res + (size_t)b * Co * DHWo : nullptr;
+  constexpr int NE4 = 32 * C::MT * 16;
+  for (int e = threadIdx.x; e < NE4; e += C::NTHREADS) {
+    const int row = e / (C::MT * 16), c4 = e - row * (C::MT * 16), mt = c4 >> 4, jj = (c4 & 15) * 4;   // jj: column of the 64-wide strip
+    const float* pp = lds + row * C::PP + mt * 64 + jj;
+    float4 s = *reinterpret_cast<const float4*>(pp);
+#pragma unroll
+    for (int w = 1; w < C::NW; ++w) {
+      const float4 q = *reinterpret_cast<const float4*>(pp + w * C::PART);
+      s.x += q.x;
+      s.y += q.y;
+      s.z += q.z;
+      s.w += q.w;
+    }
+    const int co = nt0 * 32 + row;
+    const int ly = jj >> 5, ox = jj & 31;   // input row of the pair, output column inside the tile's 32
+    const int gz = 2 * z0 + PZ, gy = 2 * (y0 + ly) + PY, gx = 2 * (x0 + 16 * mt) + ox;
+    if (co >= cvalid || y0 + ly >= H || gx >= Wout) continue;
+    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+    float v[4] = {fmaf(s.x, sc, sh), fmaf(s.y, sc, sh), fmaf(s.z, sc, sh), fmaf(s.w, sc, sh)};
+    const size_t o = (size_t)co * DHWo + (size_t)gz * HWo + (size_t)gy * Wout + gx;
+    if (relu == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (rb) {
+      const float4 r4 = *reinterpret_cast<const float4*>(rb + o);
+      v[0] += r4.x;
+      v[1] += r4.y;
+      v[2] += r4.z;
+      v[3] += r4.w;
+    }
+    if (relu == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS) void deconv3d_sk_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ res, float* __restrict__ y, int Ci, int D,
+                                                                  int H, int W, int Wout, int ntx, int nty, int NTT, int cvalid,
+                                                                  int relu) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt0 = t % NTT;
+  t /= NTT;
+  const int cls = t & 3;   // heaviest class first: (pz, py) = (1, 1), (1, 0), (0, 1), (0, 0)
+  t >>= 2;
+  const int tx = t % ntx;
+  t /= ntx;
+  const int ty = t % nty;
+  t /= nty;
+  const int z0 = t % D, b = t / D;
+  const int x0 = tx * C::TXI, y0 = ty * C::TYI;
+  if (cls == 0)
+    deconv_sk_body<C, 1, 1>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
+  else if (cls == 1)
+    deconv_sk_body<C, 1, 0>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
+  else if (cls == 2)
+    deconv_sk_body<C, 0, 1>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
+  else
+    deconv_sk_body<C, 0, 0>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
+}
+
+template <class C>
+static int launch_dsk(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
+                      int Ci, int Co, int D, int H, int W, int Wout, int relu, hipStream_t st) {
+  const int ntx = cdiv(W, C::TXI), nty = cdiv(H, C::TYI), NTT = cdiv(Co, 32);
+  const long long nblk = (long long)B * D * nty * ntx * 4 * NTT;
+  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
+  const size_t in_floats = (size_t)Ci * C::IN_MAX, part_floats = (size_t)C::NW * C::PART;
+  const size_t lds = (in_floats > part_floats ? in_floats : part_floats) * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  DMB_ENSURE_LDS((&deconv3d_sk_kernel<C>), (size_t)(160 * 1024));
+  hipLaunchKernelGGL((deconv3d_sk_kernel<C>), dim3((unsigned)nblk), dim3(C::NTHREADS), lds, st, x, wp, scale, shift, res, y, Ci, D, H,
+                     W, Wout, ntx, nty, NTT, Co, relu);
+  return launch_status("deconv3d split-K launch failed");
+}
+
+// variant: 1 = 16 x 2 input positions per workgroup, eight waves; 2 = 32 x 2, eight waves; 3 = 16 x 2, four waves; 4 = 32 x 2, four waves.
+// -1: the shape does not qualify.
+int deconv3d_sk_try(int variant, const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                    int B, int Ci, int Co, int D, int H, int W, int Wout, int relu, hipStream_t st) {
+  if (Co > 64 || W % 4 != 0 || Wout % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) != 0) return -1;
+  const int nw = variant <= 2 ? 8 : 4;
+  if (Ci % (2 * nw) != 0 || Ci / (2 * nw) > 4 * (variant <= 2 ? 1 : 2)) return -1;
+  if ((long long)(Ci / nw) * D * H * W * 4 >= 0x7fffffffLL) return -1;
+  switch (variant) {
+    case 1: return launch_dsk<DSKCfg<8, 1, 4>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
+    case 2: return launch_dsk<DSKCfg<8, 2, 4>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
+    case 3: return launch_dsk<DSKCfg<4, 1, 8>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
+    case 4: return launch_dsk<DSKCfg<4, 2, 8>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
+  }
+  return -1;
+}
+
+}  // namespace dmb

@@ -34,6 +34,8 @@ int num_cus() {
 //   17  extra KB of LDS per stride-1 workgroup (occupancy)              18  = 1: default tile height for the 64-channel conv2d layers
 //   19  stride-1 tile override (see dmb_conv3d_k3_f32)                   20  = 1: zy items from ONE counter instead of one per XCD
 //   21  = 32 / 64: options 16 and 20 for that output width only         22  up-sampling: 1 = row form, 2 = flat form
+//   23  split-K conv3d: 1 = never, k >= 2 = force variant k - 1          24  32 -> 1 head: 1 = never the split-channel form, 2 = always
+//   25  split-K transposed conv: 1 = never, k >= 2 = force variant k - 1
 namespace dmb {
 int g_dev_opts[32] = {0};
 }
@@ -42,5 +44,5 @@ extern "C" void dmb_dev_set_option(int key, int value) {
 }
 #endif
 
-extern "C" int dmb_abi_version(void) { return 6; }
+extern "C" int dmb_abi_version(void) { return 7; }
 extern "C" const char* dmb_last_error(void) { return dmb::g_last_error; }

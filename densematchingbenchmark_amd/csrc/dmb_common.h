@@ -115,4 +115,11 @@ __device__ __forceinline__ int cd_row(int r, int h) { return (r & 3) + 8 * (r >>
 int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                     int B, int Ci, int Co, int D, int H, int W, int Wout, int relu, int* workspace, hipStream_t st);
 
+// csrc/conv3d_sk.hip: split-K form of the stride-1 / stride-2 convolution for launches that do not fill the chip; -1 = does not apply.
+int conv3d_sk_try(int variant, const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                  int B, int Ci, int Co, int D, int H, int W, int stride, int relu, hipStream_t st);
+
+int deconv3d_sk_try(int variant, const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
+                    int B, int Ci, int Co, int D, int H, int W, int Wout, int relu, hipStream_t st);
+
 }  // namespace dmb

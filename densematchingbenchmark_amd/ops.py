@@ -260,6 +260,29 @@ def _relu_mode(relu):
     return int(relu) if relu in (0, 1, 2) else int(bool(relu))
 
 
+# ---------------------------------------------------------------------------------------------- small-launch policy
+# A convolution launch that would leave most of the chip idle (one small pair per call) takes a split-K kernel form: the input
+# channels of a voxel split over the waves of a workgroup, partial sums added in a fixed order (include/dmb_hip.h,
+# DMB_CONV_SINGLE_CHAIN; csrc/conv3d_sk.hip).  Reproducible run to run, but the last bits then depend on the launch's SIZE: the
+# same pair at batch 1 and inside a batch of 4 may differ by an FP32 rounding.  ``set_split_k(False)`` keeps every launch on the
+# single-chain kernels: results bit-identical across batch sizes, small launches 2-3x slower.
+_split_k = True
+
+
+def set_split_k(flag):
+    """True / "auto" (default): small launches may take the split-K forms; False: single-chain kernels only (batch-invariant bits)."""
+    global _split_k
+    _split_k = bool(flag)
+
+
+def split_k():
+    return _split_k
+
+
+def _conv_flags():
+    return 0 if _split_k else _lib.CONV_SINGLE_CHAIN
+
+
 def _out_tensor(out, shape, device, what):
     """The caller's pre-allocated output (as the reference's native op takes it, ops/spn/functions/gaterecurrent2dnoind.py:8-39)
     or a fresh one."""
@@ -287,7 +310,7 @@ def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, rel
         _kernel_timer.start(tag)
     check(lib.dmb_conv3d_k3_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                 dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
-                                B, Ci, Co, D, H, W, stride, _relu_mode(relu), stream_ptr(x.device)), "dmb_conv3d_k3_f32")
+                                B, Ci, Co, D, H, W, stride, _relu_mode(relu) | _conv_flags(), stream_ptr(x.device)), "dmb_conv3d_k3_f32")
     if _kernel_timer is not None:
         _kernel_timer.stop(tag)
     return y
@@ -618,7 +641,7 @@ def conv3d_k3_c1(x, w, bias=0.0, residual=None):
     if residual is not None:
         _same_shape(residual, y, "conv3d_k3_c1 residual")
     check(lib.dmb_conv3d_k3_c1_f32(dev_ptr(x), dev_ptr(w), float(bias), dev_ptr(residual, allow_none=True), dev_ptr(y),
-                                   B, Ci, D, H, W, stream_ptr(x.device)), "dmb_conv3d_k3_c1_f32")
+                                   B, Ci, D, H, W, _conv_flags(), stream_ptr(x.device)), "dmb_conv3d_k3_c1_f32")
     return y
 
 
@@ -665,7 +688,7 @@ def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=Fals
                                    % (_lib.DECONV3D_WORKSPACE_BYTES, x.device))
     check(lib.dmb_deconv3d_k3s2_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                                     dev_ptr(shift, allow_none=True), dev_ptr(residual, allow_none=True), dev_ptr(y),
-                                    B, Ci, Co, D, H, W, Wout, _relu_mode(relu),
+                                    B, Ci, Co, D, H, W, Wout, _relu_mode(relu) | _conv_flags(),
                                     None if workspace is None else ctypes.c_void_p(workspace.data_ptr()), stream_ptr(x.device)), "dmb_deconv3d_k3s2_f32")
     return y
 

@@ -44,7 +44,8 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes (6: dmb_stereo_pad_normalize_f32 / _u8 added; 5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
+/* ABI version: bumped whenever a signature below changes (7: DMB_CONV_SINGLE_CHAIN in the `relu` argument of the convolution
+ * entry points, `flags` argument of dmb_conv3d_k3_c1_f32; 6: dmb_stereo_pad_normalize_f32 / _u8 added; 5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
  * optional gradient buffer for per-pixel samples; 4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads entry
  * points of version 3 removed). */
 int dmb_abi_version(void);
@@ -185,8 +186,17 @@ int dmb_cat_fms_into_f32(const float* L, const float* R, float* out, int B, int 
  *                                           aggregators/GCNet.py:108-116)
  *     v = v + residual[...]                (residual may be NULL; same shape as y)
  *     v = max(v, 0)                        (if relu == 1: hourglass.py:67-81 activates after the skip add)
- * acc is an FP32 fma chain over (ci, kd, kh, kw).
+ * acc is an FP32 fma chain over (ci, kd, kh, kw) -- ONE chain per output voxel in the kernels a launch that fills the chip
+ * takes.  A launch that would leave most of the chip idle (one small stereo pair per call: dmb/apis/inference.py:191-225)
+ * takes a split-K form instead (csrc/conv3d_sk.hip, conv3d_c1s_kernel): the input channels of a voxel are split over the waves
+ * of a workgroup and the partial chains added in a fixed order -- reproducible run to run, but the last bits then depend on which
+ * form the launch's SIZE selects (batch 1 and batch 4 of the same pair may differ by an FP32 rounding of the sum).
+ * DMB_CONV_SINGLE_CHAIN, or-ed into the `relu` argument of dmb_conv3d_k3_f32 / dmb_deconv3d_k3s2_f32 (bits 0-7 stay the
+ * activation mode) or passed as `flags` of dmb_conv3d_k3_c1_f32, keeps a launch on the single-chain kernels whatever its size:
+ * results are then bit-identical across batch sizes (slower for small launches: 31-35 us instead of 13-15 us per layer of the
+ * deepest hourglass level of one 256x512 pair).
  * ---------------------------------------------------------------------------------------- */
+#define DMB_CONV_SINGLE_CHAIN 0x100
 
 /* Number of floats of the packed-weight buffer for a k=3 convolution / transposed convolution (input channels are
  * zero-padded to a multiple of 8 inside the packed stream, so any Ci >= 1 is accepted). */
@@ -208,9 +218,9 @@ int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float* scale, co
 
 /* Conv3d kernel 3 pad 1 stride 1 with ONE output channel (classifier heads: PSMNet.py:46,50,54,
  * StereoNet.py:39).  w: raw [1, Ci, 3, 3, 3]; bias_host: scalar added to every output; residual may be
- * NULL (PSMNet.py:71-72 adds the previous level's cost).  y: [B, 1, D, H, W]. */
+ * NULL (PSMNet.py:71-72 adds the previous level's cost).  y: [B, 1, D, H, W].  flags: 0 or DMB_CONV_SINGLE_CHAIN. */
 int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, const float* residual, float* y,
-                         int B, int Ci, int D, int H, int W, void* stream);
+                         int B, int Ci, int D, int H, int W, int flags, void* stream);
 
 /* ConvTranspose3d kernel 3, stride 2, padding 1, output_padding 1 (hourglass.py:52-60):
  * x: [B, Ci, D, H, W] -> y: [B, Co, 2D, 2H, Wout];  y[o] += x[i] * w[k] with o = 2i - 1 + k.  Co = 64 or any Co <= 32

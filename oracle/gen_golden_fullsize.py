@@ -8,6 +8,7 @@ files at the sizes the CPU suite can afford).
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py          (about five minutes on 8 cores)
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py round3   (only the families added in round 3)
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py kitti    (round 4: the reference's KITTI operating point)
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py spread   (round 6: the reference against itself at 1 / 3 / 8 threads)
 
 Round 3 added (parity): PSMNet pair 0 at classifier gain 30 (fullsize_psmnet_gain30.npz); one FULL AcfNet
 disparity / confidence map instead of every 64th pixel (fullsize_acfnet_map.npz); and the regression tail -- trilinear x4
@@ -170,6 +171,52 @@ def kitti():
         print("psmnet full map: disp3 range %.2f..%.2f" % (d3.min().item(), d3.max().item()), flush=True)
 
 
+def spread():
+    """Round 6: how far the reference is from ITSELF.  The real reference on pair 0 of BASELINE configs[1]
+    (544x960, D = 192) and of the KITTI operating point (384x1248), the same weights and inputs, at 1, 3 and 8 host threads
+    (torch.set_num_threads): the convolution back end splits its reductions differently, the costs move by a few 1e-7 and the
+    k-ascending FP32 soft-argmin chain (faster_soft_argmin.py:46-71) by up to 1e-4.  Stored: the three sub-sampled map sets of
+    every level, the whole-map spread max_ij |ref_i - ref_j| per level (scalars) and the whole best-level maps as differences
+    against the 8-thread one (float32, zlib-friendly: mostly small multiples of one ulp).  The tests replace their
+    "measured + 10 %" constants by max(1e-4, 1.6 x this spread)."""
+    from dmb.modeling.stereo.cost_processors import build_cost_processor
+    from dmb.modeling.stereo.disp_predictors import build_disp_predictor
+    from densematchingbenchmark_amd import synthetic
+
+    out = {}
+    threads = (8, 3, 1)
+    with torch.no_grad():
+        for tag, rel, (fh, fw) in (("s544", "configs/PSMNet/scene_flow.py", (136, 240)),
+                                   ("kitti", "configs/PSMNet/kitti_2015.py", (96, 312))):
+            cfg = G.load_cfg(rel)
+            m = _M()
+            m.cost_processor = build_cost_processor(cfg)
+            m.disp_predictor = build_disp_predictor(cfg)
+            m.eval()
+            synthetic.init_params_(m, seed=0, classif_gain=10.0)
+            lf, rf = synthetic.feature_pair(0, 32, fh, fw)
+            maps = {}
+            for t in threads:
+                torch.set_num_threads(t)
+                costs = m.cost_processor(lf, rf)
+                maps[t] = [m.disp_predictor(c) for c in costs]
+                del costs
+                for lvl, d in enumerate(maps[t]):
+                    out["%s_t%d_disp%d" % (tag, t, 3 - lvl)] = G.npy(d[SUB])
+                print(tag, "threads", t, "disp3 range %.2f..%.2f" % (maps[t][0].min().item(), maps[t][0].max().item()), flush=True)
+            for lvl in range(3):
+                full = max((maps[a][lvl] - maps[b][lvl]).abs().max().item() for a in threads for b in threads if a < b)
+                sub = max((maps[a][lvl][SUB] - maps[b][lvl][SUB]).abs().max().item() for a in threads for b in threads if a < b)
+                out["%s_spread_full_disp%d" % (tag, 3 - lvl)] = np.float64(full)
+                out["%s_spread_sub_disp%d" % (tag, 3 - lvl)] = np.float64(sub)
+                print(tag, "level", 3 - lvl, "self-spread: whole map %.3e, sub-sample %.3e" % (full, sub), flush=True)
+            for t in threads[1:]:
+                out["%s_t%d_minus_t8_disp3_full" % (tag, t)] = G.npy(maps[t][0] - maps[8][0])
+    torch.set_num_threads(int(os.environ.get("DMB_THREADS", "8")))
+    np.savez_compressed(os.path.join(OUT, "fullsize_psmnet_spread.npz"), **out)
+    print("fullsize_psmnet_spread.npz %8.1f KB" % (os.path.getsize(os.path.join(OUT, "fullsize_psmnet_spread.npz")) / 1024))
+
+
 def main():
     G.import_reference()
     torch.set_num_threads(int(os.environ.get("DMB_THREADS", "8")))
@@ -178,6 +225,9 @@ def main():
         return
     if "kitti" in sys.argv[1:]:
         kitti()
+        return
+    if "spread" in sys.argv[1:]:
+        spread()
         return
     from dmb.modeling.stereo.cost_processors import build_cost_processor
     from dmb.modeling.stereo.disp_predictors import build_disp_predictor

@@ -33,3 +33,15 @@ def _library_present():
     from densematchingbenchmark_amd import build
     if not os.path.exists(build.LIB_PATH):
         build.build_library(verbose=False)
+
+
+@pytest.fixture
+def single_chain():
+    """The convolution launches of this test stay on the single-chain kernels whatever their size (ops.set_split_k(False) =
+    DMB_CONV_SINGLE_CHAIN, include/dmb_hip.h): the tests that compare two forms of those kernels BIT for bit, or a batch with its
+    single pairs, need launches whose summation order does not depend on the launch's size."""
+    from densematchingbenchmark_amd import ops
+    before = ops.split_k()
+    ops.set_split_k(False)
+    yield
+    ops.set_split_k(before)

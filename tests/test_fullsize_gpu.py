@@ -455,9 +455,12 @@ def test_fp64_yardstick_psmnet_other_shapes(dev, hw):
 
 
 # ------------------------------------------------------------------------------------------------- BASELINE configs[3] / [4] at their bench batches
-def _batch_vs_single(model, left, right, dev, keys=("disps", "costs", "confs")):
+def _batch_vs_single(model, left, right, dev, keys=("disps", "costs", "confs"), exact=True, disp_tol=DISP_TOL):
     """Every pair of a batch against its own single-pair evaluation.  A batch changes tile counts, XCD ranges and the multi-job
-    launches, never the arithmetic of a pixel: the outputs must be BIT-IDENTICAL."""
+    launches, never the arithmetic of a pixel: on the single-chain kernels the outputs must be BIT-IDENTICAL (``exact``).  Under
+    the default policy (round 6) a launch that leaves most of the chip idle takes a split-K form -- the same FP32 products, the
+    partial sums of a voxel added in a fixed but different order -- so a single small pair may differ from its evaluation inside
+    a batch by FP32 roundings: costs within COST_TOL, disparities within ``disp_tol``."""
     with torch.no_grad():
         whole, _ = model(dict(leftFeature=left, rightFeature=right))
         B = left.shape[0]
@@ -467,7 +470,11 @@ def _batch_vs_single(model, left, right, dev, keys=("disps", "costs", "confs")):
                 if k not in whole:
                     continue
                 for lvl, (a, b) in enumerate(zip(whole[k], single[k])):
-                    assert torch.equal(a[i:i + 1], b), (k, lvl, i, (a[i:i + 1] - b).abs().max().item())
+                    d = (a[i:i + 1] - b).abs().max().item()
+                    if exact:
+                        assert torch.equal(a[i:i + 1], b), (k, lvl, i, d)
+                    else:
+                        assert d <= {"disps": disp_tol, "costs": COST_TOL, "confs": 2e-5}[k], (k, lvl, i, d)
             del single
     return whole
 
@@ -488,28 +495,42 @@ def test_fullsize_acfnet_bench_batch_equals_single_pairs(dev):
         assert maxdiff(whole["costs"][lvl][0:1][CROWS], g["cost%d_rows" % k]) <= COST_TOL
 
 
-def test_fullsize_stereonet_bench_batch_equals_single_pairs(dev):
-    """BASELINE configs[4] as bench.py runs it per GPU: StereoNet-8x cost path at 384x1248, batch 8."""
-    from densematchingbenchmark_amd import synthetic
+@pytest.mark.parametrize("split_k", [False, True])
+def test_fullsize_stereonet_bench_batch_equals_single_pairs(dev, split_k):
+    """BASELINE configs[4] as bench.py runs it per GPU: StereoNet-8x cost path at 384x1248, batch 8 -- bit-identical to the single
+    pairs on the single-chain kernels; under the default policy the single pairs' small launches take the split-K forms."""
+    from densematchingbenchmark_amd import ops, synthetic
     g = golden("fullsize_stereonet.npz")
     cfg, model = _built("StereoNet/scene_flow_8x_2stage.py", 6)
     model = model.to(dev)
     left, right = synthetic.feature_batch(0, 1, 8, 32, 48, 156, dev)
-    whole = _batch_vs_single(model, left, right, dev)
+    ops.set_split_k(split_k)
+    try:
+        whole = _batch_vs_single(model, left, right, dev, exact=not split_k)
+    finally:
+        ops.set_split_k(True)
     assert maxdiff(whole["disps"][0][0:1], g["disp"]) <= 1e-4
     assert maxdiff(whole["costs"][0][0:1][:, :, 1::2, :], g["cost"]) <= 2e-5
 
 
-def test_psmnet_batch_one_equals_batch_four(dev):
+@pytest.mark.parametrize("split_k", [False, True])
+def test_psmnet_batch_one_equals_batch_four(dev, split_k):
     """The batch-1 (latency) regime selects other tiles than the bench batch (the tile cost model sees a quarter of the voxels): the
-    same pairs through batch 4 and one at a time, bit-identical, at 544x960 and at BASELINE configs[0]'s 256x512 / max_disp 64."""
-    from densematchingbenchmark_amd import synthetic
-    cfg, model = _built("PSMNet/scene_flow.py", 0)
-    model = model.to(dev)
-    left, right = synthetic.feature_batch(0, 1, 4, 32, 136, 240, dev)
-    _batch_vs_single(model, left, right, dev)
-    cfg0, model0 = _built("PSMNet/baseline_cfg0_256x512_d64.py", 2)
-    model0 = model0.to(dev)
-    left, right = synthetic.feature_batch(40, 1, 4, 32, 64, 128, dev)
-    whole = _batch_vs_single(model0, left, right, dev)
+    same pairs through batch 4 and one at a time, at 544x960 and at BASELINE configs[0]'s 256x512 / max_disp 64.  On the
+    single-chain kernels (ops.set_split_k(False)): bit-identical.  Under the default policy one 256x512 pair's deepest hourglass
+    levels and heads take the split-K forms (round 6): costs within COST_TOL, disparities within 1e-4 of the batch's; at 544x960
+    no launch of one pair is small enough for them, so that shape stays bit-identical either way."""
+    from densematchingbenchmark_amd import ops, synthetic
+    ops.set_split_k(split_k)
+    try:
+        cfg, model = _built("PSMNet/scene_flow.py", 0)
+        model = model.to(dev)
+        left, right = synthetic.feature_batch(0, 1, 4, 32, 136, 240, dev)
+        _batch_vs_single(model, left, right, dev)
+        cfg0, model0 = _built("PSMNet/baseline_cfg0_256x512_d64.py", 2)
+        model0 = model0.to(dev)
+        left, right = synthetic.feature_batch(40, 1, 4, 32, 64, 128, dev)
+        whole = _batch_vs_single(model0, left, right, dev, exact=not split_k)
+    finally:
+        ops.set_split_k(True)
     assert [tuple(d.shape) for d in whole["disps"]] == [(4, 1, 256, 512)] * 3

@@ -38,7 +38,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libdmb_hip.so does not export %s" % s
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and include/dmb_hip.h disagree"
-    assert lib.dmb_abi_version() == 6 == _lib.ABI_VERSION
+    assert lib.dmb_abi_version() == 7 == _lib.ABI_VERSION
     assert lib.dmb_conv3d_packed_floats(32, 64) == 32 * 64 * 27
 
 
@@ -434,7 +434,8 @@ def test_binding_constants_match_the_header():
     import re
     text = open(_lib.HEADER_PATH).read()
     assert int(re.search(r"#define DMB_DECONV3D_WORKSPACE_BYTES (\d+)", text).group(1)) == _lib.DECONV3D_WORKSPACE_BYTES
-    assert "ABI version" in text and "(6:" in text and _lib.ABI_VERSION == 6
+    assert int(re.search(r"#define DMB_CONV_SINGLE_CHAIN (0x[0-9a-f]+)", text).group(1), 16) == _lib.CONV_SINGLE_CHAIN
+    assert "ABI version" in text and "(7:" in text and _lib.ABI_VERSION == 7
 
 
 def test_data_side_and_serving_api_refuse_host_tensors():

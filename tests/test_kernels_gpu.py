@@ -351,6 +351,7 @@ def test_conv3d_c1(dev, Ci):
 
 
 @pytest.mark.parametrize("shape", [(2, 6, 9, 72), (1, 17, 10, 240), (1, 3, 19, 64), (1, 9, 8, 124)])
+@pytest.mark.usefixtures("single_chain")
 def test_conv3d_c1_vector_rows(dev, shape):
     """Rows that are 16-byte aligned (W % 4 == 0) take the register-staged kernel (16-byte fetches, one LDS word per input
     row and thread, halo columns by lane shifts): same accumulation order as the dword kernel -> BIT-identical to it, and
@@ -785,6 +786,7 @@ def test_conv3d_relu_before_skip(dev, kind, shape):
 @pytest.mark.parametrize("Ci,Co,shape", [(32, 32, (1, 6, 10, 96)), (64, 32, (2, 5, 7, 48)), (5, 32, (1, 4, 6, 48)),
                                          (32, 32, (1, 9, 13, 240)), (64, 64, (1, 6, 10, 72)), (32, 64, (2, 5, 7, 24)),
                                          (64, 64, (1, 9, 13, 120))])
+@pytest.mark.usefixtures("single_chain")
 def test_conv3d_bf16x6_is_as_accurate_as_fp32(dev, Ci, Co, shape):
     """The split kernel against an FP64 convolution: its error must not exceed the exact FP32 kernel's by more than
     noise, and both stay inside the FP32 tolerance of the other conv tests."""
@@ -809,6 +811,7 @@ def test_conv3d_bf16x6_is_as_accurate_as_fp32(dev, Ci, Co, shape):
 
 @pytest.mark.parametrize("kind,shape", [("s2", (1, 6, 9, 48)), ("s2", (2, 5, 8, 120)), ("deconv", (1, 3, 5, 60)), ("deconv", (2, 2, 3, 24)),
                                         ("s1_32", (1, 5, 9, 312)), ("s1_32", (2, 4, 12, 48)), ("s1_64", (1, 4, 8, 156)), ("s1_64", (1, 3, 7, 40))])
+@pytest.mark.usefixtures("single_chain")
 def test_conv3d_vector_and_scalar_staging_agree(dev, kind, shape):
     """Rows that are 16-byte aligned are staged with 16-byte LDS-DMA words; the result must be bit-identical to the dword
     staging path (same MFMA sequence, same epilogue), which stays in use for other widths and for misaligned operands -- a
@@ -831,6 +834,7 @@ def test_conv3d_vector_and_scalar_staging_agree(dev, kind, shape):
 
 @pytest.mark.parametrize("Ci,shape", [(32, (1, 8, 16, 120)), (64, (2, 5, 9, 60)), (32, (1, 6, 8, 240)), (32, (1, 4, 4, 124))])
 @pytest.mark.parametrize("mode", ["plain", "skip_relu", "relu_then_skip"])
+@pytest.mark.usefixtures("single_chain")
 def test_conv3d_s2_pair_epilogue_is_bit_identical(dev, Ci, shape, mode):
     """The stride-2 kernel's 8-byte epilogue (S2Cfg VEP: 32 x 32 accumulator tiles through a per-wave LDS scratch, a lane stores two
     adjacent columns of one channel) against the dword epilogue (taken when the output is not 8-byte aligned: the caller's ``out``
@@ -995,6 +999,7 @@ def test_deconv_k8s4_zcol_with_regression_is_bit_identical(dev, shape):
 
 
 @pytest.mark.parametrize("Co,shape", [(32, (1, 5, 6, 120)), (64, (2, 3, 5, 60)), (32, (1, 4, 7, 64))])
+@pytest.mark.usefixtures("single_chain")
 def test_deconv3d_vector_and_scalar_epilogues_agree(dev, Co, shape):
     """The transposed convolution's 16-byte epilogue (two x parities interleaved through a per-wave LDS scratch, residual
     ring) against its 8-byte scattered form: same fma / add / max sequence per output -> bit-identical, with and without the
@@ -1093,6 +1098,7 @@ def test_spn_refuses_cpu_tensors_and_long_lines(dev):
 
 @pytest.mark.parametrize("Ci,shape", [(64, (1, 4, 5, 60)), (64, (2, 3, 34, 60)), (20, (1, 2, 1, 60)), (64, (4, 12, 34, 60)),
                                       (64, (1, 3, 9, 32)), (64, (2, 5, 7, 44)), (64, (1, 2, 24, 64))])
+@pytest.mark.usefixtures("single_chain")
 def test_conv3d_linear_runs_for_narrow_planes(dev, Ci, shape):
     """The 64-channel stride-1 layer on 64-voxel runs of the (y, x) plane (S1Cfg LIN: rows of 32 .. 64 voxels -- the deepest
     hourglass level; 768 equal workgroups for [4, 64, 12, 34, 60], exactly three per CU) against the flattened dword form (what a
@@ -1116,6 +1122,7 @@ def test_conv3d_linear_runs_for_narrow_planes(dev, Ci, shape):
 
 
 @pytest.mark.parametrize("Co,shape", [(64, (2, 3, 5, 78)), (32, (1, 4, 6, 130)), (64, (1, 2, 24, 78))])
+@pytest.mark.usefixtures("single_chain")
 def test_row_padded_hourglass_level_matches_the_unpadded_one(dev, Co, shape):
     """Rows that are not a 16-byte multiple (W % 4 == 2: the KITTI hourglass's deepest level is 78 columns wide) padded with
     zero columns to the next multiple of 4 -- the stride-1 unit over the padded tensor, its padding columns cleared again
@@ -1146,3 +1153,53 @@ def test_row_padded_hourglass_level_matches_the_unpadded_one(dev, Co, shape):
     from densematchingbenchmark_amd._lib import DmbLibraryError
     with pytest.raises(DmbLibraryError):
         ops.deconv3d_k3s2(midp, wp5, Co, sc5.to(dev), sh5.to(dev), res, True, out_width=2 * W, workspace=None)
+
+
+# ------------------------------------------------------------------------------- round 6: split-K forms for launches that leave the chip idle
+@pytest.mark.parametrize("kind,Ci,Co,shape", [("s1", 64, 64, (1, 4, 16, 32)), ("s2", 64, 64, (1, 8, 32, 64)), ("s2", 32, 64, (1, 16, 64, 128)),
+                                              ("deconv", 64, 64, (1, 4, 16, 32)), ("deconv", 64, 32, (1, 8, 32, 64)), ("c1", 32, 1, (1, 16, 64, 128)),
+                                              ("s1", 32, 32, (1, 3, 10, 44)), ("s2", 48, 32, (2, 5, 9, 52)), ("deconv", 16, 64, (1, 3, 5, 20))])
+def test_split_k_forms_of_small_launches(dev, kind, Ci, Co, shape):
+    """The layers of the hourglass (hourglass.py:62-86) and the heads (PSMNet.py:46-54) at the sizes ONE 256x512 pair gives them
+    (BASELINE configs[0]; dmb/apis/inference.py:191-225 serves one pair per call) take the split-K forms (csrc/conv3d_sk.hip,
+    conv3d_c1s_kernel): within 2e-5 of the CPU convolution, within 2e-5 of the single-chain kernels (the same FP32 products, the
+    partial sums of a voxel added in another fixed order), NOT bit-identical to them at the configs[0] shapes (that is how the test
+    knows the form was taken), and reproducible bit for bit from run to run."""
+    ops = _ops()
+    B, D, H, W = shape
+    x = _rand((B, Ci, D, H, W), 601)
+    if kind == "c1":
+        w = _rand((1, Ci, 3, 3, 3), 602, 1.0 / math.sqrt(Ci * 27))
+        res = _rand((B, 1, D, H, W), 603)
+        ref = F.conv3d(x, w, None, padding=1) - 0.5 + res
+        run = lambda: ops.conv3d_k3_c1(x.to(dev), w.to(dev), -0.5, res.to(dev))   # noqa: E731
+    else:
+        sc, sh = _affine(Co, 604)
+        if kind == "deconv":
+            w = _rand((Ci, Co, 3, 3, 3), 602, 1.0 / math.sqrt(Ci * 27 / 8))
+            y = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+            wp = ops.pack_deconv3d_weights(w.to(dev))
+        else:
+            w = _rand((Co, Ci, 3, 3, 3), 602, 1.0 / math.sqrt(Ci * 27))
+            y = F.conv3d(x, w, None, stride=2 if kind == "s2" else 1, padding=1)
+            wp = ops.pack_conv3d_weights(w.to(dev))
+        y = y * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)
+        res = _rand(y.shape, 603)
+        ref = F.relu(y + res)
+        if kind == "deconv":
+            run = lambda: ops.deconv3d_k3s2(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), res.to(dev), True)   # noqa: E731
+        else:
+            run = lambda: ops.conv3d_k3(x.to(dev), wp, Co, sc.to(dev), sh.to(dev), res.to(dev), 2 if kind == "s2" else 1, True)   # noqa: E731
+    assert ops.split_k()
+    got = run()
+    assert (got.cpu() - ref).abs().max().item() <= 2e-5
+    assert torch.equal(run(), got)
+    ops.set_split_k(False)
+    try:
+        single = run()
+    finally:
+        ops.set_split_k(True)
+    assert (single.cpu() - ref).abs().max().item() <= 2e-5
+    assert (single - got).abs().max().item() <= 2e-5
+    if (B, D, H, W) in ((1, 4, 16, 32), (1, 8, 32, 64), (1, 16, 64, 128)):
+        assert not torch.equal(single, got)
