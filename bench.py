@@ -557,8 +557,10 @@ def main():
         acc.acc.zero_()
         counter[0] = 0
         # live HIP-event timing of the dominant kernel's launches inside the timed region: every launch of every step for short
-        # runs, of every 4th step from 16 steps on (>= 24 timed launches either way; each bracketed launch costs its stream ~10 us)
-        timer = ops.KernelTimer([DOMINANT], every=4 if args.steps >= 16 else 1)
+        # runs, of every (steps / 4)-th step from 16 steps on (>= 24 timed launches either way; each bracketed launch costs its stream ~10 us)
+        # (round 6: every (steps / 4)-th step = 24 timed launches of a PSMNet step's six -- at one 256x512 pair the 10 us per bracketed
+        # launch were 1.5 % of the step when every 4th step was timed)
+        timer = ops.KernelTimer([DOMINANT], every=max(1, args.steps // 4) if args.steps >= 16 else 1)
         ops.set_kernel_timer(timer)
         fence()
         t0 = time.perf_counter()

@@ -155,6 +155,53 @@ def load():
     return lib
 
 
+_shim = None
+_shim_state = "untried"      # "untried" | "loaded" | the reason it is not in use
+
+
+def shim():
+    """The thin torch extension over the same C ABI (csrc/torch_shim.cpp -> lib/_dmb_torch_shim.so: unwraps tensors, takes the
+    current HIP stream from c10, raises DmbLibraryError on a non-zero code) for the entry points on the per-pair launch path, or
+    None -- then the ctypes table above binds them, as it binds every other entry point: the SAME functions of the SAME library,
+    only more interpreter time per launch (profiles/r06_binding_overhead.log).  Refused (-> None) unless it was built from the
+    csrc/torch_shim.cpp / dmb_hip.h / torch next to it and linked against the library that is loaded.  DMB_SHIM=0: never;
+    DMB_SHIM=require: raise instead of returning None."""
+    global _shim, _shim_state
+    if _shim_state != "untried":
+        return _shim
+    mode = os.environ.get("DMB_SHIM", "auto")
+    try:
+        if mode == "0":
+            raise DmbLibraryError("disabled by DMB_SHIM=0")
+        if DEV_BUILD:
+            raise DmbLibraryError("the development library is bound through ctypes only")
+        lib = load()
+        path = os.path.join(_PKG, "lib", "_dmb_torch_shim.so")
+        if not os.path.exists(path):
+            raise DmbLibraryError("%s is not built (python -m densematchingbenchmark_amd.build --shim)" % path)
+        import importlib.util
+        from . import build
+        spec = importlib.util.spec_from_file_location("_dmb_torch_shim", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.build_id() != build.shim_digest():
+            raise DmbLibraryError("lib/_dmb_torch_shim.so was not built from the csrc/torch_shim.cpp, dmb_hip.h and torch next to it")
+        if mod.library_build_id() != lib.dmb_build_id().decode() or mod.abi_version() != ABI_VERSION:
+            raise DmbLibraryError("lib/_dmb_torch_shim.so is bound to another libdmb_hip.so than the one loaded")
+        mod.set_error_class(DmbLibraryError)
+        _shim, _shim_state = mod, "loaded"
+    except Exception as e:  # noqa: BLE001  (any failure to bring the shim up leaves the ctypes binding of the same C ABI)
+        _shim, _shim_state = None, "%s: %s" % (type(e).__name__, e)
+        if mode == "require":
+            raise
+    return _shim
+
+
+def shim_state():
+    shim()
+    return _shim_state
+
+
 def check(code, what):
     if code != 0:
         msg = load().dmb_last_error()

@@ -1782,6 +1782,11 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
 #ifdef DMB_DEV
       if (DMB_OPT(0) == 1) return launch_s1<S1Cfg<0, 32, 4, 60, 2, 1, 0, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
 #endif
+#ifdef DMB_DEV
+      // (round 6 experiment) chunks of 4 input channels for the 32-column tiles
+      if (vec && DMB_OPT(19) == 8) return launch_s1<S1Cfg<0, 32, 4, 32, 4, 1, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
+      if (vec && DMB_OPT(19) == 9) return launch_s1<S1Cfg<0, 32, 2, 32, 4, 1, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
+#endif
       if (vec) {
         // row pairs (16 columns x 2 rows per 32-voxel column tile) of 48 or 32 columns x 4 rows, row quads (8 x 4) of 24 columns x 8
         // rows; one z-slice per wave, three workgroups per CU each
@@ -1806,11 +1811,11 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
         // (round 5) + row pairs of 16 columns x 2 rows: ONE column tile per wave, for launches that do not fill the chip (batch 1,
         // small images: 62 -> 37 us at [1, 64, 8, 32, 64], 59 -> 33 us at [1, 64, 4, 16, 32]); twice the halo per output of the quads
         static const S1Tile cand[5] = {{64, 3, 2, 2, 3, true, 1.0}, {40, 4, 2, 5, 3, false, 1.0}, {24, 4, 2, 3, 3, false, 1.0}, {32, 4, 2, 4, 3, false, 1.0},
-                                       {16, 2, 2, 1, 3, false, 0.95}};
+                                       {16, 2, 2, 1, 2, false, 0.95}};
         const bool ok[5] = {W >= 32 && W <= 64 && (H * W) % 4 == 0 && DMB_OPT(13) == 0, true, true, true, true};
 #ifdef DMB_DEV
-        // (round 6 experiment) the 16 x 2 tile with chunks of 4 / 8 input channels: fewer, longer chunks per barrier
-        if (DMB_OPT(19) == 6) return launch_s1<S1Cfg<0, 64, 2, 16, 4, 2, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
+        // (round 6 experiment) the 16 x 2 tile with chunks of 2 / 8 input channels (the library's: 4)
+        if (DMB_OPT(19) == 6) return DMB_S1(64, 2, 16, 2, 16, 0);   // (the round-5 form of the tile: chunks of 2)
         if (DMB_OPT(19) == 7) return launch_s1<S1Cfg<0, 64, 2, 16, 8, 2, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
 #endif
         switch (s1_pick(cand, ok, 5, B, D, H, W)) {
@@ -1818,7 +1823,9 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
           case 1: return DMB_S1(64, 4, 40, 2, 8, 56);
           case 2: return DMB_S1(64, 4, 24, 2, 8, 40);
           case 3: return DMB_S1(64, 4, 32, 2, 8, 40);
-          default: return DMB_S1(64, 2, 16, 2, 16, 0);
+          // (round 6: chunks of four input channels for this tile -- a chunk of two is 27 MFMAs per wave between two barriers, less than
+          // the copies' round trip: [1, 64, 8, 32, 64] 33.5 -> 31.6 us, [1, 64, 12, 34, 60] 59.6 -> 56.0 us; two workgroups per CU)
+          default: return launch_s1<S1Cfg<0, 64, 2, 16, 4, 2, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
         }
       }
       return tx == 52 ? DMB_S1(64, 4, 52, 2, 0, 0) : DMB_S1(64, 4, 60, 2, 0, 0);
@@ -1883,11 +1890,13 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
 static int dsk_variant(int B, int Ci, int Co, int D, int H, int W) {
   const long long tiles = (long long)B * D * cdiv(H, 2) * cdiv(W, 16);
   const int ncu = num_cus();
-  // measured: [1, 64, 4, 16, 32] -> 64 channels 37.3 -> 14.1 us (variant 1: 512 workgroups of eight waves, 3 - 12 MFMAs per channel
-  // pair); [1, 64, 8, 32, 64] -> 32 channels 50.3 -> 41.3 us (variant 4: 32 x 2 positions, four waves); from 6000 tiles on the
-  // work-queue kernel (deconv3d_zy.hip) wins by 2x
-  if (tiles * cdiv(Co, 32) <= ncu / 2) return 1;
-  if (Ci % 8 == 0 && Ci <= 64 && tiles * cdiv(Co, 32) <= 2LL * ncu) return 4;
+  // measured (profiles/r06_sk_probe.log; units = tiles x row tiles): 128 units ([1, 64, 4, 16, 32] -> 64 channels) 37.7 -> 14.0 us,
+  // 288 units 37.7 -> 25.0, 360 units 38.5 -> 28.3 (four waves) / 29.9 (eight), 576 units 59.4 -> 42.1 (four waves);
+  // 512 units ([1, 64, 8, 32, 64] -> 32 channels) 50.2 -> 41.2, 768 units 69.3 -> 58.5, 960 units 71.9 against 73.2 (a tie),
+  // 1200 units 81.0 against 89.4: from there on the work-queue kernel (deconv3d_zy.hip) wins
+  const long long units = tiles * cdiv(Co, 32);
+  if (units <= ncu + ncu / 2) return 1;                          // eight waves: 16 x 2 input positions per workgroup
+  if (Ci % 8 == 0 && Ci <= 64 && units <= 3LL * ncu) return 3;   // four waves
   return 0;
 }
 
@@ -1948,7 +1957,8 @@ extern "C" int dmb_conv3d_k3_c1_f32(const float* x, const float* w, float bias, 
     const int vx = cdiv(W, C1V_TX), vy = cdiv(H, C1V_TY), vz = cdiv(D, C1V_TZ);
     // (round 6) fewer tiles than one round of two workgroups per CU: the channels split over the waves of a workgroup
     // (conv3d_c1s_kernel).  DMB_OPT(24) (development build): 1 = never, 2 = always.
-    const bool small = !(flags & DMB_CONV_SINGLE_CHAIN) && (long long)B * vx * vy * vz <= num_cus() / 2;   // ([1, 32, 16, 64, 128]: 48 tiles, 52 -> 18 us; 408 tiles: 70 against 107 us)
+    // (tiles of the single-chain kernel: 48 ([1, 32, 16, 64, 128]) 52 -> 18 us, 72 - 90: 56 - 60 -> 33 us, 192: 62 -> 48 us, 408: 70 against 107 us)
+    const bool small = !(flags & DMB_CONV_SINGLE_CHAIN) && (long long)B * vx * vy * vz <= num_cus();
     if ((small && DMB_OPT(24) != 1) || DMB_OPT(24) == 2) {
       const int sz = cdiv(D, C1S_TZ);
       hipLaunchKernelGGL(conv3d_c1s_kernel, dim3((unsigned)((long long)B * vx * vy * sz)), dim3(256), 0, (hipStream_t)stream, x, w,

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void deconv_k8s4_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------
 // EPE accumulator.  Pass 1: EPE_SLICES workgroups per image reduce a slice each and write six partial sums to the slice's
 // workspace row; pass 2: one thread per image adds the slices in ascending order, turns the sums into the image's means and
-// adds those to acc.
+// adds those to acc (one wave: see epe_finalize_kernel).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int EPE_SLICES = 64;
 
@@ -544,19 +544,24 @@ __global__ __launch_bounds__(256) void epe_partial_kernel(EpeMaps maps, const fl
   }
 }
 
-// One 64-lane wave per estimate: lane l takes images l, l + 64, ... in ascending order, the lanes' sums are combined by a fixed
-// butterfly and lane 0 adds the six totals to the accumulator row -- no atomics anywhere: the metrics of a run are reproducible
-// bit for bit, whatever the dispatch order.
+// One 64-lane wave per estimate.  Per image the 64 slices are read by the 64 lanes at once and combined by a fixed butterfly
+// (round 6: one lane walking 64 x 6 dependent FP64 adds took 13 us -- as long as a convolution layer of one small pair); the
+// images are folded in ascending order and lane 0 adds the six totals to the accumulator row -- no atomics anywhere: the metrics
+// of a run are reproducible bit for bit, whatever the dispatch order.  (The counts are integers below 2^53: exact in any order.)
 __global__ __launch_bounds__(64) void epe_finalize_kernel(const double* __restrict__ ws, double* __restrict__ acc, int B) {
+  static_assert(EPE_SLICES == 64, "one slice per lane");
   const double* maps = ws + (size_t)blockIdx.x * B * EPE_SLICES * 6;   // blockIdx.x: the estimate; its accumulator row follows
   acc += blockIdx.x * 6;
   double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int b = threadIdx.x; b < B; b += 64) {
-    const double* slices = maps + (size_t)b * EPE_SLICES * 6;
-    double r[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int sl = 0; sl < EPE_SLICES; ++sl)   // slices in ascending order
+  for (int b = 0; b < B; ++b) {
+    const double* slice = maps + ((size_t)b * EPE_SLICES + threadIdx.x) * 6;
+    double r[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) r[k] += slices[sl * 6 + k];
+    for (int k = 0; k < 6; ++k) {
+      double t = slice[k];
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);   // every lane ends with the same total
+      r[k] = t;
+    }
     tot[0] += 1.0;
     if (r[0] >= 1.0) {  // pixel_error.py:48: an empty mask yields all-zero errors for this image
       tot[1] += r[1] / r[0];
@@ -564,11 +569,9 @@ __global__ __launch_bounds__(64) void epe_finalize_kernel(const double* __restri
       for (int k = 2; k < 6; ++k) tot[k] += 100.0 * r[k] / r[0];
     }
   }
+  if (threadIdx.x == 0) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    double t = tot[k];
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-    if (threadIdx.x == 0) acc[k] += t;
+    for (int k = 0; k < 6; ++k) acc[k] += tot[k];
   }
 }
 

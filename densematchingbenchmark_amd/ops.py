@@ -294,6 +294,15 @@ def _out_tensor(out, shape, device, what):
 
 
 def conv3d_k3(x, wpack, Co, scale=None, shift=None, residual=None, stride=1, relu=False, out=None):
+    sh = _lib.shim()
+    if sh is not None:      # the torch-extension shim: the same checks and the same C-ABI call, without the interpreter
+        if _kernel_timer is not None:
+            _kernel_timer.start("conv3d_k3_s%d_%dto%d" % (stride, x.shape[1], Co))
+        y = sh.conv3d_k3(x if x.is_contiguous() else x.contiguous(), wpack, Co, scale, shift, residual, stride,
+                         _relu_mode(relu) | _conv_flags(), out)
+        if _kernel_timer is not None:
+            _kernel_timer.stop("conv3d_k3_s%d_%dto%d" % (stride, x.shape[1], Co))
+        return y
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Ci, D, H, W = x.shape
@@ -445,6 +454,9 @@ def set_first_layer_streams(flag):
 
 def copy_window(src, Wd, xs):
     """dst[..., j] = src[..., j + xs] (zero outside [0, W)), j in [0, Wd): zero-filled column window of a [.., W] tensor."""
+    sh = _lib.shim()
+    if sh is not None:
+        return sh.copy_window(src if src.is_contiguous() else src.contiguous(), int(Wd), int(xs))
     lib = _lib.load()
     src = _f32c(src, "src")
     W = src.shape[-1]
@@ -632,6 +644,10 @@ def conv3d_k3_x6(x, wpack, Co, scale=None, shift=None, residual=None, relu=False
 
 
 def conv3d_k3_c1(x, w, bias=0.0, residual=None):
+    sh = _lib.shim()
+    if sh is not None:
+        return sh.conv3d_k3_c1(x if x.is_contiguous() else x.contiguous(), w if w.is_contiguous() else w.contiguous(), float(bias),
+                               residual, _conv_flags())
     lib = _lib.load()
     x, w = _f32c(x, "x"), _f32c(w, "weight")
     B, Ci, D, H, W = x.shape
@@ -669,6 +685,12 @@ def deconv3d_k3s2(x, wpack, Co, scale=None, shift=None, residual=None, relu=Fals
     """``workspace``: "auto" = the per-stream workspace above; None = the kernel form without counters; or an int32 tensor of
     DECONV3D_WORKSPACE_BYTES holding zeros.  ``out_width``: for an input whose rows are zero-padded on the right to a multiple
     of 4 columns, the real output width (2 x the unpadded input width); default 2 W."""
+    sh = _lib.shim()
+    if sh is not None:
+        if isinstance(workspace, str):
+            workspace = deconv3d_workspace(x.device)
+        return sh.deconv3d_k3s2(x if x.is_contiguous() else x.contiguous(), wpack, Co, scale, shift, residual,
+                                _relu_mode(relu) | _conv_flags(), workspace, out, -1 if out_width is None else int(out_width))
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Ci, D, H, W = x.shape
@@ -1070,6 +1092,11 @@ def trilinear_soft_argmin(x, out_size, disp_values, alpha=1.0):
 def trilinear_ac_soft_argmin(x, out_size, disp_values, alpha=1.0):
     """Up-sampled cost volume AND its soft-argmin (normalize=True) in one pass: returns (cost [B, Do, Ho, Wo],
     disp [B, 1, Ho, Wo]) with disp == soft_argmin(cost, disp_values, alpha, True) bit for bit."""
+    sh = _lib.shim()
+    if sh is not None:
+        y, disp = sh.trilinear_ac_soft_argmin(x if x.is_contiguous() else x.contiguous(), int(out_size[0]), int(out_size[1]), int(out_size[2]),
+                                              float(alpha), [float(v) for v in disp_values])
+        return y, disp
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Di, Hi, Wi = x.shape
@@ -1326,6 +1353,11 @@ def conv2d(x, wpack, Co, ksize, stride=1, dilation=1, scale=None, shift=None, re
            in_window=None, out=None, out_ch_offset=0, res_ch_offset=0):
     """x: [B, Cx, H, W]; ``in_window=(offset, Ci)`` reads channels [offset, offset + Ci) of it (default: all).
     ``out``: optional pre-allocated [B, Ctot, Ho, Wo] tensor written at channel ``out_ch_offset``."""
+    sh = _lib.shim()
+    if sh is not None:
+        coff, Ci = in_window if in_window is not None else (0, x.shape[1])
+        return sh.conv2d(x if x.is_contiguous() else x.contiguous(), coff, Ci, wpack, Co, ksize, stride, dilation, scale, shift, residual,
+                         res_ch_offset, bool(relu), out, out_ch_offset)
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Cx, H, W = x.shape

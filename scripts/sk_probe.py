@@ -137,7 +137,8 @@ def line(name, us, fl, ug=None):
 
 
 check()
-for D, H, W in ((16, 64, 128), (48, 136, 240), (48, 96, 312)):
+SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("KB_SHAPES", "16x64x128,48x136x240,48x96x312").split(",")]
+for D, H, W in SHAPES:
     print("B = %d, quarter-resolution volume %d x %d x %d" % (B, D, H, W))
     for name, (Ci, Co, s, sc, res) in (("dres 32->32 full", (32, 32, 1, 1, False)), ("conv1 s2 32->64 full->half", (32, 64, 2, 1, False)),
                                        ("conv2 s1 64->64 half", (64, 64, 1, 2, True)), ("conv3 s2 64->64 half->quarter", (64, 64, 2, 2, False)),
@@ -153,8 +154,13 @@ for D, H, W in ((16, 64, 128), (48, 136, 240), (48, 96, 312)):
             except Exception as e:  # noqa: BLE001
                 print("  %s %s: %r" % (name, what, e))
         lib.dmb_dev_set_option(23, 1)
+        if Co == 32 and s == 1:
+            for c, what in ((3, "32x4 tile"), (4, "32x2 tile"), (8, "32x4 tile, chunks of 4"), (9, "32x2 tile, chunks of 4")):
+                lib.dmb_dev_set_option(19, c)
+                line(name + ": full-grid " + what, timeit(f), fl, timeit_graph(f))
+            lib.dmb_dev_set_option(19, 0)
         if Co == 64:   # the full-grid kernels' small tiles with longer chunks
-            opt, cands = (19, ((6, "16x2 tile, chunks of 4"), (7, "16x2 tile, chunks of 8"))) if s == 1 else (10, ((5, "one-row tile, chunks of 4"), (6, "two-row tile, chunks of 4")))
+            opt, cands = (19, ((6, "16x2 tile, chunks of 2 (round 5)"), (7, "16x2 tile, chunks of 8"))) if s == 1 else (10, ((5, "one-row tile, chunks of 4"), (6, "two-row tile, chunks of 4")))
             for c, what in cands:
                 lib.dmb_dev_set_option(opt, c)
                 line(name + ": full-grid " + what, timeit(f), fl, timeit_graph(f))

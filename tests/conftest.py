@@ -33,6 +33,8 @@ def _library_present():
     from densematchingbenchmark_amd import build
     if not os.path.exists(build.LIB_PATH):
         build.build_library(verbose=False)
+    if not os.path.exists(build.SHIM_PATH):     # the thin torch extension over the same C ABI (host code only)
+        build.build_torch_shim(verbose=False)
 
 
 @pytest.fixture

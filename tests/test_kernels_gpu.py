@@ -1203,3 +1203,42 @@ def test_split_k_forms_of_small_launches(dev, kind, Ci, Co, shape):
     assert (single - got).abs().max().item() <= 2e-5
     if (B, D, H, W) in ((1, 4, 16, 32), (1, 8, 32, 64), (1, 16, 64, 128)):
         assert not torch.equal(single, got)
+
+
+def test_torch_extension_shim_and_ctypes_bind_the_same_functions(dev):
+    """The thin torch extension (csrc/torch_shim.cpp; the reference's native-op pattern, dmb/ops/spn/src/gaterecurrent2dnoind_cuda.cpp:86-89)
+    is loaded on a GPU box and gives, call for call, what the ctypes binding of the same C ABI gives -- outputs bit for bit, the
+    library's own error type for a host tensor, a wrong shape, a foreign dtype."""
+    from densematchingbenchmark_amd import _lib
+    ops = _ops()
+    shim = _lib.shim()
+    assert shim is not None, _lib.shim_state()
+    x = _rand((2, 32, 5, 9, 40), 701).to(dev)
+    w = _rand((64, 32, 3, 3, 3), 702, 0.05).to(dev)
+    wd = _rand((32, 64, 3, 3, 3), 703, 0.05).to(dev)
+    sc, sh = (t.to(dev) for t in _affine(64, 704))
+    res = _rand((2, 64, 5, 9, 40), 705).to(dev)
+    x2 = _rand((2, 16, 20, 36), 706).to(dev)
+    w2 = _rand((32, 16, 3, 3), 707, 0.1).to(dev)
+    q = _rand((1, 6, 5, 8), 708).to(dev)
+
+    def run():
+        wp = ops.pack_conv3d_weights(w)
+        outs = [ops.conv3d_k3(x, wp, 64, sc, sh, res, 1, True), ops.conv3d_k3(x, wp, 64, sc, sh, None, 2, "pre"),
+                ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(wd), 64, sc, sh, None, True),
+                ops.conv3d_k3_c1(x, w[:1].contiguous(), 0.5, None), ops.copy_window(x, 48, -3),
+                ops.conv2d(x2, ops.pack_conv2d_weights(w2), 32, 3, 1, 1, sc[:32].contiguous(), sh[:32].contiguous(), None, True)]
+        outs += list(ops.trilinear_ac_soft_argmin(q, (24, 20, 32), ops.disp_sample_values(24, 0, 1), 1.0))
+        return outs
+
+    try:
+        a = run()
+        _lib._shim = None
+        b = run()
+    finally:
+        _lib._shim = shim
+    assert len(a) == len(b) == 8 and all(torch.equal(u, v) for u, v in zip(a, b))
+    for bad in (lambda: ops.conv3d_k3(x.cpu(), ops.pack_conv3d_weights(w), 64), lambda: ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 32),
+                lambda: ops.conv3d_k3(x.double(), ops.pack_conv3d_weights(w), 64), lambda: ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 64, None, None, res[:1])):
+        with pytest.raises(_lib.DmbLibraryError):
+            bad()
