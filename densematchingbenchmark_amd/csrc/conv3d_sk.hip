@@ -43,48 +43,64 @@ struct SKCfg {
   static_assert(P % 4 == 0 && CHS % 4 == 0, "16-byte units");
 };
 
+// The kernel is PERSISTENT: workgroup g walks work items g, g + G, ... (item = voxel tile x row-tile group; G is a multiple of the
+// row-tile groups, so a workgroup keeps ITS row tiles and with them its A fragments: the weights are read once per workgroup, not
+// once per tile -- at 1500 tile chains the one-item-per-workgroup form re-read 0.34 GB of weights from L2 and ran at 0.45 of the
+// matrix peak).  With fewer items than workgroup slots every workgroup has exactly one item.  Where two input tiles fit the LDS
+// the next item's copies are in flight while the current one is multiplied.
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ res, float* __restrict__ y, int Ci, int D,
                                                                 int H, int W, int Do, int Ho, int Wo, int ntx, int nty, int NTT,
-                                                                int relu) {
+                                                                int relu, int items, int buf_floats, int nbuf) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
   const int NTS = NTT / C::NT;
-  const int nt0 = (t % NTS) * C::NT;   // first 32-channel row tile of this workgroup (innermost: the row tiles of a voxel tile share its input in L2)
-  t /= NTS;
-  const int tx = t % ntx;
-  t /= ntx;
-  const int ty = t % nty;
-  t /= nty;
-  const int z0 = t % Do, b = t / Do;
-  const int x0 = tx * C::TXO, y0 = ty * C::TYO;   // output coordinates
+  const int nt0 = (wg % NTS) * C::NT;   // first 32-channel row tile of this workgroup (innermost: the row tiles of a voxel tile share its input in L2)
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   const int CW = Ci / C::NW;           // input channels of this wave (even: checked on the host)
   const int c0 = wave * CW;
-  float* region = lds + c0 * C::CHS;   // the wave's own part of the staged tile
 
-  // ---- staging: one burst; unit u = 4 consecutive floats of a staged row, the units of the wave's channels are linear in LDS
-  {
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)b * Ci + c0) * DHW, (unsigned)CW * DHW * 4u);
+  struct Tile {
+    int b, z0, y0, x0;
+  };
+  auto tile_of = [&](int item) {
+    int t = item / NTS;
+    Tile tl;
+    tl.x0 = (t % ntx) * C::TXO;
+    t /= ntx;
+    tl.y0 = (t % nty) * C::TYO;
+    t /= nty;
+    tl.z0 = t % Do;
+    tl.b = t / Do;
+    return tl;
+  };
+  // ---- staging: one burst per item; unit u = 4 consecutive floats of a staged row, the units of the wave's channels are linear in
+  // its own part of the buffer
+  auto stage = [&](const Tile& tl, float* buf) {
+    float* region = buf + c0 * C::CHS;
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)tl.b * Ci + c0) * DHW, (unsigned)CW * DHW * 4u);
     const int NU = CW * C::UPC;
     for (int u0 = 0; u0 < NU; u0 += 64) {
       const int u = u0 + lane;
       const int cl = u / C::UPC, r0 = u - cl * C::UPC;
       const int zz = r0 / (C::ROWS * C::UPR), r1 = r0 - zz * (C::ROWS * C::UPR), yy = r1 / C::UPR, sg = r1 - yy * C::UPR;
-      const int gz = C::S * z0 - 1 + zz, gy = C::S * y0 - 1 + yy, gx = C::S * x0 - 4 + sg * 4;
+      const int gz = C::S * tl.z0 - 1 + zz, gy = C::S * tl.y0 - 1 + yy, gx = C::S * tl.x0 - 4 + sg * 4;
       const bool ok = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
       if (u < NU)
         dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB, 0u, region + u0 * 4);
     }
-  }
+  };
+  if (wg >= items) return;
+  stage(tile_of(wg), lds);
 
-  // ---- A fragments: ALL of the wave's channel pairs (27 taps x NT row tiles each) are requested before the barrier, next to the
-  // copies: one memory round trip for the launch's whole operand set.  (Requested a pair ahead of their MFMAs they arrived late:
+  // ---- A fragments: ALL of the wave's channel pairs (27 taps x NT row tiles each) are requested once, next to the first item's
+  // copies: one memory round trip for the workgroup's whole weight set.  (Requested a pair ahead of their MFMAs they arrived late:
   // a pair's 27 MFMAs last 0.7 us, an L2 round trip under load longer -- 16 us instead of 10 for the [1, 64, 4, 16, 32] layer.)
   const int NP = CW / 2;   // <= NPR (checked on the host)
   const float* wbase = wp + ((size_t)(c0 / 2) * 27 * NTT + nt0) * 64 + lane;
@@ -99,99 +115,133 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
         for (int nt = 0; nt < C::NT; ++nt) a[p][tap][nt] = wq[(tap * NTT + nt) * 64];
     }
 
-  f32x16 acc[C::MT][C::NT];
+  const unsigned HWo = (unsigned)Ho * Wo, DHWo = (unsigned)Do * HWo;
+  const int Co = NTT * 32;
+  const bool vec = (Wo & 3) == 0;
+  // epilogue operands that do not depend on the item (a thread owns the same rows of every output tile): requested here, under the
+  // first item's copies, not after its multiply phase (an exposed L2 round trip per launch in the one-item case)
+  constexpr int NE4 = C::NT * 32 * C::MT * 8;   // 16-byte words of the workgroup's output tile
+  constexpr int NEPT = (NE4 + C::NTHREADS - 1) / C::NTHREADS;
+  float scv[NEPT], shv[NEPT];
 #pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
+  for (int q = 0; q < NEPT; ++q) {
+    const int e = threadIdx.x + q * C::NTHREADS, co = nt0 * 32 + (e < NE4 ? e / (C::MT * 8) : 0);
+    scv[q] = scale ? scale[co] : 1.f;
+    shv[q] = shift ? shift[co] : 0.f;
+  }
+  int it = 0;
+  for (int item = wg; item < items; item += G, ++it) {
+    const Tile tl = tile_of(item);
+    float* buf = lds + (nbuf == 2 ? (it & 1) * buf_floats : 0);
+    __syncthreads();   // (the compiler drains the copies -- vmcnt(0) -- here): this item's tile is in `buf`; the other buffer is free
+    if (nbuf == 2 && item + G < items) stage(tile_of(item + G), lds + ((it + 1) & 1) * buf_floats);   // lands while this item is multiplied
+    float* yb = y + (size_t)tl.b * Co * DHWo;
+    const float* rb = res ? res + (size_t)tl.b * Co * DHWo : nullptr;
+    // this thread's words of the output tile and its skip operand (requested now, consumed after the multiply phase)
+    size_t off[NEPT];
+    bool live[NEPT];
+    float4 rv[NEPT];
 #pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  __syncthreads();   // (the compiler drains the copies -- vmcnt(0) -- here)
-
-  // B fragment of (pair p, tap, column tile): lane (j, h) reads channel 2 p + h at the tap's input voxel of output (j / 16, j % 16)
-  const float* bb = region + h * C::CHS + C::S * (j >> 4) * C::P + C::S * (j & 15) + 3;
-#pragma unroll
-  for (int p = 0; p < C::NPR; ++p)
-    if (p < NP) {
-      const float* bp = bb + 2 * p * C::CHS;
-#pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        float bf[C::MT];
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
-          bf[mt] = bp[dz * C::PLANE + (dy + C::S * 2 * (mt / C::XS)) * C::P + dx + C::S * 16 * (mt % C::XS)];
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(a[p][tap][nt], bf[mt], acc[mt][nt]);
-      }
+    for (int q = 0; q < NEPT; ++q) {
+      const int e = threadIdx.x + q * C::NTHREADS;
+      const int row = e / (C::MT * 8), c4 = e - row * (C::MT * 8), mt = c4 >> 3, jj = (c4 & 7) * 4;
+      const int gy = tl.y0 + 2 * (mt / C::XS) + (jj >> 4), gx = tl.x0 + 16 * (mt % C::XS) + (jj & 15);
+      live[q] = e < NE4 && gy < Ho && gx < Wo;
+      off[q] = (size_t)(nt0 * 32 + row) * DHWo + (size_t)tl.z0 * HWo + (size_t)gy * Wo + gx;
+      rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rb && live[q] && vec) rv[q] = *reinterpret_cast<const float4*>(rb + off[q]);
     }
 
-  // ---- partial tiles -> LDS (the staged tile is dead once every wave has left the loop), summed in ascending wave order
-  __syncthreads();
-  {
-    float* part = lds + wave * C::PART;
+    f32x16 acc[C::MT][C::NT];
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[(nt * 32 + cd_row(r, h)) * C::PP + mt * 32 + j] = acc[mt][nt][r];
-  }
-  __syncthreads();
-  const unsigned HWo = (unsigned)Ho * Wo, DHWo = (unsigned)Do * HWo;
-  const int Co = NTT * 32;
-  float* yb = y + (size_t)b * Co * DHWo;
-  const float* rb = res ? res + (size_t)b * Co * DHWo : nullptr;
-  const bool vec = (Wo & 3) == 0;
-  constexpr int NE4 = C::NT * 32 * C::MT * 8;   // 16-byte words of the workgroup's output tile
-  for (int e = threadIdx.x; e < NE4; e += C::NTHREADS) {
-    const int row = e / (C::MT * 8), c4 = e - row * (C::MT * 8), mt = c4 >> 3, jj = (c4 & 7) * 4;
-    const float* pp = lds + row * C::PP + mt * 32 + jj;
-    float4 s = *reinterpret_cast<const float4*>(pp);
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // B fragment of (pair p, tap, column tile): lane (j, h) reads channel 2 p + h at the tap's input voxel of output (j / 16, j % 16)
+    const float* bb = buf + c0 * C::CHS + h * C::CHS + C::S * (j >> 4) * C::P + C::S * (j & 15) + 3;
 #pragma unroll
-    for (int w = 1; w < C::NW; ++w) {
-      const float4 q = *reinterpret_cast<const float4*>(pp + w * C::PART);
-      s.x += q.x;
-      s.y += q.y;
-      s.z += q.z;
-      s.w += q.w;
+    for (int p = 0; p < C::NPR; ++p)
+      if (p < NP) {
+        const float* bp = bb + 2 * p * C::CHS;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+          float bf[C::MT];
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt)
+            bf[mt] = bp[dz * C::PLANE + (dy + C::S * 2 * (mt / C::XS)) * C::P + dx + C::S * 16 * (mt % C::XS)];
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = DMB_MFMA(a[p][tap][nt], bf[mt], acc[mt][nt]);
+        }
+      }
+
+    // ---- partial tiles -> the consumed buffer (dead once every wave has left the loop above), summed in ascending wave order
+    __syncthreads();
+    {
+      float* part = buf + wave * C::PART;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[(nt * 32 + cd_row(r, h)) * C::PP + mt * 32 + j] = acc[mt][nt][r];
     }
-    const int co = nt0 * 32 + row;
-    const int gy = y0 + 2 * (mt / C::XS) + (jj >> 4), gx = x0 + 16 * (mt % C::XS) + (jj & 15);
-    if (gy >= Ho || gx >= Wo) continue;
-    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-    float v[4] = {fmaf(s.x, sc, sh), fmaf(s.y, sc, sh), fmaf(s.z, sc, sh), fmaf(s.w, sc, sh)};
-    const size_t o = (size_t)co * DHWo + (size_t)z0 * HWo + (size_t)gy * Wo + gx;
-    if (vec) {
-      if (relu == 2) {
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-      }
-      if (rb) {
-        const float4 r4 = *reinterpret_cast<const float4*>(rb + o);
-        v[0] += r4.x;
-        v[1] += r4.y;
-        v[2] += r4.z;
-        v[3] += r4.w;
-      }
-      if (relu == 1) {
+    for (int q = 0; q < NEPT; ++q) {
+      const int e = threadIdx.x + q * C::NTHREADS;
+      if (!live[q]) continue;
+      const int row = e / (C::MT * 8), c4 = e - row * (C::MT * 8), mt = c4 >> 3, jj = (c4 & 7) * 4;
+      const float* pp = buf + row * C::PP + mt * 32 + jj;
+      float4 s = *reinterpret_cast<const float4*>(pp);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      for (int w = 1; w < C::NW; ++w) {
+        const float4 qq = *reinterpret_cast<const float4*>(pp + w * C::PART);
+        s.x += qq.x;
+        s.y += qq.y;
+        s.z += qq.z;
+        s.w += qq.w;
       }
-      *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
+      const float sc = scv[q], sh = shv[q];
+      float v[4] = {fmaf(s.x, sc, sh), fmaf(s.y, sc, sh), fmaf(s.z, sc, sh), fmaf(s.w, sc, sh)};
+      const size_t o = off[q];
+      if (vec) {
+        if (relu == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (gx + i >= Wo) break;
-        float q = v[i];
-        if (relu == 2) q = fmaxf(q, 0.f);
-        if (rb) q += rb[o + i];
-        if (relu == 1) q = fmaxf(q, 0.f);
-        yb[o + i] = q;
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (rb) {
+          v[0] += rv[q].x;
+          v[1] += rv[q].y;
+          v[2] += rv[q].z;
+          v[3] += rv[q].w;
+        }
+        if (relu == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        const int gx = tl.x0 + 16 * (mt % C::XS) + (jj & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (gx + i >= Wo) break;
+          float qv = v[i];
+          if (relu == 2) qv = fmaxf(qv, 0.f);
+          if (rb) qv += rb[o + i];
+          if (relu == 1) qv = fmaxf(qv, 0.f);
+          yb[o + i] = qv;
+        }
       }
+    }
+    if (nbuf == 1 && item + G < items) {
+      __syncthreads();   // the partial sums have been read: the buffer may take the next item's tile
+      stage(tile_of(item + G), lds);
     }
   }
 }
@@ -200,14 +250,21 @@ template <class C>
 static int launch_sk(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
                      int Ci, int Co, int D, int H, int W, int relu, hipStream_t st) {
   const int Do = (D - 1) / C::S + 1, Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
-  const int ntx = cdiv(Wo, C::TXO), nty = cdiv(Ho, C::TYO), NTT = Co / 32;
-  const long long nblk = (long long)B * Do * nty * ntx * (NTT / C::NT);
-  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
+  const int ntx = cdiv(Wo, C::TXO), nty = cdiv(Ho, C::TYO), NTT = Co / 32, NTS = NTT / C::NT;
+  const long long items = (long long)B * Do * nty * ntx * NTS;
+  if (items > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
   const size_t in_floats = (size_t)Ci * C::CHS, part_floats = (size_t)C::NW * C::PART;
-  const size_t lds = (in_floats > part_floats ? in_floats : part_floats) * sizeof(float);
+  const size_t buf_floats = in_floats > part_floats ? in_floats : part_floats;
+  // one workgroup per CU (the A fragments take half of the register file); persistent when there are more items than CUs, then
+  // with a second input buffer where it fits
+  long long G = num_cus() / NTS * NTS;
+  if (G < NTS) G = NTS;
+  if (items <= G) G = items;
+  const int nbuf = (items > G && 2 * buf_floats * sizeof(float) <= 160 * 1024) ? 2 : 1;
+  const size_t lds = nbuf * buf_floats * sizeof(float);
   DMB_ENSURE_LDS((&conv3d_sk_kernel<C>), (size_t)(160 * 1024));
-  hipLaunchKernelGGL((conv3d_sk_kernel<C>), dim3((unsigned)nblk), dim3(C::NTHREADS), lds, st, x, wp, scale, shift, res, y, Ci, D, H, W,
-                     Do, Ho, Wo, ntx, nty, NTT, relu);
+  hipLaunchKernelGGL((conv3d_sk_kernel<C>), dim3((unsigned)G), dim3(C::NTHREADS), lds, st, x, wp, scale, shift, res, y, Ci, D, H, W,
+                     Do, Ho, Wo, ntx, nty, NTT, relu, (int)items, (int)buf_floats, nbuf);
   return launch_status("conv3d split-K launch failed");
 }
 

@@ -186,14 +186,15 @@ def spread():
     out = {}
     threads = (8, 3, 1)
     with torch.no_grad():
-        for tag, rel, (fh, fw) in (("s544", "configs/PSMNet/scene_flow.py", (136, 240)),
-                                   ("kitti", "configs/PSMNet/kitti_2015.py", (96, 312))):
+        for tag, rel, (fh, fw), gain in (("s544", "configs/PSMNet/scene_flow.py", (136, 240), 10.0),
+                                         ("kitti", "configs/PSMNet/kitti_2015.py", (96, 312), 10.0),
+                                         ("g30", "configs/PSMNet/scene_flow.py", (136, 240), 30.0)):   # the gain-30 family of round 3
             cfg = G.load_cfg(rel)
             m = _M()
             m.cost_processor = build_cost_processor(cfg)
             m.disp_predictor = build_disp_predictor(cfg)
             m.eval()
-            synthetic.init_params_(m, seed=0, classif_gain=10.0)
+            synthetic.init_params_(m, seed=0, classif_gain=gain)
             lf, rf = synthetic.feature_pair(0, 32, fh, fw)
             maps = {}
             for t in threads:
@@ -210,8 +211,9 @@ def spread():
                 out["%s_spread_full_disp%d" % (tag, 3 - lvl)] = np.float64(full)
                 out["%s_spread_sub_disp%d" % (tag, 3 - lvl)] = np.float64(sub)
                 print(tag, "level", 3 - lvl, "self-spread: whole map %.3e, sub-sample %.3e" % (full, sub), flush=True)
-            for t in threads[1:]:
-                out["%s_t%d_minus_t8_disp3_full" % (tag, t)] = G.npy(maps[t][0] - maps[8][0])
+            if tag != "g30":
+                for t in threads[1:]:
+                    out["%s_t%d_minus_t8_disp3_full" % (tag, t)] = G.npy(maps[t][0] - maps[8][0])
     torch.set_num_threads(int(os.environ.get("DMB_THREADS", "8")))
     np.savez_compressed(os.path.join(OUT, "fullsize_psmnet_spread.npz"), **out)
     print("fullsize_psmnet_spread.npz %8.1f KB" % (os.path.getsize(os.path.join(OUT, "fullsize_psmnet_spread.npz")) / 1024))
