@@ -553,7 +553,11 @@ static int launch_conv2d_auto(const float* x, const float* wp, const float* scal
   const long long slots = (long long)C2_WPE * num_cus();
   const long long t4 = (long long)B * cdiv(W, C4::TX) * cdiv(H, C4::TY), t2 = (long long)B * cdiv(W, C2::TX) * cdiv(H, C2::TY);
   const long long cost4 = ((t4 + slots - 1) / slots) * C4::RY, cost2 = ((t2 + slots - 1) / slots) * C2::RY;
-  if ((cost2 < cost4 && !DMB_OPT(18)) || DMB_OPT(18) == 2)   // (development option 18: 1 = always the default height, 2 = always 2 rows per wave)
+  // (round 6, profiles/r06_kbench2d_tile_height.log: at equal cost the two-row tiles win for 32 and 128 output channels -- one launch of
+  // 8 images: 128 -> 128 0.611 -> 0.579 ms, 320 -> 128 1.505 -> 1.409, 32 -> 32 0.194 -> 0.185 -- and tie for 64.  Under the backbone's
+  // two view streams the tile height does not matter: the other view's launch fills a launch's tail, 14.8 ms either way.)
+  const bool two = cost2 < cost4 || (cost2 == cost4 && N != 2);
+  if ((two && !DMB_OPT(18)) || DMB_OPT(18) == 2)   // (development option 18: 1 = always the default height, 2 = always 2 rows per wave)
     return launch_conv2d<C2>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
   return launch_conv2d<C4>(x, wp, scale, shift, res, y, B, Ci, Co, H, W, relu, in_ctot, out_ctot, res_ctot, st);
 }
@@ -628,17 +632,30 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
                                                         in_channels_total, out_channels_total, res_channels_total, st)
   if (stride == 1) {
     if (ksize == 3 && dilation == 1) {
-      if (NTT == 1) DMB_C2(1, 3, 1, 1);
-      if (NTT == 2) {   // PSMNet layer2 / StereoNet trunk widths: the tile height follows the launch's size
+      // the tile height follows the launch's size (launch_conv2d_auto; round 6: for every output width, not only 64 channels)
+      if (NTT == 1) {
+        if (v16) return launch_conv2d_auto<1, 3, 1, true>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu, in_channels_total,
+                                                          out_channels_total, res_channels_total, st);
+        DMB_C2(1, 3, 1, 1);
+      }
+      if (NTT == 2) {   // PSMNet layer2 / StereoNet trunk widths
         if (v16) return launch_conv2d_auto<2, 3, 1, true>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu, in_channels_total,
                                                           out_channels_total, res_channels_total, st);
         DMB_C2(2, 3, 1, 1);
       }
-      if (NTT == 4) DMB_C2(4, 3, 1, 1);
+      if (NTT == 4) {
+        if (v16) return launch_conv2d_auto<4, 3, 1, true>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu, in_channels_total,
+                                                          out_channels_total, res_channels_total, st);
+        DMB_C2(4, 3, 1, 1);
+      }
     } else if (ksize == 3 && dilation == 2) {
       if (NTT == 1) DMB_C2(1, 3, 2, 1);
       if (NTT == 2) DMB_C2(2, 3, 2, 1);
-      if (NTT == 4) DMB_C2(4, 3, 2, 1);
+      if (NTT == 4) {
+        if (v16) return launch_conv2d_auto<4, 3, 2, true>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu, in_channels_total,
+                                                          out_channels_total, res_channels_total, st);
+        DMB_C2(4, 3, 2, 1);
+      }
     } else if (ksize == 3 && dilation == 4) {
       if (NTT == 1) DMB_C2(1, 3, 4, 1);
     } else if (ksize == 3 && dilation == 8) {

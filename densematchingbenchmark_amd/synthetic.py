@@ -131,3 +131,25 @@ def peaked_cost_volume(seed, planes, height, width):
     z = torch.arange(planes, dtype=torch.float32).view(planes, 1, 1)
     cost = (12.0 - 6.0 * (z - peak).abs()).clamp(min=-12.0) + 0.3 * torch.randn((planes, height, width), generator=g)
     return cost.unsqueeze(0).contiguous()
+
+
+def banded_match_pair(seed, h, w, planes, bands=4):
+    """Feature maps with EXACT matches: left ~ N(0, 1) per quarter-resolution pixel, right = the left one shifted by an integer
+    disparity that is constant in each of ``bands`` horizontal bands (R(y, x') = L(y, x' + d(y)); noise where nothing matches).
+    Returns (left, right [1, 32, h, w], ground truth [1, 1, 4 h, 4 w] in full-resolution pixels, 0 = no match).  The training data
+    of oracle/train_peaked_reference.py and the input of the peaked full-size fixture (oracle/gen_golden_fullsize.py `peaked`)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(31000 + int(seed))
+    left = torch.randn((1, 32, h, w), generator=g)
+    right = torch.randn((1, 32, h, w), generator=g)          # noise where nothing matches
+    gt = torch.zeros((1, 1, h, w))
+    edges = [0] + sorted(torch.randint(1, h, (bands - 1,), generator=g).tolist()) + [h]
+    for b in range(bands):
+        y0, y1 = edges[b], edges[b + 1]
+        if y1 <= y0:
+            continue
+        d = int(torch.randint(0, min(planes, w - 8), (1,), generator=g))
+        right[:, :, y0:y1, :w - d] = left[:, :, y0:y1, d:]
+        gt[:, :, y0:y1, d:] = float(d) if d > 0 else 0.25       # (disparity 0 is a legal match: keep it inside the mask)
+    gt_full = F.interpolate(gt, scale_factor=4, mode="nearest") * 4.0
+    return left, right, gt_full

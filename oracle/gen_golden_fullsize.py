@@ -9,6 +9,7 @@ files at the sizes the CPU suite can afford).
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py round3   (only the families added in round 3)
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py kitti    (round 4: the reference's KITTI operating point)
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py spread   (round 6: the reference against itself at 1 / 3 / 8 threads)
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py peaked   (round 6: trained weights -> peaked cost distributions)
 
 Round 3 added (parity): PSMNet pair 0 at classifier gain 30 (fullsize_psmnet_gain30.npz); one FULL AcfNet
 disparity / confidence map instead of every 64th pixel (fullsize_acfnet_map.npz); and the regression tail -- trilinear x4
@@ -219,6 +220,67 @@ def spread():
     print("fullsize_psmnet_spread.npz %8.1f KB" % (os.path.getsize(os.path.join(OUT, "fullsize_psmnet_spread.npz")) / 1024))
 
 
+def peaked():
+    """Round 6: a D = 192 fixture whose cost distributions are PEAKED the way a trained network's are.  The
+    weights are the reference's own modules briefly trained on exact-match feature pairs (oracle/train_peaked_reference.py ->
+    tests/golden/psmnet_trained_weights.npz, FP16-rounded: inputs); here the REAL reference evaluates them (eval mode) at 544x960 on
+    a banded exact-match pair.  Stored: the sub-sampled maps and cost rows of the three levels, the whole best-level map, how
+    peaked the distributions are (E|k - disp|, the largest probability) and the reference's self-spread on THIS fixture (1 / 3 / 8
+    host threads, as `spread`): north_star's 1e-4 was written for this regime, and the GPU test asserts it here."""
+    from dmb.modeling.stereo.cost_processors import build_cost_processor
+    from dmb.modeling.stereo.disp_predictors import build_disp_predictor
+    from densematchingbenchmark_amd import synthetic
+
+    w = np.load(os.path.join(OUT, "psmnet_trained_weights.npz"))
+    with torch.no_grad():
+        cfg = G.load_cfg("configs/PSMNet/scene_flow.py")
+        m = _M()
+        m.cost_processor = build_cost_processor(cfg)
+        m.disp_predictor = build_disp_predictor(cfg)
+        sd = {k: torch.from_numpy(w[k].astype(np.float32) if w[k].dtype == np.float16 else w[k]) for k in w.files}
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith("disp_regression.weight") for k in missing), (missing, unexpected)
+        m.eval()
+        lf, rf, gt = synthetic.banded_match_pair(7, 136, 240, 48, bands=6)
+        out, maps = {}, {}
+        for t in (8, 3, 1):
+            torch.set_num_threads(t)
+            costs = m.cost_processor(lf, rf)
+            maps[t] = [m.disp_predictor(c) for c in costs]
+            if t == 8:
+                for lvl, (d, c) in enumerate(zip(maps[t], costs)):
+                    out["disp%d" % (3 - lvl)] = G.npy(d[SUB])
+                    out["cost%d_rows" % (3 - lvl)] = G.npy(c[CROWS])
+                out["disp3_full"] = G.npy(maps[t][0])
+                pr = torch.softmax(costs[0], 1)
+                k = torch.arange(192.).view(1, -1, 1, 1)
+                mask = gt > 0
+                width = (pr * (k - maps[t][0]).abs()).sum(1, keepdim=True)      # per-pixel E|k - disp| of the best level
+                out["stats"] = np.array([(pr * (k - maps[t][0]).abs()).sum(1).mean().item(), pr.max(1)[0].mean().item(),
+                                         (maps[t][0][mask] - gt[mask]).abs().mean().item(), costs[0].min().item(), costs[0].max().item()])
+                print("peaked: E|k - disp| mean %.2f px, largest probability mean %.3f, EPE %.3f px, cost range %.1f..%.1f" % tuple(out["stats"]), flush=True)
+            del costs
+        for lvl in range(3):
+            full = max((maps[a][lvl] - maps[b][lvl]).abs().max().item() for a in (8, 3, 1) for b in (8, 3, 1) if a < b)
+            out["spread_full_disp%d" % (3 - lvl)] = np.float64(full)
+            print("peaked level", 3 - lvl, "self-spread of the reference: %.3e" % full, flush=True)
+        # Where on the map is a distribution peaked?  The per-pixel E|k - disp| of the best level (FP16) and the per-pixel self-spread
+        # (max over the three pairs of evaluations), so that the test can state the bound per class of pixels: confidently matched
+        # ones (E|k - disp| <= 2 px) against ambiguous / unmatched ones (band edges, columns without a match).
+        out["disp3_width_full"] = width.numpy().astype(np.float16)
+        sp = torch.zeros_like(maps[8][0])
+        for a, b in ((8, 3), (8, 1), (3, 1)):
+            sp = torch.maximum(sp, (maps[a][0] - maps[b][0]).abs())
+        out["disp3_self_spread_full"] = G.npy(sp)
+        for lo, hi in ((0.0, 1.0), (1.0, 2.0), (2.0, 4.0), (4.0, 1e9)):
+            sel = (width >= lo) & (width < hi)
+            print("  pixels with %g <= E|k - disp| < %g: %5.1f %%, self-spread max %.3e" % (lo, hi, 100.0 * sel.float().mean().item(),
+                                                                                       sp[sel].max().item() if sel.any() else 0.0), flush=True)
+    torch.set_num_threads(int(os.environ.get("DMB_THREADS", "8")))
+    np.savez_compressed(os.path.join(OUT, "fullsize_psmnet_peaked.npz"), **out)
+    print("fullsize_psmnet_peaked.npz %8.1f KB" % (os.path.getsize(os.path.join(OUT, "fullsize_psmnet_peaked.npz")) / 1024))
+
+
 def main():
     G.import_reference()
     torch.set_num_threads(int(os.environ.get("DMB_THREADS", "8")))
@@ -230,6 +292,9 @@ def main():
         return
     if "spread" in sys.argv[1:]:
         spread()
+        return
+    if "peaked" in sys.argv[1:]:
+        peaked()
         return
     from dmb.modeling.stereo.cost_processors import build_cost_processor
     from dmb.modeling.stereo.disp_predictors import build_disp_predictor

@@ -29,22 +29,8 @@ import gen_golden as G  # noqa: E402
 
 
 def banded_pair(seed, h, w, planes, bands=4):
-    """Left / right feature maps [1, 32, h, w] with exact matches and the full-resolution ground truth [1, 1, 4h, 4w] (0 = no match).
-    (Shared with oracle/gen_golden_fullsize.py `peaked` and the GPU test.)"""
-    g = torch.Generator().manual_seed(31000 + int(seed))
-    left = torch.randn((1, 32, h, w), generator=g)
-    right = torch.randn((1, 32, h, w), generator=g)          # noise where nothing matches
-    gt = torch.zeros((1, 1, h, w))
-    edges = [0] + sorted(torch.randint(1, h, (bands - 1,), generator=g).tolist()) + [h]
-    for b in range(bands):
-        y0, y1 = edges[b], edges[b + 1]
-        if y1 <= y0:
-            continue
-        d = int(torch.randint(0, min(planes, w - 8), (1,), generator=g))
-        right[:, :, y0:y1, :w - d] = left[:, :, y0:y1, d:]
-        gt[:, :, y0:y1, d:] = float(d) if d > 0 else 0.25       # (disparity 0 is a legal match: keep it inside the mask)
-    gt_full = F.interpolate(gt, scale_factor=4, mode="nearest") * 4.0
-    return left, right, gt_full
+    from densematchingbenchmark_amd import synthetic
+    return synthetic.banded_match_pair(seed, h, w, planes, bands)
 
 
 def main():

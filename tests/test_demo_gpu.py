@@ -15,7 +15,8 @@ from tests.test_oracle_golden import _demo_files
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DISP_MAX_FULL = 1.6e-4       # tests/test_fullsize_gpu.py: max |disparity - reference| over a whole 544x960 map
+# max |disparity - reference| over a whole 544x960 map: 1.6 x the reference's own self-spread at that size (tests/test_fullsize_gpu.py)
+DISP_MAX_FULL = max(1e-4, 1.6 * max(float(golden("fullsize_psmnet_spread.npz")["s544_spread_full_disp%d" % k]) for k in (1, 2, 3)))
 KEYS = ("epe", "1px", "2px", "3px", "5px")
 
 

@@ -21,8 +21,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUB = (slice(None), slice(None), slice(3, None, 8), slice(5, None, 8))        # as in oracle/gen_golden_fullsize.py
 CROWS = (slice(None), slice(7, None, 48), slice(11, None, 136), slice(None))
 
-DISP_MAX_FULL = 1.6e-4    # max |disparity - reference| over a 544x960 map (measured 0.8e-4 .. 1.45e-4: measured + 10 %)
 DISP_TOL = 1e-4           # north_star's bound; at D = 192 the tested contract is max(DISP_TOL, the reference's own FP32 error)
+# How far the reference is from ITSELF (round 6): the real reference, same weights and inputs, at 1, 3 and 8 host threads
+# (oracle/gen_golden_fullsize.py `spread` -> fullsize_psmnet_spread.npz): max_ij |ref_i - ref_j| over a whole map is 0.84 - 0.99e-4
+# at 544x960 and 0.76 - 0.92e-4 at 384x1248 -- the golden file is ONE sample of a distribution as wide as north_star's bound.  The
+# bounds on |hip - reference| below are max(1e-4, SPREAD_MARGIN x that spread) (two independent FP32 evaluations differ by more than
+# two thread counts of one implementation do: 1.6), no longer "the measured difference + 10 %".
+SPREAD_MARGIN = 1.6
+_SPREAD = golden("fullsize_psmnet_spread.npz")
+
+
+def self_spread(tag):
+    """Largest whole-map distance between two of the reference's own evaluations, over the three levels (tag: s544 / kitti / g30)."""
+    return max(float(_SPREAD["%s_spread_full_disp%d" % (tag, k)]) for k in (1, 2, 3))
+
+
+def disp_bound(tag):
+    return max(DISP_TOL, SPREAD_MARGIN * self_spread(tag))
+
+
+DISP_MAX_FULL = disp_bound("s544")      # 544x960, gain-10 families (1.59e-4)
+DISP_MAX_KITTI = disp_bound("kitti")    # 384x1248 (1.46e-4)
+DISP_MAX_G30 = disp_bound("g30")        # 544x960, classifier gain 30
 DISP_MEAN_FULL = 3e-5     # mean |.| = EPE delta against the reference (measured 2e-5)
 COST_TOL = 5e-5
 
@@ -152,14 +172,12 @@ def _f64(p, device="cpu"):
 def _truth(fn, dev):
     """The FP64 yardstick: ``fn(device)`` evaluates the oracle in double precision.  It runs on the GPU through torch's OWN
     double-precision kernels (test infrastructure: nothing of libdmb_hip.so) -- 0.3 s per pair against 28 s on 32 host threads,
-    equal to the host evaluation to 6e-15 (tests/fp64_gpu_probe.py) -- and on the host if the GPU evaluation is unavailable."""
-    try:
-        with torch.no_grad():
-            return [c.cpu() for c in fn(dev)]
-    except Exception as e:  # noqa: BLE001  (e.g. no double-precision convolution in this torch build)
-        print("FP64 evaluation on the GPU unavailable (%s): falling back to the host" % repr(e)[:120])
-        with torch.no_grad():
+    equal to the host evaluation to 6e-15 (tests/fp64_gpu_probe.py).  A failure of the GPU evaluation FAILS the test (round 6: it
+    used to fall back to the host behind a print); DMB_FP64_ON_HOST=1 asks for the host evaluation explicitly."""
+    with torch.no_grad():
+        if os.environ.get("DMB_FP64_ON_HOST") == "1":
             return fn(torch.device("cpu"))
+        return [c.cpu() for c in fn(dev)]
 
 
 def _assert_yardstick(tag, gpu_disps, ref32_disps, costs64):
@@ -292,8 +310,8 @@ def test_fullsize_psmnet_gain30_vs_reference(dev):
         assert maxdiff(ref32[lvl][SUB], ref) <= 2e-5          # the oracle IS the reference here too
         assert err_gpu <= max(DISP_TOL, YARD_MARGIN * err_ref)
         # measured against the reference's outputs (round 3, gpurun_out/r3e): 1.07e-4 .. 1.53e-4 at the worst sampled pixel, 2e-5
-        # on average -- the bounds are those figures + 10 %, as for the gain-10 family (a 3x regression must not pass)
-        assert maxdiff(gpu[lvl][SUB], ref) <= 1.7e-4 and _meandiff(gpu[lvl][SUB], ref) <= DISP_MEAN_FULL
+        # on average; the bound is 1.6 x the reference's self-spread of THIS family (round 6)
+        assert maxdiff(gpu[lvl][SUB], ref) <= DISP_MAX_G30 and _meandiff(gpu[lvl][SUB], ref) <= DISP_MEAN_FULL
         # cost rows: the gain-10 bound scaled by the ratio of the two families' cost ranges (both read from the fixtures)
         rows30, rows10 = g["pair0_cost%d_rows" % (3 - lvl)], g10["pair0_cost%d_rows" % (3 - lvl)]
         scale = max(1.0, float(abs(rows30).max()) / float(abs(rows10).max()))
@@ -367,12 +385,12 @@ def test_fullsize_psmnet_kitti_vs_reference(dev):
             d = results["disps"][lvl][i:i + 1][SUB]
             ref = g["pair%d_disp%d" % (i, 3 - lvl)]
             worst = max(worst, maxdiff(d, ref))
-            assert maxdiff(d, ref) <= DISP_MAX_FULL, (lvl, i, maxdiff(d, ref))
+            assert maxdiff(d, ref) <= DISP_MAX_KITTI, (lvl, i, maxdiff(d, ref))
             assert _meandiff(d, ref) <= DISP_MEAN_FULL
         assert maxdiff(results["costs"][lvl][0:1][KROWS], g["pair0_cost%d_rows" % (3 - lvl)]) <= COST_TOL
     full = maxdiff(results["disps"][0][0:1], g["pair0_disp3_full"])
     print("KITTI PSMNet: worst sampled |disp - reference| = %.3g, whole best-level map = %.3g" % (worst, full))
-    assert full <= DISP_MAX_FULL and _meandiff(results["disps"][0][0:1], g["pair0_disp3_full"]) <= DISP_MEAN_FULL
+    assert full <= DISP_MAX_KITTI and _meandiff(results["disps"][0][0:1], g["pair0_disp3_full"]) <= DISP_MEAN_FULL
 
 
 def test_fullsize_acfnet_kitti_vs_reference(dev):
@@ -390,7 +408,7 @@ def test_fullsize_acfnet_kitti_vs_reference(dev):
         k = 3 - lvl
         print("KITTI AcfNet level %d: |disp - reference| = %.3g, conf %.3g" % (k, maxdiff(results["disps"][lvl][SUB], g["disp%d" % k]),
                                                                              maxdiff(results["confs"][lvl][SUB], g["conf%d" % k])))
-        assert maxdiff(results["disps"][lvl][SUB], g["disp%d" % k]) <= DISP_MAX_FULL
+        assert maxdiff(results["disps"][lvl][SUB], g["disp%d" % k]) <= DISP_MAX_KITTI
         assert _meandiff(results["disps"][lvl][SUB], g["disp%d" % k]) <= DISP_MEAN_FULL
         assert maxdiff(results["confs"][lvl][SUB], g["conf%d" % k]) <= 2e-5
         assert maxdiff(variance[lvl][SUB], g["var%d" % k]) <= 2e-5
@@ -452,6 +470,74 @@ def test_fp64_yardstick_psmnet_other_shapes(dev, hw):
         ref32, _ = O.psmnet_path(lf, rf, p, 192)
         c64 = _truth(lambda d: O.psm_aggregator(O.cat_fms(lf, rf, 48, 0, 1).double().to(d), _f64(p, d), 192, "cost_processor.aggregator."), dev)
         _assert_yardstick("psmnet %dx%d" % (4 * h, 4 * w), gpu, ref32, c64)
+
+
+# ------------------------------------------------------------------------------------------------- round 6: trained weights, peaked distributions
+def test_fullsize_psmnet_trained_weights_peaked_fixture(dev):
+    """a D = 192 fixture whose cost distributions are peaked the way a trained network's are.  The weights are
+    the reference's own modules trained for 500 steps on exact-match feature pairs (oracle/train_peaked_reference.py: EPE 1.2 px,
+    E|k - disp| = 1.8 px instead of the random-weight families' 48 px, costs -28 .. 65); the expected outputs are the REAL
+    reference's at 544x960 (oracle/gen_golden_fullsize.py `peaked`).
+    What the fixture shows: north_star's 1e-4 is not a property of flat distributions.  On the 94 % of the pixels that are
+    confidently matched (E|k - disp| < 2 px) the reference differs from ITSELF by 1.07e-4 when only its host thread count changes
+    (14 ulp of a disparity between 64 and 128: the k-ascending FP32 chain over 192 samples carries that much rounding), 1.6e-4
+    over the whole map.  So the assertion here is the same rule as for every other D = 192 family -- max(1e-4, 1.6 x the
+    reference's self-spread on THIS fixture), per pixel class -- plus the FP64 contract, not a bare 1e-4."""
+    from densematchingbenchmark_amd import synthetic
+    g, w = golden("fullsize_psmnet_peaked.npz"), golden("psmnet_trained_weights.npz")
+    cfg, model = _built("PSMNet/scene_flow.py", 0)
+    sd = {k: torch.from_numpy(w[k].astype("float32") if w[k].dtype.kind == "f" else w[k]) for k in w.files}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("disp_regression.weight") for k in missing), (missing, unexpected)
+    p = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    lf, rf, gt = synthetic.banded_match_pair(7, 136, 240, 48, bands=6)
+    with torch.no_grad():
+        results, _ = model(dict(leftFeature=lf.to(dev), rightFeature=rf.to(dev)))
+    gpu = [d.cpu() for d in results["disps"]]
+    g10 = golden("fullsize_psmnet.npz")
+    for lvl in range(3):
+        k = 3 - lvl
+        bound = max(DISP_TOL, SPREAD_MARGIN * float(g["spread_full_disp%d" % k]))
+        d = maxdiff(gpu[lvl][SUB], g["disp%d" % k])
+        print("peaked level %d: |hip - reference| = %.3g (sampled), reference self-spread %.3g, bound %.3g" % (k, d, float(g["spread_full_disp%d" % k]), bound))
+        assert d <= bound and _meandiff(gpu[lvl][SUB], g["disp%d" % k]) <= DISP_MEAN_FULL
+        rows, rows10 = g["cost%d_rows" % k], g10["pair0_cost%d_rows" % k]
+        scale = max(1.0, float(abs(rows).max()) / float(abs(rows10).max()))     # costs reach 65 here against 2 in the gain-10 family
+        assert maxdiff(results["costs"][lvl][CROWS], rows) <= COST_TOL * scale, (lvl, scale)
+    # the whole best-level map, by how peaked a pixel's distribution is
+    diff = (gpu[0] - torch.from_numpy(g["disp3_full"])).abs()
+    width = torch.from_numpy(g["disp3_width_full"].astype("float32"))
+    spread = torch.from_numpy(g["disp3_self_spread_full"])
+    sharp = width < 2.0
+    assert sharp.float().mean().item() >= 0.9          # the fixture IS peaked
+    for name, sel in (("confidently matched (E|k - disp| < 2 px)", sharp), ("ambiguous / unmatched", ~sharp)):
+        print("peaked, %s pixels (%.1f %%): |hip - reference| max %.3g, reference self-spread max %.3g" % (
+            name, 100.0 * sel.float().mean().item(), diff[sel].max().item(), spread[sel].max().item()))
+    # the rule of every D = 192 family on the peaked pixels; the ambiguous ones (band edges, columns without a match: multi-modal
+    # distributions over costs up to 65, where two FP32 evaluations are up to 3e-4 apart) are held to the FP64 contract below
+    assert diff[sharp].max().item() <= max(DISP_TOL, SPREAD_MARGIN * spread[sharp].max().item())
+    # end-point error against the pair's ground truth: the same to 1e-5 px
+    mask = gt > 0
+    epe_hip, epe_ref = (gpu[0][mask] - gt[mask]).abs().mean().item(), (torch.from_numpy(g["disp3_full"])[mask] - gt[mask]).abs().mean().item()
+    assert abs(epe_hip - epe_ref) <= 1e-5 and abs(epe_ref - float(g["stats"][2])) <= 1e-5, (epe_hip, epe_ref)
+    # the FP64 contract on this fixture
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref32, _ = O.psmnet_path(lf, rf, p, 192)
+    c64 = _truth(lambda d: O.psm_aggregator(O.cat_fms(lf, rf, 48, 0, 1).double().to(d), _f64(p, d), 192, "cost_processor.aggregator."), dev)
+    for lvl in range(3):
+        truth = O.soft_argmin_f64(c64[lvl], 192)
+        err_gpu, err_ref = (gpu[lvl].double() - truth).abs(), (ref32[lvl].double() - truth).abs()
+        print("peaked level %d: |hip - fp64| = %.3g (mean %.3g)   |reference arithmetic - fp64| = %.3g (mean %.3g)" % (
+            3 - lvl, err_gpu.max().item(), err_gpu.mean().item(), err_ref.max().item(), err_ref.mean().item()))
+        assert maxdiff(ref32[lvl][SUB], g["disp%d" % (3 - lvl)]) <= SPREAD_MARGIN * float(g["spread_full_disp%d" % (3 - lvl)])   # the oracle IS the reference (another thread count)
+        assert err_gpu.max().item() <= max(DISP_TOL, YARD_MARGIN * err_ref.max().item())
+        assert err_gpu.mean().item() <= err_ref.mean().item()
+        if lvl == 0:
+            for name, sel in (("confidently matched", sharp), ("ambiguous / unmatched", ~sharp)):
+                print("peaked, %s pixels: |hip - fp64| max %.3g   |reference arithmetic - fp64| max %.3g" % (name, err_gpu[sel].max().item(), err_ref[sel].max().item()))
+                assert err_gpu[sel].max().item() <= max(DISP_TOL, YARD_MARGIN * err_ref[sel].max().item()), name
 
 
 # ------------------------------------------------------------------------------------------------- BASELINE configs[3] / [4] at their bench batches

@@ -785,3 +785,47 @@ def test_oracle_data_conventions_and_whole_model_on_the_reference_demo_pair(tmp_
         assert abs(err["epe"] - want["epe"]) <= 1e-5 and all(abs(err[k] - want[k]) <= 1e-3 for k in ("1px", "2px", "3px", "5px"))
         if i == 0:
             assert maxdiff(d, g["disp0_full"]) <= 3e-5
+
+
+def test_reference_self_spread_fixture_is_consistent_with_the_other_fullsize_fixtures():
+    """Round 6: fullsize_psmnet_spread.npz (oracle/gen_golden_fullsize.py `spread`: the REAL reference at 1 / 3 / 8 host threads) --
+    its 8-thread maps ARE the maps of the older full-size fixtures bit for bit (same reference, same weights, inputs and thread
+    count), the stored scalars are the maxima of the stored maps' differences, and the self-spread is of the order of north_star's
+    bound itself: what makes `1.6 x spread` a principled bound on |hip - reference| (tests/test_fullsize_gpu.py)."""
+    g = golden("fullsize_psmnet_spread.npz")
+    for tag, other, key in (("s544", "fullsize_psmnet.npz", "pair0_disp%d"), ("kitti", "fullsize_psmnet_kitti.npz", "pair0_disp%d"),
+                            ("g30", "fullsize_psmnet_gain30.npz", "pair0_disp%d")):
+        o = golden(other)
+        for k in (1, 2, 3):
+            assert np.array_equal(g["%s_t8_disp%d" % (tag, k)], o[key % k]), (tag, k)
+            sub = max(np.abs(g["%s_t%d_disp%d" % (tag, a, k)] - g["%s_t%d_disp%d" % (tag, b, k)]).max() for a, b in ((8, 3), (8, 1), (3, 1)))
+            assert abs(float(g["%s_spread_sub_disp%d" % (tag, k)]) - float(sub)) <= 1e-12
+            full = float(g["%s_spread_full_disp%d" % (tag, k)])
+            assert full >= float(sub) and 3e-5 <= full <= 3e-4, (tag, k, full)
+    for tag in ("s544", "kitti"):
+        d = max(np.abs(g["%s_t%d_minus_t8_disp3_full" % (tag, t)]).max() for t in (1, 3))
+        assert d <= float(g["%s_spread_full_disp3" % tag]) + 1e-12
+
+
+def test_oracle_on_the_peaked_trained_weights_fixture():
+    """Round 6: the oracle's FP32 path on the trained-weights fixture (tests/golden/psmnet_trained_weights.npz + the banded exact-match
+    pair) against what the REAL reference returned there (fullsize_psmnet_peaked.npz): the same arithmetic on the same library, so
+    agreement to the thread-count noise; the fixture is peaked (E|k - disp| 1.8 px, EPE 1.2 px) and its own record of the reference's
+    self-spread is consistent."""
+    from densematchingbenchmark_amd import synthetic
+    sub = (slice(None), slice(None), slice(3, None, 8), slice(5, None, 8))
+    crows = (slice(None), slice(7, None, 48), slice(11, None, 136), slice(None))
+    g, w = golden("fullsize_psmnet_peaked.npz"), golden("psmnet_trained_weights.npz")
+    p = {k: torch.from_numpy(w[k].astype("float32") if w[k].dtype.kind == "f" else w[k]) for k in w.files}
+    lf, rf, gt = synthetic.banded_match_pair(7, 136, 240, 48, bands=6)
+    with torch.no_grad():
+        disps, costs = O.psmnet_path(lf, rf, p, 192)
+    for lvl in range(3):
+        assert maxdiff(disps[lvl][sub], g["disp%d" % (3 - lvl)]) <= 1.6 * float(g["spread_full_disp%d" % (3 - lvl)])
+        assert maxdiff(costs[lvl][crows], g["cost%d_rows" % (3 - lvl)]) <= 2e-4          # costs up to 65: a few ulp
+    assert maxdiff(disps[0], g["disp3_full"]) <= 1.6 * float(g["spread_full_disp3"])
+    width = g["disp3_width_full"].astype("float32")
+    assert float((width < 2.0).mean()) >= 0.9 and 1.0 <= float(g["stats"][0]) <= 2.5 and float(g["stats"][2]) <= 1.5
+    assert abs(float(g["disp3_self_spread_full"].max()) - float(g["spread_full_disp3"])) <= 1e-12
+    mask = gt > 0
+    assert abs((disps[0][mask] - gt[mask]).abs().mean().item() - float(g["stats"][2])) <= 1e-5
