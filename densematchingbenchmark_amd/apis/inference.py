@@ -49,19 +49,22 @@ def load_disp(item, filename, disp_div_factor=1.0):
     return raw.astype(np.float32) / disp_div_factor
 
 
-def init_model(config, checkpoint=None, device='cuda:0'):
+def init_model(config, checkpoint=None, device='cuda:0', strict=True):
     """inference.py:60-85: config file (or object) -> eval-mode model on ``device``, optionally with a checkpoint
-    (``{'state_dict': ...}`` as mmcv writes it, or a bare state dict) loaded STRICTLY -- the reference's own keys."""
+    (``{'state_dict': ...}`` as mmcv writes it, or a bare state dict).  ``strict=True`` (default here: a key that does not match
+    is an error) | False = mmcv's ``load_checkpoint`` default, which the reference calls: missing / unexpected keys are tolerated.
+    A checkpoint PATH is read with ``torch.load(weights_only=False)``: mmcv checkpoints pickle a 'meta' dict next to the tensors
+    (load only files you trust, as with the reference)."""
     if isinstance(config, str):
         config = Config.fromfile(config)
     elif not isinstance(config, ConfigDict):
         raise TypeError('config must be a filename or Config object, but got {}'.format(type(config)))
     model = build_model(config)
     if checkpoint is not None:
-        ckpt = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, str) else checkpoint
+        ckpt = torch.load(checkpoint, map_location="cpu", weights_only=False) if isinstance(checkpoint, str) else checkpoint
         state = ckpt.get("state_dict", ckpt)
         state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}   # (mmcv strips DataParallel's prefix)
-        model.load_state_dict(state, strict=True)
+        model.load_state_dict(state, strict=bool(strict))
     model.cfg = config
     model.to(device)
     model.eval()

@@ -114,7 +114,7 @@ struct S1Cfg {
   // collide and every such read takes two LDS cycles (counters of the dominant layer: 45 % of its LDS cycles were conflicts).
   // Pairing rows (r, r + 2) of a four-row tile instead -- tile q of a column = rows q and q + 2 -- puts the second row
   // 2 P = 16 (mod 32) banks on: conflict-free.  Same MFMAs on the same operands; only which accumulator holds which row changes
-  // (bit-identical: scripts/kbench_s1_ab.py prints a checksum).  What it buys is LDS cycles, not time: 2.389 / 2.396 against
+  // (bit-identical: scripts/attic/kbench_s1_ab.py prints a checksum).  What it buys is LDS cycles, not time: 2.389 / 2.396 against
   // 2.386 / 2.391 ms at [4, 32, 48, 136, 240] (noise), 2.236 / 2.240 against 2.244 / 2.243 ms at [4, 32, 48, 96, 312] (-0.3 %) --
   // the LDS pipe is a quarter busy either way and the fragment reads run a k-step ahead of their MFMAs.
   static constexpr int GSTR = (G_ == 16 && TY_ == 4 && !LIN_ && (2 * P) % 32 == 16 && P % 32 != 16 && DMB_S1_GSTR) ? 2 : 1;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
   relu &= 0xff;
   if (stg > 0 && blockIdx.x < 256u * C::WPE) {
     // the first round's workgroups of a CU start together: delay them by their slot on the CU (HW_ID.TG_ID) x stg x 3.4 us so that
-    // set-up and epilogue of one fall under the matrix work of the others (scripts/s1_stagger_probe.py: -0.3 % at best)
+    // set-up and epilogue of one fall under the matrix work of the others (scripts/attic/s1_stagger_probe.py: -0.3 % at best)
     const int n = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 15u) * stg;   // HW_REG_HW_ID bits 19:16
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }

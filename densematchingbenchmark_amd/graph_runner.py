@@ -53,7 +53,9 @@ def wants_graph(batch, max_elements=AUTO_GRAPH_MAX_ELEMENTS):
 
 class GraphedForward:
     def __init__(self, model, warmup=2, max_graphs=4, track_parameters=True):
-        """``track_parameters``: compare every parameter's / buffer's (pointer, version) before each replay (~0.15 ms of host
+        """``max_graphs``: graphs held at once (one per input signature, least recently used evicted).  Each pins a private
+        memory pool with every intermediate of a forward -- for a 544x960 pair the three full-resolution cost volumes alone are
+        1.2 GB -- until it is evicted or ``reset()`` is called.  ``track_parameters``: compare every parameter's / buffer's (pointer, version) before each replay (~0.15 ms of host
         time for PSMNet's 517 tensors) and re-capture after a change; False = the caller promises frozen weights (or calls
         ``reset()`` after changing them)."""
         self.model = model
@@ -112,6 +114,9 @@ class GraphedForward:
                 self._graphs.pop(self._order.pop(0), None)
             entry = self._capture(batch, flat)
             self._graphs[sig] = entry
+            self._order.append(sig)
+        elif self._order[-1] != sig:       # least-recently-USED eviction: a hit moves the signature to the young end
+            self._order.remove(sig)
             self._order.append(sig)
         graph, static, out = entry
         for p, t in flat:

@@ -384,7 +384,7 @@ def side_stream(device, which=0):
 # The two views of a stereo pair go through a shared-weight backbone independently.  As ONE batch of 2B images a layer's tiles
 # rarely divide over the persistent grid (8 images of 136 x 240 at 64 channels: 1360 tiles on 512 slots = 2.66 rounds, 5.3 tiles
 # per CU however they are dealt); as two chains of B images on two streams the partial rounds of one chain are filled by the
-# other's.  Measured on the PSMNet backbone (scripts/backbone_streams_probe.py): 16.15 -> 14.67 ms at B = 4, 5.60 -> 5.14 at
+# other's.  Measured on the PSMNet backbone (scripts/attic/backbone_streams_probe.py): 16.15 -> 14.67 ms at B = 4, 5.60 -> 5.14 at
 # B = 1, 30.4 -> 28.6 at B = 8; four or eight chains are slower than one batch.  Same launches per image: identical results.
 _view_streams = True
 
@@ -401,11 +401,21 @@ def view_streams():
 def warm_packed_parameters(module):
     """Fill (on the CURRENT stream) every lazily packed / folded parameter cache below ``module``: each fused unit keeps its packed
     weights and folded BatchNorm affine keyed by the parameters' versions (``_prepacked()``) and refills them inside its first
-    forward after a change -- pack kernels and torch ops on whatever stream that forward runs on."""
+    forward after a change -- pack kernels and torch ops on whatever stream that forward runs on.
+    Cheap when nothing changed: the walk over the module tree (1.6 ms for PSMNet's backbone) only happens when the (pointer, version)
+    key of the module's parameters and buffers differs from the one of the last warm-up (0.1 ms to compute)."""
+    tensors = module.__dict__.get("_dmb_warm_tensors")
+    if tensors is None:
+        tensors = list(module.parameters()) + list(module.buffers())     # the objects persist across .to() and load_state_dict()
+        module.__dict__["_dmb_warm_tensors"] = tensors
+    key = (module.training,) + tuple((t.data_ptr(), t._version) for t in tensors)
+    if module.__dict__.get("_dmb_warm_key") == key:
+        return
     for m in module.modules():
         pre = getattr(m, "_prepacked", None)
         if pre is not None:
             pre()
+    module.__dict__["_dmb_warm_key"] = key
 
 
 def two_view_forward(fn, left, right, module=None):

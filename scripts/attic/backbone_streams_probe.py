@@ -4,7 +4,7 @@ fill, and 5.3 tiles per CU however they are dealt); two chains in flight fill ea
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from densematchingbenchmark_amd import ops, synthetic

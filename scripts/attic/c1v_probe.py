@@ -1,5 +1,5 @@
 """Development aid: the 32 -> 1 head convolution (conv3d_c1v_kernel) at the BASELINE shape, with and without the skip operand, and its
-checksum (the kernel's summation order is fixed: any restructuring has to reproduce the bits).   python scripts/c1v_probe.py"""
+checksum (the kernel's summation order is fixed: any restructuring has to reproduce the bits).   python scripts/attic/c1v_probe.py"""
 import os, sys
 os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,6 +1,6 @@
 """Is the dominant kernel power/clock limited?  Same launch on zero-filled vs random data, short vs long bursts."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from densematchingbenchmark_amd import ops
 dev = torch.device("cuda:0")

@@ -1,8 +1,8 @@
 """Development aid: back-to-back launches of one kernel at several grid sizes under `rocprofv3 --kernel-trace`, to see what the
 ~5 us dispatch gaps on either side of the full-resolution stride-1 launches depend on (kernel, grid size, bytes written).
-    rocprofv3 --kernel-trace -d DIR -o t --output-format csv -- python scripts/gap_probe.py ; python scripts/gap_probe.py report DIR/t_kernel_trace.csv"""
+    rocprofv3 --kernel-trace -d DIR -o t --output-format csv -- python scripts/attic/gap_probe.py ; python scripts/attic/gap_probe.py report DIR/t_kernel_trace.csv"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if len(sys.argv) > 2 and sys.argv[1] == "report":
     import csv
     rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))

@@ -1,5 +1,5 @@
 """Development probe: what a plain linear fill / copy reaches on this chip (the practical ceiling next to the 8 TB/s of the data sheet).
-    python scripts/hbm_ceiling_probe.py"""
+    python scripts/attic/hbm_ceiling_probe.py"""
 import torch
 dev = torch.device("cuda:0")
 def timeit(fn, n=30, warm=10):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Development aid: compile one csrc/*.hip for gfx950 with -Rpass-analysis=kernel-resource-usage and print a table
-(kernel, VGPRs, AGPRs, SGPRs, spills, scratch, LDS, occupancy).   python scripts/kres.py conv3d.hip [filter]"""
+(kernel, VGPRs, AGPRs, SGPRs, spills, scratch, LDS, occupancy).   python scripts/attic/kres.py conv3d.hip [filter]"""
 import os
 import re
 import subprocess

@@ -1,9 +1,9 @@
 """Development probe: what merging the three head / up-sampling launches of a step into one would buy (a batch of 12 in one launch
-against three launches of 4: the same work, 9.6 instead of 3 x 3.2 tile rounds).   python scripts/merge_probe.py"""
+against three launches of 4: the same work, 9.6 instead of 3 x 3.2 tile rounds).   python scripts/attic/merge_probe.py"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from densematchingbenchmark_amd import ops

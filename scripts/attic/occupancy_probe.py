@@ -1,6 +1,6 @@
 """Development aid: the dominant stride-1 layer with 3, 2 and 1 workgroups per CU (development option 17 = extra KB of LDS per
 workgroup), complete and as bare MFMA + LDS-read structure (option 6 = 35): how much of the matrix pipe ONE wave per SIMD can use --
-i.e. whether a workgroup in its set-up / epilogue costs its third of the CU or nothing.   python scripts/occupancy_probe.py"""
+i.e. whether a workgroup in its set-up / epilogue costs its third of the CU or nothing.   python scripts/attic/occupancy_probe.py"""
 import os, sys
 os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,5 +1,5 @@
 """Development aid: what the skip operand costs the stride-1 layers (64 -> 64 at half resolution, 32 -> 32 at full resolution):
-without it, with it, and with the outputs of the launch before it as the operand (warm in L2 or not).   python scripts/res_probe.py"""
+without it, with it, and with the outputs of the launch before it as the operand (warm in L2 or not).   python scripts/attic/res_probe.py"""
 import os, sys
 os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,6 +1,6 @@
 """Development aid: the dominant stride-1 layer (32 -> 32, full resolution) and the 64 -> 64 half-resolution layer under a start-up
 stagger of the first round's workgroups by their slot on the CU (g_dev_opts[14], unit 3.4 us), alternated inside one process; and
-the launch at 2, 4 and 8 pairs (fixed cost per launch against cost per workgroup).   python scripts/s1_stagger_probe.py"""
+the launch at 2, 4 and 8 pairs (fixed cost per launch against cost per workgroup).   python scripts/attic/s1_stagger_probe.py"""
 import os, sys
 os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,7 +1,7 @@
 """Development aid: per-step times of the PSMNet cost path over a few hundred back-to-back steps (one HIP event per step), to see
 whether single steps are stretched by something outside the kernels (clock / power management, another client of the GPU)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from densematchingbenchmark_amd import synthetic
 from densematchingbenchmark_amd.config import Config

@@ -5,7 +5,7 @@ time of the sequential form, of this form and of the opt-in form, alternated in 
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 RESERVE_KB = int(os.environ.get("TAIL_RESERVE_KB", "0"))   # needs DMB_LIB=dev

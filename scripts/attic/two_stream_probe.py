@@ -1,11 +1,11 @@
 """Development probe: does running the batch as S independent sub-batches on S HIP streams fill the tail rounds and the
 under-filled quarter-resolution launches?  Pairs are independent in eval mode, so results are identical.
-    python scripts/two_stream_probe.py [steps]"""
+    python scripts/attic/two_stream_probe.py [steps]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from densematchingbenchmark_amd import synthetic

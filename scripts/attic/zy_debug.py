@@ -1,11 +1,11 @@
 """Development aid for csrc/deconv3d_zy.hip: compare the (tile, z parity, y parity) form with deconv3d_kernel on one shape,
 optionally with a forced small grid (few workgroups walk many items: cross-item pipelining and class switches), and say WHERE
-they differ.   python scripts/zy_debug.py Ci Co B D H W [grid]"""
+they differ.   python scripts/attic/zy_debug.py Ci Co B D H W [grid]"""
 import os
 os.environ.setdefault("DMB_LIB", "dev")   # kernel-variant switches exist only in the development build (build.py --dev)
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from densematchingbenchmark_amd import _lib, ops

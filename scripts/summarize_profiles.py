@@ -31,7 +31,7 @@ def short(name):
 
 # Per-kernel statistics from the per-dispatch trace.  Under rocprofv3 a launch now and then comes back 5-10x its normal duration
 # (seen at ~0.9 s into a traced run, the following launches slow for a few ms: 15-28 ms for a 2.4 ms kernel; 300 back-to-back steps
-# WITHOUT the profiler show nothing of the kind, scripts/step_jitter_probe.py: max 27.23 against a median of 26.93 ms): such a
+# WITHOUT the profiler show nothing of the kind, scripts/attic/step_jitter_probe.py: max 27.23 against a median of 26.93 ms): such a
 # launch (> 4x the median of its kernel) is left out of the averages and listed in the last column.
 tr = os.path.join(SRC, "trace", "trace_kernel_trace.csv")
 d = collections.defaultdict(list)
