@@ -24,6 +24,7 @@ TOL = 3e-5           # one layer, unit-variance inputs, fan-in-normalised weight
 CASES_PER_CHUNK = 25
 CHUNKS = 12
 FLOP_BUDGET = 1.5e9   # per case, so that the CPU reference of a chunk takes a few seconds
+SEED_BASE = int(os.environ.get("DMB_FUZZ_SEED_BASE", "60000"))   # (fixed by default; another base = another 300 cases, for bug hunts)
 
 
 def _rnd(shape, g, scale=1.0):
@@ -184,7 +185,7 @@ def test_random_shapes_and_batches_against_torch_cpu(dev, chunk):
     failures, ran = [], 0
     try:
         for i in range(CASES_PER_CHUNK):
-            seed = 60000 + chunk * 1000 + i
+            seed = SEED_BASE + chunk * 1000 + i
             try:
                 out = _case(seed, dev, ops)
             except Exception as e:  # noqa: BLE001  (a shape the library refuses is a failure too: every drawn shape is legal)

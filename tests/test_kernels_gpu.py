@@ -1158,7 +1158,10 @@ def test_row_padded_hourglass_level_matches_the_unpadded_one(dev, Co, shape):
 # ------------------------------------------------------------------------------- round 6: split-K forms for launches that leave the chip idle
 @pytest.mark.parametrize("kind,Ci,Co,shape", [("s1", 64, 64, (1, 4, 16, 32)), ("s2", 64, 64, (1, 8, 32, 64)), ("s2", 32, 64, (1, 16, 64, 128)),
                                               ("deconv", 64, 64, (1, 4, 16, 32)), ("deconv", 64, 32, (1, 8, 32, 64)), ("c1", 32, 1, (1, 16, 64, 128)),
-                                              ("s1", 32, 32, (1, 3, 10, 44)), ("s2", 48, 32, (2, 5, 9, 52)), ("deconv", 16, 64, (1, 3, 5, 20))])
+                                              ("s1", 32, 32, (1, 3, 10, 44)), ("s2", 48, 32, (2, 5, 9, 52)), ("deconv", 16, 64, (1, 3, 5, 20)),
+                                              # 300 work items on 256 workgroups: the persistent walk -- with a second input buffer
+                                              # (stride 1: 2 x 74 KB) and with one (stride 2: 138 KB) -- and two batch items
+                                              ("s1", 64, 64, (1, 5, 12, 80)), ("s2", 64, 64, (1, 10, 24, 160)), ("s1", 64, 64, (2, 3, 10, 76))])
 def test_split_k_forms_of_small_launches(dev, kind, Ci, Co, shape):
     """The layers of the hourglass (hourglass.py:62-86) and the heads (PSMNet.py:46-54) at the sizes ONE 256x512 pair gives them
     (BASELINE configs[0]; dmb/apis/inference.py:191-225 serves one pair per call) take the split-K forms (csrc/conv3d_sk.hip,
