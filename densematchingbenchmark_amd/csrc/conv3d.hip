@@ -1794,7 +1794,11 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
         static const S1Tile cand[4] = {{48, 4, 4, 6, 3, false, 1.0}, {24, 8, 4, 6, 3, false, 0.972}, {32, 4, 4, 4, 3, false, 1.0},
                                        {32, 2, 4, 2, 3, false, S1_EFF_32x2}};
         const bool ok[4] = {true, true, true, true};
-        switch (s1_pick(cand, ok, 4, B, D, H, W)) {
+        int pick = s1_pick(cand, ok, 4, B, D, H, W);
+        // (round 6) a launch of at most ONE 32 x 4 workgroup per CU: two 32 x 2 workgroups per CU instead, so that one's prologue and
+        // epilogue fall under the other's multiply phase ([1, 32, 16, 64, 128]: 57.6 -> 55.7 us, profiles/r06_sk_probe_midsizes.log)
+        if (pick == 2 && DMB_OPT(19) == 0 && (long long)B * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 32) <= num_cus()) pick = 3;
+        switch (pick) {
           case 0: return DMB_S1(32, 4, 48, 1, 16, 0);
           case 1: return DMB_S1(32, 8, 24, 1, 8, 40);
           case 2: return DMB_S1(32, 4, 32, 1, 16, 0);
@@ -1890,13 +1894,12 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
 static int dsk_variant(int B, int Ci, int Co, int D, int H, int W) {
   const long long tiles = (long long)B * D * cdiv(H, 2) * cdiv(W, 16);
   const int ncu = num_cus();
-  // measured (profiles/r06_sk_probe.log; units = tiles x row tiles): 128 units ([1, 64, 4, 16, 32] -> 64 channels) 37.7 -> 14.0 us,
-  // 288 units 37.7 -> 25.0, 360 units 38.5 -> 28.3 (four waves) / 29.9 (eight), 576 units 59.4 -> 42.1 (four waves);
-  // 512 units ([1, 64, 8, 32, 64] -> 32 channels) 50.2 -> 41.2, 768 units 69.3 -> 58.5, 960 units 71.9 against 73.2 (a tie),
-  // 1200 units 81.0 against 89.4: from there on the work-queue kernel (deconv3d_zy.hip) wins
+  // measured (profiles/r06_sk_probe_deconv.log, persistent form, four waves per workgroup; units = tiles x row tiles):
+  // 128 units ([1, 64, 4, 16, 32] -> 64 channels) 37.3 -> 14.2 us, 192 units 38.0 -> 16.7, 360 units 37.8 -> 26.7, 576 units 59.3 -> 40.3,
+  // 1632 units 99 against 103 (a tie); 512 units ([1, 64, 8, 32, 64] -> 32 channels) 50.2 -> 36.9, 768 units 69.2 -> 52.5, 1200 units
+  // 80.6 -> 76.6, 2304 units 136 against 143: from there on the work-queue kernel (deconv3d_zy.hip) wins
   const long long units = tiles * cdiv(Co, 32);
-  if (units <= ncu + ncu / 2) return 1;                          // eight waves: 16 x 2 input positions per workgroup
-  if (Ci % 8 == 0 && Ci <= 64 && units <= 3LL * ncu) return 3;   // four waves
+  if (Ci % 8 == 0 && Ci <= 64 && units <= 5LL * ncu) return 3;   // 16 x 2 input positions per workgroup, four waves
   return 0;
 }
 

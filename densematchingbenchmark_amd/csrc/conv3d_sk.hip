@@ -101,7 +101,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
 
   // ---- A fragments: ALL of the wave's channel pairs (27 taps x NT row tiles each) are requested once, next to the first item's
   // copies: one memory round trip for the workgroup's whole weight set.  (Requested a pair ahead of their MFMAs they arrived late:
-  // a pair's 27 MFMAs last 0.7 us, an L2 round trip under load longer -- 16 us instead of 10 for the [1, 64, 4, 16, 32] layer.)
+  // a pair's 27 MFMAs last 0.7 us, an L2 round trip under load longer -- 16 us instead of 13 for the [1, 64, 4, 16, 32] layer.)
   const int NP = CW / 2;   // <= NPR (checked on the host)
   const float* wbase = wp + ((size_t)(c0 / 2) * 27 * NTT + nt0) * 64 + lane;
   float a[C::NPR][27][C::NT];
@@ -291,13 +291,18 @@ int conv3d_sk_try(int variant, const float* x, const float* wp, const float* sca
     if (NP > NPR || sk_lds_bytes<C>(Ci) > 160 * 1024) return -1;                                               \
     return launch_sk<C>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, relu, st);                            \
   } while (0)
+  // (variant 2 and the stride-1 form of variant 3 are never picked by sk_variant: measured, kept in the development build only)
   if (stride == 1) {
     if (variant == 1) DMB_SK(1, 1, 1, 1, 4);
+#ifdef DMB_DEV
     if (variant == 2) DMB_SK(1, 1, 2, 1, 4);
     if (variant == 3 && Co == 64) DMB_SK(1, 2, 2, 1, 2);
+#endif
   } else if (stride == 2) {
     if (variant == 1) DMB_SK(2, 1, 1, 1, 4);
+#ifdef DMB_DEV
     if (variant == 2) DMB_SK(2, 1, 2, 1, 4);
+#endif
     if (variant == 3 && Co == 64) DMB_SK(2, 2, 2, 1, 2);
   }
 #undef DMB_SK
@@ -325,31 +330,55 @@ struct DSKCfg {
   static constexpr int IN_MAX = 2 * 3 * P;            // floats per channel of the largest class
 };
 
+// Persistent, as the convolution above: a workgroup belongs to ONE (parity class, row tile) -- so its A fragments are loaded once --
+// and walks that class's tiles slot, slot + nslots, ...; the classes get workgroups in proportion to their arithmetic (4 : 2 : 2 : 1).
+// (One workgroup per (tile, class) re-read the weights from L2 for every tile: 2048 workgroups x 55 KB = 113 MB for the 64 -> 32
+// layer of one 256x512 pair -- 41 us for 11.5 us of MFMAs.)
+struct DSKGeom {
+  int Ci, D, H, W, Wout, ntx, nty, NTT, cvalid, relu, ntiles, buf_floats, nbuf;
+};
+
 template <class C, int PZ, int PY>
 __device__ __forceinline__ void deconv_sk_body(float* lds, const float* __restrict__ x, const float* __restrict__ wp,
                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                               const float* __restrict__ res, float* __restrict__ y, int Ci, int D, int H, int W,
-                                               int Wout, int NTT, int cvalid, int relu, int b, int z0, int y0, int x0, int nt0) {
+                                               const float* __restrict__ res, float* __restrict__ y, const DSKGeom& gm, int slot,
+                                               int nslots, int nt0) {
   constexpr int ZS = 1 + PZ, ROWS = 2 + PY, PLANE = ROWS * C::P, CHS = ZS * PLANE, UPC = ZS * ROWS * C::UPR;
   constexpr int NA = (1 + PZ) * (1 + PY);   // (kz, ky) pairs an output of the class sees
+  const int Ci = gm.Ci, D = gm.D, H = gm.H, W = gm.W, Wout = gm.Wout, NTT = gm.NTT, cvalid = gm.cvalid, relu = gm.relu;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const unsigned HW = (unsigned)H * W, DHW = (unsigned)D * HW;
   const int CW = Ci / C::NW, c0 = wave * CW;
-  float* region = lds + c0 * CHS;
-  {
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)b * Ci + c0) * DHW, (unsigned)CW * DHW * 4u);
+  struct Tile {
+    int b, z0, y0, x0;
+  };
+  auto tile_of = [&](int t) {
+    Tile tl;
+    tl.x0 = (t % gm.ntx) * C::TXI;
+    t /= gm.ntx;
+    tl.y0 = (t % gm.nty) * C::TYI;
+    t /= gm.nty;
+    tl.z0 = t % D;
+    tl.b = t / D;
+    return tl;
+  };
+  auto stage = [&](const Tile& tl, float* buf) {
+    float* region = buf + c0 * CHS;
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)tl.b * Ci + c0) * DHW, (unsigned)CW * DHW * 4u);
     const int NU = CW * UPC;
     for (int u0 = 0; u0 < NU; u0 += 64) {
       const int u = u0 + lane;
       const int cl = u / UPC, r0 = u - cl * UPC;
       const int zz = r0 / (ROWS * C::UPR), r1 = r0 - zz * (ROWS * C::UPR), yy = r1 / C::UPR, sg = r1 - yy * C::UPR;
-      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + sg * 4;
+      const int gz = tl.z0 + zz, gy = tl.y0 + yy, gx = tl.x0 + sg * 4;
       const bool ok = gz < D && gy < H && gx < W;
       if (u < NU)
         dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB, 0u, region + u0 * 4);
     }
-  }
+  };
+  if (slot >= gm.ntiles) return;
+  stage(tile_of(slot), lds);
   const int NP = CW / 2;
   const float* wbase = wp + ((size_t)(c0 / 2) * 27 * NTT + nt0) * 64 + lane;
   float a[C::NPR][NA][3];
@@ -364,130 +393,174 @@ __device__ __forceinline__ void deconv_sk_body(float* lds, const float* __restri
         for (int kx = 0; kx < 3; ++kx) a[p][q][kx] = wbase[((size_t)(p * 27 + kz * 9 + ky * 3 + kx) * NTT) * 64];
       }
     }
-  f32x16 acc[2][C::MT];   // [x parity][column tile]
+  // epilogue operands that do not depend on the tile
+  constexpr int NE4 = 32 * C::MT * 16;
+  constexpr int NEPT = (NE4 + C::NTHREADS - 1) / C::NTHREADS;
+  float scv[NEPT], shv[NEPT];
 #pragma unroll
-  for (int px = 0; px < 2; ++px)
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[px][mt][r] = 0.f;
-  __syncthreads();
-  const float* bb = region + h * CHS + (j >> 4) * C::P + (j & 15);
-#pragma unroll
-  for (int p = 0; p < C::NPR; ++p)
-    if (p < NP) {
-      const float* bp = bb + 2 * p * CHS;
-#pragma unroll
-      for (int q = 0; q < NA; ++q) {
-        const int az = q / (1 + PY), ay = q % (1 + PY);
-        float b0[C::MT], b1[C::MT];
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          b0[mt] = bp[az * PLANE + ay * C::P + 16 * mt];
-          b1[mt] = bp[az * PLANE + ay * C::P + 16 * mt + 1];
-        }
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          acc[0][mt] = DMB_MFMA(a[p][q][1], b0[mt], acc[0][mt]);   // even x: kx = 1 from input m
-          acc[1][mt] = DMB_MFMA(a[p][q][2], b0[mt], acc[1][mt]);   // odd x: kx = 2 from input m ...
-          acc[1][mt] = DMB_MFMA(a[p][q][0], b1[mt], acc[1][mt]);   // ... and kx = 0 from input m + 1
-        }
-      }
-    }
-  __syncthreads();
-  {
-    float* part = lds + wave * C::PART;
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        *reinterpret_cast<float2*>(part + cd_row(r, h) * C::PP + mt * 64 + (j >> 4) * 32 + 2 * (j & 15)) = make_float2(acc[0][mt][r], acc[1][mt][r]);
+  for (int q = 0; q < NEPT; ++q) {
+    const int e = threadIdx.x + q * C::NTHREADS, co = nt0 * 32 + (e < NE4 ? e / (C::MT * 16) : 0);
+    scv[q] = (scale && co < cvalid) ? scale[co] : 1.f;
+    shv[q] = (shift && co < cvalid) ? shift[co] : 0.f;
   }
-  __syncthreads();
   const int Do = 2 * D, Ho = 2 * H;
   const unsigned HWo = (unsigned)Ho * Wout, DHWo = (unsigned)Do * HWo;
   const int Co = cvalid;
-  float* yb = y + (size_t)b * Co * DHWo;
-  const float* rb = res ? res + (size_t)b * Co * DHWo : nullptr;
-  constexpr int NE4 = 32 * C::MT * 16;
-  for (int e = threadIdx.x; e < NE4; e += C::NTHREADS) {
-    const int row = e / (C::MT * 16), c4 = e - row * (C::MT * 16), mt = c4 >> 4, jj = (c4 & 15) * 4;   // jj: column of the 64-wide strip
-    const float* pp = lds + row * C::PP + mt * 64 + jj;
-    float4 s = *reinterpret_cast<const float4*>(pp);
+  int it = 0;
+  for (int t = slot; t < gm.ntiles; t += nslots, ++it) {
+    const Tile tl = tile_of(t);
+    float* buf = lds + (gm.nbuf == 2 ? (it & 1) * gm.buf_floats : 0);
+    __syncthreads();   // this tile's copies have landed (the compiler drains them here); the other buffer is free
+    if (gm.nbuf == 2 && t + nslots < gm.ntiles) stage(tile_of(t + nslots), lds + ((it + 1) & 1) * gm.buf_floats);
+    float* yb = y + (size_t)tl.b * Co * DHWo;
+    const float* rb = res ? res + (size_t)tl.b * Co * DHWo : nullptr;
+    size_t off[NEPT];
+    bool live[NEPT];
+    float4 rv[NEPT];
 #pragma unroll
-    for (int w = 1; w < C::NW; ++w) {
-      const float4 q = *reinterpret_cast<const float4*>(pp + w * C::PART);
-      s.x += q.x;
-      s.y += q.y;
-      s.z += q.z;
-      s.w += q.w;
+    for (int q = 0; q < NEPT; ++q) {   // this thread's words of the output tile and its skip operand (consumed after the multiply phase)
+      const int e = threadIdx.x + q * C::NTHREADS;
+      const int row = e / (C::MT * 16), c4 = e - row * (C::MT * 16), mt = c4 >> 4, jj = (c4 & 15) * 4;
+      const int co = nt0 * 32 + row, ly = jj >> 5, ox = jj & 31;
+      const int gz = 2 * tl.z0 + PZ, gy = 2 * (tl.y0 + ly) + PY, gx = 2 * (tl.x0 + 16 * mt) + ox;
+      live[q] = e < NE4 && co < cvalid && tl.y0 + ly < H && gx < Wout;
+      off[q] = (size_t)co * DHWo + (size_t)gz * HWo + (size_t)gy * Wout + gx;
+      rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rb && live[q]) rv[q] = *reinterpret_cast<const float4*>(rb + off[q]);
     }
-    const int co = nt0 * 32 + row;
-    const int ly = jj >> 5, ox = jj & 31;   // input row of the pair, output column inside the tile's 32
-    const int gz = 2 * z0 + PZ, gy = 2 * (y0 + ly) + PY, gx = 2 * (x0 + 16 * mt) + ox;
-    if (co >= cvalid || y0 + ly >= H || gx >= Wout) continue;
-    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
-    float v[4] = {fmaf(s.x, sc, sh), fmaf(s.y, sc, sh), fmaf(s.z, sc, sh), fmaf(s.w, sc, sh)};
-    const size_t o = (size_t)co * DHWo + (size_t)gz * HWo + (size_t)gy * Wout + gx;
-    if (relu == 2) {
+    f32x16 acc[2][C::MT];   // [x parity][column tile]
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-    }
-    if (rb) {
-      const float4 r4 = *reinterpret_cast<const float4*>(rb + o);
-      v[0] += r4.x;
-      v[1] += r4.y;
-      v[2] += r4.z;
-      v[3] += r4.w;
-    }
-    if (relu == 1) {
+    for (int px = 0; px < 2; ++px)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[px][mt][r] = 0.f;
+    const float* bb = buf + c0 * CHS + h * CHS + (j >> 4) * C::P + (j & 15);
+#pragma unroll
+    for (int p = 0; p < C::NPR; ++p)
+      if (p < NP) {
+        const float* bp = bb + 2 * p * CHS;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          const int az = q / (1 + PY), ay = q % (1 + PY);
+          float b0[C::MT], b1[C::MT];
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            b0[mt] = bp[az * PLANE + ay * C::P + 16 * mt];
+            b1[mt] = bp[az * PLANE + ay * C::P + 16 * mt + 1];
+          }
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            acc[0][mt] = DMB_MFMA(a[p][q][1], b0[mt], acc[0][mt]);   // even x: kx = 1 from input m
+            acc[1][mt] = DMB_MFMA(a[p][q][2], b0[mt], acc[1][mt]);   // odd x: kx = 2 from input m ...
+            acc[1][mt] = DMB_MFMA(a[p][q][0], b1[mt], acc[1][mt]);   // ... and kx = 0 from input m + 1
+          }
+        }
+      }
+    __syncthreads();
+    {
+      float* part = buf + wave * C::PART;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<float2*>(part + cd_row(r, h) * C::PP + mt * 64 + (j >> 4) * 32 + 2 * (j & 15)) = make_float2(acc[0][mt][r], acc[1][mt][r]);
     }
-    *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NEPT; ++q) {
+      if (!live[q]) continue;
+      const int e = threadIdx.x + q * C::NTHREADS;
+      const int row = e / (C::MT * 16), c4 = e - row * (C::MT * 16), mt = c4 >> 4, jj = (c4 & 15) * 4;   // jj: column of the 64-wide strip
+      const float* pp = buf + row * C::PP + mt * 64 + jj;
+      float4 s = *reinterpret_cast<const float4*>(pp);
+#pragma unroll
+      for (int w = 1; w < C::NW; ++w) {
+        const float4 qq = *reinterpret_cast<const float4*>(pp + w * C::PART);
+        s.x += qq.x;
+        s.y += qq.y;
+        s.z += qq.z;
+        s.w += qq.w;
+      }
+      const float sc = scv[q], sh = shv[q];
+      float v[4] = {fmaf(s.x, sc, sh), fmaf(s.y, sc, sh), fmaf(s.z, sc, sh), fmaf(s.w, sc, sh)};
+      if (relu == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      if (rb) {
+        v[0] += rv[q].x;
+        v[1] += rv[q].y;
+        v[2] += rv[q].z;
+        v[3] += rv[q].w;
+      }
+      if (relu == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      *reinterpret_cast<float4*>(yb + off[q]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (gm.nbuf == 1 && t + nslots < gm.ntiles) {
+      __syncthreads();   // the partial sums have been read: the buffer may take the next tile
+      stage(tile_of(t + nslots), lds);
+    }
   }
 }
 
+// Workgroups [0, g1) belong to class (pz, py) = (1, 1), [g1, g2) to (1, 0), [g2, g3) to (0, 1), the rest to (0, 0); inside a class
+// workgroup l has row tile l % NTT and walks the tiles l / NTT, l / NTT + slots, ...
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS) void deconv3d_sk_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                  const float* __restrict__ res, float* __restrict__ y, int Ci, int D,
-                                                                  int H, int W, int Wout, int ntx, int nty, int NTT, int cvalid,
-                                                                  int relu) {
+                                                                  const float* __restrict__ res, float* __restrict__ y, const DSKGeom gm,
+                                                                  int g1, int g2, int g3) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt0 = t % NTT;
-  t /= NTT;
-  const int cls = t & 3;   // heaviest class first: (pz, py) = (1, 1), (1, 0), (0, 1), (0, 0)
-  t >>= 2;
-  const int tx = t % ntx;
-  t /= ntx;
-  const int ty = t % nty;
-  t /= nty;
-  const int z0 = t % D, b = t / D;
-  const int x0 = tx * C::TXI, y0 = ty * C::TYI;
-  if (cls == 0)
-    deconv_sk_body<C, 1, 1>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
-  else if (cls == 1)
-    deconv_sk_body<C, 1, 0>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
-  else if (cls == 2)
-    deconv_sk_body<C, 0, 1>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
+  const int G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
+  const int NTT = gm.NTT;
+  if (wg < g1)
+    deconv_sk_body<C, 1, 1>(lds, x, wp, scale, shift, res, y, gm, wg / NTT, g1 / NTT, wg % NTT);
+  else if (wg < g2)
+    deconv_sk_body<C, 1, 0>(lds, x, wp, scale, shift, res, y, gm, (wg - g1) / NTT, (g2 - g1) / NTT, (wg - g1) % NTT);
+  else if (wg < g3)
+    deconv_sk_body<C, 0, 1>(lds, x, wp, scale, shift, res, y, gm, (wg - g2) / NTT, (g3 - g2) / NTT, (wg - g2) % NTT);
   else
-    deconv_sk_body<C, 0, 0>(lds, x, wp, scale, shift, res, y, Ci, D, H, W, Wout, NTT, cvalid, relu, b, z0, y0, x0, nt0);
+    deconv_sk_body<C, 0, 0>(lds, x, wp, scale, shift, res, y, gm, (wg - g3) / NTT, (G - g3) / NTT, (wg - g3) % NTT);
 }
 
 template <class C>
 static int launch_dsk(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
                       int Ci, int Co, int D, int H, int W, int Wout, int relu, hipStream_t st) {
   const int ntx = cdiv(W, C::TXI), nty = cdiv(H, C::TYI), NTT = cdiv(Co, 32);
-  const long long nblk = (long long)B * D * nty * ntx * 4 * NTT;
-  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
+  const long long ntiles = (long long)B * D * nty * ntx;
+  if (ntiles * 4 * NTT > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "deconv3d: grid too large");
   const size_t in_floats = (size_t)Ci * C::IN_MAX, part_floats = (size_t)C::NW * C::PART;
-  const size_t lds = (in_floats > part_floats ? in_floats : part_floats) * sizeof(float);
-  if (lds > 160 * 1024) return -1;
+  const size_t buf_floats = in_floats > part_floats ? in_floats : part_floats;
+  if (buf_floats * sizeof(float) > 160 * 1024) return -1;
+  // with at most two single-buffered workgroups per CU's worth of items every workgroup takes ONE tile; beyond that the walk is
+  // persistent on the chip's workgroup slots: two per CU where two double-buffered workgroups fit the LDS, else one
+  const int two_bufs = 2 * buf_floats * sizeof(float) <= 160 * 1024;
+  const int per_cu = (two_bufs && 4 * buf_floats * sizeof(float) <= 160 * 1024) ? 2 : 1;
+  const long long slots = (long long)per_cu * num_cus();
+  long long gc[4];
+  int nbuf = 1;
+  if (ntiles * 4 * NTT <= (long long)(two_bufs ? 2 : 1) * num_cus()) {
+    for (int c = 0; c < 4; ++c) gc[c] = ntiles * NTT;    // one tile per workgroup
+  } else {
+    static const int weight[4] = {4, 2, 2, 1};           // (kz, ky) pairs of the classes (1, 1), (1, 0), (0, 1), (0, 0)
+    for (int c = 0; c < 4; ++c) {
+      long long g = slots * weight[c] / 9 / NTT * NTT;
+      if (g < NTT) g = NTT;
+      if (g > ntiles * NTT) g = ntiles * NTT;
+      gc[c] = g;
+    }
+    nbuf = two_bufs ? 2 : 1;
+  }
+  DSKGeom gm = {Ci, D, H, W, Wout, ntx, nty, NTT, Co, relu, (int)ntiles, (int)buf_floats, nbuf};
+  const size_t lds = nbuf * buf_floats * sizeof(float);
   DMB_ENSURE_LDS((&deconv3d_sk_kernel<C>), (size_t)(160 * 1024));
-  hipLaunchKernelGGL((deconv3d_sk_kernel<C>), dim3((unsigned)nblk), dim3(C::NTHREADS), lds, st, x, wp, scale, shift, res, y, Ci, D, H,
-                     W, Wout, ntx, nty, NTT, Co, relu);
+  hipLaunchKernelGGL((deconv3d_sk_kernel<C>), dim3((unsigned)(gc[0] + gc[1] + gc[2] + gc[3])), dim3(C::NTHREADS), lds, st, x, wp, scale, shift,
+                     res, y, gm, (int)gc[0], (int)(gc[0] + gc[1]), (int)(gc[0] + gc[1] + gc[2]));
   return launch_status("deconv3d split-K launch failed");
 }
 
@@ -499,11 +572,13 @@ int deconv3d_sk_try(int variant, const float* x, const float* wp, const float* s
   const int nw = variant <= 2 ? 8 : 4;
   if (Ci % (2 * nw) != 0 || Ci / (2 * nw) > 4 * (variant <= 2 ? 1 : 2)) return -1;
   if ((long long)(Ci / nw) * D * H * W * 4 >= 0x7fffffffLL) return -1;
-  switch (variant) {
+  switch (variant) {   // (dsk_variant picks 3 only: the others lost every measured shape and exist in the development build)
+    case 3: return launch_dsk<DSKCfg<4, 1, 8>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
+#ifdef DMB_DEV
     case 1: return launch_dsk<DSKCfg<8, 1, 4>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
     case 2: return launch_dsk<DSKCfg<8, 2, 4>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
-    case 3: return launch_dsk<DSKCfg<4, 1, 8>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
     case 4: return launch_dsk<DSKCfg<4, 2, 8>>(x, wp, scale, shift, res, y, B, Ci, Co, D, H, W, Wout, relu, st);
+#endif
   }
   return -1;
 }

@@ -241,7 +241,10 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float* __restrict_
 // WITH_DISP (zsplit == 1): the thread also folds every up-sampled logit of its 4 pixels into the soft-argmin, in the
 // same blocks of SA_BLK planes and the same order as soft_argmin_kernel, and writes the disparity: the regression then
 // costs no second pass over the [B, Do, Ho, Wo] volume (the volume is still written: the reference returns it).
-template <bool WITH_DISP>
+// NX: consecutive output columns per thread: 4 (16-byte stores) -- or 1 for outputs so small that four columns per thread leave the chip
+// with less than one wave per SIMD (round 6: one 256x512 map, 32768 threads walking 64 planes each, 20 us; 131072 threads: see
+// dmb_trilinear_ac_soft_argmin_f32).  The arithmetic of a pixel does not depend on NX: bit-identical.
+template <bool WITH_DISP, int NX = 4>
 __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __restrict__ x, float* __restrict__ y, int Di,
                                                              int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh,
                                                              float sw, int zsplit, float* __restrict__ disp, float alpha,
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
   // 4 q -- dealt to the threads in order, so every lane of every workgroup but the last has a word (a grid of rows x 256-word
   // blocks leaves 200 of the second block's 256 lanes idle on a 1248-column row: 0.40 -> 0.31 ms at the KITTI shape).
   // Otherwise blockIdx.y is the row and a row's words are dealt in blocks of 256.
-  const int nxq = cdiv(Wo, 4);
+  const int nxq = cdiv(Wo, NX);
   const int nxb = flat ? (int)(((long long)Ho * nxq + 255) / 256) : cdiv(nxq, 256);
   const int idx = (blockIdx.x % nxb) * 256 + threadIdx.x;
   const int yo = flat ? idx / nxq : (int)blockIdx.y;
@@ -258,20 +261,20 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
   if (xq >= nxq || yo >= Ho) return;
   const int zpart = blockIdx.x / nxb;   // this thread walks output planes [zbeg, zend)
   const int zbeg = (int)((long long)Do * zpart / zsplit), zend = (int)((long long)Do * (zpart + 1) / zsplit);
-  const int xo = xq * 4, b = blockIdx.z;
+  const int xo = xq * NX, b = blockIdx.z;
   const Lerp ly = lerp_setup(yo, Hi, sh);
-  Lerp lx[4];
+  Lerp lx[NX];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) lx[j] = lerp_setup(min(xo + j, Wo - 1), Wi, sw);
+  for (int j = 0; j < NX; ++j) lx[j] = lerp_setup(min(xo + j, Wo - 1), Wi, sw);
   const float* xb = x + (size_t)b * Di * Hi * Wi;
   const size_t plane = (size_t)Hi * Wi;
   const float* r0 = xb + (size_t)ly.i0 * Wi;
   const float* r1 = xb + (size_t)ly.i1 * Wi;
-  auto hw = [&](int zi, float (&o)[4]) {
+  auto hw = [&](int zi, float (&o)[NX]) {
     const float* p0 = r0 + (size_t)zi * plane;
     const float* p1 = r1 + (size_t)zi * plane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NX; ++j) {
       const float a0 = lerp2(p0[lx[j].i0], lx[j].w0, p0[lx[j].i1], lx[j].w1);
       const float a1 = lerp2(p1[lx[j].i0], lx[j].w0, p1[lx[j].i1], lx[j].w1);
       o[j] = lerp2(a0, ly.w0, a1, ly.w1);
@@ -280,13 +283,13 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
   // The input plane after the newest cached one is fetched AHEAD as raw values (16 registers) and only blended when it is
   // promoted, about four output planes later: loads and stores retire through one in-order counter on this chip, so a load
   // issued and awaited between two stores drains every store before it (one full write round trip per input plane).
-  float raw[16];
+  float raw[4 * NX];
   int pz = -1;
   auto prefetch = [&](int zi) {
     const float* p0 = r0 + (size_t)zi * plane;
     const float* p1 = r1 + (size_t)zi * plane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NX; ++j) {
       raw[4 * j + 0] = p0[lx[j].i0];
       raw[4 * j + 1] = p0[lx[j].i1];
       raw[4 * j + 2] = p1[lx[j].i0];
@@ -294,32 +297,32 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
     }
     pz = zi;
   };
-  auto from_raw = [&](float (&o)[4]) {
+  auto from_raw = [&](float (&o)[NX]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NX; ++j) {
       const float a0 = lerp2(raw[4 * j + 0], lx[j].w0, raw[4 * j + 1], lx[j].w1);
       const float a1 = lerp2(raw[4 * j + 2], lx[j].w0, raw[4 * j + 3], lx[j].w1);
       o[j] = lerp2(a0, ly.w0, a1, ly.w1);
     }
   };
-  float h0[4], h1[4];
+  float h0[NX], h1[NX];
   int cz0 = -1, cz1 = -1;
   const size_t ostride = (size_t)Ho * Wo;
   float* yp = y + ((size_t)b * Do * Ho + yo) * Wo + xo + (size_t)zbeg * ostride;
-  const bool vec = (Wo & 3) == 0;
-  SoftState st[WITH_DISP ? 4 : 1];
-  float vb[WITH_DISP ? 4 : 1][SA_BLK];
+  const bool vec = NX == 4 && (Wo & 3) == 0;
+  SoftState st[WITH_DISP ? NX : 1];
+  float vb[WITH_DISP ? NX : 1][SA_BLK];
   if constexpr (WITH_DISP) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st[j].init();
+    for (int j = 0; j < NX; ++j) st[j].init();
   }
   // one output plane: blend the two cached input planes, store the 4 columns, return them
-  auto out_plane = [&](int zo, float (&o)[4]) {
+  auto out_plane = [&](int zo, float (&o)[NX]) {
     const Lerp lz = lerp_setup(zo, Di, sd);
     if (lz.i0 != cz0) {
       if (lz.i0 == cz1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h0[j] = h1[j];
+        for (int j = 0; j < NX; ++j) h0[j] = h1[j];
       } else {
         hw(lz.i0, h0);
       }
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
     if (lz.i1 != cz1) {
       if (lz.i1 == cz0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h1[j] = h0[j];
+        for (int j = 0; j < NX; ++j) h1[j] = h0[j];
       } else if (lz.i1 == pz) {
         from_raw(h1);
       } else {
@@ -338,13 +341,13 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
       if (cz1 + 1 < Di) prefetch(cz1 + 1);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = lerp2(h0[j], lz.w0, h1[j], lz.w1);
+    for (int j = 0; j < NX; ++j) o[j] = lerp2(h0[j], lz.w0, h1[j], lz.w1);
     if (vec) {
       // streaming store: 1.6 GB per launch that nothing re-reads soon must not wash the L2
-      __builtin_nontemporal_store(f32x4_t{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4_t*>(yp));
+      if constexpr (NX == 4) __builtin_nontemporal_store(f32x4_t{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4_t*>(yp));
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NX; ++j)
         if (xo + j < Wo) yp[j] = o[j];
     }
     yp += ostride;
@@ -356,20 +359,20 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
       float d[SA_BLK];
 #pragma unroll
       for (int i = 0; i < SA_BLK; ++i) {
-        float o[4];
+        float o[NX];
         out_plane(zb + i, o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vb[j][i] = o[j] * alpha;
+        for (int j = 0; j < NX; ++j) vb[j][i] = o[j] * alpha;
         d[i] = dv.v[zb + i];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) st[j].template fold<SA_BLK>(vb[j], d);
+      for (int j = 0; j < NX; ++j) st[j].template fold<SA_BLK>(vb[j], d);
     }
     for (int zo = full; zo < Do; ++zo) {
-      float o[4];
+      float o[NX];
       out_plane(zo, o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NX; ++j) {
         float v1[1] = {o[j] * alpha};
         float d1[1] = {dv.v[zo]};
         st[j].template fold<1>(v1, d1);
@@ -377,14 +380,14 @@ __global__ __launch_bounds__(256) void trilinear_zcol_kernel(const float* __rest
     }
   } else {
     for (int zo = zbeg; zo < zend; ++zo) {
-      float o[4];
+      float o[NX];
       out_plane(zo, o);
     }
   }
   if constexpr (WITH_DISP) {
     float* dp = disp + ((size_t)b * Ho + yo) * Wo + xo;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NX; ++j)
       if (xo + j < Wo) dp[j] = st[j].result();
   }
 }
@@ -680,6 +683,14 @@ extern "C" int dmb_trilinear_ac_soft_argmin_f32(const float* x, float* y, float*
   DispVal dv;
   if (int e = fill_samples(disp_sample_host, Do, dv)) return e;
   const int flat = trilinear_flat(Ho, Wo);
+  // (round 6) fewer than one wave per SIMD at four columns per thread: one column per thread -- four times the waves, each with a
+  // quarter of the per-plane arithmetic of its serial walk over the Do planes (one 256x512 map: 20 -> 12 us); same bits
+  if ((long long)B * Ho * cdiv(Wo, 4) < 4LL * 64 * num_cus() && (long long)Ho * Wo < 0x7fffff00LL) {
+    const long long nxb1 = flat ? ((long long)Ho * Wo + 255) / 256 : cdiv(Wo, 256);
+    hipLaunchKernelGGL((trilinear_zcol_kernel<true, 1>), dim3((unsigned)nxb1, flat ? 1 : Ho, B), dim3(256), 0, (hipStream_t)stream, x, y,
+                       Di, Hi, Wi, Do, Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), 1, disp, alpha, dv, flat);
+    return launch_status("trilinear_ac_soft_argmin launch failed");
+  }
   const long long nxb = flat ? ((long long)Ho * (Wo / 4) + 255) / 256 : cdiv(cdiv(Wo, 4), 256);
   hipLaunchKernelGGL(trilinear_zcol_kernel<true>, dim3((unsigned)nxb, flat ? 1 : Ho, B), dim3(256), 0, (hipStream_t)stream, x, y,
                      Di, Hi, Wi, Do, Ho, Wo, ac_scale(Di, Do), ac_scale(Hi, Ho), ac_scale(Wi, Wo), 1, disp, alpha, dv, flat);
