@@ -23,6 +23,7 @@
 namespace dmb {
 
 constexpr int C2_WPE = DMB_C2_WPE;
+constexpr long long C2_SK_MAX_UNITS_PER_CU = 5;   // split-K form of small 3x3 launches (dmb_conv2d_f32): calibrated in profiles/r06_c2d_sk_probe.log
 constexpr int C2_LDS_BUDGET = 160 * 1024 / C2_WPE;
 constexpr int C2_CK = 8;  // packed weight streams are zero-padded to a multiple of this many input channels
 
@@ -621,10 +622,23 @@ extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* s
     return fail(DMB_EUNSUPPORTED, "conv2d: one batch item must stay below 2 GiB");
   const int NTT = cdiv(Co, 32);
   hipStream_t st = (hipStream_t)stream;
+  const bool single_chain = (relu & DMB_CONV_SINGLE_CHAIN) != 0;
+  relu &= 0xff;
   // vector path: every row of x, y and residual starts on a 16-byte boundary
   const int Wo_ = (W - 1) / stride + 1;
   const bool v16 = W % 4 == 0 && Wo_ % 4 == 0 && !DMB_OPT(3) &&
                    (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+  // (round 6) a 3x3 layer that would leave most of the chip idle (one small image per view: backbones/PSMNet.py:8-129 as
+  // dmb/apis/inference.py:191-225 calls it) takes the split-K form of csrc/conv3d_sk.hip: units = 16 x 2 pixel tiles x 32-channel
+  // row tiles.  DMB_OPT(26) (development build): 1 = never, 2 = always.
+  if (stride == 1 && ksize == 3 && (dilation == 1 || dilation == 2) && v16) {
+    const long long units = (long long)B * cdiv(H, 2) * cdiv(W, 16) * NTT;
+    if (((!single_chain && units <= C2_SK_MAX_UNITS_PER_CU * num_cus()) && DMB_OPT(26) != 1) || DMB_OPT(26) == 2) {
+      const int rc = conv2d_sk_try(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, dilation, relu, in_channels_total,
+                                   out_channels_total, res_channels_total, st);
+      if (rc != -1) return rc;
+    }
+  }
 #define DMB_C2(N, K, DL, S)                                                                                           \
   return v16 ? launch_conv2d<C2Cfg<N, K, DL, S, true>>(x, wpack, scale, shift, residual, y, B, Ci, Co, H, W, relu,     \
                                                        in_channels_total, out_channels_total, res_channels_total, st)  \

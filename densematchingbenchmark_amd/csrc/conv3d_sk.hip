@@ -27,15 +27,23 @@
 
 namespace dmb {
 
-template <int S_, int NW_, int NT_, int XS_, int YS_, int NPR_>
+// KZ = 3: the 3x3x3 convolution; KZ = 1: a 3x3 convolution of [B, C, H, W] maps (D = 1, no z taps) -- the 2-D layers of the backbones
+// (layers/basic_layers.py:12-66, backbones/PSMNet.py:8-129) for ONE small image pair, where conv2d.hip's persistent tiles leave most
+// of the chip idle in the same way (31 of PSMNet's layers at [1, 64, 64, 128]: 31.7 us each for 3.8 us of MFMAs).  DIL: dilation
+// (stride 1 only; 2 = PSMNet's layer4).
+template <int S_, int NW_, int NT_, int XS_, int YS_, int NPR_, int KZ_ = 3, int DIL_ = 1>
 struct SKCfg {
-  static constexpr int S = S_, NW = NW_, NT = NT_, XS = XS_, YS = YS_;
+  static constexpr int S = S_, NW = NW_, NT = NT_, XS = XS_, YS = YS_, KZ = KZ_, DIL = DIL_;
+  static constexpr int TAPS = KZ * 9;
   static constexpr int NPR = NPR_;   // channel pairs per wave whose A fragments are resident in registers (Ci <= 2 NW NPR)
   static constexpr int NTHREADS = 64 * NW;
   static constexpr int TXO = 16 * XS, TYO = 2 * YS, MT = XS * YS;   // output tile; 32-voxel column tiles = row pairs of 16 columns
-  static constexpr int ROWS = S == 1 ? TYO + 2 : 2 * TYO + 1;      // staged input rows
-  static constexpr int P = S == 1 ? TXO + 8 : 2 * TXO + 4;         // staged row: from the 16-byte aligned column S x0 - 4
-  static constexpr int ZS = 3;
+  static constexpr int ROWS = S == 1 ? TYO + 2 * DIL : 2 * TYO + 1;                   // staged input rows
+  static constexpr int P = S == 1 ? (4 + TXO + DIL + 3) / 4 * 4 : 2 * TXO + 4;       // staged row: from the 16-byte aligned column S x0 - 4
+  static constexpr int XOFF = S == 1 ? 4 - DIL : 3;                                  // staged column of the first tap of output column 0
+  static constexpr int ZS = KZ;
+  static_assert(DIL == 1 || S == 1, "dilated layers are stride 1");
+  static_assert(DIL <= 4, "the staged row starts 4 columns left of the tile");
   static constexpr int PLANE = ROWS * P, CHS = ZS * PLANE;         // one channel of the tile (a whole number of 16-byte units)
   static constexpr int UPR = P / 4, UPC = ZS * ROWS * UPR;         // 16-byte units per row / per channel
   static constexpr int PP = MT * 32 + 4;                           // pitch of a partial tile's rows
@@ -53,7 +61,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const float* __restrict__ res, float* __restrict__ y, int Ci, int D,
                                                                 int H, int W, int Do, int Ho, int Wo, int ntx, int nty, int NTT,
-                                                                int relu, int items, int buf_floats, int nbuf) {
+                                                                int relu, int items, int buf_floats, int nbuf, long long in_bs,
+                                                                long long out_bs, long long res_bs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int G = gridDim.x;
   const int wg = xcd_remap(blockIdx.x, G);
@@ -84,13 +93,13 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
   // its own part of the buffer
   auto stage = [&](const Tile& tl, float* buf) {
     float* region = buf + c0 * C::CHS;
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + ((size_t)tl.b * Ci + c0) * DHW, (unsigned)CW * DHW * 4u);
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(x + (size_t)tl.b * in_bs + (size_t)c0 * DHW, (unsigned)CW * DHW * 4u);
     const int NU = CW * C::UPC;
     for (int u0 = 0; u0 < NU; u0 += 64) {
       const int u = u0 + lane;
       const int cl = u / C::UPC, r0 = u - cl * C::UPC;
       const int zz = r0 / (C::ROWS * C::UPR), r1 = r0 - zz * (C::ROWS * C::UPR), yy = r1 / C::UPR, sg = r1 - yy * C::UPR;
-      const int gz = C::S * tl.z0 - 1 + zz, gy = C::S * tl.y0 - 1 + yy, gx = C::S * tl.x0 - 4 + sg * 4;
+      const int gz = C::S * tl.z0 - (C::KZ == 3 ? 1 : 0) + zz, gy = C::S * tl.y0 - (C::S == 1 ? C::DIL : 1) + yy, gx = C::S * tl.x0 - 4 + sg * 4;
       const bool ok = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
       if (u < NU)
         dma16(xrs, ok ? ((unsigned)cl * DHW + (unsigned)gz * HW + (unsigned)gy * W + (unsigned)gx) * 4u : DMA_OOB, 0u, region + u0 * 4);
@@ -103,20 +112,19 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
   // copies: one memory round trip for the workgroup's whole weight set.  (Requested a pair ahead of their MFMAs they arrived late:
   // a pair's 27 MFMAs last 0.7 us, an L2 round trip under load longer -- 16 us instead of 13 for the [1, 64, 4, 16, 32] layer.)
   const int NP = CW / 2;   // <= NPR (checked on the host)
-  const float* wbase = wp + ((size_t)(c0 / 2) * 27 * NTT + nt0) * 64 + lane;
-  float a[C::NPR][27][C::NT];
+  const float* wbase = wp + ((size_t)(c0 / 2) * C::TAPS * NTT + nt0) * 64 + lane;
+  float a[C::NPR][C::TAPS][C::NT];
 #pragma unroll
   for (int p = 0; p < C::NPR; ++p)
     if (p < NP) {
-      const float* wq = wbase + (size_t)p * 27 * NTT * 64;
+      const float* wq = wbase + (size_t)p * C::TAPS * NTT * 64;
 #pragma unroll
-      for (int tap = 0; tap < 27; ++tap)
+      for (int tap = 0; tap < C::TAPS; ++tap)
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) a[p][tap][nt] = wq[(tap * NTT + nt) * 64];
     }
 
   const unsigned HWo = (unsigned)Ho * Wo, DHWo = (unsigned)Do * HWo;
-  const int Co = NTT * 32;
   const bool vec = (Wo & 3) == 0;
   // epilogue operands that do not depend on the item (a thread owns the same rows of every output tile): requested here, under the
   // first item's copies, not after its multiply phase (an exposed L2 round trip per launch in the one-item case)
@@ -135,8 +143,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
     float* buf = lds + (nbuf == 2 ? (it & 1) * buf_floats : 0);
     __syncthreads();   // (the compiler drains the copies -- vmcnt(0) -- here): this item's tile is in `buf`; the other buffer is free
     if (nbuf == 2 && item + G < items) stage(tile_of(item + G), lds + ((it + 1) & 1) * buf_floats);   // lands while this item is multiplied
-    float* yb = y + (size_t)tl.b * Co * DHWo;
-    const float* rb = res ? res + (size_t)tl.b * Co * DHWo : nullptr;
+    float* yb = y + (size_t)tl.b * out_bs;
+    const float* rb = res ? res + (size_t)tl.b * res_bs : nullptr;
     // this thread's words of the output tile and its skip operand (requested now, consumed after the multiply phase)
     size_t off[NEPT];
     bool live[NEPT];
@@ -161,18 +169,18 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     // B fragment of (pair p, tap, column tile): lane (j, h) reads channel 2 p + h at the tap's input voxel of output (j / 16, j % 16)
-    const float* bb = buf + c0 * C::CHS + h * C::CHS + C::S * (j >> 4) * C::P + C::S * (j & 15) + 3;
+    const float* bb = buf + c0 * C::CHS + h * C::CHS + C::S * (j >> 4) * C::P + C::S * (j & 15) + C::XOFF;
 #pragma unroll
     for (int p = 0; p < C::NPR; ++p)
       if (p < NP) {
         const float* bp = bb + 2 * p * C::CHS;
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int tap = 0; tap < C::TAPS; ++tap) {
           const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
           float bf[C::MT];
 #pragma unroll
           for (int mt = 0; mt < C::MT; ++mt)
-            bf[mt] = bp[dz * C::PLANE + (dy + C::S * 2 * (mt / C::XS)) * C::P + dx + C::S * 16 * (mt % C::XS)];
+            bf[mt] = bp[dz * C::PLANE + (dy * C::DIL + C::S * 2 * (mt / C::XS)) * C::P + dx * C::DIL + C::S * 16 * (mt % C::XS)];
 #pragma unroll
           for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -248,8 +256,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3d_sk_kernel(const float* __r
 
 template <class C>
 static int launch_sk(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
-                     int Ci, int Co, int D, int H, int W, int relu, hipStream_t st) {
+                     int Ci, int Co, int D, int H, int W, int relu, hipStream_t st, long long in_ctot = 0, long long out_ctot = 0,
+                     long long res_ctot = 0) {
   const int Do = (D - 1) / C::S + 1, Ho = (H - 1) / C::S + 1, Wo = (W - 1) / C::S + 1;
+  // channels a batch item of the three tensors holds (the 2-D entry point reads / writes channel windows of wider tensors)
+  const long long in_bs = (in_ctot ? in_ctot : Ci) * (long long)D * H * W, out_bs = (out_ctot ? out_ctot : Co) * (long long)Do * Ho * Wo,
+                  res_bs = (res_ctot ? res_ctot : Co) * (long long)Do * Ho * Wo;
   const int ntx = cdiv(Wo, C::TXO), nty = cdiv(Ho, C::TYO), NTT = Co / 32, NTS = NTT / C::NT;
   const long long items = (long long)B * Do * nty * ntx * NTS;
   if (items > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
@@ -264,7 +276,7 @@ static int launch_sk(const float* x, const float* wp, const float* scale, const 
   const size_t lds = nbuf * buf_floats * sizeof(float);
   DMB_ENSURE_LDS((&conv3d_sk_kernel<C>), (size_t)(160 * 1024));
   hipLaunchKernelGGL((conv3d_sk_kernel<C>), dim3((unsigned)G), dim3(C::NTHREADS), lds, st, x, wp, scale, shift, res, y, Ci, D, H, W,
-                     Do, Ho, Wo, ntx, nty, NTT, relu, (int)items, (int)buf_floats, nbuf);
+                     Do, Ho, Wo, ntx, nty, NTT, relu, (int)items, (int)buf_floats, nbuf, in_bs, out_bs, res_bs);
   return launch_status("conv3d split-K launch failed");
 }
 
@@ -306,6 +318,33 @@ int conv3d_sk_try(int variant, const float* x, const float* wp, const float* sca
     if (variant == 3 && Co == 64) DMB_SK(2, 2, 2, 1, 2);
   }
 #undef DMB_SK
+  return -1;
+}
+
+// The 2-D layers (dmb_conv2d_f32, kernel 3, stride 1, dilation 1 or 2) in the same form: x / y / residual are the channel windows
+// the caller has already offset, `*_ctot` the channels a batch item of each tensor holds.  relu: after the skip add (conv2d.hip).
+// -1: the shape does not qualify (every row tile of a pixel tile goes to one workgroup when the A fragments fit, else one each).
+int conv2d_sk_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B, int Ci,
+                  int Co, int H, int W, int dilation, int relu, int in_ctot, int out_ctot, int res_ctot, hipStream_t st) {
+  constexpr int NW = 8;
+  if (Ci % (2 * NW) != 0 || Co % 32 != 0 || Co > 128 || W % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) != 0) return -1;
+  if ((long long)(Ci / NW) * H * W * 4 >= 0x7fffffffLL) return -1;
+  const int NP = Ci / (2 * NW), NTT = Co / 32;
+#define DMB_SK2(NT, NPR, DL)                                                                                        \
+  do {                                                                                                              \
+    using C = SKCfg<1, NW, NT, 1, 1, NPR, 1, DL>;                                                                   \
+    if (NP > NPR || sk_lds_bytes<C>(Ci) > 160 * 1024) return -1;                                                    \
+    return launch_sk<C>(x, wp, scale, shift, res, y, B, Ci, Co, 1, H, W, relu ? 1 : 0, st, in_ctot, out_ctot, res_ctot); \
+  } while (0)
+  // A fragments per wave = NP x 9 x NT registers: both row tiles of a pair up to 64 input channels, one above
+  if (dilation == 1) {
+    if (NTT % 2 == 0 && NP <= 4) DMB_SK2(2, 4, 1);
+    DMB_SK2(1, 8, 1);
+  } else if (dilation == 2) {
+    if (NTT % 2 == 0 && NP <= 4) DMB_SK2(2, 4, 2);
+    DMB_SK2(1, 8, 2);
+  }
+#undef DMB_SK2
   return -1;
 }
 

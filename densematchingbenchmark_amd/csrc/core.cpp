@@ -35,7 +35,7 @@ int num_cus() {
 //   19  stride-1 tile override (see dmb_conv3d_k3_f32)                   20  = 1: zy items from ONE counter instead of one per XCD
 //   21  = 32 / 64: options 16 and 20 for that output width only         22  up-sampling: 1 = row form, 2 = flat form
 //   23  split-K conv3d: 1 = never, k >= 2 = force variant k - 1          24  32 -> 1 head: 1 = never the split-channel form, 2 = always
-//   25  split-K transposed conv: 1 = never, k >= 2 = force variant k - 1
+//   25  split-K transposed conv: 1 = never, k >= 2 = force variant k - 1    26  split-K 3x3 conv2d: 1 = never, 2 = always
 namespace dmb {
 int g_dev_opts[32] = {0};
 }

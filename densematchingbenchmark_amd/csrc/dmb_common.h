@@ -119,6 +119,8 @@ int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const f
 int conv3d_sk_try(int variant, const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                   int B, int Ci, int Co, int D, int H, int W, int stride, int relu, hipStream_t st);
 
+int conv2d_sk_try(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B, int Ci,
+                  int Co, int H, int W, int dilation, int relu, int in_ctot, int out_ctot, int res_ctot, hipStream_t st);
 int deconv3d_sk_try(int variant, const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y,
                     int B, int Ci, int Co, int D, int H, int W, int Wout, int relu, hipStream_t st);
 

@@ -137,7 +137,8 @@ std::vector<at::Tensor> trilinear_ac_soft_argmin(const at::Tensor& x, int64_t Do
 // x [B, Cx, H, W], channels [coff, coff + Ci) read; out [B, Ctot, Ho, Wo] written at channel out_off; residual read at res_off.
 at::Tensor conv2d(const at::Tensor& x, int64_t coff, int64_t Ci, const at::Tensor& wpack, int64_t Co, int64_t ksize, int64_t stride,
                   int64_t dilation, const c10::optional<at::Tensor>& scale, const c10::optional<at::Tensor>& shift,
-                  const c10::optional<at::Tensor>& residual, int64_t res_off, bool relu, const c10::optional<at::Tensor>& out, int64_t out_off) {
+                  const c10::optional<at::Tensor>& residual, int64_t res_off, int64_t relu_flags, const c10::optional<at::Tensor>& out,
+                  int64_t out_off) {
   f32(x, "x");
   if (x.dim() != 4) raise("conv2d: x must be [B, C, H, W]");
   const int64_t B = x.size(0), Cx = x.size(1), H = x.size(2), W = x.size(3);
@@ -165,7 +166,7 @@ at::Tensor conv2d(const at::Tensor& x, int64_t coff, int64_t Ci, const at::Tenso
   if (wpack.numel() != dmb_conv2d_packed_floats((int)Co, (int)Ci, (int)ksize)) raise("conv2d: packed weights do not belong to this layer");
   chk(dmb_conv2d_f32(x.data_ptr<float>() + coff * H * W, ptr(wpack, "wpack"), optr(scale, "scale"), optr(shift, "shift"), rp,
                      y.data_ptr<float>() + out_off * Ho * Wo, (int)B, (int)Ci, (int)Co, (int)H, (int)W, (int)ksize, (int)stride, (int)dilation,
-                     relu ? 1 : 0, (int)Cx, (int)y.size(1), (int)Cres, stream_of(x)),
+                     (int)relu_flags, (int)Cx, (int)y.size(1), (int)Cres, stream_of(x)),
       "dmb_conv2d_f32");
   return y;
 }

@@ -1367,7 +1367,7 @@ def conv2d(x, wpack, Co, ksize, stride=1, dilation=1, scale=None, shift=None, re
     if sh is not None:
         coff, Ci = in_window if in_window is not None else (0, x.shape[1])
         return sh.conv2d(x if x.is_contiguous() else x.contiguous(), coff, Ci, wpack, Co, ksize, stride, dilation, scale, shift, residual,
-                         res_ch_offset, bool(relu), out, out_ch_offset)
+                         res_ch_offset, int(bool(relu)) | _conv_flags(), out, out_ch_offset)
     lib = _lib.load()
     x = _f32c(x, "x")
     B, Cx, H, W = x.shape
@@ -1383,7 +1383,7 @@ def conv2d(x, wpack, Co, ksize, stride=1, dilation=1, scale=None, shift=None, re
     check(lib.dmb_conv2d_f32(_window_ptr(x, coff), dev_ptr(wpack), dev_ptr(scale, allow_none=True),
                              dev_ptr(shift, allow_none=True),
                              _window_ptr(residual, res_ch_offset) if residual is not None else None,
-                             _window_ptr(out, out_ch_offset), B, Ci, Co, H, W, ksize, stride, dilation, int(bool(relu)),
+                             _window_ptr(out, out_ch_offset), B, Ci, Co, H, W, ksize, stride, dilation, int(bool(relu)) | _conv_flags(),
                              Cx, out.shape[1], residual.shape[1] if residual is not None else 0, stream_ptr(x.device)),
           "dmb_conv2d_f32")
     return out

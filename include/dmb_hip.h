@@ -191,8 +191,8 @@ int dmb_cat_fms_into_f32(const float* L, const float* R, float* out, int B, int 
  * takes a split-K form instead (csrc/conv3d_sk.hip, conv3d_c1s_kernel): the input channels of a voxel are split over the waves
  * of a workgroup and the partial chains added in a fixed order -- reproducible run to run, but the last bits then depend on which
  * form the launch's SIZE selects (batch 1 and batch 4 of the same pair may differ by an FP32 rounding of the sum).
- * DMB_CONV_SINGLE_CHAIN, or-ed into the `relu` argument of dmb_conv3d_k3_f32 / dmb_deconv3d_k3s2_f32 (bits 0-7 stay the
- * activation mode) or passed as `flags` of dmb_conv3d_k3_c1_f32, keeps a launch on the single-chain kernels whatever its size:
+ * DMB_CONV_SINGLE_CHAIN, or-ed into the `relu` argument of dmb_conv3d_k3_f32 / dmb_deconv3d_k3s2_f32 / dmb_conv2d_f32 (bits 0-7
+ * stay the activation mode) or passed as `flags` of dmb_conv3d_k3_c1_f32, keeps a launch on the single-chain kernels whatever its size:
  * results are then bit-identical across batch sizes (slower for small launches: 31-35 us instead of 13-15 us per layer of the
  * deepest hourglass level of one 256x512 pair).
  * ---------------------------------------------------------------------------------------- */

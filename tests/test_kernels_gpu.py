@@ -581,6 +581,7 @@ def test_conv2d(dev, Ci, Co, k, stride, dil, shape):
     (32, 32, 3, 1, 8, (1, 40, 96)),
     (32, 1, 3, 1, 1, (2, 19, 52)),
 ])
+@pytest.mark.usefixtures("single_chain")
 def test_conv2d_vector_path(dev, Ci, Co, k, stride, dil, shape):
     """Widths that are multiples of 4 take the 16-byte staging + transposed-store path; it must agree bit for bit with the
     scalar path (same MFMA sequence, same epilogue arithmetic) and with torch within the FP32 tolerance."""
@@ -864,6 +865,7 @@ def test_conv3d_s2_pair_epilogue_is_bit_identical(dev, Ci, shape, mode):
 # ------------------------------------------------------------------------------- first conv on a cat volume, 2-D form
 @pytest.mark.parametrize("B,C,Co,D,H,W", [(2, 32, 32, 16, 12, 64), (1, 32, 32, 48, 9, 240), (1, 8, 32, 4, 5, 12),
                                           (2, 6, 20, 8, 7, 16), (1, 32, 32, 2 * 4, 6, 20)])
+@pytest.mark.usefixtures("single_chain")
 def test_catconv_first_layer(dev, B, C, Co, D, H, W):
     """dres0[0] on the concatenation volume WITHOUT the volume (csrc/catconv.hip) against (a) an FP64 evaluation of the
     reference arithmetic -- F.conv3d on the oracle's cat_fms volume -- and (b) this library's own 3-D kernel on the
@@ -1245,3 +1247,38 @@ def test_torch_extension_shim_and_ctypes_bind_the_same_functions(dev):
                 lambda: ops.conv3d_k3(x.double(), ops.pack_conv3d_weights(w), 64), lambda: ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 64, None, None, res[:1])):
         with pytest.raises(_lib.DmbLibraryError):
             bad()
+
+
+@pytest.mark.parametrize("Ci,Co,dil,shape", [(64, 64, 1, (1, 64, 128)), (128, 128, 2, (1, 64, 128)), (32, 32, 1, (1, 128, 256)), (64, 128, 1, (2, 9, 44)),
+                                             (128, 32, 1, (1, 6, 28)), (16, 64, 2, (3, 11, 36))])
+def test_split_k_form_of_small_conv2d_launches(dev, Ci, Co, dil, shape):
+    """The 3x3 layers of the backbones (layers/basic_layers.py:12-66, backbones/PSMNet.py:8-129) for ONE small image per view take the
+    split-K form (csrc/conv3d_sk.hip with KZ = 1: [1, 64, 64, 128] 30 -> 11 us): within 2e-5 of the CPU convolution with folded
+    BatchNorm, skip and ReLU, within 2e-5 of the tile kernel (DMB_CONV_SINGLE_CHAIN), not bit-identical to it at the 256x512 shapes,
+    reproducible run to run, and correct into / out of channel windows of wider tensors (the SPP concat is written in place)."""
+    ops = _ops()
+    B, H, W = shape
+    x = _rand((B, Ci + 8, H, W), 801)
+    w = _rand((Co, Ci, 3, 3), 802, 1.0 / math.sqrt(Ci * 9))
+    sc, sh = _affine(Co, 803)
+    res = _rand((B, Co + 32, H, W), 804)
+    ref = F.relu(F.conv2d(x[:, 8:], w, None, padding=dil, dilation=dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res[:, 32:])
+    wp = ops.pack_conv2d_weights(w.to(dev))
+
+    def run():
+        out = torch.full((B, Co + 16, H, W), -7.0, device=dev)
+        ops.conv2d(x.to(dev), wp, Co, 3, 1, dil, sc.to(dev), sh.to(dev), res.to(dev), True, in_window=(8, Ci), out=out, out_ch_offset=16,
+                   res_ch_offset=32)
+        return out
+
+    got = run()
+    assert (got[:, 16:].cpu() - ref).abs().max().item() <= 2e-5 and float(got[:, :16].min()) == -7.0 == float(got[:, :16].max())
+    assert torch.equal(run(), got)
+    ops.set_split_k(False)
+    try:
+        tiles = run()
+    finally:
+        ops.set_split_k(True)
+    assert (tiles[:, 16:].cpu() - ref).abs().max().item() <= 2e-5 and (tiles - got).abs().max().item() <= 2e-5
+    if H * W >= 64 * 128:
+        assert not torch.equal(tiles, got)
