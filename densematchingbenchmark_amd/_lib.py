@@ -24,7 +24,7 @@ _P = _c_void_p  # device pointer
 _HI = ctypes.POINTER(ctypes.c_int)  # host int array
 _HF = ctypes.POINTER(ctypes.c_float)  # host float array
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # name -> (restype, argtypes)
 SIGNATURES = {
@@ -88,7 +88,8 @@ SIGNATURES = {
     "dmb_bn_workspace_doubles": (_c_ll, [_c_int, _c_ll]),
     "dmb_bn_train_stats_f32": (_c_int, [_P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_bn_act_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _c_int, _P]),
-    "dmb_bn_act_bwd_f32": (_c_int, [_P] * 12 + [_c_int, _c_int, _c_ll, _c_int, _c_int, _P]),
+    "dmb_bn_train_fwd_f32": (_c_int, [_P] * 6 + [_c_float, _c_float] + [_P] * 7 + [_c_int, _c_int, _c_ll, _c_int, _P]),
+    "dmb_bn_act_bwd_f32": (_c_int, [_P] * 13 + [_c_int, _c_int, _c_ll, _c_int, _c_int, _P]),
     "dmb_cat_fms_bwd_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
     "dmb_dif_fms_bwd_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _P]),
     "dmb_soft_argmin_bwd_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _HF, _P]),

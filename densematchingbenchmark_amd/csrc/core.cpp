@@ -44,5 +44,5 @@ extern "C" void dmb_dev_set_option(int key, int value) {
 }
 #endif
 
-extern "C" int dmb_abi_version(void) { return 7; }
+extern "C" int dmb_abi_version(void) { return 8; }
 extern "C" const char* dmb_last_error(void) { return dmb::g_last_error; }

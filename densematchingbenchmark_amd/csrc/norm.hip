@@ -151,6 +151,79 @@ __global__ __launch_bounds__(NB) void bn_act_kernel(const float* __restrict__ c,
   }
 }
 
+// Channel totals of the per-slice partial sums, in the order bn_stats_finalize_kernel adds them (lanes 64 slices apart, then the
+// butterfly): a consuming kernel whose workgroups each re-create the totals of their channel from the
+// same <= 2 KB of partials gets the same doubles everywhere -- and the finalising launch between the two passes goes away
+// (round 6: 25 + 25 launches of 4.7 us in a PSMNet training step).
+__device__ __forceinline__ void channel_totals(const double* __restrict__ ws, int ch, int nsplit, double* sm2, double& a, double& b) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = lane; s < nsplit; s += 64) {
+      s0 += ws[((long long)ch * nsplit + s) * 2];
+      s1 += ws[((long long)ch * nsplit + s) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s0 += __shfl_down(s0, o, 64);
+      s1 += __shfl_down(s1, o, 64);
+    }
+    if (lane == 0) sm2[0] = s0, sm2[1] = s1;
+  }
+  __syncthreads();
+  a = sm2[0];
+  b = sm2[1];
+}
+
+// bn_stats_finalize_kernel + bn_act_kernel in one launch: workgroup (s, ch) finishes channel ch's statistics itself (the
+// arithmetic of bn_stats_finalize_kernel, operation for operation) and normalises slice s of the channel; workgroup (0, ch)
+// also writes the per-channel outputs and updates the running buffers, workgroup (0, 0) counts the batch.
+__global__ __launch_bounds__(NB) void bn_act_train_kernel(const float* __restrict__ c, const double* __restrict__ ws,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          long long* __restrict__ num_batches_tracked, float momentum, float eps,
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                          float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                                          const float* __restrict__ res, float* __restrict__ y, int B, int C,
+                                                          long long S, int nsplit, int nact, int relu, int vec) {
+  __shared__ double tot[2];
+  const int ch = blockIdx.y, s = blockIdx.x;
+  double sum, sq;
+  channel_totals(ws, ch, nsplit, tot, sum, sq);
+  const double n = (double)B * (double)S;
+  const double dm = sum / n;                      // mean - pivot
+  double var = sq / n - dm * dm;
+  if (var < 0.0) var = 0.0;
+  const double mean = (double)c[(long long)ch * S] + dm;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[ch] : 1.f, bta = beta ? beta[ch] : 0.f;
+  const float sc = g * invstd;
+  const float sh = bta - (float)mean * sc;
+  if (s == 0 && threadIdx.x == 0) {
+    mean_out[ch] = (float)mean;
+    invstd_out[ch] = invstd;
+    scale_out[ch] = sc;
+    shift_out[ch] = sh;
+    if (running_mean) running_mean[ch] = running_mean[ch] + momentum * ((float)mean - running_mean[ch]);
+    if (running_var) {
+      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+      running_var[ch] = running_var[ch] + momentum * ((float)unbiased - running_var[ch]);
+    }
+    if (ch == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  }
+  const float lo1 = relu == 1 ? 0.f : -INFINITY, lo2 = relu == 2 ? 0.f : -INFINITY;
+  auto one = [&](float v, float r) { return fmaxf(fmaxf(fmaf(v, sc, sh), lo2) + r, lo1); };
+  for_slice(S, B, C, ch, s, nact, vec != 0,
+            [&](long long o) {
+              const float4 v = *reinterpret_cast<const float4*>(c + o);
+              float4 r = {0.f, 0.f, 0.f, 0.f};
+              if (res) r = *reinterpret_cast<const float4*>(res + o);
+              float4 q = {one(v.x, r.x), one(v.y, r.y), one(v.z, r.z), one(v.w, r.w)};
+              *reinterpret_cast<float4*>(y + o) = q;
+            },
+            [&](long long o) { y[o] = one(c[o], res ? res[o] : 0.f); });
+}
+
 // gradient entering the normalisation: dy masked by the unit's ReLU.
 //   relu 1 (activation after the skip add): the mask is the unit's output y > 0
 //   relu 2 (activation before the skip add): the mask is the normalised value c*scale + shift > 0
@@ -205,63 +278,56 @@ __global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const float* __restri
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                       int nsplit) {
-  const int ch = blockIdx.x, lane = threadIdx.x;   // one wave per channel (see bn_stats_finalize_kernel)
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = lane; s < nsplit; s += 64) {
-    s1 += ws[((long long)ch * nsplit + s) * 2];
-    s2 += ws[((long long)ch * nsplit + s) * 2 + 1];
+// dc = scale*(dpre - dbeta/N - xhat*dgamma/N) (training) or scale*dpre (eval).  The channel sums are finished by every workgroup
+// itself (channel_totals: rounds 1-5 had a finalising launch between the two passes), and the skip branch's gradient is an
+// ACCUMULATING output: dres = (what flows into the skip branch) + dres_acc, where dres_acc is the gradient the skip operand has
+// already collected from its other consumers -- the addition torch.autograd would launch on its own (three tensor passes) costs
+// one extra read here.  Workgroup (0, ch) writes dgamma / dbeta.
+__global__ __launch_bounds__(NB) void bn_bwd_apply_fin_kernel(const float* __restrict__ dy, const float* __restrict__ c,
+                                                              const float* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const double* __restrict__ ws,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dc, float* __restrict__ dres,
+                                                              const float* __restrict__ dres_acc, int B, int C, long long S,
+                                                              int nsplit, int nact, float inv_n, int relu, int training, int vec) {
+  __shared__ double tot[2];
+  const int ch = blockIdx.y, s = blockIdx.x;
+  double s1, s2;
+  channel_totals(ws, ch, nsplit, tot, s1, s2);
+  const float db = (float)s1, dg = (float)s2;
+  if (s == 0 && threadIdx.x == 0) {
+    dbeta[ch] = db;
+    dgamma[ch] = dg;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_down(s1, o, 64);
-    s2 += __shfl_down(s2, o, 64);
-  }
-  if (lane != 0) return;
-  dbeta[ch] = (float)s1;
-  dgamma[ch] = (float)s2;
-}
-
-// dc = scale*(dpre - dbeta/N - xhat*dgamma/N) (training) or scale*dpre (eval); dres = dpre (relu 1) when asked for
-__global__ __launch_bounds__(NB) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ c,
-                                                          const float* __restrict__ y, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, const float* __restrict__ mean,
-                                                          const float* __restrict__ invstd, const float* __restrict__ dgamma,
-                                                          const float* __restrict__ dbeta, float* __restrict__ dc,
-                                                          float* __restrict__ dres, int C, long long S, long long total,
-                                                          float inv_n, int relu, int training, int vec) {
-  auto one = [&](float g, float cv, float yv, int ch, float& dr) {
-    const float sc = scale[ch];
-    const float d = dpre_of(g, cv, yv, sc, shift[ch], relu);
-    dr = relu == 2 ? g : d;   // what flows into the skip branch
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  auto one = [&](float g, float cv, float yv, float av, float& dr) {
+    const float d = dpre_of(g, cv, yv, sc, sh, relu);
+    dr = (relu == 1 ? d : g) + av;   // what flows into the skip branch (+ what it already holds)
     if (!training) return sc * d;
-    const float xh = (cv - mean[ch]) * invstd[ch];
-    return sc * (d - dbeta[ch] * inv_n - xh * (dgamma[ch] * inv_n));
+    const float xh = (cv - mu) * is;
+    return sc * (d - db * inv_n - xh * (dg * inv_n));
   };
-  if (vec) {
-    for (long long i = (blockIdx.x * (long long)NB + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * NB * 4) {
-      const int ch = (int)((i / S) % C);
-      const float4 g = *reinterpret_cast<const float4*>(dy + i);
-      const float4 cv = *reinterpret_cast<const float4*>(c + i);
-      float4 yv = {0.f, 0.f, 0.f, 0.f};
-      if (relu == 1) yv = *reinterpret_cast<const float4*>(y + i);
-      float4 o, r;
-      o.x = one(g.x, cv.x, yv.x, ch, r.x);
-      o.y = one(g.y, cv.y, yv.y, ch, r.y);
-      o.z = one(g.z, cv.z, yv.z, ch, r.z);
-      o.w = one(g.w, cv.w, yv.w, ch, r.w);
-      *reinterpret_cast<float4*>(dc + i) = o;
-      if (dres) *reinterpret_cast<float4*>(dres + i) = r;
-    }
-  } else {
-    for (long long i = blockIdx.x * (long long)NB + threadIdx.x; i < total; i += (long long)gridDim.x * NB) {
-      const int ch = (int)((i / S) % C);
-      float r;
-      dc[i] = one(dy[i], c[i], relu == 1 ? y[i] : 0.f, ch, r);
-      if (dres) dres[i] = r;
-    }
-  }
+  for_slice(S, B, C, ch, s, nact, vec != 0,
+            [&](long long o) {
+              const float4 g = *reinterpret_cast<const float4*>(dy + o);
+              const float4 cv = *reinterpret_cast<const float4*>(c + o);
+              float4 yv = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+              if (relu == 1) yv = *reinterpret_cast<const float4*>(y + o);
+              if (dres_acc) av = *reinterpret_cast<const float4*>(dres_acc + o);
+              float4 q, r;
+              q.x = one(g.x, cv.x, yv.x, av.x, r.x);
+              q.y = one(g.y, cv.y, yv.y, av.y, r.y);
+              q.z = one(g.z, cv.z, yv.z, av.z, r.z);
+              q.w = one(g.w, cv.w, yv.w, av.w, r.w);
+              *reinterpret_cast<float4*>(dc + o) = q;
+              if (dres) *reinterpret_cast<float4*>(dres + o) = r;
+            },
+            [&](long long o) {
+              float r;
+              dc[o] = one(dy[o], c[o], relu == 1 ? y[o] : 0.f, dres_acc ? dres_acc[o] : 0.f, r);
+              if (dres) dres[o] = r;
+            });
 }
 
 // out[c] = sum_{b, s} a[b, c, s] * g[b, 0, s]: the weight gradient of a 1x1 convolution with one output channel
@@ -313,6 +379,15 @@ static int bn_nsplit(int C, long long S) {
   return (int)(n < 1 ? 1 : n);
 }
 
+// slices per channel of the consuming (normalising) kernels: ~1024 workgroups, at least ~2048 elements per slice and batch item
+static int bn_nact(int C, long long S) {
+  long long n = 1024 / (C > 0 ? C : 1);
+  if (n < 1) n = 1;
+  const long long most = (S + 2047) / 2048;
+  if (n > most) n = most;
+  return (int)(n < 1 ? 1 : n);
+}
+
 static int elementwise_blocks(long long total, int per_thread) {
   long long b = (total + (long long)NB * per_thread - 1) / ((long long)NB * per_thread);
   if (b > 16384) b = 16384;
@@ -343,6 +418,22 @@ extern "C" int dmb_bn_train_stats_f32(const float* c, const float* gamma, const 
   return launch_status("bn_train_stats launch failed");
 }
 
+extern "C" int dmb_bn_train_fwd_f32(const float* c, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                    float* mean_out, float* invstd_out, float* scale_out, float* shift_out, const float* residual,
+                                    float* y, double* workspace, int B, int C, long long S, int relu, void* stream) {
+  if (!c || !mean_out || !invstd_out || !scale_out || !shift_out || !y || !workspace || B <= 0 || C <= 0 || S <= 0 || relu < 0 || relu > 2)
+    return fail(DMB_EINVAL, "bn_train_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = bn_nsplit(C, S), nact = bn_nact(C, S);
+  const int vec = S % 4 == 0 && (((uintptr_t)c | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NB), 0, st, c, workspace, B, C, S, nsplit, vec);
+  hipLaunchKernelGGL(bn_act_train_kernel, dim3(nact, C), dim3(NB), 0, st, c, workspace, gamma, beta, running_mean, running_var,
+                     num_batches_tracked, momentum, eps, mean_out, invstd_out, scale_out, shift_out, residual, y, B, C, S, nsplit, nact,
+                     relu, vec);
+  return launch_status("bn_train_fwd launch failed");
+}
+
 extern "C" int dmb_bn_act_f32(const float* c, const float* scale, const float* shift, const float* residual, float* y, int B,
                               int C, long long S, int relu, void* stream) {
   if (!c || !scale || !shift || !y || B <= 0 || C <= 0 || S <= 0 || relu < 0 || relu > 2) return fail(DMB_EINVAL, "bn_act: bad argument");
@@ -355,19 +446,18 @@ extern "C" int dmb_bn_act_f32(const float* c, const float* scale, const float* s
 
 extern "C" int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* y, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, double* workspace, float* dgamma, float* dbeta,
-                                  float* dc, float* dres, int B, int C, long long S, int relu, int training, void* stream) {
+                                  float* dc, float* dres, const float* dres_acc, int B, int C, long long S, int relu, int training,
+                                  void* stream) {
   if (!dy || !c || !scale || !shift || !mean || !invstd || !workspace || !dgamma || !dbeta || !dc || B <= 0 || C <= 0 || S <= 0 ||
-      relu < 0 || relu > 2 || (relu == 1 && !y))
+      relu < 0 || relu > 2 || (relu == 1 && !y) || (dres_acc && !dres))
     return fail(DMB_EINVAL, "bn_act_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  const int nsplit = bn_nsplit(C, S);
-  const long long total = (long long)B * C * S;
-  const int vec = S % 4 == 0 && (((uintptr_t)dy | (uintptr_t)c | (uintptr_t)y | (uintptr_t)dc | (uintptr_t)dres) & 15) == 0;
+  const int nsplit = bn_nsplit(C, S), nact = bn_nact(C, S);
+  const int vec = S % 4 == 0 && (((uintptr_t)dy | (uintptr_t)c | (uintptr_t)y | (uintptr_t)dc | (uintptr_t)dres | (uintptr_t)dres_acc) & 15) == 0;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nsplit, C), dim3(NB), 0, st, dy, c, y, scale, shift, mean, invstd, workspace, B, C, S,
                      nsplit, relu, vec);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, dgamma, dbeta, C, nsplit);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(total, vec ? 8 : 2)), dim3(NB), 0, st, dy, c, y, scale, shift, mean,
-                     invstd, dgamma, dbeta, dc, dres, C, S, total, (float)(1.0 / ((double)B * (double)S)), relu, training, vec);
+  hipLaunchKernelGGL(bn_bwd_apply_fin_kernel, dim3(nact, C), dim3(NB), 0, st, dy, c, y, scale, shift, mean, invstd, workspace, dgamma,
+                     dbeta, dc, dres, dres_acc, B, C, S, nsplit, nact, (float)(1.0 / ((double)B * (double)S)), relu, training, vec);
   return launch_status("bn_act_bwd launch failed");
 }
 

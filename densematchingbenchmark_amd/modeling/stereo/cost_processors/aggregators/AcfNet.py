@@ -32,7 +32,8 @@ class AcfAggregator(PSMAggregator):
         B, C, D, H, W = raw_cost.shape
         if D * 4 != self.max_disp:
             raise ValueError("AcfAggregator up-samples exactly 4x: raw volume has %d planes, max_disp=%d" % (D, self.max_disp))
-        cost1, cost2, cost3 = self.trunk(raw_cost)
+        with train_fn.carry_scope():
+            cost1, cost2, cost3 = self.trunk(raw_cost)
         pairs = ((cost3, self.deconv3), (cost2, self.deconv2), (cost1, self.deconv1))
         if train_fn.wants_grad(self, cost1):   # differentiable up-sampling
             return [train_fn.DeconvK8S4Fn.apply(c.squeeze(1), m.weight) for c, m in pairs]

@@ -84,7 +84,8 @@ class PSMAggregator(nn.Module):
         B, C, D, H, W = raw_cost.shape
         if ops.branch_overlap(raw_cost) and raw_cost.device.type == "cuda" and not train_fn.wants_grad(self, raw_cost):
             return self._forward_overlapped(raw_cost)
-        cost1, cost2, cost3 = self.trunk(raw_cost)
+        with train_fn.carry_scope():                                     # (shares the model's scope when called from one)
+            cost1, cost2, cost3 = self.trunk(raw_cost)
         size = (self.max_disp, H * 4, W * 4)                             # PSMNet.py:75-88, align_corners=True
         # The up-sampling kernel also regresses the standard soft-argmin (alpha 1, samples 0..max_disp-1) of the volume
         # it writes and leaves it as a hint on the tensor: FasterSoftArgmin / SoftArgmin with exactly those parameters

@@ -15,12 +15,67 @@ whose forward and backward are HIP kernel launches:
 
 There is no fallback to torch's convolution backward: without the library these raise like every other op.
 """
+import contextlib
+
 import torch
 
 from .... import ops
 
 _RELU = {0: False, 1: True, 2: "pre"}
 _CONST = {}
+
+# ---------------------------------------------------------------------------------------------- gradient carry (round 6)
+# A tensor with several consumers (the skip operands of hourglass.py:62-86 and PSMNet.py:58-72: cost0 has four, pre1 three)
+# gets its gradient as a SUM over them, and torch.autograd forms that sum with one addition launch per extra consumer -- three
+# passes over a 200 MB tensor each, 18 of them per PSMNet step (0.75 ms of 31).  Inside a ``carry_scope()`` every unit hands
+# the tensors it consumes on as identity outputs ("aliases": the same storage, a new autograd edge) and the NEXT consumer of the
+# tensor is quietly given the alias instead.  The consumers then form a chain, each one's backward receives what the later
+# consumers have already collected, and adds its own share inside a kernel that runs anyway: the data-gradient convolution
+# takes it as its skip operand (one extra read), the BatchNorm backward as ``dres_acc``.  Same gradients up to the order of
+# the FP32 additions; ``set_gradient_carry(False)`` switches it off (tests/test_train_gpu.py compares the two).
+_carry_enabled = True
+_scopes = []
+
+
+def set_gradient_carry(flag):
+    global _carry_enabled
+    _carry_enabled = bool(flag)
+
+
+@contextlib.contextmanager
+def carry_scope():
+    """One forward pass of a model / aggregator.  The registry maps id(tensor) -> (tensor, its latest alias) and lives exactly as
+    long as the scope (a tensor object the caller re-uses across steps must never meet an alias of an earlier graph); nested
+    scopes share the outermost registry."""
+    if _scopes:
+        yield
+        return
+    _scopes.append({})
+    try:
+        yield
+    finally:
+        _scopes.pop().clear()
+
+
+def _latest(reg, t):
+    while True:
+        e = reg.get(id(t))
+        if e is None:
+            return t
+        t = e[1]
+
+
+def _carry_plan(x, skip):
+    """(registry or None, x, skip, carry_x, carry_skip) for a unit about to consume x (and skip)."""
+    if not (_scopes and _carry_enabled and torch.is_grad_enabled()):
+        return None, x, skip, False, False
+    reg = _scopes[0]
+    x = _latest(reg, x)
+    if skip is not None:
+        skip = _latest(reg, skip)
+    cx = x.requires_grad and x.is_contiguous() and x.dtype == torch.float32
+    cs = skip is not None and skip is not x and skip.requires_grad and skip.is_contiguous() and skip.dtype == torch.float32
+    return reg, x, skip, cx, cs
 
 
 def _const(value, C, device):
@@ -36,6 +91,14 @@ def _relu_code(relu):
     return 2 if relu == "pre" else (1 if relu else 0)
 
 
+def _mask_mode(code, has_skip):
+    """Which tensor the backward takes the ReLU mask from.  Without a skip operand ``y = max(fma(raw, scale, shift), 0)``, so
+    ``y > 0`` IS ``fma(raw, scale, shift) > 0`` bit for bit: the backward passes re-create the mask from ``raw`` (which they read
+    anyway) and the unit's output is neither read again nor kept alive for it -- one tensor less in each of the two passes for
+    16 of PSMNet's 25 units."""
+    return _RELU[2 if code == 1 and not has_skip else code]
+
+
 def _conv_raw(unit, x, weight, bias):
     """The unit's convolution without BatchNorm / activation (+ bias through the kernel's shift operand)."""
     Co = unit.out_planes
@@ -47,37 +110,79 @@ def _conv_raw(unit, x, weight, bias):
     return ops.conv3d_k3(x, ops.pack_conv3d_weights(weight), Co, scale, shift, None, unit.stride, False)
 
 
+def _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, device):
+    """BatchNorm (+ skip, + ReLU) of a unit's raw convolution output -> (y, mean, invstd, scale, shift, batch_stats).  A
+    batch-statistics BatchNorm takes the two-launch form (ops.bn_train_fwd: block sums, then one kernel that finishes the
+    statistics, updates the running buffers and the batch counter and normalises); running statistics / no BatchNorm: bn_act."""
+    if bn is not None and bn.training:
+        if bn.momentum is None:   # nn.BatchNorm: cumulative moving average, factor 1 / (batches seen including this one)
+            momentum = 1.0 / float(int(bn.num_batches_tracked) + 1) if bn.track_running_stats else 0.0
+        else:
+            momentum = bn.momentum
+        nbt = bn.num_batches_tracked if bn.track_running_stats and bn.num_batches_tracked is not None else None
+        if nbt is not None and nbt.device != raw.device:
+            nbt += 1
+            nbt = None
+        y, mean, invstd, scale, shift = ops.bn_train_fwd(raw, gamma.detach() if gamma is not None else None,
+                                                         beta.detach() if beta is not None else None,
+                                                         bn.running_mean if bn.track_running_stats else None,
+                                                         bn.running_var if bn.track_running_stats else None, nbt, momentum, bn.eps,
+                                                         skip, _RELU[code])
+        return y, mean, invstd, scale, shift, True
+    mean, invstd, scale, shift, _ = _bn_forward(bn, False, raw, gamma, beta, C, device)
+    y = raw if (bn is None and skip is None and code == 0) else ops.bn_act(raw, scale, shift, skip, _RELU[code])
+    return y, mean, invstd, scale, shift, False
+
+
+def _carried_outputs(ctx, y, x, skip, carry_x, carry_skip):
+    ctx.carry = (bool(carry_x), bool(carry_skip))
+    if not (carry_x or carry_skip):
+        return y
+    ctx.set_materialize_grads(False)   # an alias nobody consumed has no gradient: None, not a tensor of zeros
+    return (y,) + ((x,) if carry_x else ()) + ((skip,) if carry_skip else ())
+
+
+def _carried_grads(ctx, grads):
+    """(dy, what x's later consumers collected, what skip's later consumers collected) from backward's arguments."""
+    g = list(grads)
+    dy = g.pop(0)
+    dxa = g.pop(0) if ctx.carry[0] else None
+    dsa = g.pop(0) if ctx.carry[1] else None
+    return dy, dxa, dsa
+
+
 class ConvUnitFn(torch.autograd.Function):
-    """y = act(BN(conv(x)) (+ skip)) of one FusedConv3d unit; ``unit`` supplies the geometry and the BN buffers."""
+    """y = act(BN(conv(x)) (+ skip)) of one FusedConv3d unit; ``unit`` supplies the geometry and the BN buffers.  With
+    ``carry_x`` / ``carry_skip`` the inputs are handed on as identity outputs (gradient carry, top of this file)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, skip, unit, relu):
+    def forward(ctx, x, weight, bias, gamma, beta, skip, unit, relu, carry_x=False, carry_skip=False):
+        x_in = x
         x = x.contiguous()
         w = weight.detach().contiguous()
         raw = _conv_raw(unit, x, w, bias)
         C = unit.out_planes
         bn = unit[1] if unit.has_bn else None
-        mean, invstd, scale, shift, batch_stats = _bn_forward(bn, unit.training, raw, gamma, beta, C, x.device)
         code = _relu_code(relu)
-        if bn is None and skip is None and code == 0:
-            y = raw
-        else:
-            y = ops.bn_act(raw, scale, shift, skip, _RELU[code])
+        y, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, x.device)
         ctx.unit, ctx.code, ctx.batch_stats = unit, code, batch_stats
         ctx.has = (bias is not None, gamma is not None, beta is not None, skip is not None)
-        ctx.save_for_backward(x, w, raw, y if code == 1 else None, scale, shift, mean, invstd)
-        return y
+        ctx.save_for_backward(x, w, raw, y if code == 1 and skip is not None else None, scale, shift, mean, invstd)
+        return _carried_outputs(ctx, y, x_in, skip, carry_x, carry_skip)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
+        dy, dx_acc, dres_acc = _carried_grads(ctx, grads)
         x, w, raw, y, scale, shift, mean, invstd = ctx.saved_tensors
         unit, code = ctx.unit, ctx.code
         has_bias, has_gamma, has_beta, has_skip = ctx.has
-        dy = dy.contiguous()
+        dy = torch.zeros_like(raw) if dy is None else dy.contiguous()
         need_dres = has_skip and ctx.needs_input_grad[5]
-        dc, dgamma, dbeta, dres = ops.bn_act_bwd(dy, raw, y, scale, shift, mean, invstd, _RELU[code], ctx.batch_stats,
-                                                 want_dres=need_dres and code == 1)
-        if need_dres and code != 1:
+        if not need_dres:
+            dres_acc = None
+        dc, dgamma, dbeta, dres = ops.bn_act_bwd(dy, raw, y, scale, shift, mean, invstd, _mask_mode(code, has_skip), ctx.batch_stats,
+                                                 want_dres=need_dres and code == 1, dres_acc=dres_acc)
+        if need_dres and code != 1 and dres_acc is None:
             dres = dy                       # the skip branch joins after the activation (or there is none)
         dw = dx = dbias = None
         if ctx.needs_input_grad[1]:
@@ -88,14 +193,15 @@ class ConvUnitFn(torch.autograd.Function):
             else:
                 dw = ops.conv3d_k3_wgrad(x, dc)
         if ctx.needs_input_grad[0]:
-            dx = ops.deconv3d_k3s2_dgrad(dc, w) if unit.transposed else ops.conv3d_k3_dgrad(dc, w, unit.stride, tuple(x.shape[2:]))
+            dx = (ops.deconv3d_k3s2_dgrad(dc, w, residual=dx_acc) if unit.transposed
+                  else ops.conv3d_k3_dgrad(dc, w, unit.stride, tuple(x.shape[2:]), residual=dx_acc))
         if has_bias and ctx.needs_input_grad[2]:
             # sum of dc over (batch, voxels) without another pass: dc = scale * (dpre - mean terms), so it is scale * dbeta
             # with running statistics (or no BatchNorm: scale = 1) and exactly zero behind batch statistics
             # (sum xhat = 0: the normalisation removes any constant the bias adds)
             dbias = torch.zeros_like(dbeta) if ctx.batch_stats else scale * dbeta
         return (dx, dw, dbias, dgamma if has_gamma and ctx.needs_input_grad[3] else None,
-                dbeta if has_beta and ctx.needs_input_grad[4] else None, dres if need_dres else None, None, None)
+                dbeta if has_beta and ctx.needs_input_grad[4] else None, dres if need_dres else None, None, None, None, None)
 
 
 def conv_unit(unit, x, residual=None, relu=False):
@@ -104,7 +210,17 @@ def conv_unit(unit, x, residual=None, relu=False):
     bn = unit[1] if unit.has_bn else None
     gamma = bn.weight if bn is not None and bn.affine else None
     beta = bn.bias if bn is not None and bn.affine else None
-    return ConvUnitFn.apply(x, conv.weight, conv.bias, gamma, beta, residual, unit, relu)
+    reg, x, residual, cx, cs = _carry_plan(x, residual)
+    out = ConvUnitFn.apply(x, conv.weight, conv.bias, gamma, beta, residual, unit, relu, cx, cs)
+    if not (cx or cs):
+        return out
+    i = 1
+    if cx:
+        reg[id(x)] = (x, out[i])
+        i += 1
+    if cs:
+        reg[id(residual)] = (residual, out[i])
+    return out[0]
 
 
 class HeadConvFn(torch.autograd.Function):
@@ -271,8 +387,7 @@ class ConfHeadFn(torch.autograd.Function):
         Cm = w1d.shape[0]
         raw = ops.conv2d(cost, ops.pack_conv2d_weights(w1d), Cm, 3)
         bn = head.conf_net[0][1] if head.batch_norm else None
-        mean, invstd, scale, shift, batch_stats = _bn_forward(bn, head.training, raw, gamma, beta, Cm, cost.device)
-        h = ops.bn_act(raw, scale, shift, None, True)
+        h, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, None, 1, Cm, cost.device)
         logit = ops.conv2d(h, ops.pack_conv2d_weights(w2d), 1, 1)
         ctx.batch_stats = batch_stats
         ctx.has = (gamma is not None, beta is not None)
@@ -285,7 +400,7 @@ class ConfHeadFn(torch.autograd.Function):
         dlogit = dlogit.contiguous()
         dh = ops.conv2d_dgrad(dlogit, w2)                                  # 1 -> Cm channels
         dw2 = ops.channel_dot(h, dlogit).view_as(w2) if ctx.needs_input_grad[4] else None
-        dc, dgamma, dbeta, _ = ops.bn_act_bwd(dh, raw, h, scale, shift, mean, invstd, True, ctx.batch_stats)
+        dc, dgamma, dbeta, _ = ops.bn_act_bwd(dh, raw, None, scale, shift, mean, invstd, "pre", ctx.batch_stats)   # mask from raw (_mask_mode)
         dw1 = ops.conv2d_k3_wgrad(cost, dc) if ctx.needs_input_grad[1] else None
         dcost = ops.conv2d_dgrad(dc, w1) if ctx.needs_input_grad[0] else None
         return (dcost, dw1, dgamma if ctx.has[0] and ctx.needs_input_grad[2] else None,
@@ -334,7 +449,8 @@ class Conv2dUnitFn(torch.autograd.Function):
     3-D stride-2 kernels with a depth of one."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, skip, unit, relu):
+    def forward(ctx, x, weight, bias, gamma, beta, skip, unit, relu, carry_x=False, carry_skip=False):
+        x_in = x
         x = x.contiguous()
         w = weight.detach().contiguous()
         C, k, s, d = unit.out_planes, unit.kernel_size, unit.stride, unit.dilation
@@ -348,25 +464,27 @@ class Conv2dUnitFn(torch.autograd.Function):
             sc, sh = _const(1.0, bias.numel(), bias.device), bias.detach().contiguous()
         raw = ops.conv2d(x, ops.pack_conv2d_weights(w), C, k, s, d, sc, sh, None, False)
         bn = unit[1] if unit.has_bn else None
-        mean, invstd, scale, shift, batch_stats = _bn_forward(bn, unit.training, raw, gamma, beta, C, x.device)
         code = _relu_code(relu)
-        y = raw if (bn is None and skip is None and code == 0) else ops.bn_act(raw, scale, shift, skip, _RELU[code])
+        y, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, x.device)
         ctx.unit, ctx.code, ctx.batch_stats = unit, code, batch_stats
         ctx.has = (bias is not None, gamma is not None, beta is not None, skip is not None)
-        ctx.save_for_backward(x, w, raw, y if code == 1 else None, scale, shift, mean, invstd)
-        return y
+        ctx.save_for_backward(x, w, raw, y if code == 1 and skip is not None else None, scale, shift, mean, invstd)
+        return _carried_outputs(ctx, y, x_in, skip, carry_x, carry_skip)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
+        dy, dx_acc, dres_acc = _carried_grads(ctx, grads)
         x, w, raw, y, scale, shift, mean, invstd = ctx.saved_tensors
         unit, code = ctx.unit, ctx.code
         k, s, d = unit.kernel_size, unit.stride, unit.dilation
         has_bias, has_gamma, has_beta, has_skip = ctx.has
-        dy = dy.contiguous()
+        dy = torch.zeros_like(raw) if dy is None else dy.contiguous()
         need_dres = has_skip and ctx.needs_input_grad[5]
-        dc, dgamma, dbeta, dres = ops.bn_act_bwd(dy, raw, y, scale, shift, mean, invstd, _RELU[code], ctx.batch_stats,
-                                                 want_dres=need_dres and code == 1)
-        if need_dres and code != 1:
+        if not need_dres:
+            dres_acc = None
+        dc, dgamma, dbeta, dres = ops.bn_act_bwd(dy, raw, y, scale, shift, mean, invstd, _mask_mode(code, has_skip), ctx.batch_stats,
+                                                 want_dres=need_dres and code == 1, dres_acc=dres_acc)
+        if need_dres and code != 1 and dres_acc is None:
             dres = dy
         dw = dx = dbias = None
         if ctx.needs_input_grad[1]:
@@ -382,16 +500,19 @@ class Conv2dUnitFn(torch.autograd.Function):
             if k == 5:
                 dx = _depth_to_space(ops.conv2d_dgrad(dc, _k5s2_as_k3(w))).contiguous()
             elif s == 1:
-                dx = ops.conv2d_dgrad(dc, w, d)
+                dx = ops.conv2d_dgrad(dc, w, d, residual=dx_acc)
+                dx_acc = None
             elif k == 3:
                 dx = ops.conv3d_k3_dgrad(dc.unsqueeze(2), _as3d_weight(w), 2, (1,) + tuple(x.shape[2:])).squeeze(2)
             else:
                 dx = torch.zeros_like(x)
                 dx[:, :, ::2, ::2] = ops.conv2d_dgrad(dc, w, 1)
+            if dx_acc is not None:   # the forms without a skip operand in their data-gradient launch
+                dx = dx + dx_acc
         if has_bias and ctx.needs_input_grad[2]:
             dbias = torch.zeros_like(dbeta) if ctx.batch_stats else scale * dbeta
         return (dx, dw, dbias, dgamma if has_gamma and ctx.needs_input_grad[3] else None,
-                dbeta if has_beta and ctx.needs_input_grad[4] else None, dres if need_dres else None, None, None)
+                dbeta if has_beta and ctx.needs_input_grad[4] else None, dres if need_dres else None, None, None, None, None)
 
 
 def conv2d_unit(unit, x, residual=None, relu=False):
@@ -399,7 +520,17 @@ def conv2d_unit(unit, x, residual=None, relu=False):
     bn = unit[1] if unit.has_bn else None
     gamma = bn.weight if bn is not None and bn.affine else None
     beta = bn.bias if bn is not None and bn.affine else None
-    return Conv2dUnitFn.apply(x, conv.weight, conv.bias, gamma, beta, residual, unit, relu)
+    reg, x, residual, cx, cs = _carry_plan(x, residual)
+    out = Conv2dUnitFn.apply(x, conv.weight, conv.bias, gamma, beta, residual, unit, relu, cx, cs)
+    if not (cx or cs):
+        return out
+    i = 1
+    if cx:
+        reg[id(x)] = (x, out[i])
+        i += 1
+    if cs:
+        reg[id(residual)] = (residual, out[i])
+    return out[0]
 
 
 class BareConv1x1Fn(torch.autograd.Function):
@@ -468,7 +599,7 @@ class BareConv2dFn(torch.autograd.Function):
         else:
             y = raw
         ctx.relu, ctx.has = bool(relu), (bias is not None, skip is not None)
-        ctx.save_for_backward(x, w, raw, y if relu else None, one, zero)
+        ctx.save_for_backward(x, w, raw, y if relu and skip is not None else None, one, zero)
         return y
 
     @staticmethod
@@ -477,7 +608,8 @@ class BareConv2dFn(torch.autograd.Function):
         has_bias, has_skip = ctx.has
         dy = dy.contiguous()
         need_dres = has_skip and ctx.needs_input_grad[3]
-        dc, _, dsum, dres = ops.bn_act_bwd(dy, raw, y, one, zero, zero, one, ctx.relu, False, want_dres=need_dres and ctx.relu)
+        dc, _, dsum, dres = ops.bn_act_bwd(dy, raw, y, one, zero, zero, one, _mask_mode(1 if ctx.relu else 0, has_skip), False,
+                                           want_dres=need_dres and ctx.relu)
         if need_dres and not ctx.relu:
             dres = dy
         k, Ci = w.shape[2], w.shape[1]

@@ -14,6 +14,7 @@ import torch.nn as nn
 from ..cmn import build_cmn
 from ..cost_processors import build_cost_processor
 from ..disp_predictors import build_disp_predictor
+from ..layers import train_fn
 
 
 class GeneralizedStereoModel(nn.Module):
@@ -68,6 +69,14 @@ class GeneralizedStereoModel(nn.Module):
         return {}, loss_dict
 
     def forward(self, batch):
+        if self.training:
+            # one gradient-carry scope per forward pass (layers/train_fn.py: the sums autograd would form for tensors with several
+            # consumers are taken over by the consumers' own backward kernels)
+            with train_fn.carry_scope():
+                return self._forward(batch)
+        return self._forward(batch)
+
+    def _forward(self, batch):
         if 'leftFeature' in batch:
             ref_fms, tgt_fms = batch['leftFeature'], batch['rightFeature']
         else:

@@ -738,18 +738,21 @@ def pack_conv3d_dgrad_weights(w):
     return wp
 
 
-def conv3d_k3_dgrad(dc, w, stride=1, in_size=None):
+def conv3d_k3_dgrad(dc, w, stride=1, in_size=None, residual=None):
     """Gradient of nn.Conv3d(k=3, padding=1, stride) w.r.t. its input; w is the layer's weight [Co, Ci, 3, 3, 3].
     ``in_size`` = (D, H, W) of that input; needed for stride 2 when an extent is odd (the adjoint is computed for the even
-    size 2 x output and its last plane / row / column dropped)."""
+    size 2 x output and its last plane / row / column dropped).  ``residual``: a tensor of the input's shape added to the result
+    in the kernel's epilogue (the gradient the input already holds from its other consumers: train_fn's gradient carry)."""
     Co, Ci = w.shape[0], w.shape[1]
     if stride == 1:
-        return conv3d_k3(dc, pack_conv3d_dgrad_weights(w), Ci)
+        return conv3d_k3(dc, pack_conv3d_dgrad_weights(w), Ci, residual=residual)
     if stride == 2:
         # the adjoint of a stride-2 convolution is the transposed convolution with the same weight tensor; the transposed kernel
         # takes 64 or <= 32 output channels per launch, so wider inputs (GC-Net: 96, 128) are done in channel chunks
+        full = tuple(2 * e for e in dc.shape[2:])
+        fused = residual is not None and (Ci == 64 or Ci <= 32) and (in_size is None or tuple(in_size) == full)
         if Ci == 64 or Ci <= 32:
-            dx = deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci)
+            dx = deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci, residual=residual if fused else None)
         else:
             parts, c0 = [], 0
             while c0 < Ci:
@@ -762,13 +765,16 @@ def conv3d_k3_dgrad(dc, w, stride=1, in_size=None):
             if any(a not in (b, b - 1) for a, b in zip((D, H, W), dx.shape[2:])):
                 raise _lib.DmbLibraryError("conv3d_k3_dgrad: input size %s does not belong to output size %s" % (tuple(in_size), tuple(dc.shape[2:])))
             dx = dx[:, :, :D, :H, :W].contiguous()
+        if residual is not None and not fused:
+            dx = dx + residual
         return dx
     raise _lib.DmbLibraryError("conv3d_k3_dgrad: stride must be 1 or 2")
 
 
-def deconv3d_k3s2_dgrad(dy, w):
-    """Gradient of nn.ConvTranspose3d(k=3, s=2, p=1, output_padding=1) w.r.t. its input; w is [Ci, Co, 3, 3, 3]."""
-    return conv3d_k3(dy, pack_conv3d_weights(w), w.shape[0], stride=2)
+def deconv3d_k3s2_dgrad(dy, w, residual=None):
+    """Gradient of nn.ConvTranspose3d(k=3, s=2, p=1, output_padding=1) w.r.t. its input; w is [Ci, Co, 3, 3, 3].  ``residual`` as
+    in conv3d_k3_dgrad."""
+    return conv3d_k3(dy, pack_conv3d_weights(w), w.shape[0], residual=residual, stride=2)
 
 
 def conv3d_k3_wgrad(x, dc):
@@ -835,18 +841,22 @@ def conv2d_k3_wgrad(x, dc):
     return conv2d_wgrad(x, dc, 3, 1)
 
 
-def conv2d_dgrad(dc, w, dilation=1):
+def conv2d_dgrad(dc, w, dilation=1, residual=None):
     """Gradient of a stride-1 nn.Conv2d (k in {1, 3}, padding = dilation * (k // 2)) w.r.t. its input; w is the layer's weight
-    [Co, Ci, k, k].  The same convolution kernel on mirrored, channel-exchanged weights, at most 128 output channels per launch."""
+    [Co, Ci, k, k].  The same convolution kernel on mirrored, channel-exchanged weights, at most 128 output channels per launch.
+    ``residual`` ([B, Ci, H, W]) is added in the epilogue (conv3d_k3_dgrad)."""
     w = _f32c(w, "weight")
     Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
     wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()           # [Ci, Co, k, k]: a convolution Co -> Ci
     dc = _f32c(dc, "dc")
     B, _, H, W = dc.shape
     dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dc.device)
+    if residual is not None:
+        residual = _f32c(residual, "residual")
     for c0 in range(0, Ci, 128):
         n = min(128, Ci - c0)
-        conv2d(dc, pack_conv2d_weights(wt[c0:c0 + n].contiguous()), n, k, dilation=dilation, out=dx, out_ch_offset=c0)
+        conv2d(dc, pack_conv2d_weights(wt[c0:c0 + n].contiguous()), n, k, dilation=dilation, residual=residual, out=dx, out_ch_offset=c0,
+               res_ch_offset=c0)
     return dx
 
 
@@ -884,22 +894,50 @@ def bn_act(c, scale, shift, residual=None, relu=False):
     return y
 
 
-def bn_act_bwd(dy, c, y, scale, shift, mean, invstd, relu=False, training=True, want_dres=False):
-    """Backward of bn_act (+ the batch statistics if training): returns (dc, dgamma, dbeta, dres or None)."""
+def bn_train_fwd(c, gamma=None, beta=None, running_mean=None, running_var=None, num_batches_tracked=None, momentum=0.1, eps=1e-5,
+                 residual=None, relu=False):
+    """bn_train_stats + bn_act of a batch-statistics unit in two launches (dmb_bn_train_fwd_f32): returns
+    (y, mean, invstd, scale, shift); updates the running buffers and adds 1 to ``num_batches_tracked`` (an int64 device tensor)."""
+    lib = _lib.load()
+    c = _f32c(c, "c")
+    B, C, S = _bcs(c)
+    y = torch.empty_like(c)
+    if residual is not None and (tuple(residual.shape) != tuple(c.shape) or not residual.is_contiguous() or residual.dtype != torch.float32):
+        raise _lib.DmbLibraryError("bn_train_fwd: residual must be a contiguous float32 tensor of shape %s" % (tuple(c.shape),))
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or num_batches_tracked.device != c.device):
+        raise _lib.DmbLibraryError("bn_train_fwd: num_batches_tracked must be an int64 tensor on %s" % c.device)
+    stats = torch.empty((4, C), dtype=torch.float32, device=c.device)
+    ws = torch.empty((lib.dmb_bn_workspace_doubles(C, S),), dtype=torch.float64, device=c.device)
+    check(lib.dmb_bn_train_fwd_f32(dev_ptr(c), dev_ptr(gamma, allow_none=True), dev_ptr(beta, allow_none=True),
+                                   dev_ptr(running_mean, allow_none=True), dev_ptr(running_var, allow_none=True),
+                                   None if num_batches_tracked is None else ctypes.c_void_p(num_batches_tracked.data_ptr()),
+                                   float(momentum), float(eps), dev_ptr(stats[0]), dev_ptr(stats[1]), dev_ptr(stats[2]),
+                                   dev_ptr(stats[3]), dev_ptr(residual, allow_none=True), dev_ptr(y), dev_ptr(ws), B, C, S,
+                                   _relu_mode(relu), stream_ptr(c.device)), "dmb_bn_train_fwd_f32")
+    return y, stats[0], stats[1], stats[2], stats[3]
+
+
+def bn_act_bwd(dy, c, y, scale, shift, mean, invstd, relu=False, training=True, want_dres=False, dres_acc=None):
+    """Backward of bn_act (+ the batch statistics if training): returns (dc, dgamma, dbeta, dres or None).  ``dres_acc``: a
+    gradient the skip operand already holds, added into ``dres`` by the same pass (implies ``want_dres``)."""
     lib = _lib.load()
     dy, c = _f32c(dy, "dy"), _f32c(c, "c")
     B, C, S = _bcs(c)
     mode = _relu_mode(relu)
     dc = torch.empty_like(c)
+    if dres_acc is not None:
+        dres_acc = _f32c(dres_acc, "dres_acc")
+        if tuple(dres_acc.shape) != tuple(c.shape):
+            raise _lib.DmbLibraryError("bn_act_bwd: dres_acc shape %s != %s" % (tuple(dres_acc.shape), tuple(c.shape)))
+        want_dres = True
     dres = torch.empty_like(c) if want_dres else None
-    dgamma = torch.empty((C,), dtype=torch.float32, device=c.device)
-    dbeta = torch.empty((C,), dtype=torch.float32, device=c.device)
+    gb = torch.empty((2, C), dtype=torch.float32, device=c.device)
     ws = torch.empty((lib.dmb_bn_workspace_doubles(C, S),), dtype=torch.float64, device=c.device)
     check(lib.dmb_bn_act_bwd_f32(dev_ptr(dy), dev_ptr(c), dev_ptr(y, allow_none=mode != 1), dev_ptr(scale), dev_ptr(shift),
-                                 dev_ptr(mean), dev_ptr(invstd), dev_ptr(ws), dev_ptr(dgamma), dev_ptr(dbeta), dev_ptr(dc),
-                                 dev_ptr(dres, allow_none=True), B, C, S, mode, 1 if training else 0,
-                                 stream_ptr(c.device)), "dmb_bn_act_bwd_f32")
-    return dc, dgamma, dbeta, dres
+                                 dev_ptr(mean), dev_ptr(invstd), dev_ptr(ws), dev_ptr(gb[0]), dev_ptr(gb[1]), dev_ptr(dc),
+                                 dev_ptr(dres, allow_none=True), dev_ptr(dres_acc, allow_none=True), B, C, S, mode,
+                                 1 if training else 0, stream_ptr(c.device)), "dmb_bn_act_bwd_f32")
+    return dc, gb[0], gb[1], dres
 
 
 def channel_dot(a, g):

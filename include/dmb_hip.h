@@ -44,7 +44,8 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes (7: DMB_CONV_SINGLE_CHAIN in the `relu` argument of the convolution
+/* ABI version: bumped whenever a signature below changes (8: dmb_bn_train_fwd_f32 added, dmb_bn_act_bwd_f32 takes the gradient its
+ * skip operand already holds (`dres_acc`); 7: DMB_CONV_SINGLE_CHAIN in the `relu` argument of the convolution
  * entry points, `flags` argument of dmb_conv3d_k3_c1_f32; 6: dmb_stereo_pad_normalize_f32 / _u8 added; 5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
  * optional gradient buffer for per-pixel samples; 4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads entry
  * points of version 3 removed). */
@@ -492,18 +493,28 @@ int dmb_conv2d_wgrad_f32(const float* x, const float* dc, float* dw, float* work
  *   running_mean / running_var (may be NULL) are updated as nn.BatchNorm does (momentum, unbiased variance).
  *   gamma / beta may be NULL (1 / 0).  workspace: dmb_bn_workspace_doubles(C, S) doubles.
  * dmb_bn_act_f32: y = act(c*scale + shift (+ residual)).
+ * dmb_bn_train_fwd_f32 (ABI 8): both of the above for a batch-statistics unit in TWO launches instead of four -- the block
+ *   sums, then one kernel whose workgroups finish their channel's statistics themselves (same arithmetic, same bits as
+ *   dmb_bn_train_stats_f32), write mean / invstd / scale / shift, update the running buffers, add 1 to *num_batches_tracked (an
+ *   int64 on the device, may be NULL: nn.BatchNorm's counter, basic_layers.py:68-83 under train()) and normalise.
  * dmb_bn_act_bwd_f32: dpre = dy * [ReLU mask];  dbeta = sum dpre;  dgamma = sum dpre * (c - mean)*invstd;
  *   dc = scale*(dpre - dbeta/N - xhat*dgamma/N) if training else scale*dpre;  dres (may be NULL) = the gradient flowing
- *   into the skip branch (dpre for relu 1, dy otherwise).  y (the unit's output) is only read for relu == 1. */
+ *   into the skip branch (dpre for relu 1, dy otherwise) + dres_acc (may be NULL; ABI 8: what the skip operand has already
+ *   collected from its other consumers, so that autograd's own addition -- three tensor passes -- is one extra read here).
+ *   y (the unit's output) is only read for relu == 1.  Two launches (block sums; apply, which finishes the sums itself). */
 long long dmb_bn_workspace_doubles(int C, long long S);
 int dmb_bn_train_stats_f32(const float* c, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* mean_out, float* invstd_out,
                            float* scale_out, float* shift_out, double* workspace, int B, int C, long long S, void* stream);
 int dmb_bn_act_f32(const float* c, const float* scale, const float* shift, const float* residual, float* y, int B, int C,
                    long long S, int relu, void* stream);
+int dmb_bn_train_fwd_f32(const float* c, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float momentum, float eps, float* mean_out, float* invstd_out,
+                         float* scale_out, float* shift_out, const float* residual, float* y, double* workspace, int B, int C,
+                         long long S, int relu, void* stream);
 int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* y, const float* scale, const float* shift,
                        const float* mean, const float* invstd, double* workspace, float* dgamma, float* dbeta, float* dc,
-                       float* dres, int B, int C, long long S, int relu, int training, void* stream);
+                       float* dres, const float* dres_acc, int B, int C, long long S, int relu, int training, void* stream);
 
 /* out[c] = sum_{b, s} a[b, c, s] * g[b, 0, s] (FP64 sums): the weight gradient of a 1x1 convolution with one output channel
  * (second layer of AcfNet's confidence heads, cmn/cmn.py:30).  workspace: dmb_bn_workspace_doubles(C, S) doubles. */

@@ -78,16 +78,21 @@ def _grad_worker(rank, world, port, out):
     torch.manual_seed(0)                      # same initial weights on every rank
     model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
     res = {}
-    for mode in ("flat", "coalesced", "one_by_one"):
+    for mode in ("flat", "flat_accumulate", "coalesced", "one_by_one"):
         model.zero_grad(set_to_none=True)
         if hasattr(model, "_dmb_flat_grads"):
             del model._dmb_flat_grads
-        flat = FlatGradients(model).zero_() if mode == "flat" else None
+        flat = None
+        if mode.startswith("flat"):
+            flat = FlatGradients(model, mode="accumulate" if mode == "flat_accumulate" else "gather").zero_()
         x = torch.randn(4, 5, generator=torch.Generator().manual_seed(100 + rank))   # this rank's shard of the batch
         model(x).square().mean().backward()
         if flat is not None:
-            assert flat.attached()            # autograd accumulated into the views, not into fresh tensors
+            # "accumulate": autograd accumulated into the views; "gather": fresh tensors that the exchange packs
+            assert flat.attached() == (mode == "flat_accumulate")
         all_reduce_grads(model, coalesce=(mode != "one_by_one"))
+        if flat is not None:
+            assert flat.attached()            # after the exchange every grad IS a view of the reduced buffer
         res[mode] = [p.grad.clone() for p in model.parameters()]
     out.put((rank, {k: [g.numpy() for g in v] for k, v in res.items()}))
     dist.barrier()
@@ -96,7 +101,7 @@ def _grad_worker(rank, world, port, out):
 
 def test_two_rank_gradient_all_reduce():
     """dist_utils.all_reduce_grads (reference dmb/utils/dist_utils.py:36-48): the averaged gradient of two ranks equals
-    the gradient of the mean of the two shard losses, identically on both ranks and for all three exchange modes."""
+    the gradient of the mean of the two shard losses, identically on both ranks and for all four exchange modes."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -38,7 +38,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libdmb_hip.so does not export %s" % s
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and include/dmb_hip.h disagree"
-    assert lib.dmb_abi_version() == 7 == _lib.ABI_VERSION
+    assert lib.dmb_abi_version() == 8 == _lib.ABI_VERSION
     assert lib.dmb_conv3d_packed_floats(32, 64) == 32 * 64 * 27
 
 
@@ -281,12 +281,12 @@ def test_whole_model_configs_match_reference_keys(rel, want):
 
 
 def test_flat_gradients_views():
-    """dist_utils.FlatGradients without a process group: every grad is a view into one buffer, autograd accumulates into the
-    views, zero_() clears them in place and re-attaches views an optimizer dropped."""
+    """dist_utils.FlatGradients("accumulate") without a process group: every grad is a view into one buffer, autograd accumulates
+    into the views, zero_() clears them in place and re-attaches views an optimizer dropped."""
     from densematchingbenchmark_amd.dist_utils import FlatGradients
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
-    flat = FlatGradients(model)
+    flat = FlatGradients(model, mode="accumulate")
     assert flat.attached() and flat.flat.numel() >= sum(p.numel() for p in model.parameters())
     model(torch.randn(4, 5)).sum().backward()
     assert flat.attached() and flat.flat.abs().sum().item() > 0
@@ -297,6 +297,37 @@ def test_flat_gradients_views():
     assert not flat.attached()
     flat.zero_()
     assert flat.attached() and flat.flat.abs().sum().item() == 0
+
+
+def test_flat_gradients_gather_mode():
+    """The default mode (round 6): zero_() drops the gradients, backward leaves fresh tensors on the parameters (no accumulation
+    launch per parameter), gather_() packs them into the buffer with one multi-tensor copy and turns every grad into its view;
+    a parameter that took no part in the step contributes zeros."""
+    from densematchingbenchmark_amd.dist_utils import FlatGradients
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    unused = torch.nn.Parameter(torch.ones(3))
+    model.register_parameter("unused", unused)
+    flat = FlatGradients(model)
+    assert flat.mode == "gather" and not flat.attached()
+    flat.flat.fill_(7.0)                                       # stale contents must not survive a gather
+    x = torch.randn(4, 5)
+    flat.zero_()
+    assert all(p.grad is None for p in model.parameters())
+    model(x).sum().backward()
+    assert not flat.attached() and unused.grad is None
+    ref = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in model.parameters()]
+    flat.gather_()
+    assert flat.attached()
+    assert all(torch.equal(p.grad, r) for p, r in zip(model.parameters(), ref))
+    covered = torch.zeros_like(flat.flat, dtype=torch.bool)
+    for p, o in zip(flat.params, flat.offsets):
+        covered[o:o + p.numel()] = True
+    assert not covered.all() and float(flat.flat[~covered].abs().sum()) == 7.0 * int((~covered).sum())   # only alignment gaps keep old bytes
+    model(x).sum().backward()                                  # a second pass without zero_() accumulates into the views
+    assert flat.attached() and all(torch.allclose(p.grad, 2 * r) for p, r in zip(model.parameters(), ref))
+    flat.zero_()
+    assert all(p.grad is None for p in model.parameters())
 
 
 def test_confidence_head_composed_with_upsampling_weights():
@@ -435,7 +466,7 @@ def test_binding_constants_match_the_header():
     text = open(_lib.HEADER_PATH).read()
     assert int(re.search(r"#define DMB_DECONV3D_WORKSPACE_BYTES (\d+)", text).group(1)) == _lib.DECONV3D_WORKSPACE_BYTES
     assert int(re.search(r"#define DMB_CONV_SINGLE_CHAIN (0x[0-9a-f]+)", text).group(1), 16) == _lib.CONV_SINGLE_CHAIN
-    assert "ABI version" in text and "(7:" in text and _lib.ABI_VERSION == 7
+    assert "ABI version" in text and "(8:" in text and _lib.ABI_VERSION == 8
 
 
 def test_data_side_and_serving_api_refuse_host_tensors():
