@@ -25,10 +25,12 @@ class _VolumeThenAggregate(nn.Module):
 
     def forward(self, ref_fms, tgt_fms, disp_sample=None):
         if ((self.vol_func is cat_fms or self.vol_func is dif_fms) and getattr(self.aggregator, "accepts_lazy_cat", False)
-                and ops.cat_fusion() and torch.is_tensor(ref_fms) and not train_fn.wants_grad(self, ref_fms, tgt_fms)):
-            # eval mode: the aggregator's first convolution consumes the volume's description (csrc/catconv.hip); the raw
-            # volume is not part of the result contract (general_stereo_model.py:82-85) and is never written
-            raw_cost = LazyCatVolume(ref_fms, tgt_fms, kind="cat" if self.vol_func is cat_fms else "dif", **self.default_args)
+                and ops.cat_fusion() and torch.is_tensor(ref_fms)):
+            # the aggregator's first convolution consumes the volume's description (csrc/catconv.hip); the raw volume is not part
+            # of the result contract (general_stereo_model.py:82-85) and is never written by the forward pass -- in eval mode and
+            # (round 6) on the training path, where the first unit's backward builds it for its weight gradient
+            raw_cost = LazyCatVolume(ref_fms, tgt_fms, kind="cat" if self.vol_func is cat_fms else "dif",
+                                     differentiable=train_fn.wants_grad(self, ref_fms, tgt_fms), **self.default_args)
         elif (self.vol_func is gwc_cat_fms and getattr(self.aggregator, "accepts_lazy_cat", False) and ops.cat_fusion()
               and not train_fn.wants_grad(self, *ref_fms, *tgt_fms)):
             raw_cost = LazyGwcCatVolume(ref_fms, tgt_fms, **self.default_args)   # concat channels as 2-D maps, correlation channels 3-D

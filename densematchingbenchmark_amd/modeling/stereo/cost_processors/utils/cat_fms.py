@@ -18,19 +18,26 @@ class LazyCatVolume:
     """The volume of cat_fms(reference_fm, target_fm, ...) -- or, ``kind="dif"``, of dif_fms -- as a DESCRIPTION: an
     aggregator whose first convolution knows the volume's structure (FusedConv3d on csrc/catconv.hip) consumes it without
     the tensor (1.6 GB at the BASELINE size) ever being written; anything else calls ``materialize()`` and gets exactly the
-    builder's tensor.  Built by the cost processor in eval mode only (cost_processors/builder.py)."""
+    builder's tensor.  Built by the cost processor (cost_processors/builder.py).  ``differentiable`` (round 6: the training
+    path): the first convolution runs its FORWARD on the 2-D form as well and builds the volume only inside its backward pass
+    (train_fn.CatConvUnitFn); ``materialize()`` then goes through the builders' autograd Functions."""
 
-    def __init__(self, reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, kind="cat", **unused):
+    def __init__(self, reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1, kind="cat", differentiable=False, **unused):
         self.reference_fm, self.target_fm, self.kind = reference_fm.float(), target_fm.float(), kind
         self.disp_idx = ops.disp_index_list(max_disp, start_disp, dilation)
         B, C, H, W = reference_fm.shape
         self.shape = torch.Size((B, 2 * C if kind == "cat" else C, len(self.disp_idx), H, W))
-        self.device, self.dtype, self.requires_grad = reference_fm.device, torch.float32, False
+        self.device, self.dtype = reference_fm.device, torch.float32
+        self.differentiable = bool(differentiable)
+        self.requires_grad = self.differentiable and torch.is_grad_enabled() and (reference_fm.requires_grad or target_fm.requires_grad)
 
     def dim(self):
         return 5
 
     def materialize(self):
+        if self.requires_grad:
+            fn = train_fn.CatFmsFn if self.kind == "cat" else train_fn.DifFmsFn
+            return fn.apply(self.reference_fm.contiguous(), self.target_fm.contiguous(), tuple(self.disp_idx))
         build = ops.cat_fms if self.kind == "cat" else ops.dif_fms
         return build(self.reference_fm, self.target_fm, self.disp_idx)
 

@@ -107,10 +107,13 @@ class FusedConv3d(nn.Sequential):
                 part = ops.catconv_first(x.reference_fm, x.target_fm, len(x.disp_idx), packs, scale, None, False)
                 return ops.conv3d_k3(x.correlation_part(), wp_g, self.out_planes, scale, shift, part, 1, act)
             x = x.materialize()
-        elif hasattr(x, "materialize"):   # LazyCatVolume: the concatenation volume as a description (eval mode only)
-            if (residual is None and skip is None and not self.transposed and self.stride == 1 and not self.training
+        elif hasattr(x, "materialize"):   # LazyCatVolume: the concatenation volume as a description
+            if (residual is None and skip is None and not self.transposed and self.stride == 1
                     and x.shape[1] == self.in_planes
                     and ops.catconv_applicable(x.reference_fm, x.target_fm, x.disp_idx, self.out_planes)):
+                if getattr(x, "differentiable", False) or self.training:
+                    # training path: the 2-D form in the forward pass, the volume only inside the backward pass
+                    return train_fn.cat_conv_unit(self, x, act)
                 _, scale, shift = self._prepacked()
                 return ops.catconv_first(x.reference_fm, x.target_fm, len(x.disp_idx), self._prepacked_cat(x.kind), scale, shift, act)
             x = x.materialize()

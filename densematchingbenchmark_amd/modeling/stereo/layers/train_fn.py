@@ -223,6 +223,64 @@ def conv_unit(unit, x, residual=None, relu=False):
     return out[0]
 
 
+class CatConvUnitFn(torch.autograd.Function):
+    """The aggregator's FIRST unit on a concatenation / difference volume of unit disparity step (aggregators/PSMNet.py:31-35 on
+    cat_fms.py:7-48, aggregators/StereoNet.py on dif_fms.py:7-46) without the volume in the forward pass: the convolution runs
+    in its 2-D form on the two feature maps (csrc/catconv.hip, as the eval path does since round 2 -- a third of the layer's
+    multiplications, no 400 MB volume written and read), BatchNorm / ReLU as in ConvUnitFn.  The backward pass builds the volume
+    (one launch, 0.06 ms at the training crop) for the weight gradient, runs the data gradient as the 3-D convolution it is, and
+    folds it onto the feature maps with the builders' adjoint.  A PSMNet training step at 4 x 256x512: forward of the first unit
+    1.24 -> 0.2 ms, nothing changes in the backward."""
+
+    @staticmethod
+    def forward(ctx, left, right, weight, bias, gamma, beta, unit, relu, disp_idx, kind):
+        left, right = left.contiguous(), right.contiguous()
+        w = weight.detach().contiguous()
+        C = unit.out_planes
+        sc = sh = None
+        if bias is not None:
+            sc, sh = _const(1.0, bias.numel(), bias.device), bias.detach().contiguous()
+        raw = ops.catconv_first(left, right, len(disp_idx), ops.catconv_pack(w, kind), sc, sh, False)
+        bn = unit[1] if unit.has_bn else None
+        code = _relu_code(relu)
+        y, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, None, code, C, left.device)
+        ctx.unit, ctx.code, ctx.batch_stats, ctx.disp_idx, ctx.kind = unit, code, batch_stats, tuple(disp_idx), kind
+        ctx.has = (bias is not None, gamma is not None, beta is not None)
+        ctx.save_for_backward(left, right, w, raw, scale, shift, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        left, right, w, raw, scale, shift, mean, invstd = ctx.saved_tensors
+        has_bias, has_gamma, has_beta = ctx.has
+        idx = list(ctx.disp_idx)
+        dc, dgamma, dbeta, _ = ops.bn_act_bwd(dy.contiguous(), raw, None, scale, shift, mean, invstd, _mask_mode(ctx.code, False),
+                                              ctx.batch_stats)
+        dw = dL = dR = dbias = None
+        if ctx.needs_input_grad[2]:
+            vol = ops.cat_fms(left, right, idx) if ctx.kind == "cat" else ops.dif_fms(left, right, idx)
+            dw = ops.conv3d_k3_wgrad(vol, dc)
+            del vol
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dvol = ops.conv3d_k3_dgrad(dc, w, 1)
+            dL, dR = ops.cat_fms_bwd(dvol, idx) if ctx.kind == "cat" else ops.dif_fms_bwd(dvol, idx)
+        if has_bias and ctx.needs_input_grad[3]:
+            dbias = torch.zeros_like(dbeta) if ctx.batch_stats else scale * dbeta
+        return (dL if ctx.needs_input_grad[0] else None, dR if ctx.needs_input_grad[1] else None, dw, dbias,
+                dgamma if has_gamma and ctx.needs_input_grad[4] else None, dbeta if has_beta and ctx.needs_input_grad[5] else None,
+                None, None, None, None)
+
+
+def cat_conv_unit(unit, lazy, relu=False):
+    """Differentiable forward of a FusedConv3d unit on a LazyCatVolume (the caller has checked ops.catconv_applicable)."""
+    conv = unit[0]
+    bn = unit[1] if unit.has_bn else None
+    gamma = bn.weight if bn is not None and bn.affine else None
+    beta = bn.bias if bn is not None and bn.affine else None
+    return CatConvUnitFn.apply(lazy.reference_fm, lazy.target_fm, conv.weight, conv.bias, gamma, beta, unit, relu,
+                               tuple(lazy.disp_idx), lazy.kind)
+
+
 class HeadConvFn(torch.autograd.Function):
     """nn.Conv3d(C, 1, 3, 1, 1) (+ bias) (+ the cumulative cost add of PSMNet.py:71-72)."""
 

@@ -914,6 +914,11 @@ def bn_train_fwd(c, gamma=None, beta=None, running_mean=None, running_var=None, 
                                    float(momentum), float(eps), dev_ptr(stats[0]), dev_ptr(stats[1]), dev_ptr(stats[2]),
                                    dev_ptr(stats[3]), dev_ptr(residual, allow_none=True), dev_ptr(y), dev_ptr(ws), B, C, S,
                                    _relu_mode(relu), stream_ptr(c.device)), "dmb_bn_train_fwd_f32")
+    # the kernel wrote these through their pointers: tell torch (the modules' folded-parameter caches key on the versions --
+    # rounds 1-5 relied on the ``num_batches_tracked += 1`` launch for that)
+    written = [t for t in (running_mean, running_var, num_batches_tracked) if t is not None]
+    if written:
+        torch.autograd.graph.increment_version(written)
     return y, stats[0], stats[1], stats[2], stats[3]
 
 

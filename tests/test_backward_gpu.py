@@ -936,3 +936,59 @@ def test_gradient_carry_equals_autograd_sums(dev):
     # autograd's own additions: 18 tensors with several consumers without the carry (cost0 x 3, out1 / out2, pre / post of the
     # hourglasses, ...); with it only the two the chain cannot reach remain (cost1 / cost2 feed a head's skip AND the regression)
     assert adds_off >= adds_on + 12, (adds_on, adds_off)
+
+
+def test_first_unit_without_the_volume_in_training(dev):
+    """The training path's first unit on a concatenation volume (train_fn.CatConvUnitFn: 2-D form forward, volume only inside the
+    backward) against the materialised volume + ConvUnitFn (``ops.set_cat_fusion(False)``): losses within 1e-5 relative, every
+    gradient within 1e-4 of its range (the two forwards differ by FP32 summation order; everything downstream sees that)."""
+    import os
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    from densematchingbenchmark_amd import ops, synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 4
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cfg.model.disp_predictor.max_disp = md
+    cfg.model.losses.l1_loss.max_disp = md
+    model = build_model(cfg, backbone=None).to(dev)
+    synthetic.init_params_(model, seed=5)
+    model.train()
+    lf, rf = _rand((2, 32, 8, 24), 71).to(dev), _rand((2, 32, 8, 24), 72).to(dev)
+    gt = (torch.rand((2, 1, 32, 96), generator=torch.Generator().manual_seed(73)) * 30.0 + 1.0).to(dev)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(flag):
+        ops.set_cat_fusion(flag)
+        try:
+            model.load_state_dict(state)
+            model.zero_grad(set_to_none=True)
+            a, b = lf.clone().requires_grad_(True), rf.clone().requires_grad_(True)
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                _, losses = model(dict(leftFeature=a, rightFeature=b, leftDisp=gt))
+                torch.cuda.synchronize()
+            volumes = sum(e.count for e in prof.key_averages() if "volume_kernel" in e.key)
+            sum(losses.values()).backward()
+            grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            grads["ref_fms"], grads["tgt_fms"] = a.grad.clone(), b.grad.clone()
+            return [float(v) for v in losses.values()], grads, volumes
+        finally:
+            ops.set_cat_fusion(True)
+
+    l_on, g_on, vol_on = run(True)
+    l_off, g_off, vol_off = run(False)
+    assert vol_on == 0 and vol_off == 1          # the forward pass of the fused form never writes the volume
+    for a, b in zip(l_on, l_off):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
+    assert set(g_on) == set(g_off) and len(g_on) == 80
+    worst = 0.0
+    for k in g_on:
+        scale = g_off[k].abs().max().item()
+        worst = max(worst, (g_on[k] - g_off[k]).abs().max().item() / (scale + 1e-30))
+    # a ReLU within rounding of zero may flip between the two forwards (see test_psmnet_training_step): 3e-2 of the range at worst,
+    # and without such a flip (this seed) 1e-4
+    assert worst <= 3e-2, worst
+    print("first unit 2-D form vs materialised volume: worst gradient difference %.2e of its range" % worst)
