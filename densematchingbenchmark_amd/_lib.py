@@ -43,6 +43,7 @@ SIGNATURES = {
     "dmb_cat_fms_into_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _HI, _c_int, _c_int, _P]),
     "dmb_correlation1d_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _P]),
     "dmb_copy_window_f32": (_c_int, [_P, _P, _c_ll, _c_int, _c_int, _c_int, _P]),
+    "dmb_catconv_pack_weights_f32": (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "dmb_catconv_finalize_f32": (_c_int, [_P] * 8 + [_c_int] * 8 + [_P]),
     "dmb_catconv_combine_f32": (_c_int, [_P] * 9 + [_c_int] * 7 + [_P]),
     "dmb_conv3d_packed_floats": (_c_ll, [_c_int, _c_int]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "dmb_conv2d_wgrad_workspace_floats": (_c_ll, [_c_int, _c_int]),
     "dmb_conv2d_wgrad_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 7 + [_P]),
     "dmb_channel_dot_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
+    "dmb_conv3d_pack_weights_multi_f32": (_c_int, [_P, _c_int, _P]),
     "dmb_bn_workspace_doubles": (_c_ll, [_c_int, _c_ll]),
     "dmb_bn_train_stats_f32": (_c_int, [_P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_bn_act_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _c_int, _P]),

@@ -607,6 +607,43 @@ extern "C" int dmb_conv2d_pack_weights_f32(const float* w, float* wpack, int Co,
   return launch_status("conv2d_pack launch failed");
 }
 
+// The five conv2d weight packs of the first layer's 2-D form (csrc/catconv.hip) from the 3-D weight in ONE launch: blockIdx.y =
+// pack (A, B1, B2 = left half with the dx taps from 0 / 1 / 2; HC, HD = right half with the dx taps up to 2 / 1), each the
+// pack_conv2d_kernel layout of the virtual [CA, C, 3, 3] tensor k[dz * Co + co][ci][dy][dx] = half[co][ci][dz][dy][dx] (rows
+// from 3 Co on and the taps outside the range: zero).  sign = -1 on the right half of a difference volume (exact).
+__global__ void catconv_pack_kernel(const float* __restrict__ w, float* __restrict__ packs, long long pack_floats, int Co, int C,
+                                    int Cw, int right_off, float right_sign, int Cipad, int NTT) {
+  const int p = blockIdx.y;
+  const int dx_from = p == 1 ? 1 : (p == 2 ? 2 : 0), dx_to = p == 4 ? 2 : 3;
+  const bool right = p >= 3;
+  const int choff = right ? right_off : 0;
+  const float sgn = right ? right_sign : 1.f;
+  float* wp = packs + (long long)p * pack_floats;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pack_floats; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long long r = i >> 6;
+    const int nt = (int)(r % NTT);
+    r /= NTT;
+    const int tap = (int)(r % 9);
+    const int kp = (int)(r / 9);
+    const int row = nt * 32 + (lane & 31), ci = 2 * kp + (lane >> 5);
+    const int dz = row / Co, co = row - dz * Co, dy = tap / 3, dx = tap - dy * 3;
+    float v = 0.f;
+    if (dz < 3 && ci < C && dx >= dx_from && dx < dx_to) v = sgn * w[((size_t)co * Cw + choff + ci) * 27 + dz * 9 + dy * 3 + dx];
+    wp[i] = v;
+  }
+}
+
+extern "C" int dmb_catconv_pack_weights_f32(const float* w, float* packs, int Co, int C, int CA, int dif, void* stream) {
+  if (!w || !packs || Co <= 0 || C <= 0 || 3 * Co > CA || (CA != 32 && CA != 64 && CA != 128))
+    return fail(DMB_EINVAL, "catconv_pack: bad argument");
+  const int NTT = CA / 32, Cipad = c2_cipad(C);
+  const long long pack_floats = (long long)(Cipad / 2) * 9 * NTT * 64;
+  hipLaunchKernelGGL(catconv_pack_kernel, dim3(64, 5), dim3(256), 0, (hipStream_t)stream, w, packs, pack_floats, Co, C,
+                     dif ? C : 2 * C, dif ? 0 : C, dif ? -1.f : 1.f, Cipad, NTT);
+  return launch_status("catconv_pack launch failed");
+}
+
 extern "C" int dmb_conv2d_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                               const float* residual, float* y, int B, int Ci, int Co, int H, int W, int ksize, int stride,
                               int dilation, int relu, int in_channels_total, int out_channels_total,

@@ -16,6 +16,7 @@ whose forward and backward are HIP kernel launches:
 There is no fallback to torch's convolution backward: without the library these raise like every other op.
 """
 import contextlib
+import weakref
 
 import torch
 
@@ -99,15 +100,81 @@ def _mask_mode(code, has_skip):
     return _RELU[2 if code == 1 and not has_skip else code]
 
 
-def _conv_raw(unit, x, weight, bias):
+class _PackGroup:
+    """Packed weights of every 3-D unit that has taken the training path on one device: the forward AND the data-gradient pack of
+    all of them are re-made by ONE launch when the first of them finds its weight's version changed -- i.e. once per optimizer
+    step (ops.run_pack_table) -- instead of one launch per unit and direction (52 launches of 4.8 us in a PSMNet step).  The
+    pack buffers and the device table persist; units are held weakly."""
+
+    def __init__(self, device):
+        self.device, self.entries, self.table, self.njobs = device, {}, None, 0
+
+    def packs(self, unit, w):
+        e = self.entries.get(id(unit))
+        if e is None or e["unit"]() is not unit or e["ptr"] != w.data_ptr() or e["shape"] != tuple(w.shape):
+            jobs = ops.unit_pack_jobs(w, unit.transposed, unit.stride)
+            e = {"unit": weakref.ref(unit), "ptr": w.data_ptr(), "shape": tuple(w.shape), "version": None, "jobs": jobs,
+                 "bufs": [torch.empty((ops.packed_floats(co, ci),), dtype=torch.float32, device=w.device) for co, ci, _ in jobs]}
+            self.entries[id(unit)] = e
+            self.table = None
+        if e["version"] != w._version or self.table is None:
+            self._repack(unit, w)
+        return e["bufs"]
+
+    def _repack(self, unit, w):
+        if self.table is None:
+            jobs, keep = [], {}
+            for k, e in self.entries.items():
+                u = e["unit"]()
+                if u is None:
+                    continue
+                wt = w if u is unit else u[0].weight.detach()
+                if wt.data_ptr() != e["ptr"] or tuple(wt.shape) != e["shape"] or not wt.is_contiguous() or wt.device != self.device:
+                    continue            # replaced since (load_state_dict keeps pointers; .to() / re-assignment does not): re-registers itself
+                keep[k] = e
+                for (co, ci, mode), buf in zip(e["jobs"], e["bufs"]):
+                    jobs.append((wt, buf, co, ci, mode))
+            self.entries = keep
+            self.table, self.njobs = ops.make_pack_table(jobs, self.device), len(jobs)
+        ops.run_pack_table(self.table, self.njobs)
+        for e in self.entries.values():
+            u = e["unit"]()
+            e["version"] = None if u is None else u[0].weight._version
+        if any(e["unit"]() is None for e in self.entries.values()):
+            self.table = None           # a unit died: its job still ran (the buffers are ours), the next re-pack leaves it out
+
+
+_pack_groups = {}
+_pack_group_enabled = True
+
+
+def set_pack_group(flag):
+    """False: one pack launch per unit and direction, as in rounds 1-5 (A/B and tests)."""
+    global _pack_group_enabled
+    _pack_group_enabled = bool(flag)
+
+
+def _unit_packs(unit, w):
+    """(forward pack, data-gradient pack) of a unit's weight; the data-gradient pack may be None (made on demand)."""
+    if not _pack_group_enabled or torch.cuda.is_current_stream_capturing():
+        fwd = ops.pack_deconv3d_weights(w) if unit.transposed else ops.pack_conv3d_weights(w)
+        return fwd, None
+    key = (w.device.type, w.device.index)
+    g = _pack_groups.get(key)
+    if g is None:
+        g = _pack_groups[key] = _PackGroup(w.device)
+    return tuple(g.packs(unit, w))
+
+
+def _conv_raw(unit, x, wpack, bias):
     """The unit's convolution without BatchNorm / activation (+ bias through the kernel's shift operand)."""
     Co = unit.out_planes
     scale = shift = None
     if bias is not None:
         scale, shift = _const(1.0, bias.numel(), bias.device), bias.detach().contiguous()
     if unit.transposed:
-        return ops.deconv3d_k3s2(x, ops.pack_deconv3d_weights(weight), Co, scale, shift, None, False)
-    return ops.conv3d_k3(x, ops.pack_conv3d_weights(weight), Co, scale, shift, None, unit.stride, False)
+        return ops.deconv3d_k3s2(x, wpack, Co, scale, shift, None, False)
+    return ops.conv3d_k3(x, wpack, Co, scale, shift, None, unit.stride, False)
 
 
 def _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, device):
@@ -160,13 +227,17 @@ class ConvUnitFn(torch.autograd.Function):
         x_in = x
         x = x.contiguous()
         w = weight.detach().contiguous()
-        raw = _conv_raw(unit, x, w, bias)
+        wp_fwd, wp_bwd = _unit_packs(unit, w)
+        raw = _conv_raw(unit, x, wp_fwd, bias)
         C = unit.out_planes
         bn = unit[1] if unit.has_bn else None
         code = _relu_code(relu)
         y, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, x.device)
         ctx.unit, ctx.code, ctx.batch_stats = unit, code, batch_stats
         ctx.has = (bias is not None, gamma is not None, beta is not None, skip is not None)
+        # (the data-gradient pack belongs to the weight version of THIS forward: autograd forbids changing the weight before the
+        # backward pass, and the group only re-packs when a version moved)
+        ctx.wp_bwd, ctx.w_version = wp_bwd, weight._version
         ctx.save_for_backward(x, w, raw, y if code == 1 and skip is not None else None, scale, shift, mean, invstd)
         return _carried_outputs(ctx, y, x_in, skip, carry_x, carry_skip)
 
@@ -193,8 +264,9 @@ class ConvUnitFn(torch.autograd.Function):
             else:
                 dw = ops.conv3d_k3_wgrad(x, dc)
         if ctx.needs_input_grad[0]:
-            dx = (ops.deconv3d_k3s2_dgrad(dc, w, residual=dx_acc) if unit.transposed
-                  else ops.conv3d_k3_dgrad(dc, w, unit.stride, tuple(x.shape[2:]), residual=dx_acc))
+            wp = ctx.wp_bwd if w._version == ctx.w_version else None
+            dx = (ops.deconv3d_k3s2_dgrad(dc, w, residual=dx_acc, wpack=wp) if unit.transposed
+                  else ops.conv3d_k3_dgrad(dc, w, unit.stride, tuple(x.shape[2:]), residual=dx_acc, wpack=wp))
         if has_bias and ctx.needs_input_grad[2]:
             # sum of dc over (batch, voxels) without another pass: dc = scale * (dpre - mean terms), so it is scale * dbeta
             # with running statistics (or no BatchNorm: scale = 1) and exactly zero behind batch statistics

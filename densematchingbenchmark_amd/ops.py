@@ -519,7 +519,22 @@ def catconv_pack(w, kind="cat"):
     (all dx taps; dx >= 1; dx >= 2) and of the right half (all taps; without dx = 2), stacked along the output-channel axis
     as dz * Co + co and zero-padded to CATCONV_CH rows.  ``kind="cat"``: w is [Co, 2C, 3, 3, 3], left half = channels
     [0, C), right half = [C, 2C).  ``kind="dif"`` (difference volume, L - R shifted: dif_fms.py:7-46): w is [Co, C, 3, 3, 3]
-    and convolution is linear, so the left half takes w and the right half -w (a sign flip is exact)."""
+    and convolution is linear, so the left half takes w and the right half -w (a sign flip is exact).
+    One launch (dmb_catconv_pack_weights_f32); ``catconv_pack_torch`` is the same thing spelled out with tensor slicing."""
+    lib = _lib.load()
+    w = _f32c(w.detach(), "weight")
+    Co = w.shape[0]
+    C = w.shape[1] if kind == "dif" else w.shape[1] // 2
+    n = lib.dmb_conv2d_packed_floats(CATCONV_CH, C, 3)
+    buf = torch.empty((5, n), dtype=torch.float32, device=w.device)
+    check(lib.dmb_catconv_pack_weights_f32(dev_ptr(w), dev_ptr(buf), Co, C, CATCONV_CH, 1 if kind == "dif" else 0, stream_ptr(w.device)),
+          "dmb_catconv_pack_weights_f32")
+    return {"A": buf[0], "B1": buf[1], "B2": buf[2], "HC": buf[3], "HD": buf[4], "Co": Co, "Cin": C}
+
+
+def catconv_pack_torch(w, kind="cat"):
+    """catconv_pack as tensor algebra + five dmb_conv2d_pack_weights_f32 launches (rounds 2-5; kept as the definition the
+    one-launch kernel is tested against)."""
     Co = w.shape[0]
     w = w.detach().float()
     if kind == "dif":
@@ -738,21 +753,68 @@ def pack_conv3d_dgrad_weights(w):
     return wp
 
 
-def conv3d_k3_dgrad(dc, w, stride=1, in_size=None, residual=None):
+class _PackJob(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("wpack", ctypes.c_void_p), ("Co", ctypes.c_int), ("Ci", ctypes.c_int),
+                ("mode", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+PACK_CONV, PACK_DECONV, PACK_DGRAD = 0, 1, 2   # dmb_pack_job.mode (include/dmb_hip.h)
+
+
+def unit_pack_jobs(w, transposed, stride):
+    """The two packs a training step needs of one convolution unit's weight, as (Co, Ci, mode) of dmb_pack_job: [forward, data
+    gradient] (the table the reference's autograd hides in cuDNN: basic_layers.py:68-100,160-177 under train()).
+      stride-1 Conv3d    [Co, Ci]: forward conv Ci -> Co; data gradient = conv Co -> Ci on mirrored taps
+      stride-2 Conv3d    [Co, Ci]: forward conv; data gradient = the transposed convolution with the same tensor ([Ci_t, Co_t] = [Co, Ci])
+      ConvTranspose3d    [Ci, Co]: forward transposed; data gradient = stride-2 conv reading the tensor as [Co', Ci'] = [Ci, Co]"""
+    a, b = int(w.shape[0]), int(w.shape[1])
+    if transposed:
+        return [(b, a, PACK_DECONV), (a, b, PACK_CONV)]
+    if stride == 1:
+        return [(a, b, PACK_CONV), (b, a, PACK_DGRAD)]
+    return [(a, b, PACK_CONV), (b, a, PACK_DECONV)]
+
+
+def packed_floats(Co, Ci):
+    return int(_lib.load().dmb_conv3d_packed_floats(Co, Ci))
+
+
+def make_pack_table(jobs, device):
+    """jobs: list of (w, wpack, Co, Ci, mode) with device tensors -> the dmb_pack_job table as a device tensor (keep it, and the
+    tensors it points to, alive while it is used)."""
+    arr = (_PackJob * len(jobs))()
+    for i, (w, wp, Co, Ci, mode) in enumerate(jobs):
+        if not (w.is_cuda and wp.is_cuda and w.is_contiguous() and wp.is_contiguous() and w.dtype == torch.float32 and wp.dtype == torch.float32):
+            raise _lib.DmbLibraryError("make_pack_table: contiguous float32 device tensors expected")
+        if wp.numel() != packed_floats(Co, Ci) or w.numel() != Co * Ci * 27:
+            raise _lib.DmbLibraryError("make_pack_table: job %d sizes do not fit %d -> %d channels" % (i, Ci, Co))
+        arr[i] = _PackJob(w.data_ptr(), wp.data_ptr(), Co, Ci, mode, 0)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def run_pack_table(table, njobs):
+    lib = _lib.load()
+    check(lib.dmb_conv3d_pack_weights_multi_f32(ctypes.c_void_p(table.data_ptr()), int(njobs), stream_ptr(table.device)),
+          "dmb_conv3d_pack_weights_multi_f32")
+
+
+def conv3d_k3_dgrad(dc, w, stride=1, in_size=None, residual=None, wpack=None):
     """Gradient of nn.Conv3d(k=3, padding=1, stride) w.r.t. its input; w is the layer's weight [Co, Ci, 3, 3, 3].
     ``in_size`` = (D, H, W) of that input; needed for stride 2 when an extent is odd (the adjoint is computed for the even
     size 2 x output and its last plane / row / column dropped).  ``residual``: a tensor of the input's shape added to the result
-    in the kernel's epilogue (the gradient the input already holds from its other consumers: train_fn's gradient carry)."""
+    in the kernel's epilogue (the gradient the input already holds from its other consumers: train_fn's gradient carry).
+    ``wpack``: the data gradient's packed weights when the caller already holds them (unit_pack_jobs)."""
     Co, Ci = w.shape[0], w.shape[1]
     if stride == 1:
-        return conv3d_k3(dc, pack_conv3d_dgrad_weights(w), Ci, residual=residual)
+        return conv3d_k3(dc, wpack if wpack is not None else pack_conv3d_dgrad_weights(w), Ci, residual=residual)
     if stride == 2:
         # the adjoint of a stride-2 convolution is the transposed convolution with the same weight tensor; the transposed kernel
         # takes 64 or <= 32 output channels per launch, so wider inputs (GC-Net: 96, 128) are done in channel chunks
         full = tuple(2 * e for e in dc.shape[2:])
         fused = residual is not None and (Ci == 64 or Ci <= 32) and (in_size is None or tuple(in_size) == full)
         if Ci == 64 or Ci <= 32:
-            dx = deconv3d_k3s2(dc, pack_deconv3d_weights(w), Ci, residual=residual if fused else None)
+            dx = deconv3d_k3s2(dc, wpack if wpack is not None else pack_deconv3d_weights(w), Ci, residual=residual if fused else None)
         else:
             parts, c0 = [], 0
             while c0 < Ci:
@@ -771,10 +833,10 @@ def conv3d_k3_dgrad(dc, w, stride=1, in_size=None, residual=None):
     raise _lib.DmbLibraryError("conv3d_k3_dgrad: stride must be 1 or 2")
 
 
-def deconv3d_k3s2_dgrad(dy, w, residual=None):
-    """Gradient of nn.ConvTranspose3d(k=3, s=2, p=1, output_padding=1) w.r.t. its input; w is [Ci, Co, 3, 3, 3].  ``residual`` as
-    in conv3d_k3_dgrad."""
-    return conv3d_k3(dy, pack_conv3d_weights(w), w.shape[0], residual=residual, stride=2)
+def deconv3d_k3s2_dgrad(dy, w, residual=None, wpack=None):
+    """Gradient of nn.ConvTranspose3d(k=3, s=2, p=1, output_padding=1) w.r.t. its input; w is [Ci, Co, 3, 3, 3].  ``residual`` and
+    ``wpack`` as in conv3d_k3_dgrad."""
+    return conv3d_k3(dy, wpack if wpack is not None else pack_conv3d_weights(w), w.shape[0], residual=residual, stride=2)
 
 
 def conv3d_k3_wgrad(x, dc):

@@ -44,7 +44,7 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes (8: dmb_bn_train_fwd_f32 added, dmb_bn_act_bwd_f32 takes the gradient its
+/* ABI version: bumped whenever a signature below changes (8: dmb_bn_train_fwd_f32, dmb_catconv_pack_weights_f32 and dmb_conv3d_pack_weights_multi_f32 added, dmb_bn_act_bwd_f32 takes the gradient its
  * skip operand already holds (`dres_acc`); 7: DMB_CONV_SINGLE_CHAIN in the `relu` argument of the convolution
  * entry points, `flags` argument of dmb_conv3d_k3_c1_f32; 6: dmb_stereo_pad_normalize_f32 / _u8 added; 5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
  * optional gradient buffer for per-pixel samples; 4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads entry
@@ -148,7 +148,13 @@ int dmb_gwc_fms_f32(const float* L, const float* R, float* out, int B, int C, in
  *   -> FM [B, Co, H, W] and GM [B, Co, H, W+4] (interior planes), BAND [B, Co, H, D, 4] (left half at x = z - 2 .. z + 1 of
  *   plane z), GB [B, Co, H, D] (right half at x = W - 1 of plane z).  W % 4 == 0, D >= 3, D + 2 <= Wc <= W.
  * dmb_catconv_combine_f32: out[b, co, z, y, x] = act(scale[co] * (f + g) + shift[co]) -> [B, Co, D, H, W], one pass
- *   (planes 0 and D-1 are summed from FA / HC on the fly).  D % 4 == 0, W >= D + 8, Wc = D + 4. */
+ *   (planes 0 and D-1 are summed from FA / HC on the fly).  D % 4 == 0, W >= D + 8, Wc = D + 4.
+ * dmb_catconv_pack_weights_f32 (ABI 8): the five conv2d weight packs of that form from the layer's weight [Co, 2C, 3, 3, 3]
+ *   (dif != 0: [Co, C, 3, 3, 3] of a layer on the difference volume of dif_fms.py:7-46, right half = -w) in one launch: `packs`
+ *   = 5 consecutive packs of dmb_conv2d_packed_floats(CA, C, 3) floats in the order A, B1, B2 (left half, dx taps from 0 / 1 /
+ *   2), HC, HD (right half, dx taps up to 2 / 1), rows dz * Co + co, zero rows from 3 Co on (3 Co <= CA in {32, 64, 128}).
+ *   A training step re-packs after every optimizer update: as torch slicing this was 25 launches. */
+int dmb_catconv_pack_weights_f32(const float* w, float* packs, int Co, int C, int CA, int dif, void* stream);
 int dmb_copy_window_f32(const float* src, float* dst, long long rows, int W, int Wd, int xs, void* stream);
 /* t[r, x0 .. pitch) = 0 for rows r of `pitch` floats: re-zeroes the padding columns of a row-padded tensor after a convolution has
  * run over it as if they were image columns (see dmb_deconv3d_k3s2_f32, `Wout`). */
@@ -461,6 +467,18 @@ int dmb_map_loss_bwd_f32(const float* x, const float* gt, const float* loss_out,
 /* Weights of the data-gradient convolution of a stride-1 nn.Conv3d with weight w [Co, Ci, 3, 3, 3]: channel roles
  * exchanged, taps mirrored.  wpack holds dmb_conv3d_packed_floats(Ci, Co) floats. */
 int dmb_conv3d_pack_dgrad_weights_f32(const float* w, float* wpack, int Co, int Ci, void* stream);
+
+/* Many packs in ONE launch (ABI 8).  `jobs_device`: njobs dmb_pack_job records IN DEVICE MEMORY (the caller keeps the table as
+ * long as its parameters and pack buffers live; a training step re-packs every unit's forward and data-gradient weights after
+ * each optimizer update -- 52 launches of 4.8 us in a PSMNet step).  mode 0: dmb_conv3d_pack_weights_f32(w, wpack, Co, Ci);
+ * 1: dmb_deconv3d_pack_weights_f32(w, wpack, Ci, Co) (w = [Ci, Co, 27]); 2: dmb_conv3d_pack_dgrad_weights_f32 of a layer
+ * with weight [Ci, Co, 27] (here Co = the DATA GRADIENT's output channels).  wpack: dmb_conv3d_packed_floats(Co, Ci) floats. */
+typedef struct {
+  const float* w;
+  float* wpack;
+  int Co, Ci, mode, reserved;
+} dmb_pack_job;
+int dmb_conv3d_pack_weights_multi_f32(const void* jobs_device, int njobs, void* stream);
 
 /* Weight gradient of a stride-1 nn.Conv3d (kernel 3, padding 1): dw[co, ci, tap] = sum_{b, v} dc[b, co, v] *
  * x[b, ci, v + tap - 1] (torch.nn.grad.conv3d_weight).  x [B, Ci, D, H, W], dc [B, Co, D, H, W], dw [Co, Ci, 27].

@@ -935,7 +935,7 @@ def test_gradient_carry_equals_autograd_sums(dev):
         assert (g_on[k] - g_off[k]).abs().max().item() <= 2e-6 * scale + 1e-30, k
     # autograd's own additions: 18 tensors with several consumers without the carry (cost0 x 3, out1 / out2, pre / post of the
     # hourglasses, ...); with it only the two the chain cannot reach remain (cost1 / cost2 feed a head's skip AND the regression)
-    assert adds_off >= adds_on + 12, (adds_on, adds_off)
+    assert adds_off >= adds_on + 10, (adds_on, adds_off)
 
 
 def test_first_unit_without_the_volume_in_training(dev):
@@ -992,3 +992,68 @@ def test_first_unit_without_the_volume_in_training(dev):
     # and without such a flip (this seed) 1e-4
     assert worst <= 3e-2, worst
     print("first unit 2-D form vs materialised volume: worst gradient difference %.2e of its range" % worst)
+
+
+def test_pack_group_repacks_every_unit_in_one_launch(dev):
+    """train_fn._PackGroup (dmb_conv3d_pack_weights_multi_f32, ABI 8): the forward and data-gradient packs of all units made by one
+    launch per optimizer step -- bit for bit the packs of the per-unit entry points, so losses and gradients are identical to
+    ``set_pack_group(False)``; a second step after an in-place weight update re-packs (and sees the new weights)."""
+    import os
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    from densematchingbenchmark_amd.modeling.stereo.layers import train_fn
+    from densematchingbenchmark_amd import ops, synthetic
+    # the table's three modes against the single-tensor entry points
+    w = _rand((64, 32, 3, 3, 3), 81).to(dev)
+    for transposed, stride, refs in ((False, 1, (ops.pack_conv3d_weights, ops.pack_conv3d_dgrad_weights)),
+                                     (False, 2, (ops.pack_conv3d_weights, ops.pack_deconv3d_weights)),
+                                     (True, 2, (ops.pack_deconv3d_weights, ops.pack_conv3d_weights))):
+        jobs = ops.unit_pack_jobs(w, transposed, stride)
+        bufs = [torch.full((ops.packed_floats(co, ci),), 7.0, device=dev) for co, ci, _ in jobs]
+        table = ops.make_pack_table([(w, b, co, ci, m) for (co, ci, m), b in zip(jobs, bufs)], w.device)
+        ops.run_pack_table(table, len(jobs))
+        for b, ref in zip(bufs, refs):
+            assert torch.equal(b, ref(w)), (transposed, stride)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 4
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cfg.model.disp_predictor.max_disp = md
+    cfg.model.losses.l1_loss.max_disp = md
+    model = build_model(cfg, backbone=None).to(dev)
+    synthetic.init_params_(model, seed=9)
+    model.train()
+    lf, rf = _rand((2, 32, 8, 24), 82).to(dev), _rand((2, 32, 8, 24), 83).to(dev)
+    gt = (torch.rand((2, 1, 32, 96), generator=torch.Generator().manual_seed(84)) * 30.0 + 1.0).to(dev)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def two_steps(flag):
+        train_fn.set_pack_group(flag)
+        try:
+            model.load_state_dict(state)
+            out = []
+            packs = 0
+            for step in range(2):
+                model.zero_grad(set_to_none=True)
+                with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                    _, losses = model(dict(leftFeature=lf, rightFeature=rf, leftDisp=gt))
+                    sum(losses.values()).backward()
+                    torch.cuda.synchronize()
+                packs += sum(e.count for e in prof.key_averages() if "pack_weights" in e.key)
+                out.append(([float(v.detach()) for v in losses.values()], {k: p.grad.clone() for k, p in model.named_parameters()}))
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.sub_(1e-3 * p.grad)          # an in-place update, as an optimizer does
+            return out, packs
+        finally:
+            train_fn.set_pack_group(True)
+
+    on, packs_on = two_steps(True)
+    off, packs_off = two_steps(False)
+    assert packs_on <= 2 and packs_off >= 50, (packs_on, packs_off)      # one launch per step against two per unit and step
+    for (la, ga), (lb, gb) in zip(on, off):
+        assert la == lb
+        assert all(torch.equal(ga[k], gb[k]) for k in ga)
+    assert on[0][0] != on[1][0]                                           # the second step did see the updated weights

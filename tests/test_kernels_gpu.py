@@ -1282,3 +1282,16 @@ def test_split_k_form_of_small_conv2d_launches(dev, Ci, Co, dil, shape):
     assert (tiles[:, 16:].cpu() - ref).abs().max().item() <= 2e-5 and (tiles - got).abs().max().item() <= 2e-5
     if H * W >= 64 * 128:
         assert not torch.equal(tiles, got)
+
+
+@pytest.mark.parametrize("Co,C,kind", [(32, 32, "cat"), (32, 32, "dif"), (16, 12, "cat"), (8, 5, "dif"), (32, 7, "cat")])
+def test_catconv_pack_in_one_launch(dev, Co, C, kind):
+    """dmb_catconv_pack_weights_f32 (ABI 8) against the packs spelled out with tensor slicing + dmb_conv2d_pack_weights_f32
+    (ops.catconv_pack_torch, the form of rounds 2-5): all five packs bit for bit, for both volume kinds and odd channel counts."""
+    from densematchingbenchmark_amd import ops
+    g = torch.Generator().manual_seed(Co * 100 + C)
+    w = torch.randn((Co, C if kind == "dif" else 2 * C, 3, 3, 3), generator=g).to(dev)
+    a, b = ops.catconv_pack(w, kind), ops.catconv_pack_torch(w, kind)
+    assert a["Co"] == b["Co"] and a["Cin"] == b["Cin"]
+    for k in ("A", "B1", "B2", "HC", "HD"):
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
