@@ -72,6 +72,11 @@ __global__ __launch_bounds__(256) void upsample_regress_bwd_z_kernel(const float
                                                                      const float* __restrict__ g, float* __restrict__ t, int Di,
                                                                      int Hi, int Wi, int Do, int Ho, int Wo, float sd, float sh,
                                                                      float sw, float alpha, DispVal dv) {
+  // (round 6) the z interpolation of an output plane is the same for every pixel: one table per workgroup instead of a lerp set-up
+  // per plane, pixel and walk (2 x 192 x 9 instructions of a thread's ~10 000: the walks are what this kernel's time goes into)
+  __shared__ Lerp lzt[DMB_MAX_DISP_SAMPLES];
+  for (int k = threadIdx.x; k < Do; k += 256) lzt[k] = lerp_setup(k, Di, sd);
+  __syncthreads();
   const int xo = blockIdx.x * 256 + threadIdx.x;
   if (xo >= Wo) return;
   const int yo = blockIdx.y, b = blockIdx.z;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void upsample_regress_bwd_z_kernel(const float
   int cz0 = -1, cz1 = -1;
   float h0 = 0.f, h1 = 0.f;
   auto logit = [&](int zo, Lerp& lz) {
-    lz = lerp_setup(zo, Di, sd);
+    lz = lzt[zo];
     if (lz.i0 != cz0) {
       h0 = (lz.i0 == cz1) ? h1 : hw(lz.i0);
       cz0 = lz.i0;
@@ -243,6 +248,97 @@ __global__ __launch_bounds__(256) void upsample_regress_bwd_hw_kernel(const floa
     acc = fmaf(row, wy, acc);
   }
   dx[(((size_t)b * Di + zi) * Hi + yl) * Wi + xl] = acc;
+}
+
+// (round 6) The same contraction for a group of R low-resolution rows per workgroup, in the two steps the sum above already has:
+// row[yo][xl] = sum_xo t[yo][xo] wx(xl <- xo) for the high-resolution rows the group touches (into LDS; the 16 loads of a row sum
+// are independent and a high-resolution row is contracted ONCE, not once per low-resolution row that blends it), then
+// dlow[yl][xl] = sum_yo row[yo][xl] wy(yl <- yo) from LDS.  Same terms in the same order as upsample_regress_bwd_hw_kernel's
+// windowed path: bit-identical.  That kernel walks its 9 .. 12 rows one memory round trip after the other (113 us for 100 MB at
+// the training crop); here a thread has a row's loads in flight together and a workgroup reads its rows once.
+template <int R>
+__global__ __launch_bounds__(256) void upsample_bwd_hw_rows_kernel(const float* __restrict__ t, float* __restrict__ dx, int Di, int Hi,
+                                                                   int Wi, int Ho, int Wo, float sh, float sw, int nrmax) {
+  extern __shared__ float rs[];   // [nrmax][Wi]
+  const int y0 = blockIdx.x * R, zi = blockIdx.y, b = blockIdx.z;
+  auto range = [](int i, float scale, int out, int& lo, int& hi) {   // (scale > 0: the launcher's condition)
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out - 1 ? out - 1 : hi;
+  };
+  int glo, ghi, tmp;
+  range(y0, sh, Ho, glo, tmp);
+  range(min(y0 + R - 1, Hi - 1), sh, Ho, tmp, ghi);
+  const int nr = min(ghi - glo + 1, nrmax);
+  const float* tb = t + ((size_t)b * Di + zi) * Ho * Wo;
+  constexpr int KMAX = 16;
+  const int RL = Wi >= 256 ? 1 : 256 / Wi;          // row lanes: threads (rl, xl)
+  const int XW = Wi >= 256 ? 256 : Wi;
+  const int rl = threadIdx.x / XW, xc = threadIdx.x - rl * XW;
+  for (int xb = 0; xb < Wi; xb += XW) {
+    const int xl = xb + xc;
+    if (rl < RL && xl < Wi) {
+      int xlo, xhi;
+      range(xl, sw, Wo, xlo, xhi);
+      float wxs[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const int xo = xlo + k;
+        float wv = 0.f;
+        if (xo <= xhi) {
+          const Lerp lx = lerp_setup(xo, Wi, sw);
+          wv = (lx.i0 == xl ? lx.w0 : 0.f) + (lx.i1 == xl ? lx.w1 : 0.f);
+        }
+        wxs[k] = wv;
+      }
+      for (int r = rl; r < nr; r += RL) {
+        const float* tr = tb + (size_t)(glo + r) * Wo + xlo;
+        float v[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) v[k] = wxs[k] != 0.f ? tr[k] : 0.f;
+        float row = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (wxs[k] != 0.f) row = fmaf(v[k], wxs[k], row);
+        rs[r * Wi + xl] = row;
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < R * Wi; idx += 256) {
+    const int yl = y0 + idx / Wi, xl = idx % Wi;
+    if (yl >= Hi) break;
+    int ylo, yhi;
+    range(yl, sh, Ho, ylo, yhi);
+    float acc = 0.f;
+    for (int yo = ylo; yo <= yhi; ++yo) {
+      const Lerp ly = lerp_setup(yo, Hi, sh);
+      const float wy = (ly.i0 == yl ? ly.w0 : 0.f) + (ly.i1 == yl ? ly.w1 : 0.f);
+      if (wy == 0.f) continue;
+      acc = fmaf(rs[(yo - glo) * Wi + xl], wy, acc);
+    }
+    dx[(((size_t)b * Di + zi) * Hi + yl) * Wi + xl] = acc;
+  }
+}
+
+// Launch of the (y, x) contraction: the row-group form where it applies (both scales > 0, column windows of fewer than 16
+// outputs, the group's row sums within 64 KB of LDS), else one thread per low-resolution voxel.
+static void launch_upsample_bwd_hw(const float* t, float* dx, int B, int planes, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                   hipStream_t st) {
+  constexpr int R = 8;
+  if (sh > 0.f && sw > 0.f && Hi >= 2 && Wi >= 2) {
+    const int win = (int)ceilf(2.f / sw) + 5;                 // columns a low-resolution pixel may blend (bound of xhi - xlo + 1)
+    const int nrmax = (int)ceilf((float)(R + 1) / sh) + 6;    // rows a group of R may blend (bound of ghi - glo + 1)
+    const size_t lds = (size_t)nrmax * Wi * sizeof(float);
+    if (win <= 16 && lds <= 64 * 1024 && cdiv(Hi, R) <= 65535 && planes <= 65535) {
+      hipLaunchKernelGGL((upsample_bwd_hw_rows_kernel<R>), dim3(cdiv(Hi, R), planes, B), dim3(256), lds, st, t, dx, planes, Hi, Wi, Ho, Wo,
+                         sh, sw, nrmax);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), planes * Hi, B), dim3(256), 0, st, t, dx, planes, Hi, Wi, Ho, Wo,
+                     sh, sw);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -500,8 +596,7 @@ extern "C" int dmb_trilinear_ac_soft_argmin_bwd_f32(const float* x, const float*
                      Wi, Do, Ho, Wo, sd, sh, sw, alpha, dv);
   if (grad_y)   // a loss on the volume as well: its z fold joins the regression's before the (y, x) contraction
     hipLaunchKernelGGL(upsample_bwd_z_kernel, dim3(cdiv(Wo, 256), Ho, B), dim3(256), 0, st, grad_y, scratch, Di, Do, Ho, Wo, sd, 1);
-  hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), Di * Hi, B), dim3(256), 0, st, scratch, grad_x, Di, Hi, Wi,
-                     Ho, Wo, sh, sw);
+  launch_upsample_bwd_hw(scratch, grad_x, B, Di, Hi, Wi, Ho, Wo, sh, sw, st);
   return launch_status("trilinear_soft_argmin_bwd launch failed");
 }
 
@@ -529,8 +624,7 @@ extern "C" int dmb_trilinear_ac_bwd_f32(const float* grad_y, float* scratch, flo
   hipStream_t st = (hipStream_t)stream;
   const float sd = ac_scale(Di, Do), sh = ac_scale(Hi, Ho), sw = ac_scale(Wi, Wo);
   hipLaunchKernelGGL(upsample_bwd_z_kernel, dim3(cdiv(Wo, 256), Ho, B), dim3(256), 0, st, grad_y, scratch, Di, Do, Ho, Wo, sd, 0);
-  hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), Di * Hi, B), dim3(256), 0, st, scratch, grad_x, Di, Hi, Wi,
-                     Ho, Wo, sh, sw);
+  launch_upsample_bwd_hw(scratch, grad_x, B, Di, Hi, Wi, Ho, Wo, sh, sw, st);
   return launch_status("trilinear_bwd launch failed");
 }
 
@@ -551,8 +645,7 @@ extern "C" int dmb_bilinear_ac_bwd_f32(const float* grad_y, float* grad_x, int B
     return launch_status("bilinear_bwd launch failed");
   }
   // the (y, x) contraction of the up-sampling backward, one "plane" per channel
-  hipLaunchKernelGGL(upsample_regress_bwd_hw_kernel, dim3(cdiv(Wi, 256), C * Hi, B), dim3(256), 0, (hipStream_t)stream, grad_y, grad_x, C,
-                     Hi, Wi, Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  launch_upsample_bwd_hw(grad_y, grad_x, B, C, Hi, Wi, Ho, Wo, ac_scale(Hi, Ho), ac_scale(Wi, Wo), (hipStream_t)stream);
   return launch_status("bilinear_bwd launch failed");
 }
 
