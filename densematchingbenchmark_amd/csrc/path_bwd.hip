@@ -292,16 +292,26 @@ __global__ __launch_bounds__(256) void upsample_bwd_hw_rows_kernel(const float* 
         }
         wxs[k] = wv;
       }
-      for (int r = rl; r < nr; r += RL) {
-        const float* tr = tb + (size_t)(glo + r) * Wo + xlo;
-        float v[KMAX];
+      // two rows' loads in flight per thread (a row's 16 are independent; the rows of a thread were one round trip each)
+      for (int r = rl; r < nr; r += 2 * RL) {
+        const bool two = r + RL < nr;
+        const float* tr0 = tb + (size_t)(glo + r) * Wo + xlo;
+        const float* tr1 = tr0 + (size_t)RL * Wo;
+        float v0[KMAX], v1[KMAX];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) v[k] = wxs[k] != 0.f ? tr[k] : 0.f;
-        float row = 0.f;
+        for (int k = 0; k < KMAX; ++k) {
+          v0[k] = wxs[k] != 0.f ? tr0[k] : 0.f;
+          v1[k] = (two && wxs[k] != 0.f) ? tr1[k] : 0.f;
+        }
+        float row0 = 0.f, row1 = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-          if (wxs[k] != 0.f) row = fmaf(v[k], wxs[k], row);
-        rs[r * Wi + xl] = row;
+          if (wxs[k] != 0.f) {
+            row0 = fmaf(v0[k], wxs[k], row0);
+            row1 = fmaf(v1[k], wxs[k], row1);
+          }
+        rs[r * Wi + xl] = row0;
+        if (two) rs[(r + RL) * Wi + xl] = row1;
       }
     }
   }

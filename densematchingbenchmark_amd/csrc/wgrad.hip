@@ -509,35 +509,40 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad_reduce_kernel(const float
   if (lane == 0) dw[i] = (float)s;
 }
 
-// dw[co][ci][tap] = sum over slots (fixed order, FP32 pairwise by halves of the slot range would not be more accurate than
-// the per-slot chains themselves; a plain ascending sum in double keeps the last step exact to FP32 rounding)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nslots, int transposed) {
+// dw[co][ci][tap] = sum over slots in FP64, fixed order.  A workgroup owns 64 consecutive elements of one (block, tap) plane and
+// its four waves a quarter of the slots each (eight interleaved partial sums per thread: independent loads), combined through LDS
+// as (q0 + q1) + (q2 + q3).  (Rounds 1-5: one thread per element walked all 256 slots -- 32 dependent rounds of 8 loads, 9.2 us for
+// 28 MB, 25 times per training step; more threads per element, not more bytes, is what it lacked.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int nslots, int transposed) {
+  __shared__ double sm[4][64];
   const int ncib = cdiv(Ci, 32);
-  const long long total = (long long)cdiv(Co, 32) * ncib * 27 * 1024;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int nn = (int)(i & 31), m = (int)((i >> 5) & 31);
-    long long r = i >> 10;
-    const int t = (int)(r % 27);
-    const int blk = (int)(r / 27);
-    const int cib = blk % ncib, cob = blk / ncib;
-    const int co = cob * 32 + m, ci = cib * 32 + nn;
-    if (co >= Co || ci >= Ci) continue;
-    // eight interleaved partial sums (fixed assignment slot -> partial, fixed final order): the loads of one thread are
-    // independent, a single dependent chain of 256 adds would leave the pass latency-bound
-    const float* p = ws + (size_t)blk * nslots * 27 * 1024 + t * 1024 + m * 32 + nn;
-    double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int sl = 0;
-    for (; sl + 8 <= nslots; sl += 8) {
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  long long r = blockIdx.x;
+  const int grp = (int)(r & 15);
+  r >>= 4;
+  const int t = (int)(r % 27);
+  const int blk = (int)(r / 27);
+  const int m = grp * 2 + (e >> 5), nn = e & 31;
+  const int cib = blk % ncib, cob = blk / ncib;
+  const int co = cob * 32 + m, ci = cib * 32 + nn;
+  const float* p = ws + (size_t)blk * nslots * 27 * 1024 + t * 1024 + m * 32 + nn;
+  const int per = (nslots + 3) / 4;
+  const int s0 = q * per, s1 = s0 + per < nslots ? s0 + per : nslots;
+  double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int sl = s0;
+  for (; sl + 8 <= s1; sl += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) part[u] += (double)p[(size_t)(sl + u) * 27 * 1024];
-    }
-    for (; sl < nslots; ++sl) part[sl & 7] += (double)p[(size_t)sl * 27 * 1024];
-    const double s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-    if (transposed)
-      dw[((size_t)ci * Co + co) * 27 + t] = (float)s;
-    else
-      dw[((size_t)co * Ci + ci) * 27 + t] = (float)s;
+    for (int u = 0; u < 8; ++u) part[u] += (double)p[(size_t)(sl + u) * 27 * 1024];
   }
+  for (int u = 0; sl < s1; ++sl, ++u) part[u] += (double)p[(size_t)sl * 27 * 1024];
+  sm[q][e] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+  __syncthreads();
+  if (q != 0 || co >= Co || ci >= Ci) return;
+  const double s = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+  if (transposed)
+    dw[((size_t)ci * Co + co) * 27 + t] = (float)s;
+  else
+    dw[((size_t)co * Ci + ci) * 27 + t] = (float)s;
 }
 
 static long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
@@ -625,7 +630,7 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
     hipLaunchKernelGGL((conv3d_wgrad_s1_kernel<false, 24>), grid, dim3(256), WgCfg<24>::LDS_FLOATS * 4, st, x, dc, workspace, B, Ci, Co, D, H, W, cdiv(W, 24), nty, nzs, zseg);
   int rc = launch_status("conv3d_wgrad launch failed");
   if (rc != DMB_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Co, Ci, nused, 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk * 27 * 16), dim3(256), 0, st, workspace, dw, Co, Ci, nused, 0);
   return launch_status("conv3d_wgrad reduce launch failed");
 }
 
@@ -667,7 +672,7 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
                        workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
   int rc = launch_status("conv3d_s2_wgrad launch failed");
   if (rc != DMB_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nblk * 27 * 1024, 256)), dim3(256), 0, st, workspace, dw, Cs, Cb, nused, 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk * 27 * 16), dim3(256), 0, st, workspace, dw, Cs, Cb, nused, 0);
   return launch_status("conv3d_s2_wgrad reduce launch failed");
 }
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--images", action="store_true", help="start from images: the HIP backbone trains too")
+    ap.add_argument("--foreach-adam", action="store_true", help="torch's multi-tensor Adam (11 launches) instead of its fused one (1)")
     ap.add_argument("--config", default=os.path.join("PSMNet", "scene_flow.py"), help="relative to configs/ (PSMNet/scene_flow.py, "
                     "AcfNet/scene_flow_uniform.py, AcfNet/scene_flow_adaptive.py)")
     args = ap.parse_args()
@@ -43,7 +44,7 @@ def main():
     synthetic.init_params_(model, seed=0)
     model.train()
     flat = FlatGradients(model)
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, fused=not args.foreach_adam)
     g = torch.Generator(device="cpu").manual_seed(1 + local)
     B, H, W = args.batch, args.height, args.width
     lf = torch.randn((B, 32, H // 4, W // 4), generator=g).to(dev)
