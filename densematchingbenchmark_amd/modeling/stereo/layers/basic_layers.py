@@ -39,7 +39,15 @@ def _versions(*tensors):
     """Cache key of folded / packed parameters.  BatchNorm's ``num_batches_tracked`` is part of every key that covers running
     statistics: the training-mode kernel rewrites ``running_mean`` / ``running_var`` through raw device pointers (their
     ``_version`` does not move), but every such forward bumps ``num_batches_tracked`` in place."""
-    return tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None)
+    return tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None) + (ops.param_epoch(),)
+
+
+def epoch_on_mode_switch(module, mode):
+    """Called from train(mode) of the fused modules: a switch between training and evaluation advances ops' parameter epoch, which
+    is part of every cache key above -- in-place updates that leave ``_version`` alone (torch's fused optimizers) are then seen by
+    the first eval-mode forward after training."""
+    if bool(mode) != module.training:
+        ops.bump_param_epoch()
 
 
 class FusedConv3d(nn.Sequential):
@@ -71,6 +79,10 @@ class FusedConv3d(nn.Sequential):
         self.in_planes, self.out_planes, self.stride = in_planes, out_planes, stride
         self.transposed, self.has_bn, self.has_relu = transposed, bool(batch_norm), bool(relu)
         self._cache_key, self._cache = None, None
+
+    def train(self, mode=True):
+        epoch_on_mode_switch(self, mode)
+        return super().train(mode)
 
     def _prepacked(self):
         conv = self[0]
@@ -152,6 +164,10 @@ class HeadConv3d(nn.Conv3d):
     def __init__(self, in_planes, bias=False):
         super().__init__(in_planes, 1, kernel_size=3, stride=1, padding=1, bias=bias)
         self._bias_key, self._bias_val = None, 0.0
+
+    def train(self, mode=True):
+        epoch_on_mode_switch(self, mode)
+        return super().train(mode)
 
     def forward(self, x, residual=None):
         if hasattr(x, "materialize"):   # a lazy volume reaching a head directly (an aggregator without trunk layers)

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .... import ops
 from . import train_fn
-from .basic_layers import _versions, fold_batch_norm
+from .basic_layers import _versions, epoch_on_mode_switch, fold_batch_norm
 
 __all__ = ["FusedConv2d", "conv_bn", "conv_bn_relu", "BasicBlock"]
 
@@ -35,6 +35,10 @@ class FusedConv2d(nn.Sequential):
         self.kernel_size, self.stride, self.dilation = kernel_size, stride, dilation
         self.has_bn, self.has_relu = bool(batch_norm), bool(relu)
         self._cache_key, self._cache = None, None
+
+    def train(self, mode=True):
+        epoch_on_mode_switch(self, mode)
+        return super().train(mode)
 
     def _prepacked(self):
         conv = self[0]

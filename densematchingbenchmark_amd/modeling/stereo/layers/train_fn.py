@@ -102,22 +102,30 @@ def _mask_mode(code, has_skip):
 
 class _PackGroup:
     """Packed weights of every 3-D unit that has taken the training path on one device: the forward AND the data-gradient pack of
-    all of them are re-made by ONE launch when the first of them finds its weight's version changed -- i.e. once per optimizer
-    step (ops.run_pack_table) -- instead of one launch per unit and direction (52 launches of 4.8 us in a PSMNet step).  The
-    pack buffers and the device table persist; units are held weakly."""
+    all of them are re-made by ONE launch per forward pass (ops.run_pack_table) instead of one launch per unit and direction (52
+    launches of 4.8 us in a PSMNet step).  The pack buffers and the device table persist; units are held weakly.
+
+    When to re-pack.  A weight's ``_version`` moving is one trigger, but torch's FUSED optimizers (``Adam(fused=True)``) update
+    parameters without moving it -- so the group also counts passes: a unit asking for its packs a second time within one
+    generation means a new forward pass has begun (every unit runs once per pass), the generation advances and everything is
+    re-packed, whatever the versions say.  One 19 us launch per pass either way."""
 
     def __init__(self, device):
-        self.device, self.entries, self.table, self.njobs = device, {}, None, 0
+        self.device, self.entries, self.table, self.njobs, self.gen = device, {}, None, 0, 0
 
     def packs(self, unit, w):
         e = self.entries.get(id(unit))
         if e is None or e["unit"]() is not unit or e["ptr"] != w.data_ptr() or e["shape"] != tuple(w.shape):
             jobs = ops.unit_pack_jobs(w, unit.transposed, unit.stride)
-            e = {"unit": weakref.ref(unit), "ptr": w.data_ptr(), "shape": tuple(w.shape), "version": None, "jobs": jobs,
+            e = {"unit": weakref.ref(unit), "ptr": w.data_ptr(), "shape": tuple(w.shape), "version": None, "seen": -1, "packed": -1,
+                 "jobs": jobs,
                  "bufs": [torch.empty((ops.packed_floats(co, ci),), dtype=torch.float32, device=w.device) for co, ci, _ in jobs]}
             self.entries[id(unit)] = e
             self.table = None
-        if e["version"] != w._version or self.table is None:
+        if e["seen"] == self.gen:
+            self.gen += 1                # second request within a generation: a new forward pass
+        e["seen"] = self.gen
+        if e["packed"] != self.gen or e["version"] != w._version or self.table is None:
             self._repack(unit, w)
         return e["bufs"]
 
@@ -137,10 +145,13 @@ class _PackGroup:
             self.entries = keep
             self.table, self.njobs = ops.make_pack_table(jobs, self.device), len(jobs)
         ops.run_pack_table(self.table, self.njobs)
+        dead = False
         for e in self.entries.values():
             u = e["unit"]()
+            e["packed"] = self.gen
             e["version"] = None if u is None else u[0].weight._version
-        if any(e["unit"]() is None for e in self.entries.values()):
+            dead = dead or u is None
+        if dead:
             self.table = None           # a unit died: its job still ran (the buffers are ours), the next re-pack leaves it out
 
 

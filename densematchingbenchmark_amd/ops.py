@@ -398,6 +398,22 @@ def view_streams():
     return _view_streams
 
 
+# Folded / packed parameter caches of the modules are keyed by (pointer, ``_version``) of their parameters -- and by this epoch.
+# Most in-place updates move ``_version`` (optimizer.step() of the for-loop / multi-tensor optimizers, load_state_dict, copy_), but
+# torch's FUSED optimizers (``Adam(fused=True)``) do not.  Every train() <-> eval() switch of a fused unit advances the epoch, so
+# an eval-mode forward after training re-folds whatever the versions say; code that rewrites parameters of an eval-mode model
+# behind torch's back calls ``bump_param_epoch()`` itself.
+_param_epoch = [0]
+
+
+def param_epoch():
+    return _param_epoch[0]
+
+
+def bump_param_epoch():
+    _param_epoch[0] += 1
+
+
 def warm_packed_parameters(module):
     """Fill (on the CURRENT stream) every lazily packed / folded parameter cache below ``module``: each fused unit keeps its packed
     weights and folded BatchNorm affine keyed by the parameters' versions (``_prepacked()``) and refills them inside its first
@@ -408,7 +424,7 @@ def warm_packed_parameters(module):
     if tensors is None:
         tensors = list(module.parameters()) + list(module.buffers())     # the objects persist across .to() and load_state_dict()
         module.__dict__["_dmb_warm_tensors"] = tensors
-    key = (module.training,) + tuple((t.data_ptr(), t._version) for t in tensors)
+    key = (module.training, _param_epoch[0]) + tuple((t.data_ptr(), t._version) for t in tensors)
     if module.__dict__.get("_dmb_warm_key") == key:
         return
     for m in module.modules():

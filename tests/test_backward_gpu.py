@@ -1059,3 +1059,64 @@ def test_pack_group_repacks_every_unit_in_one_launch(dev):
         assert la == lb
         assert all(torch.equal(ga[k], gb[k]) for k in ga)
     assert on[0][0] != on[1][0] != on[2][0]                                           # the second step did see the updated weights
+
+
+def test_fused_optimizer_updates_are_seen(dev):
+    """torch's fused optimizers update parameters WITHOUT moving their ``_version`` (checked here), which every packed / folded
+    parameter cache of this package keys on.  The training path's pack group therefore re-packs once per forward pass whatever the
+    versions say, and a train() -> eval() switch advances ops' parameter epoch: (a) two Adam(fused=True) steps give the same losses
+    with the pack group as with per-call packing, bit for bit; (b) the eval-mode forward after them equals a fresh model loaded
+    with the trained state."""
+    import os
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    from densematchingbenchmark_amd.modeling.stereo.layers import train_fn
+    from densematchingbenchmark_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 4
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cfg.model.disp_predictor.max_disp = md
+    cfg.model.losses.l1_loss.max_disp = md
+    lf, rf = _rand((2, 32, 8, 24), 91).to(dev), _rand((2, 32, 8, 24), 92).to(dev)
+    gt = (torch.rand((2, 1, 32, 96), generator=torch.Generator().manual_seed(93)) * 30.0 + 1.0).to(dev)
+
+    def run(flag):
+        train_fn.set_pack_group(flag)
+        try:
+            model = build_model(cfg, backbone=None).to(dev)
+            synthetic.init_params_(model, seed=11)
+            model.eval()
+            with torch.no_grad():
+                model(dict(leftFeature=lf, rightFeature=rf))          # fills the eval path's caches with the INITIAL weights
+            model.train()
+            params = [p for p in model.parameters() if p.requires_grad]
+            opt = torch.optim.Adam(params, lr=1e-2, fused=True)
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                _, ld = model(dict(leftFeature=lf, rightFeature=rf, leftDisp=gt))
+                sum(ld.values()).backward()
+                v = params[0]._version
+                opt.step()
+                assert params[0]._version == v                         # the premise: a fused step leaves the version alone
+                losses.append([float(x.detach()) for x in ld.values()])
+            model.eval()
+            with torch.no_grad():
+                out, _ = model(dict(leftFeature=lf, rightFeature=rf))
+            return losses, out["disps"][0].clone(), {k: v.clone() for k, v in model.state_dict().items()}
+        finally:
+            train_fn.set_pack_group(True)
+
+    l_on, d_on, state = run(True)
+    l_off, d_off, _ = run(False)
+    assert l_on == l_off and l_on[0] != l_on[1] != l_on[2]
+    assert torch.equal(d_on, d_off)
+    fresh = build_model(cfg, backbone=None).to(dev)
+    fresh.load_state_dict(state)
+    fresh.eval()
+    with torch.no_grad():
+        want, _ = fresh(dict(leftFeature=lf, rightFeature=rf))
+    assert torch.equal(d_on, want["disps"][0])
