@@ -87,6 +87,7 @@ SIGNATURES = {
     "dmb_conv2d_wgrad_f32": (_c_int, [_P, _P, _P, _P] + [_c_int] * 7 + [_P]),
     "dmb_channel_dot_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_conv3d_pack_weights_multi_f32": (_c_int, [_P, _c_int, _P]),
+    "dmb_cat_first_wgrad_maps_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     "dmb_bn_workspace_doubles": (_c_ll, [_c_int, _c_ll]),
     "dmb_bn_train_stats_f32": (_c_int, [_P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_bn_act_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _c_int, _P]),

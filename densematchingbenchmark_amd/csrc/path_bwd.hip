@@ -39,6 +39,62 @@ __global__ __launch_bounds__(256) void volume_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the aggregator's FIRST convolution on a concatenation / difference volume of unit disparity step, without the
+// volume (the backward twin of csrc/catconv.hip).  With V = cat_fms(L, R) (cat_fms.py:7-48: V[ci, z, y, x] = L[ci, y, x] and
+// V[C + ci, z, y, x] = R[ci, y, x - z] for x >= z, zero otherwise) and zero padding around it,
+//   dW[co, ci, dz, dy, dx]     = sum_{y, x} L[ci, y + dy - 1, x + dx - 1] * GL_{dz, dx}[co, y, x]
+//   dW[co, C + ci, dz, dy, dx] = sum_{y, u} R[ci, y + dy - 1, u]          * GR_{dz, dx}[co, y, u]
+//   GL_{dz, dx}[co, y, x] = sum_z dc[co, z, y, x]                  over 0 <= z' = z + dz - 1 < D,  x + dx - 1 >= z'
+//   GR_{dz, dx}[co, y, u] = sum_z dc[co, z, y, u + z' - dx + 1]    over 0 <= z' < D,  u + z' < W,  the column inside [0, W)
+// i.e. ONE pass over dc that folds z into 2 x 9 maps per output channel (this kernel), then two 2-D weight gradients of the feature
+// maps against those maps (dmb_conv2d_wgrad_f32; the caller picks tap dx' = dx of the left result and the centre column of the
+// right one).  The 3-D weight gradient of the materialised volume is 64 x 32 x 27 x 25 M multiply-adds (1.22 ms + 0.06 ms for the
+// volume at the training crop); this is 0.2 GB of traffic and two small GEMMs.
+// maps_*: [B, 9 * Co, H, W], channel (dz * 3 + dx) * Co + co.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cat_wgrad_maps_kernel(const float* __restrict__ dc, float* __restrict__ gl, float* __restrict__ gr,
+                                                             int Co, int D, int H, int W) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (pix >= HW) return;
+  const int y = pix / W, x = pix - y * W, co = blockIdx.y, b = blockIdx.z;
+  const float* p = dc + ((size_t)(b * Co + co) * D) * HW + (size_t)y * W;
+  float g[3][3], h[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[a][c] = h[a][c] = 0.f;
+  for (int z = 0; z < D; ++z) {
+    const float* row = p + (size_t)z * HW;
+    const float v = row[x];
+    float d[5];   // the right half's diagonal walk: dc at column x + z' - dx + 1 = x + z + (dz - dx) = x + z + k - 2, 0 outside the row
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int xx = x + z + k - 2;
+      d[k] = (xx >= 0 && xx < W) ? row[xx] : 0.f;
+    }
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+      const int zp = z + dz - 1;
+      if (zp < 0 || zp >= D) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (x + dx - 1 >= zp) g[dz][dx] += v;
+        if (x + zp < W) h[dz][dx] += d[dz - dx + 2];
+      }
+    }
+  }
+  const size_t ob = ((size_t)b * 9 * Co + co) * HW + pix;
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      gl[ob + (size_t)(dz * 3 + dx) * Co * HW] = g[dz][dx];
+      gr[ob + (size_t)(dz * 3 + dx) * Co * HW] = h[dz][dx];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Soft-argmin: disp = sum_k p_k s_k, p = softmax(alpha * cost)  =>  dcost_k = g * alpha * p_k * (s_k - disp).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void soft_argmin_bwd_kernel(const float* __restrict__ cost, const float* __restrict__ disp,
@@ -579,6 +635,16 @@ extern "C" int dmb_cat_fms_bwd_f32(const float* dvol, float* dL, float* dR, int 
 extern "C" int dmb_dif_fms_bwd_f32(const float* dvol, float* dL, float* dR, int B, int C, int H, int W, int D,
                                    const int* disp_idx_host, void* stream) {
   return launch_volume_bwd<true>(dvol, dL, dR, B, C, H, W, D, disp_idx_host, stream);
+}
+
+extern "C" int dmb_cat_first_wgrad_maps_f32(const float* dc, float* maps_left, float* maps_right, int B, int Co, int D, int H, int W,
+                                            void* stream) {
+  if (!dc || !maps_left || !maps_right || B <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(DMB_EINVAL, "cat_first_wgrad_maps: bad argument");
+  if (B > 65535 || Co > 65535) return fail(DMB_EUNSUPPORTED, "cat_first_wgrad_maps: grid too large");
+  hipLaunchKernelGGL(cat_wgrad_maps_kernel, dim3(cdiv(H * W, 256), Co, B), dim3(256), 0, (hipStream_t)stream, dc, maps_left, maps_right,
+                     Co, D, H, W);
+  return launch_status("cat_first_wgrad_maps launch failed");
 }
 
 extern "C" int dmb_soft_argmin_bwd_f32(const float* cost, const float* disp, const float* grad_disp, float* grad_cost, int B,

@@ -310,10 +310,11 @@ class CatConvUnitFn(torch.autograd.Function):
     """The aggregator's FIRST unit on a concatenation / difference volume of unit disparity step (aggregators/PSMNet.py:31-35 on
     cat_fms.py:7-48, aggregators/StereoNet.py on dif_fms.py:7-46) without the volume in the forward pass: the convolution runs
     in its 2-D form on the two feature maps (csrc/catconv.hip, as the eval path does since round 2 -- a third of the layer's
-    multiplications, no 400 MB volume written and read), BatchNorm / ReLU as in ConvUnitFn.  The backward pass builds the volume
-    (one launch, 0.06 ms at the training crop) for the weight gradient, runs the data gradient as the 3-D convolution it is, and
-    folds it onto the feature maps with the builders' adjoint.  A PSMNet training step at 4 x 256x512: forward of the first unit
-    1.24 -> 0.2 ms, nothing changes in the backward."""
+    multiplications, no 400 MB volume written and read), BatchNorm / ReLU as in ConvUnitFn.  The backward pass does not build the
+    volume either: the weight gradient folds z of dc into 2 x 9 maps per channel and is two 2-D weight gradients against them
+    (ops.cat_first_wgrad); the data gradient -- only when the feature maps want one -- is the 3-D convolution it is, folded onto
+    the maps with the builders' adjoint.  A PSMNet training step at 4 x 256x512: forward of the first unit 1.24 -> 0.2 ms, its
+    weight gradient 1.28 -> 0.2 ms."""
 
     @staticmethod
     def forward(ctx, left, right, weight, bias, gamma, beta, unit, relu, disp_idx, kind):
@@ -341,9 +342,12 @@ class CatConvUnitFn(torch.autograd.Function):
                                               ctx.batch_stats)
         dw = dL = dR = dbias = None
         if ctx.needs_input_grad[2]:
-            vol = ops.cat_fms(left, right, idx) if ctx.kind == "cat" else ops.dif_fms(left, right, idx)
-            dw = ops.conv3d_k3_wgrad(vol, dc)
-            del vol
+            if left.shape[-1] % 4 == 0:
+                dw = ops.cat_first_wgrad(left, right, dc, ctx.kind)      # z folded into 2-D maps: no volume here either
+            else:
+                vol = ops.cat_fms(left, right, idx) if ctx.kind == "cat" else ops.dif_fms(left, right, idx)
+                dw = ops.conv3d_k3_wgrad(vol, dc)
+                del vol
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dvol = ops.conv3d_k3_dgrad(dc, w, 1)
             dL, dR = ops.cat_fms_bwd(dvol, idx) if ctx.kind == "cat" else ops.dif_fms_bwd(dvol, idx)

@@ -1050,6 +1050,25 @@ def _volume_bwd(fn_name, dvol, disp_idx, C):
     return dL, dR
 
 
+def cat_first_wgrad(left, right, dc, kind="cat"):
+    """Weight gradient [Co, 2C (cat) | C (dif), 3, 3, 3] of the first convolution on the volume of cat_fms / dif_fms(left, right) with
+    unit disparity step, from dc [B, Co, D, H, W], without the volume: dmb_cat_first_wgrad_maps_f32 + two 2-D weight gradients."""
+    lib = _lib.load()
+    left, right, dc = _f32c(left, "left"), _f32c(right, "right"), _f32c(dc, "dc")
+    B, Co, D, H, W = dc.shape
+    C = left.shape[1]
+    if tuple(left.shape) != (B, C, H, W) or tuple(right.shape) != (B, C, H, W):
+        raise _lib.DmbLibraryError("cat_first_wgrad: feature maps %s / %s do not belong to dc %s" % (tuple(left.shape), tuple(right.shape), tuple(dc.shape)))
+    maps = torch.empty((2, B, 9 * Co, H, W), dtype=torch.float32, device=dc.device)
+    check(lib.dmb_cat_first_wgrad_maps_f32(dev_ptr(dc), dev_ptr(maps[0]), dev_ptr(maps[1]), B, Co, D, H, W, stream_ptr(dc.device)),
+          "dmb_cat_first_wgrad_maps_f32")
+    dl = conv2d_wgrad(left, maps[0], 3, 1).view(3, 3, Co, C, 3, 3)     # [dz, dx, co, ci, dy', dx']
+    dr = conv2d_wgrad(right, maps[1], 3, 1).view(3, 3, Co, C, 3, 3)
+    wl = torch.diagonal(dl, dim1=1, dim2=5).permute(1, 2, 0, 3, 4)      # tap dx' = dx  -> [co, ci, dz, dy, dx]
+    wr = dr[..., 1].permute(2, 3, 0, 4, 1)                              # no column shift on the right half
+    return (wl - wr).contiguous() if kind == "dif" else torch.cat([wl, wr], 1).contiguous()
+
+
 def cat_fms_bwd(dvol, disp_idx):
     """Gradient of cat_fms w.r.t. (reference_fm, target_fm); dvol [B, 2C, D, H, W]."""
     return _volume_bwd("dmb_cat_fms_bwd_f32", dvol, disp_idx, dvol.shape[1] // 2)

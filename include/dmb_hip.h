@@ -44,7 +44,7 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes (8: dmb_bn_train_fwd_f32, dmb_catconv_pack_weights_f32 and dmb_conv3d_pack_weights_multi_f32 added, dmb_bn_act_bwd_f32 takes the gradient its
+/* ABI version: bumped whenever a signature below changes (8: dmb_bn_train_fwd_f32, dmb_catconv_pack_weights_f32, dmb_conv3d_pack_weights_multi_f32 and dmb_cat_first_wgrad_maps_f32 added, dmb_bn_act_bwd_f32 takes the gradient its
  * skip operand already holds (`dres_acc`); 7: DMB_CONV_SINGLE_CHAIN in the `relu` argument of the convolution
  * entry points, `flags` argument of dmb_conv3d_k3_c1_f32; 6: dmb_stereo_pad_normalize_f32 / _u8 added; 5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
  * optional gradient buffer for per-pixel samples; 4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads entry
@@ -537,6 +537,15 @@ int dmb_bn_act_bwd_f32(const float* dy, const float* c, const float* y, const fl
 /* out[c] = sum_{b, s} a[b, c, s] * g[b, 0, s] (FP64 sums): the weight gradient of a 1x1 convolution with one output channel
  * (second layer of AcfNet's confidence heads, cmn/cmn.py:30).  workspace: dmb_bn_workspace_doubles(C, S) doubles. */
 int dmb_channel_dot_f32(const float* a, const float* g, double* workspace, float* out, int B, int C, long long S, void* stream);
+
+/* Weight gradient of the aggregators' first convolution (aggregators/PSMNet.py:31-33 on cat_fms.py:7-48, d_k = k) WITHOUT the volume
+ * (ABI 8; the backward twin of dmb_catconv_*): one pass over dc [B, Co, D, H, W] folds z into 2 x 9 maps per output channel,
+ *   maps_left [B, 9 Co, H, W] (channel (dz*3 + dx)*Co + co) = sum_z dc[co, z, y, x]               over 0 <= z+dz-1 < D, x+dx-1 >= z+dz-1
+ *   maps_right[B, 9 Co, H, W]                               = sum_z dc[co, z, y, u + z + dz - dx]  over 0 <= z+dz-1 < D, u+z+dz-1 < W
+ * and the layer's weight gradient is two 2-D weight gradients against them (dmb_conv2d_wgrad_f32 with x = the left / right feature
+ * map): dW[co, ci, dz, dy, dx] = dWL[(dz*3+dx)*Co + co, ci, dy, dx], dW[co, C + ci, dz, dy, dx] = dWR[(dz*3+dx)*Co + co, ci, dy, 1]
+ * (a difference volume, dif_fms.py:7-46: dW = the left term minus the right one). */
+int dmb_cat_first_wgrad_maps_f32(const float* dc, float* maps_left, float* maps_right, int B, int Co, int D, int H, int W, void* stream);
 
 /* Backward of the cost-volume builders: dvol [B, 2C (cat) or C (dif), D, H, W] -> dL, dR [B, C, H, W]; sums over the
  * valid columns of every disparity plane (cat_fms.py:36-44), FP32 in ascending plane order. */

@@ -1120,3 +1120,26 @@ def test_fused_optimizer_updates_are_seen(dev):
     with torch.no_grad():
         want, _ = fresh(dict(leftFeature=lf, rightFeature=rf))
     assert torch.equal(d_on, want["disps"][0])
+
+
+@pytest.mark.parametrize("kind", ["cat", "dif"])
+@pytest.mark.parametrize("B,C,Co,D,H,W", [(2, 8, 32, 8, 6, 24), (1, 32, 32, 12, 5, 36), (2, 5, 16, 4, 7, 16), (1, 4, 8, 16, 3, 20)])
+def test_first_unit_weight_gradient_without_the_volume(dev, kind, B, C, Co, D, H, W):
+    """ops.cat_first_wgrad (dmb_cat_first_wgrad_maps_f32 + two 2-D weight gradients) against the 3-D weight gradient on the
+    materialised volume and against torch's CPU autograd of conv3d(cat_fms(L, R)) in FP64: the z fold and the validity masks
+    (volume zero where x < z, zero padding around it, D larger than / close to W) are exact index work, the sums FP32."""
+    ops = _ops()
+    L, R = _rand((B, C, H, W), 101), _rand((B, C, H, W), 102)
+    dc = _rand((B, Co, D, H, W), 103)
+    idx = list(range(D))
+    vol = O.cat_fms(L, R, D, 0, 1) if kind == "cat" else O.dif_fms(L, R, D, 0, 1)
+    w = torch.zeros((Co, vol.shape[1], 3, 3, 3), dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(vol.double(), w, padding=1).backward(dc.double())
+    ref64 = w.grad
+    w32 = torch.zeros((Co, vol.shape[1], 3, 3, 3), requires_grad=True)
+    torch.nn.functional.conv3d(vol, w32, padding=1).backward(dc)
+    got = ops.cat_first_wgrad(L.to(dev), R.to(dev), dc.to(dev), kind)
+    assert got.shape == ref64.shape
+    _close(got.cpu(), ref64, w32.grad, "first-unit weight gradient (%s)" % kind)
+    volg = ops.cat_fms(L.to(dev), R.to(dev), idx) if kind == "cat" else ops.dif_fms(L.to(dev), R.to(dev), idx)
+    _close(ops.conv3d_k3_wgrad(volg, dc.to(dev)).cpu(), ref64, w32.grad, "3-D weight gradient on the volume (%s)" % kind)
