@@ -1,5 +1,5 @@
 """Development aid: the kernels of ONE training step (scripts/train_bench.py) in launch order with durations and gaps, from a
-rocprofv3 --kernel-trace CSV; one step = from one volume_kernel (the cat volume of the forward pass) to the next.
+rocprofv3 --kernel-trace CSV.
     python scripts/train_step_sequence.py DIR/**/trace_kernel_trace.csv"""
 import csv
 import sys
@@ -14,7 +14,10 @@ def short(n):
     return n[:120]
 
 
-starts = [i for i, r in enumerate(rows) if "volume_kernel" in r["Kernel_Name"] and "bwd" not in r["Kernel_Name"]]
+# one step = from one marker launch to the next: the first layer's weight pack (once per forward pass) where the training path runs
+# its first unit without the volume, else the cat volume
+marker = "catconv_pack_kernel" if any("catconv_pack_kernel" in r["Kernel_Name"] for r in rows) else "volume_kernel"
+starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"] and "bwd" not in r["Kernel_Name"]]
 a, b = starts[-3], starts[-2]
 t_first = int(rows[a]["Start_Timestamp"])
 prev_end = None
