@@ -16,6 +16,7 @@ whose forward and backward are HIP kernel launches:
 There is no fallback to torch's convolution backward: without the library these raise like every other op.
 """
 import contextlib
+import threading
 import weakref
 
 import torch
@@ -35,7 +36,7 @@ _CONST = {}
 # takes it as its skip operand (one extra read), the BatchNorm backward as ``dres_acc``.  Same gradients up to the order of
 # the FP32 additions; ``set_gradient_carry(False)`` switches it off (tests/test_train_gpu.py compares the two).
 _carry_enabled = True
-_scopes = []
+_tls = threading.local()      # the open scope's registry belongs to the thread that runs the forward pass
 
 
 def set_gradient_carry(flag):
@@ -43,19 +44,24 @@ def set_gradient_carry(flag):
     _carry_enabled = bool(flag)
 
 
+def _registry():
+    return getattr(_tls, "registry", None)
+
+
 @contextlib.contextmanager
 def carry_scope():
     """One forward pass of a model / aggregator.  The registry maps id(tensor) -> (tensor, its latest alias) and lives exactly as
     long as the scope (a tensor object the caller re-uses across steps must never meet an alias of an earlier graph); nested
-    scopes share the outermost registry."""
-    if _scopes:
+    scopes share the outermost registry; one registry per thread."""
+    if _registry() is not None:
         yield
         return
-    _scopes.append({})
+    _tls.registry = {}
     try:
         yield
     finally:
-        _scopes.pop().clear()
+        _tls.registry.clear()
+        _tls.registry = None
 
 
 def _latest(reg, t):
@@ -68,9 +74,9 @@ def _latest(reg, t):
 
 def _carry_plan(x, skip):
     """(registry or None, x, skip, carry_x, carry_skip) for a unit about to consume x (and skip)."""
-    if not (_scopes and _carry_enabled and torch.is_grad_enabled()):
+    reg = _registry()
+    if reg is None or not _carry_enabled or not torch.is_grad_enabled():
         return None, x, skip, False, False
-    reg = _scopes[0]
     x = _latest(reg, x)
     if skip is not None:
         skip = _latest(reg, skip)

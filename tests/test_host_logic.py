@@ -555,3 +555,45 @@ def test_imread_keeps_16_bit_disparity_pngs(tmp_path):
     rgb = (np.arange(36, dtype=np.uint8).reshape(3, 4, 3))
     Image.fromarray(rgb).save(str(tmp_path / "c.png"))
     assert np.array_equal(imread(str(tmp_path / "c.png")), rgb)
+
+
+def test_gradient_carry_scope_bookkeeping():
+    """train_fn's carry scope without any kernel: the registry exists only inside a scope, nested scopes share it, the latest alias
+    of a tensor is found through the chain, only gradient-requiring contiguous FP32 tensors are carried, a second thread has its
+    own (no) scope, and leaving the scope drops every reference."""
+    import threading
+    from densematchingbenchmark_amd.modeling.stereo.layers import train_fn
+    x = torch.randn(2, 3, requires_grad=True)
+    plain = torch.randn(2, 3)
+    assert train_fn._carry_plan(x, None) == (None, x, None, False, False)          # no scope: nothing is carried
+    with train_fn.carry_scope():
+        reg = train_fn._registry()
+        assert reg == {}
+        with train_fn.carry_scope():
+            assert train_fn._registry() is reg                                       # nested: the outermost registry
+        assert train_fn._registry() is reg
+        r, x1, s1, cx, cs = train_fn._carry_plan(x, plain)
+        assert r is reg and x1 is x and s1 is plain and cx and not cs               # a skip without gradient is not carried
+        a1 = x.view_as(x)
+        reg[id(x)] = (x, a1)
+        a2 = a1.view_as(a1)
+        reg[id(a1)] = (a1, a2)
+        assert train_fn._latest(reg, x) is a2 and train_fn._latest(reg, a1) is a2    # consumers chain onto the latest alias
+        r, x2, s2, cx, cs = train_fn._carry_plan(plain, x)
+        assert x2 is plain and s2 is a2 and not cx and cs
+        r, x3, s3, cx, cs = train_fn._carry_plan(x, x)
+        assert x3 is a2 and s3 is a2 and cx and not cs                               # the same tensor twice: carried once
+        assert train_fn._carry_plan(x.t(), None)[3] is False                         # not contiguous: not carried
+        with torch.no_grad():
+            assert train_fn._carry_plan(x, None)[0] is None
+        train_fn.set_gradient_carry(False)
+        try:
+            assert train_fn._carry_plan(x, None)[0] is None
+        finally:
+            train_fn.set_gradient_carry(True)
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(train_fn._registry()))
+        t.start()
+        t.join()
+        assert seen == [None]
+    assert train_fn._registry() is None and reg == {}
