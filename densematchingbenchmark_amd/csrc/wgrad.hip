@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s1_kernel(const float* __
 // Staging units are linear in LDS across channels (the unit count per channel is made odd: pitch = 4 mod 8 floats), so one LDS-DMA
 // instruction moves 64 units whatever the plane size.
 // ------------------------------------------------------------------------------------------------------------------
+// (round 6) The tile is a parameter: 2 x 12 (84 MFMAs per wave between two barriers) or 4 x 8 (112; and 64-column rows -- the
+// training crops -- tile exactly where 12-column tiles compute 72); dmb_conv3d_k3s2_wgrad_f32 picks per launch.
+template <int TY_, int TX_>
 struct Wg2Cfg {
-  static constexpr int TY = 2, TX = 12, ROWS = 2 * TY + 1, XOFF = 3;
+  static constexpr int TY = TY_, TX = TX_, ROWS = 2 * TY + 1, XOFF = 3;
   static constexpr int P = (4 + 2 * TX + 3) / 4 * 4;            // staged row of the big tile: aligned column 2 x0 - 4 ..
   static constexpr int UBU = ROWS * P / 4, USU = TY * TX / 4;   // 16-byte units per channel plane ...
   static constexpr int UB = UBU | 1, US = USU | 1;              // ... padded to an odd count (pitch = 4 mod 8 floats)
@@ -216,15 +219,14 @@ struct Wg2Cfg {
   static constexpr int KSTEPS = TY * TX / 2;
   static constexpr int NTAPW = 7;
   static constexpr int IB = (32 * UB + 255) / 256, IS = (32 * US + 255) / 256;   // copy instructions per wave and plane
-  static_assert(SB % 8 == 4 && SS % 8 == 4 && LDS_FLOATS * 4 <= 160 * 1024 && 2 * IB + IS <= KSTEPS, "tile");
+  static_assert(SB % 8 == 4 && SS % 8 == 4 && LDS_FLOATS * 4 <= 160 * 1024 && 2 * IB + IS <= KSTEPS && TX % 4 == 0, "tile");
 };
 
-template <bool V16>
+template <class C, bool V16>
 __global__ __launch_bounds__(256, 1) void conv3d_wgrad_s2_kernel(const float* __restrict__ sm, const float* __restrict__ bg,
                                                                  float* __restrict__ ws, int B, int Cs, int Cb, int Ds, int Hs,
                                                                  int Ws, int Db, int Hb, int Wb, int ntx, int nty, int nzs,
                                                                  int zseg) {
-  typedef Wg2Cfg C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ring = lds;
   float* sbuf = lds + C::NRING * C::BPLANE;
@@ -634,6 +636,8 @@ extern "C" int dmb_conv3d_k3_wgrad_f32(const float* x, const float* dc, float* d
   return launch_status("conv3d_wgrad reduce launch failed");
 }
 
+constexpr double WG2_EFF_4x8 = 1.1;   // rate of the 4 x 8 tile relative to 2 x 12 on shapes both tile exactly (calibrated below)
+
 extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, float* dw, float* workspace, int B, int Cs, int Cb,
                                          int Ds, int Hs, int Ws, int Db, int Hb, int Wb, void* stream) {
   if (!small || !big || !dw || !workspace || B <= 0 || Cs <= 0 || Cb <= 0 || Ds <= 0 || Hs <= 0 || Ws <= 0)
@@ -644,32 +648,50 @@ extern "C" int dmb_conv3d_k3s2_wgrad_f32(const float* small, const float* big, f
   const bool v16 = Ws % 4 == 0 && Wb % 4 == 0 && (((uintptr_t)small | (uintptr_t)big) & 15) == 0;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = cdiv(Cs, 32) * cdiv(Cb, 32);
-  const int ntx = cdiv(Ws, Wg2Cfg::TX), nty = cdiv(Hs, Wg2Cfg::TY);
   const int nslots = wgrad_slots_per_block(Cs, Cb);
-  int zseg = Ds;
-  {
+  // z segments and the launch's cost for a tile shape: rounds of items on the slots x (planes per item + prologue) x the tile's
+  // k-steps, over what the tile reaches between its barriers (4 x 8: 112 MFMAs per wave and barrier against 84; measured at the
+  // training crop, profiles/r06_wgrad_s2_tiles.log)
+  auto plan = [&](int TY, int TX, double eff, int& zseg_out) {
+    const int ntx_ = cdiv(Ws, TX), nty_ = cdiv(Hs, TY);
     double best = 1e30;
+    int zseg_ = Ds;
     for (int nz = 1; nz <= Ds; ++nz) {
       const int zs = cdiv(Ds, nz);
       if (zs < 4 && nz > 1) break;
-      const double cost = (double)cdiv_ll((long long)B * ntx * nty * cdiv(Ds, zs), nslots) * (zs + 1.0);
+      const double cost = (double)cdiv_ll((long long)B * ntx_ * nty_ * cdiv(Ds, zs), nslots) * (zs + 1.0);
       if (cost < best - 1e-9) {
         best = cost;
-        zseg = zs;
+        zseg_ = zs;
       }
     }
-  }
+    zseg_out = zseg_;
+    return best * (TY * TX) / eff;
+  };
+  int zseg_a, zseg_b;
+  const double cost_a = plan(2, 12, 1.0, zseg_a), cost_b = plan(4, 8, WG2_EFF_4x8, zseg_b);
+  bool wide = cost_b < cost_a;            // the 4 x 8 tile
+  if (DMB_OPT(27) == 1) wide = false;     // (development build: force a tile)
+  if (DMB_OPT(27) == 2) wide = true;
+  const int zseg = wide ? zseg_b : zseg_a;
+  const int ntx = cdiv(Ws, wide ? 8 : 12), nty = cdiv(Hs, wide ? 4 : 2);
   const int nzs = cdiv(Ds, zseg);
-  DMB_ENSURE_LDS((&conv3d_wgrad_s2_kernel<true>), (size_t)(Wg2Cfg::LDS_FLOATS * 4));
-  DMB_ENSURE_LDS((&conv3d_wgrad_s2_kernel<false>), (size_t)(Wg2Cfg::LDS_FLOATS * 4));
   const long long items2 = (long long)B * ntx * nty * nzs;
   const int nused = (int)(items2 < nslots ? items2 : nslots);
-  if (v16)
-    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<true>, dim3((unsigned)nused, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
-                       workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
-  else
-    hipLaunchKernelGGL(conv3d_wgrad_s2_kernel<false>, dim3((unsigned)nused, (unsigned)nblk), dim3(256), Wg2Cfg::LDS_FLOATS * 4, st, small, big,
-                       workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);
+#define DMB_WG2(CFG, V)                                                                                                                  \
+  do {                                                                                                                                  \
+    DMB_ENSURE_LDS((&conv3d_wgrad_s2_kernel<CFG, V>), (size_t)(CFG::LDS_FLOATS * 4));                                                    \
+    hipLaunchKernelGGL((conv3d_wgrad_s2_kernel<CFG, V>), dim3((unsigned)nused, (unsigned)nblk), dim3(256), CFG::LDS_FLOATS * 4, st, small, \
+                       big, workspace, B, Cs, Cb, Ds, Hs, Ws, Db, Hb, Wb, ntx, nty, nzs, zseg);                                         \
+  } while (0)
+  typedef Wg2Cfg<2, 12> WgA;
+  typedef Wg2Cfg<4, 8> WgB;
+  if (wide) {
+    if (v16) DMB_WG2(WgB, true); else DMB_WG2(WgB, false);
+  } else {
+    if (v16) DMB_WG2(WgA, true); else DMB_WG2(WgA, false);
+  }
+#undef DMB_WG2
   int rc = launch_status("conv3d_s2_wgrad launch failed");
   if (rc != DMB_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk * 27 * 16), dim3(256), 0, st, workspace, dw, Cs, Cb, nused, 0);

@@ -12,7 +12,7 @@ model = build_model(cfg, backbone=None).to(dev)
 synthetic.init_params_(model, seed=0, classif_gain=1.0)
 model.train()
 flat = FlatGradients(model)
-opt = torch.optim.Adam(flat.params, lr=1e-3)
+opt = torch.optim.Adam(flat.params, lr=1e-3, fused=os.environ.get("FUSED", "0") == "1")
 g = torch.Generator().manual_seed(3)
 B, H, W = 2, 256, 512
 lf = torch.randn((B, 32, H // 4, W // 4), generator=g).to(dev)

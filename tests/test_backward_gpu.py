@@ -1143,3 +1143,30 @@ def test_first_unit_weight_gradient_without_the_volume(dev, kind, B, C, Co, D, H
     _close(got.cpu(), ref64, w32.grad, "first-unit weight gradient (%s)" % kind)
     volg = ops.cat_fms(L.to(dev), R.to(dev), idx) if kind == "cat" else ops.dif_fms(L.to(dev), R.to(dev), idx)
     _close(ops.conv3d_k3_wgrad(volg, dc.to(dev)).cpu(), ref64, w32.grad, "3-D weight gradient on the volume (%s)" % kind)
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_s2_weight_gradient_tiles_at_crop_sized_volumes(dev, transposed):
+    """dmb_conv3d_k3s2_wgrad_f32 picks its tile per launch (round 6: 2 x 12 or 4 x 8 voxels of the small tensor).  A volume with
+    64-column rows and several rounds of items takes the 4 x 8 tile (checked by kernel name), one with 60-column rows the 2 x 12
+    tile; both against torch's FP64 autograd evaluated on the GPU (checker only; the CPU oracle would take minutes at this size),
+    within the tolerance an FP32 sum over 260 k voxels is held to elsewhere in this file."""
+    ops = _ops()
+    import torch.nn.functional as F
+    for Ws, want in ((64, "Wg2Cfg<4, 8>"), (60, "Wg2Cfg<2, 12>")):
+        big = _rand((2, 32, 16, 64, 2 * Ws), 111).to(dev)
+        small = _rand((2, 64, 8, 32, Ws), 112).to(dev)
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            got = ops.deconv3d_k3s2_wgrad(small, big) if transposed else ops.conv3d_k3s2_wgrad(big, small)
+            torch.cuda.synchronize()
+        names = [e.key for e in prof.key_averages() if "conv3d_wgrad_s2_kernel" in e.key]
+        assert len(names) == 1 and want in names[0], names
+        if transposed:     # ConvTranspose3d(64 -> 32): x = small, dy = big, weight [64, 32, 27]
+            w = torch.zeros((64, 32, 3, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+            F.conv_transpose3d(small.double(), w, stride=2, padding=1, output_padding=1).backward(big.double())
+        else:              # Conv3d(32 -> 64, stride 2): x = big, dc = small, weight [64, 32, 27]
+            w = torch.zeros((64, 32, 3, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+            F.conv3d(big.double(), w, stride=2, padding=1).backward(small.double())
+        ref = w.grad
+        scale = ref.abs().max().item()
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * scale, (Ws, transposed)
