@@ -1148,14 +1148,14 @@ def test_first_unit_weight_gradient_without_the_volume(dev, kind, B, C, Co, D, H
 @pytest.mark.parametrize("transposed", [False, True])
 def test_s2_weight_gradient_tiles_at_crop_sized_volumes(dev, transposed):
     """dmb_conv3d_k3s2_wgrad_f32 picks its tile per launch (round 6: 2 x 12 or 4 x 8 voxels of the small tensor).  A volume with
-    64-column rows and several rounds of items takes the 4 x 8 tile (checked by kernel name), one with 60-column rows the 2 x 12
+    64-column rows and several rounds of items takes the 4 x 8 tile (checked by kernel name), a launch of a single round the 2 x 12
     tile; both against torch's FP64 autograd evaluated on the GPU (checker only; the CPU oracle would take minutes at this size),
     within the tolerance an FP32 sum over 260 k voxels is held to elsewhere in this file."""
     ops = _ops()
     import torch.nn.functional as F
-    for Ws, want in ((64, "Wg2Cfg<4, 8>"), (60, "Wg2Cfg<2, 12>")):
-        big = _rand((2, 32, 16, 64, 2 * Ws), 111).to(dev)
-        small = _rand((2, 64, 8, 32, Ws), 112).to(dev)
+    for (Ds, Hs, Ws), want in (((8, 32, 64), "Wg2Cfg<4, 8>"), ((4, 8, 24), "Wg2Cfg<2, 12>")):
+        big = _rand((2, 32, 2 * Ds, 2 * Hs, 2 * Ws), 111).to(dev)
+        small = _rand((2, 64, Ds, Hs, Ws), 112).to(dev)
         with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
             got = ops.deconv3d_k3s2_wgrad(small, big) if transposed else ops.conv3d_k3s2_wgrad(big, small)
             torch.cuda.synchronize()
