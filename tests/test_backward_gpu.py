@@ -170,7 +170,12 @@ def test_soft_argmin_backward(dev, B, D, H, W, alpha):
     assert (got.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("lo,scale", [((6, 5, 9), 4), ((4, 7, 12), 4), ((8, 4, 6), 2), ((5, 3, 4), 1)])
+@pytest.mark.parametrize("lo,scale", [((6, 5, 9), 4), ((4, 7, 12), 4), ((8, 4, 6), 2), ((5, 3, 4), 1),
+                                      # (round 6) the row-group form of the (y, x) contraction: rows not a multiple of its groups of 8,
+                                      # more than 256 columns (two column passes), a width that does not divide 256, two row lanes
+                                      ((3, 9, 40), 4), ((2, 5, 300), 2), ((2, 17, 24), 3), ((4, 20, 96), 4),
+                                      # ... and a window of more than 16 columns (6x): the one-thread-per-voxel form
+                                      ((2, 4, 6), 6)])
 def test_upsample_regression_backward(dev, lo, scale):
     """d disp / d low-resolution cost through F.interpolate(trilinear, align_corners=True) + softmax regression."""
     import torch.nn.functional as F
