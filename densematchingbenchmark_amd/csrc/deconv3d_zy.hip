@@ -539,6 +539,13 @@ int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const f
   if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;
   // 28-column tiles where they compute fewer columns than 60-column ones (80 input columns: 96 against 128)
   const bool narrow = cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
+  // (round 6) A 64-channel launch of about one item per workgroup slot (conv5 of one 544x960 pair: 816 items of weight 1 .. 4 on
+  // 768 slots) is faster on deconv3d_kernel's items with both y parities: 0.099 -> 0.069 ms at [1, 64, 12, 34, 60]; equal at the
+  // KITTI shape and from two pairs on (scripts/kbench_hg.py, KB_B = 1 / 2).  Same arithmetic, bit-identical results.
+  if (Co == 64 && Wout == 2 * W && !DMB_OPT(28)) {   // (development option 28: keep the work-queue form)
+    const long long items = 4LL * B * cdiv(W, narrow ? 28 : 60) * H * cdiv(D, 2);
+    if (4 * items <= 5LL * 3 * num_cus()) return -1;
+  }
   if (Co == 32)
     return narrow ? launch_zy<ZYCfg<32, 1>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st)
                   : launch_zy<ZYCfg<32, 2>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
