@@ -88,6 +88,9 @@ SIGNATURES = {
     "dmb_channel_dot_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_conv3d_pack_weights_multi_f32": (_c_int, [_P, _c_int, _P]),
     "dmb_cat_first_wgrad_maps_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
+    "dmb_conv3d_k3_bnstats_partials": (_c_ll, [_c_int] * 6),
+    "dmb_conv3d_k3_bnstats_f32": (_c_int, [_P] * 4 + [_c_int] * 6 + [_P]),
+    "dmb_bn_train_act_f32": (_c_int, [_P, _P, _c_int] + [_P] * 5 + [_c_float, _c_float] + [_P] * 6 + [_c_int, _c_int, _c_ll, _c_int, _P]),
     "dmb_bn_workspace_doubles": (_c_ll, [_c_int, _c_ll]),
     "dmb_bn_train_stats_f32": (_c_int, [_P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _P]),
     "dmb_bn_act_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_ll, _c_int, _P]),

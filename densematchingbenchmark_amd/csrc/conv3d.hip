@@ -232,12 +232,18 @@ __device__ __forceinline__ void store_tile(const f32x16 (&a)[VEC], const float (
 // branch that meant spills -- a scratch segment -- for EVERY launch of the kernel, and a kernel with a scratch segment costs
 // about 6 us of dispatch gap on either side of each launch (five of the six 32 -> 32 launches of a PSMNet step carry no
 // residual).
-template <class C, bool WITH_RES>
+// STATS (round 6, row-pair tiles of the training path): the epilogue also sums the RAW convolution outputs of its tile and their
+// squares per channel -- FP64 per lane, the eight lanes of a channel by a fixed butterfly, the four waves in ascending order -- and
+// writes one partial pair per workgroup and channel to stats[(ch * gridDim.x + blockIdx.x) * 2 + {0, 1}]: the batch statistics of
+// the BatchNorm that follows (layers/basic_layers.py:68-83 under train()) without the pass over the output that
+// dmb_bn_train_stats_f32 makes.  A separate instantiation: the inference kernels do not change.
+template <class C, bool WITH_RES, bool STATS = false>
 __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ res, float* __restrict__ y, int Ci,
-                                                           int D, int H, int W, int ntx, int nty, int ntz, int relu) {
+                                                           int D, int H, int W, int ntx, int nty, int ntz, int relu,
+                                                           double* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // development build only (DMB_DBG is the constant 0 in the release build: these branches do not exist there) -- diagnostics
   // (option 6): 1 = no stores, 2 = no staging after the first chunk, 32 = no barrier in the chunk loop; option 14: start-up stagger
@@ -421,6 +427,12 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
       // set, so the register peak stays where the first tile puts it (96 accumulators + 2 sets).
       unsigned off0[C::MT];
       u32x4 rv[3][4];
+      double ssum[STATS ? 4 : 1], ssq[STATS ? 4 : 1];   // this lane's channels k * 8 + (lane >> 3)
+      (void)ssum, (void)ssq;
+      if constexpr (STATS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ssum[k] = ssq[k] = 0.0;
+      }
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt) off0[mt] = 0;
       off0[0] = offset0(0);
@@ -441,6 +453,12 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float4 v = *reinterpret_cast<const float4*>(my + (k * 8 + (lane >> 3)) * C::TR_PITCH + px);
+          if constexpr (STATS) {   // four voxels of one channel: FP32 inside the word, FP64 across words
+            if (off0[mt] != DMA_OOB) {
+              ssum[k] += (double)((v.x + v.y) + (v.z + v.w));
+              ssq[k] += (double)fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+            }
+          }
           v.x = fmaxf(fmaf(v.x, sc4[k], sh4[k]), lo2);
           v.y = fmaxf(fmaf(v.y, sc4[k], sh4[k]), lo2);
           v.z = fmaxf(fmaf(v.z, sc4[k], sh4[k]), lo2);
@@ -457,6 +475,29 @@ __global__ __launch_bounds__(256, C::WPE) void conv3d_s1_kernel(const float* __r
           o.z = __float_as_uint(fmaxf(v.z, lo));
           o.w = __float_as_uint(fmaxf(v.w, lo));
           __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(off0[mt] + k * kstep), 0, 0);   // (streaming stores: step +0.3 %)
+        }
+      }
+      if constexpr (STATS) {
+        // the eight lanes of a channel (lane & 7), then the four waves (z-slices) through LDS behind the transposition scratch
+        static_assert(C::NT == 1 && C::LDS_FLOATS >= 4 * 32 * C::TR_PITCH + 4 * 32 * 4, "statistics scratch");
+        double* sred = reinterpret_cast<double*>(lds + 4 * 32 * C::TR_PITCH);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            ssum[k] += __shfl_xor(ssum[k], o, 64);
+            ssq[k] += __shfl_xor(ssq[k], o, 64);
+          }
+          if ((lane & 7) == 0) {
+            sred[(wave * 32 + k * 8 + (lane >> 3)) * 2] = ssum[k];
+            sred[(wave * 32 + k * 8 + (lane >> 3)) * 2 + 1] = ssq[k];
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+          const int ch = threadIdx.x >> 1, st = threadIdx.x & 1;
+          const double tot = ((sred[(0 * 32 + ch) * 2 + st] + sred[(1 * 32 + ch) * 2 + st]) + sred[(2 * 32 + ch) * 2 + st]) + sred[(3 * 32 + ch) * 2 + st];
+          stats[((size_t)(wn * 32 + ch) * gridDim.x + blockIdx.x) * 2 + st] = tot;
         }
       }
     };
@@ -1638,13 +1679,26 @@ static int launch_s1(const float* x, const float* wp, const float* scale, const 
   if (res) {
     DMB_ENSURE_LDS((&conv3d_s1_kernel<C, true>), (size_t)(lds));
     hipLaunchKernelGGL((conv3d_s1_kernel<C, true>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
-                       H, W, ntx, nty, ntz, relu);
+                       H, W, ntx, nty, ntz, relu, (double*)nullptr);
   } else {
     DMB_ENSURE_LDS((&conv3d_s1_kernel<C, false>), (size_t)(lds));
     hipLaunchKernelGGL((conv3d_s1_kernel<C, false>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, scale, shift, res, y, Ci, D,
-                       H, W, ntx, nty, ntz, relu);
+                       H, W, ntx, nty, ntz, relu, (double*)nullptr);
   }
   return launch_status("conv3d stride-1 launch failed");
+}
+
+// The raw convolution (no affine, skip or ReLU) with the per-workgroup channel sums of its output (conv3d_s1_kernel, STATS).
+template <class C>
+static int launch_s1_stats(const float* x, const float* wp, float* y, double* stats, int B, int Ci, int D, int H, int W, hipStream_t st) {
+  const int ntx = cdiv(W, C::TX), nty = cdiv(H, C::TY), ntz = cdiv(D, C::TZ);
+  const long long nblk = (long long)B * ntx * nty * ntz;
+  if (nblk > 0x7fffffffLL) return fail(DMB_EUNSUPPORTED, "conv3d: grid too large");
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  DMB_ENSURE_LDS((&conv3d_s1_kernel<C, false, true>), (size_t)(lds));
+  hipLaunchKernelGGL((conv3d_s1_kernel<C, false, true>), dim3((unsigned)nblk), dim3(256), lds, st, x, wp, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, y, Ci, D, H, W, ntx, nty, ntz, 0, stats);
+  return launch_status("conv3d stride-1 (+ statistics) launch failed");
 }
 
 template <class C>
@@ -1769,6 +1823,25 @@ static int flat_tx(int W) {
   return e52 > e60 ? 52 : 60;
 }
 
+// The 32-channel row-pair / row-quad tiles of the vector path: 0 = 48 x 4, 1 = 24 x 8, 2 = 32 x 4, 3 = 32 x 2
+static int s1_pick32(int B, int D, int H, int W) {
+  // row pairs (16 columns x 2 rows per 32-voxel column tile) of 48 or 32 columns x 4 rows, row quads (8 x 4) of 24 columns x 8
+  // rows; one z-slice per wave, three workgroups per CU each
+  // (8-row quads stage a quarter more halo rows per byte of output and store 32-byte instead of 64-byte runs: 0.972)
+  static const S1Tile cand[4] = {{48, 4, 4, 6, 3, false, 1.0}, {24, 8, 4, 6, 3, false, 0.972}, {32, 4, 4, 4, 3, false, 1.0},
+                                 {32, 2, 4, 2, 3, false, S1_EFF_32x2}};
+  const bool ok[4] = {true, true, true, true};
+  int pick = s1_pick(cand, ok, 4, B, D, H, W);
+  // (round 6) a launch of at most ONE 32 x 4 workgroup per CU: two 32 x 2 workgroups per CU instead, so that one's prologue and
+  // epilogue fall under the other's multiply phase ([1, 32, 16, 64, 128]: 57.6 -> 55.7 us, profiles/r06_sk_probe_midsizes.log)
+  if (pick == 2 && DMB_OPT(19) == 0 && (long long)B * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 32) <= num_cus()) pick = 3;
+  return pick;
+}
+static long long s1_blocks32(int pick, int B, int D, int H, int W) {
+  static const int tx[4] = {48, 24, 32, 32}, ty[4] = {4, 8, 4, 2};
+  return (long long)B * cdiv(W, tx[pick]) * cdiv(H, ty[pick]) * cdiv(D, 4);
+}
+
 // ---- Which launches take the split-K form (csrc/conv3d_sk.hip): 0 = none, else its variant --------------------------------
 // A full-grid kernel gives one wave the whole chain of 27 Ci / 2 MFMAs of a tile, in chunks of two channels behind a barrier each:
 // with fewer tile chains than SIMDs a launch costs ~1 us per chunk whatever its arithmetic (31-35 us for 64 channels).  Split-K
@@ -1825,17 +1898,7 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
       if (vec && DMB_OPT(19) == 9) return launch_s1<S1Cfg<0, 32, 2, 32, 4, 1, 1, 16, 0>>(x, wpack, scale, shift, residual, y, B, Ci, D, H, W, relu_s1, st);
 #endif
       if (vec) {
-        // row pairs (16 columns x 2 rows per 32-voxel column tile) of 48 or 32 columns x 4 rows, row quads (8 x 4) of 24 columns x 8
-        // rows; one z-slice per wave, three workgroups per CU each
-        // (8-row quads stage a quarter more halo rows per byte of output and store 32-byte instead of 64-byte runs: 0.972)
-        static const S1Tile cand[4] = {{48, 4, 4, 6, 3, false, 1.0}, {24, 8, 4, 6, 3, false, 0.972}, {32, 4, 4, 4, 3, false, 1.0},
-                                       {32, 2, 4, 2, 3, false, S1_EFF_32x2}};
-        const bool ok[4] = {true, true, true, true};
-        int pick = s1_pick(cand, ok, 4, B, D, H, W);
-        // (round 6) a launch of at most ONE 32 x 4 workgroup per CU: two 32 x 2 workgroups per CU instead, so that one's prologue and
-        // epilogue fall under the other's multiply phase ([1, 32, 16, 64, 128]: 57.6 -> 55.7 us, profiles/r06_sk_probe_midsizes.log)
-        if (pick == 2 && DMB_OPT(19) == 0 && (long long)B * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 32) <= num_cus()) pick = 3;
-        switch (pick) {
+        switch (s1_pick32(B, D, H, W)) {
           case 0: return DMB_S1(32, 4, 48, 1, 16, 0);
           case 1: return DMB_S1(32, 8, 24, 1, 8, 40);
           case 2: return DMB_S1(32, 4, 32, 1, 16, 0);
@@ -1925,6 +1988,29 @@ extern "C" int dmb_conv3d_k3_f32(const float* x, const float* wpack, const float
   }
 #undef DMB_S1
   return fail(DMB_EUNSUPPORTED, "conv3d: output channels must be 32 or 64 (or 1: dmb_conv3d_k3_c1_f32), stride 1 or 2");
+}
+
+// Raw stride-1 convolution Ci -> 32 + the batch statistics' partial sums (training path).  Applies to the vector path only.
+static bool s1_stats_applicable(const float* x, const float* y, int B, int Ci, int Co, int D, int H, int W) {
+  return Co == 32 && Ci > 0 && W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (long long)Co * D * H * W * 4 < 0x7fffffffLL &&
+         (long long)8 * D * H * W * 4 < 0x7fffffffLL && DMB_OPT(2) == 0;
+}
+extern "C" long long dmb_conv3d_k3_bnstats_partials(int B, int Ci, int Co, int D, int H, int W) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || Co != 32 || Ci <= 0 || W % 4 != 0) return 0;
+  if ((long long)Co * D * H * W * 4 >= 0x7fffffffLL || (long long)8 * D * H * W * 4 >= 0x7fffffffLL) return 0;
+  return s1_blocks32(s1_pick32(B, D, H, W), B, D, H, W);
+}
+extern "C" int dmb_conv3d_k3_bnstats_f32(const float* x, const float* wpack, float* y, double* stats, int B, int Ci, int Co, int D, int H,
+                                         int W, void* stream) {
+  if (!x || !wpack || !y || !stats || B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(DMB_EINVAL, "conv3d_bnstats: bad argument");
+  if (!s1_stats_applicable(x, y, B, Ci, Co, D, H, W)) return fail(DMB_EUNSUPPORTED, "conv3d_bnstats: 32 output channels, 16-byte rows");
+  hipStream_t st = (hipStream_t)stream;
+  switch (s1_pick32(B, D, H, W)) {
+    case 0: return launch_s1_stats<S1Cfg<0, 32, 4, 48, 2, 1, 1, 16, 0>>(x, wpack, y, stats, B, Ci, D, H, W, st);
+    case 1: return launch_s1_stats<S1Cfg<0, 32, 8, 24, 2, 1, 1, 8, 40>>(x, wpack, y, stats, B, Ci, D, H, W, st);
+    case 2: return launch_s1_stats<S1Cfg<0, 32, 4, 32, 2, 1, 1, 16, 0>>(x, wpack, y, stats, B, Ci, D, H, W, st);
+    default: return launch_s1_stats<S1Cfg<0, 32, 2, 32, 2, 1, 1, 16, 0>>(x, wpack, y, stats, B, Ci, D, H, W, st);
+  }
 }
 
 // Split-K form of the transposed convolution (csrc/conv3d_sk.hip): 0 = no, else its variant.  Units: input-resolution tiles.

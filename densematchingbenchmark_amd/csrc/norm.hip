@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NB) void bn_act_train_kernel(const float* __restric
                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                           float* __restrict__ scale_out, float* __restrict__ shift_out,
                                                           const float* __restrict__ res, float* __restrict__ y, int B, int C,
-                                                          long long S, int nsplit, int nact, int relu, int vec) {
+                                                          long long S, int nsplit, int nact, int relu, int vec, int pivot_free) {
   __shared__ double tot[2];
   const int ch = blockIdx.y, s = blockIdx.x;
   double sum, sq;
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(NB) void bn_act_train_kernel(const float* __restric
   const double dm = sum / n;                      // mean - pivot
   double var = sq / n - dm * dm;
   if (var < 0.0) var = 0.0;
-  const double mean = (double)c[(long long)ch * S] + dm;
+  // pivot_free: the partial sums come from a convolution's epilogue (conv3d_s1_kernel, STATS: FP64 sums of the raw values and
+  // their squares, no pivot -- E[x^2] - mean^2 in FP64 loses nothing an FP32 tensor could show until |mean| / std ~ 1e4)
+  const double mean = (pivot_free ? 0.0 : (double)c[(long long)ch * S]) + dm;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[ch] : 1.f, bta = beta ? beta[ch] : 0.f;
   const float sc = g * invstd;
@@ -430,8 +432,23 @@ extern "C" int dmb_bn_train_fwd_f32(const float* c, const float* gamma, const fl
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nsplit, C), dim3(NB), 0, st, c, workspace, B, C, S, nsplit, vec);
   hipLaunchKernelGGL(bn_act_train_kernel, dim3(nact, C), dim3(NB), 0, st, c, workspace, gamma, beta, running_mean, running_var,
                      num_batches_tracked, momentum, eps, mean_out, invstd_out, scale_out, shift_out, residual, y, B, C, S, nsplit, nact,
-                     relu, vec);
+                     relu, vec, 0);
   return launch_status("bn_train_fwd launch failed");
+}
+
+extern "C" int dmb_bn_train_act_f32(const float* c, const double* partials, int nparts, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                    float* mean_out, float* invstd_out, float* scale_out, float* shift_out, const float* residual,
+                                    float* y, int B, int C, long long S, int relu, void* stream) {
+  if (!c || !partials || nparts <= 0 || !mean_out || !invstd_out || !scale_out || !shift_out || !y || B <= 0 || C <= 0 || S <= 0 ||
+      relu < 0 || relu > 2)
+    return fail(DMB_EINVAL, "bn_train_act: bad argument");
+  const int nact = bn_nact(C, S);
+  const int vec = S % 4 == 0 && (((uintptr_t)c | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+  hipLaunchKernelGGL(bn_act_train_kernel, dim3(nact, C), dim3(NB), 0, (hipStream_t)stream, c, partials, gamma, beta, running_mean,
+                     running_var, num_batches_tracked, momentum, eps, mean_out, invstd_out, scale_out, shift_out, residual, y, B, C, S,
+                     nparts, nact, relu, vec, 1);
+  return launch_status("bn_train_act launch failed");
 }
 
 extern "C" int dmb_bn_act_f32(const float* c, const float* scale, const float* shift, const float* residual, float* y, int B,

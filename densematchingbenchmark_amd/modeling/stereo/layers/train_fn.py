@@ -194,7 +194,16 @@ def _conv_raw(unit, x, wpack, bias):
     return ops.conv3d_k3(x, wpack, Co, scale, shift, None, unit.stride, False)
 
 
-def _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, device):
+_epilogue_stats = True
+
+
+def set_epilogue_stats(flag):
+    """False: the batch statistics always take their own pass over the raw output (A/B and tests)."""
+    global _epilogue_stats
+    _epilogue_stats = bool(flag)
+
+
+def _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, device, partials=None):
     """BatchNorm (+ skip, + ReLU) of a unit's raw convolution output -> (y, mean, invstd, scale, shift, batch_stats).  A
     batch-statistics BatchNorm takes the two-launch form (ops.bn_train_fwd: block sums, then one kernel that finishes the
     statistics, updates the running buffers and the batch counter and normalises); running statistics / no BatchNorm: bn_act."""
@@ -207,11 +216,13 @@ def _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, device):
         if nbt is not None and nbt.device != raw.device:
             nbt += 1
             nbt = None
-        y, mean, invstd, scale, shift = ops.bn_train_fwd(raw, gamma.detach() if gamma is not None else None,
-                                                         beta.detach() if beta is not None else None,
-                                                         bn.running_mean if bn.track_running_stats else None,
-                                                         bn.running_var if bn.track_running_stats else None, nbt, momentum, bn.eps,
-                                                         skip, _RELU[code])
+        args = (gamma.detach() if gamma is not None else None, beta.detach() if beta is not None else None,
+                bn.running_mean if bn.track_running_stats else None, bn.running_var if bn.track_running_stats else None, nbt, momentum,
+                bn.eps, skip, _RELU[code])
+        if partials is not None:   # the convolution's epilogue already summed its output: no pass for the block sums
+            y, mean, invstd, scale, shift = ops.bn_train_act(raw, partials, *args)
+        else:
+            y, mean, invstd, scale, shift = ops.bn_train_fwd(raw, *args)
         return y, mean, invstd, scale, shift, True
     mean, invstd, scale, shift, _ = _bn_forward(bn, False, raw, gamma, beta, C, device)
     y = raw if (bn is None and skip is None and code == 0) else ops.bn_act(raw, scale, shift, skip, _RELU[code])
@@ -245,11 +256,18 @@ class ConvUnitFn(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().contiguous()
         wp_fwd, wp_bwd = _unit_packs(unit, w)
-        raw = _conv_raw(unit, x, wp_fwd, bias)
         C = unit.out_planes
         bn = unit[1] if unit.has_bn else None
+        partials = None
+        if (_epilogue_stats and bn is not None and bn.training and bias is None and not unit.transposed and unit.stride == 1 and C == 32):
+            # the statistics' block sums come out of the convolution's own epilogue (32-channel stride-1 units: 10 of PSMNet's 25)
+            fused = ops.conv3d_k3_bnstats(x, wp_fwd, C)
+            if fused is not None:
+                raw, partials = fused
+        if partials is None:
+            raw = _conv_raw(unit, x, wp_fwd, bias)
         code = _relu_code(relu)
-        y, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, x.device)
+        y, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, x.device, partials)
         ctx.unit, ctx.code, ctx.batch_stats = unit, code, batch_stats
         ctx.has = (bias is not None, gamma is not None, beta is not None, skip is not None)
         # (the data-gradient pack belongs to the weight version of THIS forward: autograd forbids changing the weight before the

@@ -961,6 +961,53 @@ def bn_train_stats(c, gamma=None, beta=None, running_mean=None, running_var=None
     return tuple(out)
 
 
+def conv3d_k3_bnstats(x, wpack, Co):
+    """The RAW stride-1 convolution of a training-mode unit + the partial sums of its batch statistics from the kernel's epilogue
+    (dmb_conv3d_k3_bnstats_f32): returns (raw, partials [Co, P, 2] float64), or None where the shape is not covered (the caller
+    then runs conv3d_k3 and bn_train_fwd)."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    B, Ci, D, H, W = x.shape
+    P = int(lib.dmb_conv3d_k3_bnstats_partials(B, Ci, Co, D, H, W))
+    if P <= 0 or x.data_ptr() % 16:
+        return None
+    if wpack.numel() != lib.dmb_conv3d_packed_floats(Co, Ci):
+        raise _lib.DmbLibraryError("conv3d_k3_bnstats: packed weights hold %d floats, %d -> %d channels need %d"
+                                   % (wpack.numel(), Ci, Co, lib.dmb_conv3d_packed_floats(Co, Ci)))
+    raw = torch.empty((B, Co, D, H, W), dtype=torch.float32, device=x.device)
+    parts = torch.empty((Co, P, 2), dtype=torch.float64, device=x.device)
+    check(lib.dmb_conv3d_k3_bnstats_f32(dev_ptr(x), dev_ptr(wpack), dev_ptr(raw), dev_ptr(parts), B, Ci, Co, D, H, W, stream_ptr(x.device)),
+          "dmb_conv3d_k3_bnstats_f32")
+    return raw, parts
+
+
+def bn_train_act(c, partials, gamma=None, beta=None, running_mean=None, running_var=None, num_batches_tracked=None, momentum=0.1, eps=1e-5,
+                 residual=None, relu=False):
+    """bn_train_fwd without its pass over ``c`` for the block sums: the statistics are finished from ``partials`` ([C, P, 2] float64
+    sums of c and c^2, conv3d_k3_bnstats).  Returns (y, mean, invstd, scale, shift)."""
+    lib = _lib.load()
+    c = _f32c(c, "c")
+    B, C, S = _bcs(c)
+    if partials.dtype != torch.float64 or partials.dim() != 3 or partials.shape[0] != C or partials.shape[2] != 2 or not partials.is_contiguous():
+        raise _lib.DmbLibraryError("bn_train_act: partials must be a contiguous float64 [C, P, 2] tensor")
+    if residual is not None and (tuple(residual.shape) != tuple(c.shape) or not residual.is_contiguous() or residual.dtype != torch.float32):
+        raise _lib.DmbLibraryError("bn_train_act: residual must be a contiguous float32 tensor of shape %s" % (tuple(c.shape),))
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or num_batches_tracked.device != c.device):
+        raise _lib.DmbLibraryError("bn_train_act: num_batches_tracked must be an int64 tensor on %s" % c.device)
+    y = torch.empty_like(c)
+    stats = torch.empty((4, C), dtype=torch.float32, device=c.device)
+    check(lib.dmb_bn_train_act_f32(dev_ptr(c), dev_ptr(partials), int(partials.shape[1]), dev_ptr(gamma, allow_none=True),
+                                   dev_ptr(beta, allow_none=True), dev_ptr(running_mean, allow_none=True),
+                                   dev_ptr(running_var, allow_none=True), dev_ptr(num_batches_tracked, allow_none=True),
+                                   float(momentum), float(eps), dev_ptr(stats[0]), dev_ptr(stats[1]), dev_ptr(stats[2]), dev_ptr(stats[3]),
+                                   dev_ptr(residual, allow_none=True), dev_ptr(y), B, C, S, _relu_mode(relu), stream_ptr(c.device)),
+          "dmb_bn_train_act_f32")
+    written = [t for t in (running_mean, running_var, num_batches_tracked) if t is not None]
+    if written:
+        torch.autograd.graph.increment_version(written)
+    return y, stats[0], stats[1], stats[2], stats[3]
+
+
 def bn_act(c, scale, shift, residual=None, relu=False):
     """y = act(c*scale + shift (+ residual)); relu as in conv3d_k3 (False / True / 'pre')."""
     lib = _lib.load()

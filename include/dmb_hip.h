@@ -44,7 +44,7 @@ extern "C" {
 
 #define DMB_MAX_DISP_SAMPLES 256 /* upper bound on the number of disparity samples D */
 
-/* ABI version: bumped whenever a signature below changes (8: dmb_bn_train_fwd_f32, dmb_catconv_pack_weights_f32, dmb_conv3d_pack_weights_multi_f32 and dmb_cat_first_wgrad_maps_f32 added, dmb_bn_act_bwd_f32 takes the gradient its
+/* ABI version: bumped whenever a signature below changes (8: dmb_bn_train_fwd_f32, dmb_catconv_pack_weights_f32, dmb_conv3d_pack_weights_multi_f32, dmb_cat_first_wgrad_maps_f32, dmb_conv3d_k3_bnstats_f32 and dmb_bn_train_act_f32 added, dmb_bn_act_bwd_f32 takes the gradient its
  * skip operand already holds (`dres_acc`); 7: DMB_CONV_SINGLE_CHAIN in the `relu` argument of the convolution
  * entry points, `flags` argument of dmb_conv3d_k3_c1_f32; 6: dmb_stereo_pad_normalize_f32 / _u8 added; 5: dmb_fast_fms_bwd_f32 takes a mode, the forward's norm and an
  * optional gradient buffer for per-pixel samples; 4: workspace argument of dmb_deconv3d_k3s2_f32, the merged-heads entry
@@ -520,6 +520,19 @@ int dmb_conv2d_wgrad_f32(const float* x, const float* dc, float* dw, float* work
  *   into the skip branch (dpre for relu 1, dy otherwise) + dres_acc (may be NULL; ABI 8: what the skip operand has already
  *   collected from its other consumers, so that autograd's own addition -- three tensor passes -- is one extra read here).
  *   y (the unit's output) is only read for relu == 1.  Two launches (block sums; apply, which finishes the sums itself). */
+/* Batch statistics from the convolution's epilogue (ABI 8): dmb_conv3d_k3_bnstats_f32 is the RAW stride-1 convolution Ci -> 32
+ * (no affine, skip or ReLU: what a training-mode unit computes before its BatchNorm, basic_layers.py:68-83 under train()) that also
+ * writes, per workgroup and channel, the FP64 sum of its outputs and of their squares: stats[(ch * P + p) * 2 + {0, 1}], P =
+ * dmb_conv3d_k3_bnstats_partials(...) (0: the shape is not covered -- call dmb_conv3d_k3_f32 and dmb_bn_train_fwd_f32).
+ * dmb_bn_train_act_f32 then is dmb_bn_train_fwd_f32 without its pass over c for the block sums: it finishes the statistics from
+ * those partials (mean = sum / N, var = sumsq / N - mean^2 in FP64), updates the buffers and the counter, and normalises. */
+long long dmb_conv3d_k3_bnstats_partials(int B, int Ci, int Co, int D, int H, int W);
+int dmb_conv3d_k3_bnstats_f32(const float* x, const float* wpack, float* y, double* stats, int B, int Ci, int Co, int D, int H, int W,
+                              void* stream);
+int dmb_bn_train_act_f32(const float* c, const double* partials, int nparts, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                         float* mean_out, float* invstd_out, float* scale_out, float* shift_out, const float* residual, float* y,
+                         int B, int C, long long S, int relu, void* stream);
 long long dmb_bn_workspace_doubles(int C, long long S);
 int dmb_bn_train_stats_f32(const float* c, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* mean_out, float* invstd_out,

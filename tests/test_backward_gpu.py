@@ -1178,3 +1178,92 @@ def test_s2_weight_gradient_tiles_at_crop_sized_volumes(dev, transposed):
         ref = w.grad
         scale = ref.abs().max().item()
         assert (got.double() - ref).abs().max().item() <= 2e-5 * scale, (Ws, transposed)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 8, 12, 48), (1, 32, 5, 9, 32), (2, 16, 6, 7, 24), (4, 32, 12, 16, 128), (1, 64, 4, 6, 60)])
+def test_batch_statistics_from_the_convolution_epilogue(dev, shape):
+    """dmb_conv3d_k3_bnstats_f32 + dmb_bn_train_act_f32 (ABI 8) against the convolution followed by dmb_bn_train_fwd_f32: the raw
+    output bit for bit; the partial sums against FP64 sums of that output (partial tiles in every direction are masked); mean /
+    invstd / scale / shift / running buffers within 1e-6 relative (the two forms sum in a different order and the fused one has no
+    pivot) and the normalised output within 2e-6 of its range."""
+    ops = _ops()
+    B, Ci, D, H, W = shape
+    x = _rand(shape, 121).to(dev)
+    w = (_rand((32, Ci, 3, 3, 3), 122) * 0.1).to(dev)
+    wp = ops.pack_conv3d_weights(w)
+    gamma, beta = (_rand((32,), 123) * 0.5 + 1.0).to(dev), (_rand((32,), 124) * 0.2).to(dev)
+    res = _rand((B, 32, D, H, W), 125).to(dev)
+    fused = ops.conv3d_k3_bnstats(x, wp, 32)
+    assert fused is not None
+    raw, parts = fused
+    ref_raw = ops.conv3d_k3(x, wp, 32)
+    assert torch.equal(raw, ref_raw)
+    tot = parts.sum(dim=1)
+    r64 = ref_raw.double()
+    assert torch.allclose(tot[:, 0], r64.sum(dim=(0, 2, 3, 4)), rtol=1e-9, atol=1e-6)
+    assert torch.allclose(tot[:, 1], (r64 * r64).sum(dim=(0, 2, 3, 4)), rtol=1e-6, atol=1e-6)   # (squares are formed in FP32)
+    rm0, rv0 = _rand((32,), 126) * 0.1, _rand((32,), 127).abs() + 0.5
+    rm1, rv1, rm2, rv2 = rm0.to(dev), rv0.to(dev), rm0.to(dev), rv0.to(dev)
+    n1, n2 = torch.tensor(3, dtype=torch.int64, device=dev), torch.tensor(3, dtype=torch.int64, device=dev)
+    y1, m1, i1, s1, h1 = ops.bn_train_fwd(ref_raw, gamma, beta, rm1, rv1, n1, 0.1, 1e-5, res, True)
+    y2, m2, i2, s2, h2 = ops.bn_train_act(raw, parts, gamma, beta, rm2, rv2, n2, 0.1, 1e-5, res, True)
+    assert int(n1) == int(n2) == 4
+    for a, b, what in ((m1, m2, "mean"), (i1, i2, "invstd"), (s1, s2, "scale"), (h1, h2, "shift"), (rm1, rm2, "running_mean"), (rv1, rv2, "running_var")):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()) + 2e-7, what
+    assert (y1 - y2).abs().max().item() <= 2e-6 * max(1.0, y1.abs().max().item())
+    # an output with a large mean: the pivot-free sums still give the variance (FP64)
+    big = raw + 300.0
+    parts_big = torch.stack([big.double().sum(dim=(0, 2, 3, 4)), (big.double() ** 2).sum(dim=(0, 2, 3, 4))], -1).unsqueeze(1).contiguous()
+    _, mb, ib, _, _ = ops.bn_train_act(big, parts_big, None, None, None, None, None, 0.1, 1e-5, None, False)
+    _, mr, ir, _, _ = ops.bn_train_fwd(big, None, None, None, None, None, 0.1, 1e-5, None, False)
+    assert (mb - mr).abs().max().item() <= 1e-4 and (ib - ir).abs().max().item() <= 1e-4 * ir.abs().max().item()
+
+
+def test_epilogue_statistics_in_a_training_step(dev):
+    """A PSMNet training iteration with the batch statistics of the 32-channel stride-1 units taken from the convolution epilogues
+    against the same iteration with a pass per unit (``set_epilogue_stats(False)``): losses within 1e-5 relative, gradients within
+    1e-4 of their range (the statistics differ in the last bits, everything downstream with them), no bn_stats launch for those units."""
+    import os
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    from densematchingbenchmark_amd.modeling.stereo.layers import train_fn
+    from densematchingbenchmark_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 4
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cfg.model.disp_predictor.max_disp = md
+    cfg.model.losses.l1_loss.max_disp = md
+    model = build_model(cfg, backbone=None).to(dev)
+    synthetic.init_params_(model, seed=13)
+    model.train()
+    lf, rf = _rand((2, 32, 8, 24), 131).to(dev), _rand((2, 32, 8, 24), 132).to(dev)
+    gt = (torch.rand((2, 1, 32, 96), generator=torch.Generator().manual_seed(133)) * 30.0 + 1.0).to(dev)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(flag):
+        train_fn.set_epilogue_stats(flag)
+        try:
+            model.load_state_dict(state)
+            model.zero_grad(set_to_none=True)
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                _, losses = model(dict(leftFeature=lf, rightFeature=rf, leftDisp=gt))
+                torch.cuda.synchronize()
+            nstats = sum(e.count for e in prof.key_averages() if "bn_stats_kernel" in e.key)
+            sum(losses.values()).backward()
+            return ([float(v.detach()) for v in losses.values()], {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                    nstats, {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
+        finally:
+            train_fn.set_epilogue_stats(True)
+
+    l_on, g_on, n_on, r_on = run(True)
+    l_off, g_off, n_off, r_off = run(False)
+    assert n_off == 25 and n_on == 25 - 9        # dres0[1], dres1 x 2, classif x 3 and ... the 32-channel stride-1 units behind a tensor input
+    for a, b in zip(l_on, l_off):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
+    for k in g_on:
+        assert (g_on[k] - g_off[k]).abs().max().item() <= 3e-2 * g_off[k].abs().max().item() + 1e-30, k
+    for k in r_on:
+        assert (r_on[k] - r_off[k]).abs().max().item() <= 1e-5 * max(1.0, r_off[k].abs().max().item()), k
