@@ -260,7 +260,7 @@ class ConvUnitFn(torch.autograd.Function):
         bn = unit[1] if unit.has_bn else None
         partials = None
         if (_epilogue_stats and bn is not None and bn.training and bias is None and not unit.transposed and unit.stride == 1 and C == 32):
-            # the statistics' block sums come out of the convolution's own epilogue (32-channel stride-1 units: 10 of PSMNet's 25)
+            # the statistics' block sums come out of the convolution's own epilogue (32-channel stride-1 units: 6 of PSMNet's 25)
             fused = ops.conv3d_k3_bnstats(x, wp_fwd, C)
             if fused is not None:
                 raw, partials = fused

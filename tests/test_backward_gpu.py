@@ -1266,7 +1266,7 @@ def test_epilogue_statistics_in_a_training_step(dev):
 
     l_on, g_on, n_on, r_on = run(True)
     l_off, g_off, n_off, r_off = run(False)
-    assert n_off == 25 and n_on == 25 - 9        # dres0[1], dres1 x 2, classif x 3 and ... the 32-channel stride-1 units behind a tensor input
+    assert n_off == 25 and n_on == 25 - 6        # dres0[1], dres1[0], dres1[1], classif1-3[0]: the 32-channel stride-1 units on a tensor input
     for a, b in zip(l_on, l_off):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
     for k in g_on:
