@@ -156,6 +156,26 @@ __global__ __launch_bounds__(NB) void bn_act_kernel(const float* __restrict__ c,
 // same <= 2 KB of partials gets the same doubles everywhere -- and the finalising launch between the two passes goes away
 // (round 6: 25 + 25 launches of 4.7 us in a PSMNet training step).
 __device__ __forceinline__ void channel_totals(const double* __restrict__ ws, int ch, int nsplit, double* sm2, double& a, double& b) {
+  if (nsplit > 256) {
+    // thousands of partials (one per workgroup of a convolution whose epilogue summed its own output): all four waves walk them,
+    // 256 apart (one wave alone was a chain of 48 dependent rounds: 16 us in front of a 66 us pass), combined in wave order
+    __shared__ double wsum[4][2];
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = threadIdx.x; s < nsplit; s += NB) {
+      s0 += ws[((long long)ch * nsplit + s) * 2];
+      s1 += ws[((long long)ch * nsplit + s) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s0 += __shfl_down(s0, o, 64);
+      s1 += __shfl_down(s1, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][0] = s0, wsum[threadIdx.x >> 6][1] = s1;
+    __syncthreads();
+    a = ((wsum[0][0] + wsum[1][0]) + wsum[2][0]) + wsum[3][0];
+    b = ((wsum[0][1] + wsum[1][1]) + wsum[2][1]) + wsum[3][1];
+    return;
+  }
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     double s0 = 0.0, s1 = 0.0;
