@@ -194,11 +194,16 @@ def _conv_raw(unit, x, wpack, bias):
     return ops.conv3d_k3(x, wpack, Co, scale, shift, None, unit.stride, False)
 
 
-_epilogue_stats = True
+# Batch statistics out of the convolution's epilogue (conv3d_s1_kernel's STATS instantiation + ops.bn_train_act; VERDICT round 5,
+# "not attempted" twice).  Built, tested -- and OFF by default, because it does not pay: at 4 x 256x512 the six units it covers lose
+# their 33 us statistics pass each (-0.20 ms) but the convolution's epilogue grows by 16 us (+0.10 ms: the FP64 sums, the lane
+# butterfly and a barrier sit in the one part of that kernel nothing overlaps) and the normalising pass, which now finishes 3072
+# partials per channel instead of 128, by 8 us (+0.05 ms): 27.2 ms per step either way (docs/design/12-6).
+_epilogue_stats = False
 
 
 def set_epilogue_stats(flag):
-    """False: the batch statistics always take their own pass over the raw output (A/B and tests)."""
+    """True: 32-channel stride-1 units take the block sums of their batch statistics from the convolution's epilogue."""
     global _epilogue_stats
     _epilogue_stats = bool(flag)
 
