@@ -617,6 +617,25 @@ def _as3d_weight(w):
     return w3
 
 
+# Weight packs of the 2-D units across the two views of a training step.  The backbone runs the left and the right view through the
+# same modules one after the other (backbones/PSMNet.py:119-131), so every unit packed its forward weights twice per step and
+# built its data-gradient weights (a transpose, a flip, a copy, a pack) twice.  A pack now lives for a PHASE: the forward pack from
+# the first forward call until the unit's next backward call, the data-gradient packs from the first backward call until the next
+# forward call.  Parameters only change between a backward phase and the next forward phase (whatever the optimizer does to
+# ``_version``: see _PackGroup), so nothing stale survives; the version and the parameter epoch are part of the key for the
+# updates that do not follow a backward pass (load_state_dict).
+def _phase_pack(unit, w, forward):
+    key = (w.data_ptr(), tuple(w.shape), w._version, ops.param_epoch())
+    mine, other = ("_dmb_pack_fwd", "_dmb_pack_bwd") if forward else ("_dmb_pack_bwd", "_dmb_pack_fwd")
+    d = unit.__dict__
+    d[other] = None
+    c = d.get(mine)
+    if c is None or c[0] != key or torch.cuda.is_current_stream_capturing():
+        c = (key, ops.pack_conv2d_weights(w) if forward else ops.conv2d_dgrad_packs(w))
+        d[mine] = c
+    return c[1]
+
+
 class Conv2dUnitFn(torch.autograd.Function):
     """y = act(BN(conv2d(x)) (+ skip)) of one FusedConv2d unit of the 2-D networks (layers/basic_layers.py:31-46,105-123):
     kernel 1 | 3, stride 1 | 2, dilation 1 | 2.  Stride-1 gradients run on the 2-D kernels; the few stride-2 layers borrow the
@@ -636,7 +655,7 @@ class Conv2dUnitFn(torch.autograd.Function):
         sc = sh = None
         if bias is not None:
             sc, sh = _const(1.0, bias.numel(), bias.device), bias.detach().contiguous()
-        raw = ops.conv2d(x, ops.pack_conv2d_weights(w), C, k, s, d, sc, sh, None, False)
+        raw = ops.conv2d(x, _phase_pack(unit, w, True), C, k, s, d, sc, sh, None, False)
         bn = unit[1] if unit.has_bn else None
         code = _relu_code(relu)
         y, mean, invstd, scale, shift, batch_stats = _unit_bn_forward(bn, raw, gamma, beta, skip, code, C, x.device)
@@ -674,7 +693,7 @@ class Conv2dUnitFn(torch.autograd.Function):
             if k == 5:
                 dx = _depth_to_space(ops.conv2d_dgrad(dc, _k5s2_as_k3(w))).contiguous()
             elif s == 1:
-                dx = ops.conv2d_dgrad(dc, w, d, residual=dx_acc)
+                dx = ops.conv2d_dgrad(dc, w, d, residual=dx_acc, packs=_phase_pack(unit, w, False))
                 dx_acc = None
             elif k == 3:
                 dx = ops.conv3d_k3_dgrad(dc.unsqueeze(2), _as3d_weight(w), 2, (1,) + tuple(x.shape[2:])).squeeze(2)

@@ -919,22 +919,32 @@ def conv2d_k3_wgrad(x, dc):
     return conv2d_wgrad(x, dc, 3, 1)
 
 
-def conv2d_dgrad(dc, w, dilation=1, residual=None):
+def conv2d_dgrad_packs(w):
+    """Packed weights of the data-gradient convolution of a stride-1 nn.Conv2d with weight [Co, Ci, k, k]: the layer's taps mirrored,
+    channel roles exchanged, in chunks of at most 128 output (= the layer's input) channels: [(c0, n, pack), ...]."""
+    w = _f32c(w, "weight")
+    Ci = w.shape[1]
+    wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()           # [Ci, Co, k, k]: a convolution Co -> Ci
+    out = []
+    for c0 in range(0, Ci, 128):
+        n = min(128, Ci - c0)
+        out.append((c0, n, pack_conv2d_weights(wt[c0:c0 + n].contiguous() if n != Ci else wt)))
+    return out
+
+
+def conv2d_dgrad(dc, w, dilation=1, residual=None, packs=None):
     """Gradient of a stride-1 nn.Conv2d (k in {1, 3}, padding = dilation * (k // 2)) w.r.t. its input; w is the layer's weight
     [Co, Ci, k, k].  The same convolution kernel on mirrored, channel-exchanged weights, at most 128 output channels per launch.
-    ``residual`` ([B, Ci, H, W]) is added in the epilogue (conv3d_k3_dgrad)."""
-    w = _f32c(w, "weight")
-    Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
-    wt = w.detach().transpose(0, 1).flip(2, 3).contiguous()           # [Ci, Co, k, k]: a convolution Co -> Ci
+    ``residual`` ([B, Ci, H, W]) is added in the epilogue (conv3d_k3_dgrad); ``packs``: conv2d_dgrad_packs(w) when the caller holds
+    them already."""
+    Ci, k = w.shape[1], w.shape[2]
     dc = _f32c(dc, "dc")
     B, _, H, W = dc.shape
     dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=dc.device)
     if residual is not None:
         residual = _f32c(residual, "residual")
-    for c0 in range(0, Ci, 128):
-        n = min(128, Ci - c0)
-        conv2d(dc, pack_conv2d_weights(wt[c0:c0 + n].contiguous()), n, k, dilation=dilation, residual=residual, out=dx, out_ch_offset=c0,
-               res_ch_offset=c0)
+    for c0, n, pack in (packs if packs is not None else conv2d_dgrad_packs(w)):
+        conv2d(dc, pack, n, k, dilation=dilation, residual=residual, out=dx, out_ch_offset=c0, res_ch_offset=c0)
     return dx
 
 
