@@ -669,6 +669,7 @@ class Conv2dUnitFn(torch.autograd.Function):
         dy, dx_acc, dres_acc = _carried_grads(ctx, grads)
         x, w, raw, y, scale, shift, mean, invstd = ctx.saved_tensors
         unit, code = ctx.unit, ctx.code
+        unit.__dict__["_dmb_pack_fwd"] = None     # any backward call ends the forward phase of the unit's packs (_phase_pack)
         k, s, d = unit.kernel_size, unit.stride, unit.dilation
         has_bias, has_gamma, has_beta, has_skip = ctx.has
         dy = torch.zeros_like(raw) if dy is None else dy.contiguous()
