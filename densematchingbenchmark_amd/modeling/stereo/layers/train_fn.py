@@ -166,7 +166,7 @@ _pack_group_enabled = True
 
 
 def set_pack_group(flag):
-    """False: one pack launch per unit and direction, as in rounds 1-5 (A/B and tests)."""
+    """False: one pack launch per unit, direction and call, as in rounds 1-5 (A/B and tests; the 2-D units' phase packs too)."""
     global _pack_group_enabled
     _pack_group_enabled = bool(flag)
 
@@ -630,7 +630,7 @@ def _phase_pack(unit, w, forward):
     d = unit.__dict__
     d[other] = None
     c = d.get(mine)
-    if c is None or c[0] != key or torch.cuda.is_current_stream_capturing():
+    if c is None or c[0] != key or not _pack_group_enabled or torch.cuda.is_current_stream_capturing():
         c = (key, ops.pack_conv2d_weights(w) if forward else ops.conv2d_dgrad_packs(w))
         d[mine] = c
     return c[1]

@@ -1317,3 +1317,45 @@ def test_flat_gradients_gather_on_the_device(dev):
     assert flat.attached()
     for p, r in zip(flat.params, ref):
         assert (p.grad - 2 * r).abs().max().item() <= 1e-5 * max(1e-6, r.abs().max().item()) + 1e-12
+
+
+def test_fused_optimizer_updates_are_seen_by_the_backbone(dev):
+    """The same for the 2-D units (phase-lived weight packs, two views per step): three Adam(fused=True) steps of the whole PSMNet
+    model on small images give the same losses as per-call packing, bit for bit, and every step sees the previous update."""
+    import os
+    from densematchingbenchmark_amd.config import Config
+    from densematchingbenchmark_amd.modeling import build_model
+    from densematchingbenchmark_amd.modeling.stereo.layers import train_fn
+    from densematchingbenchmark_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "PSMNet", "scene_flow.py"))
+    md = 32
+    cfg.model.max_disp = md
+    cfg.model.cost_processor.cost_computation.max_disp = md // 4
+    cfg.model.cost_processor.cost_aggregator.max_disp = md
+    cfg.model.disp_predictor.max_disp = md
+    cfg.model.losses.l1_loss.max_disp = md
+    g = torch.Generator().manual_seed(151)
+    li, ri = torch.randn((1, 3, 64, 128), generator=g).to(dev), torch.randn((1, 3, 64, 128), generator=g).to(dev)
+    gt = (torch.rand((1, 1, 64, 128), generator=g) * 30.0 + 1.0).to(dev)
+
+    def run(flag):
+        train_fn.set_pack_group(flag)
+        try:
+            model = build_model(cfg, backbone="hip").to(dev)
+            synthetic.init_params_(model, seed=19)
+            model.train()
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, fused=True)
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                _, ld = model(dict(leftImage=li, rightImage=ri, leftDisp=gt))
+                sum(ld.values()).backward()
+                opt.step()
+                losses.append([float(x.detach()) for x in ld.values()])
+            return losses
+        finally:
+            train_fn.set_pack_group(True)
+
+    on, off = run(True), run(False)
+    assert on == off and on[0] != on[1] != on[2]
