@@ -1336,8 +1336,9 @@ def test_fused_optimizer_updates_are_seen_by_the_backbone(dev):
     cfg.model.disp_predictor.max_disp = md
     cfg.model.losses.l1_loss.max_disp = md
     g = torch.Generator().manual_seed(151)
-    li, ri = torch.randn((1, 3, 64, 128), generator=g).to(dev), torch.randn((1, 3, 64, 128), generator=g).to(dev)
-    gt = (torch.rand((1, 1, 64, 128), generator=g) * 30.0 + 1.0).to(dev)
+    # (256 x 512: the smallest image the backbone's 64 x 64 pooling branch admits, backbones/PSMNet.py:43)
+    li, ri = torch.randn((1, 3, 256, 512), generator=g).to(dev), torch.randn((1, 3, 256, 512), generator=g).to(dev)
+    gt = (torch.rand((1, 1, 256, 512), generator=g) * 30.0 + 1.0).to(dev)
 
     def run(flag):
         train_fn.set_pack_group(flag)
