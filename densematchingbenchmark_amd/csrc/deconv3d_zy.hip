@@ -56,13 +56,16 @@ namespace dmb {
 // MT_: 32-column MFMA tiles per input row of a work item: 2 (60 real positions + the halo column of the odd outputs in 64 staged
 // columns) or 1 (28 real positions in 32) -- the narrower tile computes fewer discarded columns where the image width is
 // awkward for 60 (80 columns: 3 x 32 computed instead of 2 x 64); deconv3d_zy_try picks per launch.
-template <int COUT_, int MT_ = 2>
+// FULL_ (round 6): all 32 MT positions of a staged row are real -- the row is staged 4 columns longer (pitch 32 MT + 4) instead of the
+// tile being 4 positions narrower than what the matrix cores compute.  For widths that are multiples of 32 (the training crops: 64
+// and 32 input columns) nothing computed is discarded, where the 28- / 60-column tiles compute 96 for 64 and 64 for 32.
+template <int COUT_, int MT_ = 2, bool FULL_ = false>
 struct ZYCfg {
   static constexpr int COUT = COUT_;
   static constexpr int NTT = COUT / 32;       // 32-channel row tiles
   static constexpr int WN = NTT;              // waves along the output channels: one row tile per wave
   static constexpr int WZ = 4 / WN, TZ = WZ;  // waves (= input planes) along z
-  static constexpr int MT = MT_, P = 32 * MT_, TX = P - 4;   // one input row: P staged columns, TX real positions, MT 32-column MFMA tiles
+  static constexpr int MT = MT_, P = FULL_ ? 32 * MT_ + 4 : 32 * MT_, TX = FULL_ ? 32 * MT_ : P - 4;   // one input row: P staged columns, TX real positions, MT 32-column MFMA tiles
   static constexpr int RUN = 3 * NTT * 64;    // weight floats of one (channel pair, kz, ky): its three kx taps
   static constexpr int SCR_PITCH = 68, PCH = 8;   // epilogue scratch: 8 channels x 64 output columns per pass and wave
   static constexpr int AFF_FLOATS = 2 * COUT;     // scale / shift table
@@ -537,8 +540,12 @@ int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const f
   if (!(Co == 32 || Co == 64) || Ci % 16 != 0 || Ci < 32 || W % 4 != 0 || Wout % 4 != 0) return -1;   // (>= 2 chunks in every class)
   if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) != 0) return -1;
   if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;
-  // 28-column tiles where they compute fewer columns than 60-column ones (80 input columns: 96 against 128)
+  // 28-column tiles where they compute fewer columns than 60-column ones (80 input columns: 96 against 128); (round 6) tiles of 32 /
+  // 64 REAL columns (a longer staged row) where those compute fewer still: 64 input columns 64 against 96, 32 columns 32 against
+  // 64, 156 (KITTI) 160 against 192.  Ties keep the older forms; same arithmetic per output whatever the tile.
   const bool narrow = cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
+  const int c_old = narrow ? cdiv(W, 28) * 32 : cdiv(W, 60) * 64, c_f32 = cdiv(W, 32) * 32, c_f64 = cdiv(W, 64) * 64;
+  const int full = DMB_OPT(29) == 1 ? 0 : (c_f64 < c_old && c_f64 <= c_f32 ? 2 : (c_f32 < c_old ? 1 : 0));   // (development option 29 = 1: never)
   // (round 6) A 64-channel launch of about one item per workgroup slot (conv5 of one 544x960 pair: 816 items of weight 1 .. 4 on
   // 768 slots) is faster on deconv3d_kernel's items with both y parities: 0.099 -> 0.069 ms at [1, 64, 12, 34, 60]; equal at the
   // KITTI shape and from two pairs on (scripts/kbench_hg.py, KB_B = 1 / 2).  Same arithmetic, bit-identical results.
@@ -546,9 +553,14 @@ int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const f
     const long long items = 4LL * B * cdiv(W, narrow ? 28 : 60) * H * cdiv(D, 2);
     if (4 * items <= 5LL * 3 * num_cus()) return -1;
   }
-  if (Co == 32)
+  if (Co == 32) {
+    if (full == 2) return launch_zy<ZYCfg<32, 2, true>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
+    if (full == 1) return launch_zy<ZYCfg<32, 1, true>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
     return narrow ? launch_zy<ZYCfg<32, 1>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st)
                   : launch_zy<ZYCfg<32, 2>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
+  }
+  if (full == 2) return launch_zy<ZYCfg<64, 2, true>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
+  if (full == 1) return launch_zy<ZYCfg<64, 1, true>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
   return narrow ? launch_zy<ZYCfg<64, 1>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st)
                 : launch_zy<ZYCfg<64, 2>>(x, wp, scale, shift, res, y, B, Ci, D, H, W, Wout, relu, ws, st);
 }
