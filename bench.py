@@ -405,10 +405,10 @@ def training_leg(cfg, dev, steps):
     # arithmetic of one iteration in the REFERENCE's formulation = forward + data gradients + weight gradients = 3 x the forward's
     # (SURVEY 8-d figure scaled by the crop's area; the data gradient of the first layer is not needed when the features are
     # inputs, but the figure is kept as the yardstick of rounds 1-5).  EXECUTED since round 6: the first layer runs as 2-D maps
-    # in the forward pass and in its weight gradient -- rocprofv3 counts 2721 GFLOP of matrix instructions per step
+    # in the forward pass and in its weight gradient -- rocprofv3 counts 2624 GFLOP of matrix instructions per step
     # (profiles/r06_train_pmc.csv; 3048 in round 5)
     gflop = 3.0 * PATH_GFLOP_PER_PAIR * (H * W) / (544.0 * 960.0) * B
-    gflop_exec = 2721.3 * B / 4.0
+    gflop_exec = 2623.5 * B / 4.0
     out = {"pairs_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "workload": "PSMNet cost path, training mode, batch %d x %dx%d crops, max_disp=192, Adam" % (B, H, W),
            "gflop_per_step": round(gflop, 1), "frac_fp32_peak": round(gflop / (dt / steps) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
