@@ -542,10 +542,14 @@ int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const f
   if ((long long)16 * D * H * W * 4 >= 0x7fffffffLL || (long long)Co * 8 * D * H * W * 4 >= 0x7fffffffLL) return -1;
   // 28-column tiles where they compute fewer columns than 60-column ones (80 input columns: 96 against 128); (round 6) tiles of 32 /
   // 64 REAL columns (a longer staged row) where those compute fewer still: 64 input columns 64 against 96, 32 columns 32 against
-  // 64, 156 (KITTI) 160 against 192.  Ties keep the older forms; same arithmetic per output whatever the tile.
+  // 64, 156 (KITTI) 160 against 192.  Same arithmetic per output whatever the tile.
   const bool narrow = cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
   const int c_old = narrow ? cdiv(W, 28) * 32 : cdiv(W, 60) * 64, c_f32 = cdiv(W, 32) * 32, c_f64 = cdiv(W, 64) * 64;
-  const int full = DMB_OPT(29) == 1 ? 0 : (c_f64 < c_old && c_f64 <= c_f32 ? 2 : (c_f32 < c_old ? 1 : 0));   // (development option 29 = 1: never)
+  // (a tie between 60- and 64-column tiles -- 120 input columns: 2 x 64 computed either way -- goes to the 64-column form: its tiles
+  // start on 512-byte boundaries of the output rows; conv6 at [4, 64, 24, 68, 120]: 849-865 -> 829 us, scripts/attic/zy_b1_tile_probe.py)
+  int full = c_f64 <= c_old && c_f64 <= c_f32 ? 2 : (c_f32 < c_old ? 1 : 0);
+  if (DMB_OPT(29) == 1) full = 0;                      // (development option 29: 1 = never, 2 / 3 = force the 32- / 64-column form)
+  if (DMB_OPT(29) >= 2) full = DMB_OPT(29) - 1;
   // (round 6) A 64-channel launch of about one item per workgroup slot (conv5 of one 544x960 pair: 816 items of weight 1 .. 4 on
   // 768 slots) is faster on deconv3d_kernel's items with both y parities: 0.099 -> 0.069 ms at [1, 64, 12, 34, 60]; equal at the
   // KITTI shape and from two pairs on (scripts/kbench_hg.py, KB_B = 1 / 2).  Same arithmetic, bit-identical results.
