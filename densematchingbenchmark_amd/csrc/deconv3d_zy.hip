@@ -545,8 +545,9 @@ int deconv3d_zy_try(const float* x, const float* wp, const float* scale, const f
   // 64, 156 (KITTI) 160 against 192.  Same arithmetic per output whatever the tile.
   const bool narrow = cdiv(W, 28) * 32 < cdiv(W, 60) * 64;
   const int c_old = narrow ? cdiv(W, 28) * 32 : cdiv(W, 60) * 64, c_f32 = cdiv(W, 32) * 32, c_f64 = cdiv(W, 64) * 64;
-  // (a tie between 60- and 64-column tiles -- 120 input columns: 2 x 64 computed either way -- goes to the 64-column form: its tiles
-  // start on 512-byte boundaries of the output rows; conv6 at [4, 64, 24, 68, 120]: 849-865 -> 829 us, scripts/attic/zy_b1_tile_probe.py)
+  // (a tie between 60- and 64-column tiles -- 120 input columns: 2 x 64 computed either way -- goes to the 64-column form, whose tiles
+  // start on 512-byte boundaries of the output rows: 849-865 -> 829 us for conv6 at [4, 64, 24, 68, 120] alone
+  // (scripts/attic/zy_b1_tile_probe.py), equal within the noise inside the step: 807 against 803 us under rocprofv3)
   int full = c_f64 <= c_old && c_f64 <= c_f32 ? 2 : (c_f32 < c_old ? 1 : 0);
   if (DMB_OPT(29) == 1) full = 0;                      // (development option 29: 1 = never, 2 / 3 = force the 32- / 64-column form)
   if (DMB_OPT(29) >= 2) full = DMB_OPT(29) - 1;
