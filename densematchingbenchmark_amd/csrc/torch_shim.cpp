@@ -17,6 +17,7 @@
 #include <c10/hip/HIPStream.h>
 
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "dmb_hip.h"
@@ -184,6 +185,92 @@ at::Tensor copy_window(const at::Tensor& src, int64_t Wd, int64_t xs) {
   return dst;
 }
 
+// ---- the per-unit launches of a training step (round 6: the backbone's 145 units make images -> loss host-bound) ---------------
+// [B, C, *spatial] -> (B, C, S)
+void bcs(const at::Tensor& t, const char* what, int64_t& B, int64_t& C, int64_t& S) {
+  if (t.dim() < 3) raise(std::string(what) + ": [B, C, spatial ...] expected");
+  B = t.size(0);
+  C = t.size(1);
+  S = B * C > 0 ? t.numel() / (B * C) : 0;
+  if (B <= 0 || C <= 0 || S <= 0) raise(std::string(what) + ": empty tensor");
+}
+float* mptr(const c10::optional<at::Tensor>& t, const char* name) { return t.has_value() ? const_cast<float*>(ptr(*t, name)) : nullptr; }
+
+// dmb_bn_train_fwd_f32 (layers/basic_layers.py:68-83 under train()): -> (y, stats [4, C] = mean, invstd, scale, shift)
+std::tuple<at::Tensor, at::Tensor> bn_train_fwd(const at::Tensor& c, const c10::optional<at::Tensor>& gamma, const c10::optional<at::Tensor>& beta,
+                                                const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                                                const c10::optional<at::Tensor>& num_batches_tracked, double momentum, double eps,
+                                                const c10::optional<at::Tensor>& residual, int64_t relu) {
+  f32(c, "c");
+  int64_t B, C, S;
+  bcs(c, "bn_train_fwd", B, C, S);
+  if (residual.has_value() && residual->sizes() != c.sizes()) raise("bn_train_fwd: residual shape != input shape");
+  for (const auto* t : {&gamma, &beta, &running_mean, &running_var})
+    if (t->has_value() && (*t)->numel() != C) raise("bn_train_fwd: per-channel tensors must have C elements");
+  long long* nbt = nullptr;
+  if (num_batches_tracked.has_value()) {
+    const at::Tensor& n = *num_batches_tracked;
+    if (!n.is_cuda() || n.scalar_type() != at::kLong || n.numel() != 1 || n.device() != c.device()) raise("bn_train_fwd: num_batches_tracked must be an int64 scalar on the input's device");
+    nbt = reinterpret_cast<long long*>(n.data_ptr<int64_t>());
+  }
+  at::Tensor y = at::empty_like(c);
+  at::Tensor stats = at::empty({4, C}, c.options());
+  at::Tensor ws = at::empty({dmb_bn_workspace_doubles((int)C, (long long)S)}, c.options().dtype(at::kDouble));
+  float* st = stats.data_ptr<float>();
+  chk(dmb_bn_train_fwd_f32(c.data_ptr<float>(), optr(gamma, "gamma"), optr(beta, "beta"), mptr(running_mean, "running_mean"),
+                           mptr(running_var, "running_var"), nbt, (float)momentum, (float)eps, st, st + C, st + 2 * C, st + 3 * C,
+                           optr(residual, "residual"), y.data_ptr<float>(), ws.data_ptr<double>(), (int)B, (int)C, (long long)S, (int)relu,
+                           stream_of(c)),
+      "dmb_bn_train_fwd_f32");
+  // the kernel wrote these through their pointers: tell torch (the modules' folded-parameter caches key on the versions)
+  for (const auto* t : {&running_mean, &running_var, &num_batches_tracked})
+    if (t->has_value()) (*t)->unsafeGetTensorImpl()->bump_version();
+  return std::make_tuple(y, stats);
+}
+
+// dmb_bn_act_bwd_f32: -> (dc, gb [2, C] = dgamma, dbeta, dres or an undefined tensor)
+std::tuple<at::Tensor, at::Tensor, c10::optional<at::Tensor>> bn_act_bwd(const at::Tensor& dy, const at::Tensor& c, const c10::optional<at::Tensor>& y,
+                                                                        const at::Tensor& scale, const at::Tensor& shift, const at::Tensor& mean,
+                                                                        const at::Tensor& invstd, int64_t relu, bool training, bool want_dres,
+                                                                        const c10::optional<at::Tensor>& dres_acc) {
+  f32(dy, "dy");
+  f32(c, "c");
+  int64_t B, C, S;
+  bcs(c, "bn_act_bwd", B, C, S);
+  if (dy.sizes() != c.sizes()) raise("bn_act_bwd: dy shape != c shape");
+  if (relu == 1 && !y.has_value()) raise("bn_act_bwd: the unit's output is needed for a ReLU after the skip add");
+  if (y.has_value() && y->sizes() != c.sizes()) raise("bn_act_bwd: y shape != c shape");
+  if (dres_acc.has_value() && dres_acc->sizes() != c.sizes()) raise("bn_act_bwd: dres_acc shape != c shape");
+  for (const at::Tensor* t : {&scale, &shift, &mean, &invstd})
+    if (t->numel() != C) raise("bn_act_bwd: per-channel tensors must have C elements");
+  at::Tensor dc = at::empty_like(c);
+  c10::optional<at::Tensor> dres;
+  if (want_dres || dres_acc.has_value()) dres = at::empty_like(c);
+  at::Tensor gb = at::empty({2, C}, c.options());
+  at::Tensor ws = at::empty({dmb_bn_workspace_doubles((int)C, (long long)S)}, c.options().dtype(at::kDouble));
+  chk(dmb_bn_act_bwd_f32(dy.data_ptr<float>(), c.data_ptr<float>(), relu == 1 ? ptr(*y, "y") : nullptr, ptr(scale, "scale"), ptr(shift, "shift"),
+                         ptr(mean, "mean"), ptr(invstd, "invstd"), ws.data_ptr<double>(), gb.data_ptr<float>(), gb.data_ptr<float>() + C,
+                         dc.data_ptr<float>(), dres.has_value() ? dres->data_ptr<float>() : nullptr, optr(dres_acc, "dres_acc"), (int)B, (int)C,
+                         (long long)S, (int)relu, training ? 1 : 0, stream_of(c)),
+      "dmb_bn_act_bwd_f32");
+  return std::make_tuple(dc, gb, dres);
+}
+
+// dmb_conv2d_wgrad_f32 (autograd of the 2-D units w.r.t. their weights): x [B, Ci, H, W], dc [B, Co, H, W], W % 4 == 0
+at::Tensor conv2d_wgrad(const at::Tensor& x, const at::Tensor& dc, int64_t ksize, int64_t dilation) {
+  f32(x, "x");
+  f32(dc, "dc");
+  if (x.dim() != 4 || dc.dim() != 4 || dc.size(0) != x.size(0) || dc.size(2) != x.size(2) || dc.size(3) != x.size(3))
+    raise("conv2d_wgrad: dc does not match x");
+  const int64_t B = x.size(0), Ci = x.size(1), H = x.size(2), W = x.size(3), Co = dc.size(1);
+  at::Tensor dw = at::empty({Co, Ci, ksize, ksize}, x.options());
+  at::Tensor ws = at::empty({dmb_conv2d_wgrad_workspace_floats((int)Co, (int)Ci)}, x.options());
+  chk(dmb_conv2d_wgrad_f32(x.data_ptr<float>(), dc.data_ptr<float>(), dw.data_ptr<float>(), ws.data_ptr<float>(), (int)B, (int)Ci, (int)Co, (int)H,
+                           (int)W, (int)ksize, (int)dilation, stream_of(x)),
+      "dmb_conv2d_wgrad_f32");
+  return dw;
+}
+
 void set_error_class(py::object cls) {
   Py_XDECREF(g_error_class);
   g_error_class = cls.ptr();
@@ -208,4 +295,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("trilinear_ac_soft_argmin", &trilinear_ac_soft_argmin);
   m.def("conv2d", &conv2d);
   m.def("copy_window", &copy_window);
+  m.def("bn_train_fwd", &bn_train_fwd);
+  m.def("bn_act_bwd", &bn_act_bwd);
+  m.def("conv2d_wgrad", &conv2d_wgrad);
 }

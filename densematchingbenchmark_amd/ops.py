@@ -908,6 +908,9 @@ def conv2d_wgrad(x, dc, ksize=3, dilation=1):
         pad = 4 - W % 4
         x, dc = torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(dc, (0, pad))
         W += pad
+    sh = _lib.shim()
+    if sh is not None:
+        return sh.conv2d_wgrad(x, dc, int(ksize), int(dilation))
     dw = torch.empty((Co, Ci, ksize, ksize), dtype=torch.float32, device=x.device)
     ws = torch.empty((lib.dmb_conv2d_wgrad_workspace_floats(Co, Ci),), dtype=torch.float32, device=x.device)
     check(lib.dmb_conv2d_wgrad_f32(dev_ptr(x), dev_ptr(dc), dev_ptr(dw), dev_ptr(ws), B, Ci, Co, H, W, int(ksize), int(dilation),
@@ -1033,6 +1036,11 @@ def bn_train_fwd(c, gamma=None, beta=None, running_mean=None, running_var=None, 
                  residual=None, relu=False):
     """bn_train_stats + bn_act of a batch-statistics unit in two launches (dmb_bn_train_fwd_f32): returns
     (y, mean, invstd, scale, shift); updates the running buffers and adds 1 to ``num_batches_tracked`` (an int64 device tensor)."""
+    sh = _lib.shim()
+    if sh is not None:      # the torch-extension shim: the same checks and the same C-ABI call without the interpreter
+        y, stats = sh.bn_train_fwd(c if c.is_contiguous() else c.contiguous(), gamma, beta, running_mean, running_var, num_batches_tracked,
+                                   float(momentum), float(eps), residual, _relu_mode(relu))
+        return y, stats[0], stats[1], stats[2], stats[3]
     lib = _lib.load()
     c = _f32c(c, "c")
     B, C, S = _bcs(c)
@@ -1060,6 +1068,12 @@ def bn_train_fwd(c, gamma=None, beta=None, running_mean=None, running_var=None, 
 def bn_act_bwd(dy, c, y, scale, shift, mean, invstd, relu=False, training=True, want_dres=False, dres_acc=None):
     """Backward of bn_act (+ the batch statistics if training): returns (dc, dgamma, dbeta, dres or None).  ``dres_acc``: a
     gradient the skip operand already holds, added into ``dres`` by the same pass (implies ``want_dres``)."""
+    sh = _lib.shim()
+    if sh is not None:
+        dc, gb, dres = sh.bn_act_bwd(dy if dy.is_contiguous() else dy.contiguous(), c if c.is_contiguous() else c.contiguous(), y, scale, shift,
+                                     mean, invstd, _relu_mode(relu), bool(training), bool(want_dres),
+                                     None if dres_acc is None else (dres_acc if dres_acc.is_contiguous() else dres_acc.contiguous()))
+        return dc, gb[0], gb[1], dres
     lib = _lib.load()
     dy, c = _f32c(dy, "dy"), _f32c(c, "c")
     B, C, S = _bcs(c)

@@ -1234,6 +1234,11 @@ def test_torch_extension_shim_and_ctypes_bind_the_same_functions(dev):
                 ops.conv3d_k3_c1(x, w[:1].contiguous(), 0.5, None), ops.copy_window(x, 48, -3),
                 ops.conv2d(x2, ops.pack_conv2d_weights(w2), 32, 3, 1, 1, sc[:32].contiguous(), sh[:32].contiguous(), None, True)]
         outs += list(ops.trilinear_ac_soft_argmin(q, (24, 20, 32), ops.disp_sample_values(24, 0, 1), 1.0))
+        # (round 6) the per-unit launches of a training step: BatchNorm forward / backward, the 2-D weight gradient
+        rm, rv, nbt = torch.zeros(64, device=dev), torch.ones(64, device=dev), torch.tensor(2, dtype=torch.int64, device=dev)
+        fwd = ops.bn_train_fwd(res, sc, sh, rm, rv, nbt, 0.1, 1e-5, res * 0.5, True)
+        bwd = ops.bn_act_bwd(res * 0.3, res, fwd[0], fwd[3], fwd[4], fwd[1], fwd[2], True, True, want_dres=True, dres_acc=res * 0.1)
+        outs += list(fwd) + [rm, rv, nbt.float()] + list(bwd) + [ops.conv2d_wgrad(x2, _rand((2, 32, 20, 36), 709).to(dev), 3, 1)]
         return outs
 
     try:
@@ -1242,9 +1247,11 @@ def test_torch_extension_shim_and_ctypes_bind_the_same_functions(dev):
         b = run()
     finally:
         _lib._shim = shim
-    assert len(a) == len(b) == 8 and all(torch.equal(u, v) for u, v in zip(a, b))
+    assert len(a) == len(b) == 21 and all(torch.equal(u, v) for u, v in zip(a, b))
     for bad in (lambda: ops.conv3d_k3(x.cpu(), ops.pack_conv3d_weights(w), 64), lambda: ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 32),
-                lambda: ops.conv3d_k3(x.double(), ops.pack_conv3d_weights(w), 64), lambda: ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 64, None, None, res[:1])):
+                lambda: ops.conv3d_k3(x.double(), ops.pack_conv3d_weights(w), 64), lambda: ops.conv3d_k3(x, ops.pack_conv3d_weights(w), 64, None, None, res[:1]),
+                lambda: ops.bn_train_fwd(res.cpu(), sc, sh), lambda: ops.bn_train_fwd(res, sc[:8].contiguous(), sh),
+                lambda: ops.bn_act_bwd(res[:1], res, None, sc, sh, sc, sh, False, True), lambda: ops.conv2d_wgrad(x2, x2[:, :, :5].contiguous(), 3, 1)):
         with pytest.raises(_lib.DmbLibraryError):
             bad()
 
